@@ -1,0 +1,378 @@
+// device.cpp -- HBM residency of the symbolic structure and the level-scheduled numeric
+// drivers (factorise, sweeps, log-determinant, selected inverse). Compiled with hipcc.
+#include "device.h"
+
+#include <algorithm>
+#include <climits>
+#include <cstring>
+#include <stdexcept>
+
+#include "kernels.h"
+
+namespace gmrfx {
+
+void hip_check(hipError_t e, const char *what) {
+    if (e != hipSuccess) throw std::runtime_error(std::string("HIP error in ") + what + ": " + hipGetErrorString(e));
+}
+#define HC(x) hip_check((x), #x)
+
+template <class T> T *Device::dalloc(size_t count) {
+    void *p = nullptr;
+    HC(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
+    allocs_.push_back(p);
+    bytes_total += (double)(std::max<size_t>(count, 1) * sizeof(T));
+    return (T *)p;
+}
+
+Device::~Device() {
+    if (stream) { (void)hipStreamSynchronize(stream); }
+    for (void *p : allocs_) (void)hipFree(p);
+    for (auto &e : ev_) if (e) (void)hipEventDestroy(e);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+template <class T, class U> static std::vector<T> conv(const std::vector<U> &v) { return std::vector<T>(v.begin(), v.end()); }
+
+void Device::init(const Symbolic &S, int dev) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) throw std::runtime_error("no HIP device available (libgmrfx has no CPU fallback)");
+    if (dev < 0) HC(hipGetDevice(&dev));
+    if (dev >= count) throw std::runtime_error("HIP device ordinal out of range");
+    device = dev;
+    HC(hipSetDevice(device));
+    HC(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    for (auto &ev : ev_) HC(hipEventCreate(&ev));
+    upload(S);
+}
+
+void Device::upload(const Symbolic &S) {
+    S_ = &S;
+    const int ns = S.nsuper;
+    if (S.nnz_in >= (i64)INT_MAX) throw std::runtime_error("nnz(Q) >= 2^31 not supported by the device scatter map yet");
+    auto up = [&](auto *&dst, const auto &host) {
+        using T = typename std::remove_const<typename std::remove_reference<decltype(host[0])>::type>::type;
+        T *p = dalloc<T>(host.size());
+        if (!host.empty()) HC(hipMemcpyAsync(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice, stream));
+        dst = p;
+    };
+    ds_.n = (int)S.n;
+    ds_.nsuper = ns;
+    const int *ip; const long long *lp;
+    up(ip, S.sfirst); ds_.sfirst = ip;
+    std::vector<long long> tmp64;
+    tmp64 = conv<long long>(S.rowptr); up(lp, tmp64); ds_.rowptr = lp; HC(hipStreamSynchronize(stream));
+    up(ip, S.rows); ds_.rows = ip;
+    up(ip, S.rel); ds_.rel = ip;
+    tmp64 = conv<long long>(S.panelptr); up(lp, tmp64); ds_.panelptr = lp; HC(hipStreamSynchronize(stream));
+    up(ip, S.ld); ds_.ld = ip;
+    tmp64 = conv<long long>(S.cbptr); up(lp, tmp64); ds_.cbptr = lp; HC(hipStreamSynchronize(stream));
+    tmp64 = conv<long long>(S.childptr); up(lp, tmp64); ds_.childptr = lp; HC(hipStreamSynchronize(stream));
+    up(ip, S.children); ds_.children = ip;
+    up(ip, S.sparent); ds_.sparent = ip;
+    tmp64 = conv<long long>(S.qptr); up(lp, tmp64); ds_.qptr = lp; HC(hipStreamSynchronize(stream));
+    {
+        std::vector<int> qs(S.qsrc.size()), qd(S.qdst.size());
+        for (i32 s = 0; s < ns; s++)
+            for (i64 q = S.qptr[s]; q < S.qptr[s + 1]; q++) {
+                qs[q] = (int)S.qsrc[q];
+                i64 rel = S.qdst[q] - S.panelptr[s];
+                if (rel >= INT_MAX) throw std::runtime_error("panel too large for 32-bit scatter offsets");
+                qd[q] = (int)rel;
+            }
+        up(ip, qs); ds_.qsrc = ip;
+        up(ip, qd); ds_.qdst = ip;
+        HC(hipStreamSynchronize(stream));
+    }
+    {
+        std::vector<long long> wptr(ns + 1, 0);
+        for (i32 s = 0; s < ns; s++) wptr[s + 1] = wptr[s] + (S.nrows(s) - S.ncols(s));
+        sum_trail_ = wptr[ns];
+        up(lp, wptr); ds_.wptr = lp;
+        HC(hipStreamSynchronize(stream));
+    }
+    tmp64 = conv<long long>(S.diagoff); up(lp, tmp64); ds_.diagoff = lp; HC(hipStreamSynchronize(stream));
+    up(ip, S.perm); ds_.perm = ip;
+    {
+        const int *ll; up(ll, S.levellist); d_levellist_ = const_cast<int *>(ll);
+    }
+    HC(hipStreamSynchronize(stream));
+
+    levels_.clear();
+    levels_.resize(S.nlevels);
+    for (i32 l = 0; l < S.nlevels; l++) {
+        LevelInfo &L = levels_[l];
+        L.first = (int)S.levelptr[l];
+        L.count = (int)(S.levelptr[l + 1] - S.levelptr[l]);
+        L.nsmall = S.level_nsmall[l];
+        L.max_rows = L.max_cols = 0;
+        int max_trail = 0;
+        for (int k = L.nsmall; k < L.count; k++) {
+            i32 s = S.levellist[L.first + k];
+            L.max_rows = std::max(L.max_rows, S.nrows(s));
+            L.max_cols = std::max(L.max_cols, S.ncols(s));
+            max_trail = std::max(max_trail, S.nrows(s) - S.ncols(s));
+        }
+        int nblk = (L.max_cols + NB - 1) / NB;
+        L.active.assign(nblk + 1, 0);
+        for (int b = 0; b <= nblk; b++) {
+            int cnt = 0;
+            for (int k = L.nsmall; k < L.count; k++) {
+                if (S.ncols(S.levellist[L.first + k]) > b * NB) cnt++; else break;  // sorted by decreasing columns
+            }
+            L.active[b] = cnt;
+        }
+        L.active.push_back(max_trail);  // stash: last element = max trailing rows of the level
+    }
+
+    l_size_ = S.panelptr[ns];
+    d_L_ = dalloc<double>((size_t)l_size_);
+    d_cb_ = dalloc<double>((size_t)S.cb_arena);
+    d_nz_ = dalloc<double>((size_t)S.nnz_in);
+    d_info_ = dalloc<int>(2);
+    d_part_ = dalloc<double>(1024 + 8);
+    HC(hipMemsetAsync(d_L_, 0, (size_t)l_size_ * sizeof(double), stream));
+    HC(hipStreamSynchronize(stream));
+}
+
+void Device::clone_from(const Device &o, const Symbolic &S) {
+    init(S, o.device);
+    if (o.factorized) {
+        HC(hipMemcpyAsync(d_L_, o.d_L_, (size_t)l_size_ * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        HC(hipMemcpyAsync(d_info_, o.d_info_, sizeof(int), hipMemcpyDeviceToDevice, stream));
+        HC(hipStreamSynchronize(stream));
+        factorized = true;
+    }
+}
+
+static inline int level_max_trail(const LevelInfo &L) { return L.active.back(); }
+static inline int level_nblk(const LevelInfo &L) { return (int)L.active.size() - 2; }
+
+void Device::factor_levels() {
+    const int big = INT_MAX;
+    HC(hipMemcpyAsync(d_info_, &big, sizeof(int), hipMemcpyHostToDevice, stream));
+    for (auto &L : levels_) {
+        const int *list = d_levellist_ + L.first + L.nsmall;
+        const int nf = L.count - L.nsmall;
+        launch_assemble(stream, ds_, list, nf, L.max_rows, d_nz_, d_L_, d_cb_);
+        const int nblk = level_nblk(L);
+        for (int b = 0; b < nblk; b++) {
+            const int kb = b * NB;
+            launch_potrf(stream, ds_, list, L.active[b], kb, d_L_, d_info_);
+            launch_trsm(stream, ds_, list, L.active[b], kb, L.max_rows - kb - 1, d_L_);
+            if (b + 1 < nblk)
+                launch_gemm_nt(stream, ds_, list, L.active[b + 1], kb, 0, L.max_rows - kb - NB, L.max_cols - kb - NB, d_L_, d_cb_);
+        }
+        launch_gemm_nt(stream, ds_, list, nf, 0, 1, level_max_trail(L), level_max_trail(L), d_L_, d_cb_);
+    }
+}
+
+void Device::refactorize(const double *nzval, bool on_device) {
+    HC(hipSetDevice(device));
+    const double *src = nzval;
+    if (!on_device) {
+        HC(hipMemcpyAsync(d_nz_, nzval, (size_t)S_->nnz_in * sizeof(double), hipMemcpyHostToDevice, stream));
+        src = d_nz_;
+    } else if (nzval != d_nz_) {
+        // keep a private copy so the caller may overwrite its buffer right after the call returns
+        HC(hipMemcpyAsync(d_nz_, nzval, (size_t)S_->nnz_in * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        src = d_nz_;
+    }
+    (void)src;
+    HC(hipEventRecord(ev_[0], stream));
+    factor_levels();
+    HC(hipEventRecord(ev_[1], stream));
+    HC(hipStreamSynchronize(stream));
+    HC(hipGetLastError());
+    float ms = 0;
+    HC(hipEventElapsedTime(&ms, ev_[0], ev_[1]));
+    ms_factor = ms;
+    factorized = true;
+    selinv_valid = false;
+}
+
+long long Device::fail_col() {
+    int v = INT_MAX;
+    HC(hipMemcpy(&v, d_info_, sizeof(int), hipMemcpyDeviceToHost));
+    return v == INT_MAX ? -1 : v;
+}
+
+void Device::ensure_rhs_capacity(long long nrhs) {
+    const long long chunk = std::min<long long>(nrhs, 64);
+    if (chunk > rhs_cap_) {
+        // (old buffers stay in allocs_ until destruction; capacity only ever grows to 64)
+        d_X_ = dalloc<double>((size_t)S_->n * 64);
+        d_W_ = dalloc<double>((size_t)std::max<long long>(sum_trail_, 1) * 64);
+        rhs_cap_ = 64;
+    }
+}
+
+void Device::forward(int nr, int ldx) {
+    for (auto &L : levels_) {
+        const int *list = d_levellist_ + L.first + L.nsmall;
+        const int nf = L.count - L.nsmall;
+        launch_fwd_assemble(stream, ds_, list, nf, L.max_rows, d_X_, d_W_, nr, ldx);
+        const int nblk = level_nblk(L);
+        for (int b = 0; b < nblk; b++) {
+            const int kb = b * NB;
+            launch_solve_diag(stream, ds_, list, L.active[b], kb, 0, d_L_, d_X_, nr, ldx);
+            launch_fwd_update(stream, ds_, list, L.active[b], kb, L.max_rows - kb - 1, d_L_, d_X_, d_W_, nr, ldx);
+        }
+    }
+}
+
+void Device::backward(int nr, int ldx) {
+    for (int l = (int)levels_.size() - 1; l >= 0; l--) {
+        auto &L = levels_[l];
+        const int *list = d_levellist_ + L.first + L.nsmall;
+        const int nf = L.count - L.nsmall;
+        if (level_max_trail(L) > 0) launch_bwd_gemm(stream, ds_, list, nf, 0, 0, L.max_cols, d_L_, d_X_, nr, ldx);
+        const int nblk = level_nblk(L);
+        for (int b = nblk - 1; b >= 0; b--) {
+            const int kb = b * NB;
+            launch_solve_diag(stream, ds_, list, L.active[b], kb, 1, d_L_, d_X_, nr, ldx);
+            if (kb > 0) launch_bwd_gemm(stream, ds_, list, L.active[b], kb, 1, kb, d_L_, d_X_, nr, ldx);
+        }
+    }
+}
+
+void Device::solve(const double *B, long long ldb, long long nrhs, double *X, long long ldx_out, bool on_device, int mode) {
+    HC(hipSetDevice(device));
+    if (nrhs <= 0) return;
+    const long long n = S_->n;
+    ensure_rhs_capacity(nrhs);
+    const double *dB = B;
+    double *dXo = X;
+    long long ldin = ldb, ldout = ldx_out;
+    if (!on_device) {
+        const long long need = n * nrhs;
+        if (need > io_cap_) { d_io_ = dalloc<double>((size_t)need); io_cap_ = need; }
+        if (ldb == n) HC(hipMemcpyAsync(d_io_, B, (size_t)need * sizeof(double), hipMemcpyHostToDevice, stream));
+        else HC(hipMemcpy2DAsync(d_io_, n * sizeof(double), B, ldb * sizeof(double), n * sizeof(double), nrhs, hipMemcpyHostToDevice, stream));
+        dB = d_io_; dXo = d_io_; ldin = n; ldout = n;
+    }
+    double t_perm = 0, t_fwd = 0, t_bwd = 0;
+    for (long long j0 = 0; j0 < nrhs; j0 += 64) {
+        const int nr = (int)std::min<long long>(64, nrhs - j0);
+        const int ldx = nr;
+        HC(hipEventRecord(ev_[0], stream));
+        // full solve: X = P b ; backward-only (F.UP \ z): z is taken in elimination order as is
+        launch_permute(stream, mode == 0 ? ds_.perm : nullptr, (int)n, const_cast<double *>(dB) + j0 * ldin, ldin, d_X_, nr, ldx, 0);
+        HC(hipEventRecord(ev_[1], stream));
+        if (mode == 0) forward(nr, ldx);
+        HC(hipEventRecord(ev_[2], stream));
+        backward(nr, ldx);
+        HC(hipEventRecord(ev_[3], stream));
+        launch_permute(stream, ds_.perm, (int)n, dXo + j0 * ldout, ldout, d_X_, nr, ldx, 1);
+        HC(hipEventRecord(ev_[4], stream));
+        HC(hipStreamSynchronize(stream));
+        float a, b, c, d;
+        HC(hipEventElapsedTime(&a, ev_[0], ev_[1]));
+        HC(hipEventElapsedTime(&b, ev_[1], ev_[2]));
+        HC(hipEventElapsedTime(&c, ev_[2], ev_[3]));
+        HC(hipEventElapsedTime(&d, ev_[3], ev_[4]));
+        t_perm += a + d; t_fwd += b; t_bwd += c;
+    }
+    HC(hipGetLastError());
+    if (!on_device) {
+        const long long need = n * nrhs;
+        if (ldx_out == n) HC(hipMemcpyAsync(X, d_io_, (size_t)need * sizeof(double), hipMemcpyDeviceToHost, stream));
+        else HC(hipMemcpy2DAsync(X, ldx_out * sizeof(double), d_io_, n * sizeof(double), n * sizeof(double), nrhs, hipMemcpyDeviceToHost, stream));
+        HC(hipStreamSynchronize(stream));
+    }
+    ms_perm = t_perm; ms_fwd = t_fwd; ms_bwd = t_bwd;
+    if (mode == 0) ms_solve = t_perm + t_fwd + t_bwd; else ms_bsolve = t_perm + t_bwd;
+    last_nrhs = nrhs;
+}
+
+double Device::logdet() {
+    HC(hipSetDevice(device));
+    const int nparts = (int)std::min<long long>(1024, std::max<long long>(1, (S_->n + 255) / 256));
+    HC(hipEventRecord(ev_[0], stream));
+    launch_logdet(stream, d_L_, ds_.diagoff, (int)S_->n, d_part_, nparts, d_part_ + 1024);
+    HC(hipEventRecord(ev_[1], stream));
+    double out = 0;
+    HC(hipMemcpyAsync(&out, d_part_ + 1024, sizeof(double), hipMemcpyDeviceToHost, stream));
+    HC(hipStreamSynchronize(stream));
+    float ms; HC(hipEventElapsedTime(&ms, ev_[0], ev_[1])); ms_logdet = ms;
+    return out;
+}
+
+void Device::selinv_compute() {
+    HC(hipSetDevice(device));
+    if (selinv_valid) return;
+    const Symbolic &S = *S_;
+    if (!d_Z_) d_Z_ = dalloc<double>((size_t)l_size_);
+    // Yh workspace: per level sum of r * NB; per-supernode offsets
+    static_assert(sizeof(long long) == 8, "");
+    long long *d_yoff = nullptr;
+    {
+        std::vector<long long> yoff(S.nsuper, 0);
+        long long mx = 0;
+        for (auto &L : levels_) {
+            long long off = 0;
+            for (int k = L.nsmall; k < L.count; k++) {
+                i32 s = S.levellist[L.first + k];
+                yoff[s] = off;
+                off += (long long)S.nrows(s) * NB;
+            }
+            mx = std::max(mx, off);
+        }
+        if (mx > tmp_cap_) { d_tmp_ = dalloc<double>((size_t)mx); tmp_cap_ = mx; }
+        HC(hipMalloc((void **)&d_yoff, std::max<size_t>(yoff.size(), 1) * sizeof(long long)));
+        HC(hipMemcpyAsync(d_yoff, yoff.data(), yoff.size() * sizeof(long long), hipMemcpyHostToDevice, stream));
+        HC(hipStreamSynchronize(stream));
+    }
+    HC(hipEventRecord(ev_[0], stream));
+    HC(hipMemsetAsync(d_Z_, 0, (size_t)l_size_ * sizeof(double), stream));
+    for (int l = (int)levels_.size() - 1; l >= 0; l--) {
+        auto &L = levels_[l];
+        const int *list = d_levellist_ + L.first + L.nsmall;
+        const int nf = L.count - L.nsmall;
+        launch_sel_gather(stream, ds_, list, nf, level_max_trail(L), d_Z_, d_cb_);
+        const int nblk = level_nblk(L);
+        for (int b = nblk - 1; b >= 0; b--) {
+            const int kb = b * NB;
+            launch_sel_yhat(stream, ds_, list, L.active[b], kb, L.max_rows - kb - 1, d_L_, d_tmp_, d_yoff);
+            launch_sel_symm(stream, ds_, list, L.active[b], kb, L.max_rows - kb - 1, d_Z_, d_cb_, d_tmp_, d_yoff);
+            launch_sel_diag(stream, ds_, list, L.active[b], kb, d_L_, d_Z_, d_tmp_, d_yoff);
+        }
+    }
+    HC(hipEventRecord(ev_[1], stream));
+    HC(hipStreamSynchronize(stream));
+    HC(hipGetLastError());
+    (void)hipFree(d_yoff);
+    float ms; HC(hipEventElapsedTime(&ms, ev_[0], ev_[1])); ms_selinv = ms;
+    selinv_valid = true;
+}
+
+void Device::selinv_diag(double *out_host) {
+    HC(hipSetDevice(device));
+    const long long n = S_->n;
+    if (n > io_cap_) { d_io_ = dalloc<double>((size_t)n); io_cap_ = n; }
+    launch_gather_diag(stream, d_Z_, ds_.diagoff, ds_.perm, (int)n, d_io_);
+    HC(hipMemcpyAsync(out_host, d_io_, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HC(hipStreamSynchronize(stream));
+}
+
+void Device::gather_z(const long long *offsets_host, long long cnt, double *out_host) {
+    HC(hipSetDevice(device));
+    if (cnt <= 0) return;
+    long long *d_off = nullptr;
+    double *d_out = nullptr;
+    HC(hipMalloc((void **)&d_off, (size_t)cnt * sizeof(long long)));
+    HC(hipMalloc((void **)&d_out, (size_t)cnt * sizeof(double)));
+    HC(hipMemcpyAsync(d_off, offsets_host, (size_t)cnt * sizeof(long long), hipMemcpyHostToDevice, stream));
+    launch_gather(stream, d_Z_, d_off, cnt, d_out);
+    HC(hipMemcpyAsync(out_host, d_out, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HC(hipStreamSynchronize(stream));
+    (void)hipFree(d_off);
+    (void)hipFree(d_out);
+}
+
+void Device::copy_factor(double *out_host) {
+    HC(hipSetDevice(device));
+    HC(hipMemcpy(out_host, d_L_, (size_t)l_size_ * sizeof(double), hipMemcpyDeviceToHost));
+}
+
+}  // namespace gmrfx

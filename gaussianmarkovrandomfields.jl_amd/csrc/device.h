@@ -1,0 +1,93 @@
+// device.h -- device-resident symbolic structure + numeric drivers (HIP, gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "symbolic.h"
+
+namespace gmrfx {
+
+// Pointers to the symbolic structure in HBM; passed to kernels by value.
+struct DevSym {
+    int n, nsuper;
+    const int *sfirst;          // nsuper+1
+    const long long *rowptr;    // nsuper+1
+    const int *rows;            // sum_rows (permuted indices; own columns first)
+    const int *rel;             // sum_rows (index in parent's row list for trailing rows)
+    const long long *panelptr;  // nsuper+1 (doubles)
+    const int *ld;              // nsuper
+    const long long *cbptr;     // nsuper (doubles, contribution-block arena)
+    const long long *childptr;  // nsuper+1
+    const int *children;
+    const int *sparent;
+    const long long *qptr;      // nsuper+1
+    const int *qsrc;            // index into caller nzval
+    const int *qdst;            // offset inside the destination panel
+    const long long *wptr;      // nsuper+1: prefix sum of trailing rows (r-c)
+    const long long *diagoff;   // n
+    const int *perm;            // n
+};
+
+struct LevelInfo {
+    int first;        // offset into levellist
+    int count;        // fronts in level
+    int nsmall;       // prefix handled by the fused small-front kernels
+    int max_rows;     // over big fronts
+    int max_cols;     // over big fronts (they are sorted by decreasing column count)
+    std::vector<int> active;  // active[k] = number of big fronts with ncols > k*NB
+};
+
+class Device {
+public:
+    Device() = default;
+    ~Device();
+    Device(const Device &) = delete;
+    Device &operator=(const Device &) = delete;
+
+    // Uploads the symbolic structure; allocates factor / arena storage. Throws on HIP errors.
+    void init(const Symbolic &S, int device);
+    void clone_from(const Device &o, const Symbolic &S);
+
+    void refactorize(const double *nzval, bool on_device);
+    // B: column-major n x nrhs (original ordering); mode 0: full solve, 1: backward only (P' L^-T Z)
+    void solve(const double *B, long long ldb, long long nrhs, double *X, long long ldx, bool on_device, int mode);
+    double logdet();
+    void selinv_compute();
+    void selinv_diag(double *out_host);
+    void gather_z(const long long *offsets_host, long long cnt, double *out_host);  // offsets into panel storage, -1 -> 0.0
+    void copy_factor(double *out_host);
+    long long fail_col();
+
+    bool factorized = false, selinv_valid = false;
+    double ms_factor = 0, ms_solve = 0, ms_fwd = 0, ms_bwd = 0, ms_perm = 0, ms_bsolve = 0, ms_logdet = 0, ms_selinv = 0;
+    long long last_nrhs = 0;
+    double bytes_total = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+
+private:
+    void upload(const Symbolic &S);
+    void ensure_rhs_capacity(long long nrhs);
+    void factor_levels();
+    void forward(int nr, int ldx);
+    void backward(int nr, int ldx);
+    template <class T> T *dalloc(size_t count);
+    std::vector<void *> allocs_;
+
+    const Symbolic *S_ = nullptr;
+    DevSym ds_{};
+    std::vector<LevelInfo> levels_;
+    int *d_levellist_ = nullptr;
+    double *d_L_ = nullptr, *d_Z_ = nullptr, *d_cb_ = nullptr, *d_nz_ = nullptr;
+    double *d_X_ = nullptr, *d_W_ = nullptr, *d_io_ = nullptr, *d_tmp_ = nullptr, *d_part_ = nullptr;
+    long long rhs_cap_ = 0, io_cap_ = 0, tmp_cap_ = 0;
+    int *d_info_ = nullptr;
+    hipEvent_t ev_[8] = {};
+    long long l_size_ = 0, sum_trail_ = 0;
+};
+
+void hip_check(hipError_t e, const char *what);
+
+}  // namespace gmrfx

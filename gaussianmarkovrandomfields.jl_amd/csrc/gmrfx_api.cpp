@@ -1,0 +1,347 @@
+// gmrfx_api.cpp -- the extern "C" boundary declared in include/gmrfx.h.
+#include "../../include/gmrfx.h"
+
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "device.h"
+#include "symbolic.h"
+
+using namespace gmrfx;
+
+struct gmrfx_handle {
+    Symbolic S;
+    std::unique_ptr<Device> D;   // null for symbolic_only handles
+    gmrfx_opts opts{};
+    std::string err;
+    // lazily built pattern of the de-permuted selected inverse
+    bool zpat_built = false;
+    std::vector<i64> zcolptr, zrow, zoff;
+};
+
+static thread_local std::string g_create_err;
+
+static gmrfx_opts default_opts() {
+    gmrfx_opts o;
+    std::memset(&o, 0, sizeof(o));
+    o.struct_size = (int32_t)sizeof(gmrfx_opts);
+    o.device = -1;
+    return o;
+}
+
+extern "C" const char *gmrfx_last_create_error(void) { return g_create_err.c_str(); }
+extern "C" const char *gmrfx_last_error(const gmrfx_handle *h) { return h ? h->err.c_str() : "null handle"; }
+
+template <class F> static int32_t guarded(gmrfx_handle *h, F &&f) {
+    if (!h) return GMRFX_ERR_INVALID_ARG;
+    try {
+        return f();
+    } catch (const std::invalid_argument &e) {
+        h->err = e.what();
+        return GMRFX_ERR_INVALID_ARG;
+    } catch (const std::bad_alloc &) {
+        h->err = "out of host memory";
+        return GMRFX_ERR_ALLOC;
+    } catch (const std::exception &e) {
+        h->err = e.what();
+        return GMRFX_ERR_HIP;
+    }
+}
+
+static int32_t need_device(gmrfx_handle *h, bool need_factor) {
+    if (!h->D) { h->err = "handle has no device state (symbolic_only or no HIP device): numeric entry points are GPU-only"; return GMRFX_ERR_NO_DEVICE; }
+    if (need_factor && !h->D->factorized) { h->err = "gmrfx_refactorize has not been called"; return GMRFX_ERR_NOT_FACTORIZED; }
+    return GMRFX_OK;
+}
+
+extern "C" int32_t gmrfx_create(int64_t n, const int64_t *colptr, const int64_t *rowval, int32_t index_base,
+                                const int64_t *perm, const gmrfx_opts *opts, gmrfx_handle **out) {
+    if (!out) { g_create_err = "out is null"; return GMRFX_ERR_INVALID_ARG; }
+    *out = nullptr;
+    if (!colptr || !rowval) { g_create_err = "colptr/rowval is null"; return GMRFX_ERR_INVALID_ARG; }
+    std::unique_ptr<gmrfx_handle> h(new gmrfx_handle());
+    h->opts = default_opts();
+    if (opts) {
+        size_t sz = std::min<size_t>((size_t)opts->struct_size, sizeof(gmrfx_opts));
+        if (opts->struct_size <= 0) { g_create_err = "opts.struct_size not set"; return GMRFX_ERR_INVALID_ARG; }
+        std::memcpy(&h->opts, opts, sz);
+    }
+    try {
+        SymOptions so;
+        so.uplo = h->opts.uplo;
+        so.ordering = h->opts.ordering;
+        so.nd_leaf = h->opts.nd_leaf;
+        so.relax_cols = h->opts.relax_cols;
+        so.relax_zeros = h->opts.relax_zeros;
+        so.coord_dim = h->opts.coords ? h->opts.coord_dim : 0;
+        so.coords = h->opts.coords;
+        if (so.coords && so.coord_dim != 2 && so.coord_dim != 3) throw std::invalid_argument("coord_dim must be 2 or 3");
+        analyze(n, colptr, rowval, index_base, perm, so, h->S);
+        h->opts.coords = nullptr;  // caller-owned, not kept
+    } catch (const std::invalid_argument &e) {
+        g_create_err = e.what();
+        return GMRFX_ERR_INVALID_ARG;
+    } catch (const std::bad_alloc &) {
+        g_create_err = "out of host memory";
+        return GMRFX_ERR_ALLOC;
+    } catch (const std::exception &e) {
+        g_create_err = e.what();
+        return GMRFX_ERR_INVALID_ARG;
+    }
+    if (!h->opts.symbolic_only) {
+        try {
+            h->D.reset(new Device());
+            h->D->init(h->S, h->opts.device);
+        } catch (const std::exception &e) {
+            g_create_err = e.what();
+            return std::string(e.what()).find("no HIP device") != std::string::npos ? GMRFX_ERR_NO_DEVICE : GMRFX_ERR_HIP;
+        }
+    }
+    *out = h.release();
+    return GMRFX_OK;
+}
+
+extern "C" void gmrfx_destroy(gmrfx_handle *h) { delete h; }
+
+extern "C" int32_t gmrfx_clone(const gmrfx_handle *h, gmrfx_handle **out) {
+    if (!h || !out) return GMRFX_ERR_INVALID_ARG;
+    *out = nullptr;
+    std::unique_ptr<gmrfx_handle> c(new gmrfx_handle());
+    try {
+        c->S = h->S;
+        c->opts = h->opts;
+        if (h->D) {
+            c->D.reset(new Device());
+            c->D->clone_from(*h->D, c->S);
+        }
+    } catch (const std::exception &e) {
+        g_create_err = e.what();
+        return GMRFX_ERR_HIP;
+    }
+    *out = c.release();
+    return GMRFX_OK;
+}
+
+static int32_t refactorize_impl(gmrfx_handle *h, const double *nz, int64_t *info, bool dev) {
+    return guarded(h, [&]() -> int32_t {
+        if (int32_t e = need_device(h, false)) return e;
+        if (!nz) throw std::invalid_argument("nzval is null");
+        h->D->refactorize(nz, dev);
+        long long fc = h->D->fail_col();
+        if (info) *info = fc < 0 ? 0 : fc + 1;
+        if (fc >= 0 && h->opts.check_posdef) {
+            h->err = "matrix is not positive definite (non-positive pivot at elimination step " + std::to_string(fc + 1) + ")";
+            return GMRFX_ERR_NOT_POSDEF;
+        }
+        return GMRFX_OK;
+    });
+}
+extern "C" int32_t gmrfx_refactorize(gmrfx_handle *h, const double *nzval, int64_t *info) { return refactorize_impl(h, nzval, info, false); }
+extern "C" int32_t gmrfx_refactorize_dev(gmrfx_handle *h, const double *d_nzval, int64_t *info) { return refactorize_impl(h, d_nzval, info, true); }
+
+static int32_t solve_impl(gmrfx_handle *h, const double *B, int64_t ldb, int64_t nrhs, double *X, int64_t ldx, bool dev, int mode) {
+    return guarded(h, [&]() -> int32_t {
+        if (int32_t e = need_device(h, true)) return e;
+        if (nrhs < 0) throw std::invalid_argument("nrhs < 0");
+        if (nrhs == 0) return GMRFX_OK;
+        if (!B || !X) throw std::invalid_argument("B/X is null");
+        if (ldb < h->S.n || ldx < h->S.n) throw std::invalid_argument("leading dimension smaller than n");
+        h->D->solve(B, ldb, nrhs, X, ldx, dev, mode);
+        return GMRFX_OK;
+    });
+}
+extern "C" int32_t gmrfx_solve(gmrfx_handle *h, const double *B, int64_t ldb, int64_t nrhs, double *X, int64_t ldx) { return solve_impl(h, B, ldb, nrhs, X, ldx, false, 0); }
+extern "C" int32_t gmrfx_solve_dev(gmrfx_handle *h, const double *B, int64_t ldb, int64_t nrhs, double *X, int64_t ldx) { return solve_impl(h, B, ldb, nrhs, X, ldx, true, 0); }
+extern "C" int32_t gmrfx_backward_solve(gmrfx_handle *h, const double *Z, int64_t ldz, int64_t nrhs, double *X, int64_t ldx) { return solve_impl(h, Z, ldz, nrhs, X, ldx, false, 1); }
+extern "C" int32_t gmrfx_backward_solve_dev(gmrfx_handle *h, const double *Z, int64_t ldz, int64_t nrhs, double *X, int64_t ldx) { return solve_impl(h, Z, ldz, nrhs, X, ldx, true, 1); }
+
+extern "C" int32_t gmrfx_logdet(gmrfx_handle *h, double *out) {
+    return guarded(h, [&]() -> int32_t {
+        if (int32_t e = need_device(h, true)) return e;
+        if (!out) throw std::invalid_argument("out is null");
+        *out = h->D->logdet();
+        return GMRFX_OK;
+    });
+}
+
+extern "C" int32_t gmrfx_selinv_compute(gmrfx_handle *h) {
+    return guarded(h, [&]() -> int32_t {
+        if (int32_t e = need_device(h, true)) return e;
+        h->D->selinv_compute();
+        return GMRFX_OK;
+    });
+}
+
+extern "C" int32_t gmrfx_selinv_diag(gmrfx_handle *h, double *out) {
+    return guarded(h, [&]() -> int32_t {
+        if (int32_t e = need_device(h, true)) return e;
+        if (!out) throw std::invalid_argument("out is null");
+        h->D->selinv_compute();
+        h->D->selinv_diag(out);
+        return GMRFX_OK;
+    });
+}
+
+// Pattern of the de-permuted selected inverse (both triangles, rows sorted) + panel offsets.
+static void build_zpattern(gmrfx_handle *h) {
+    if (h->zpat_built) return;
+    const Symbolic &S = h->S;
+    const i64 n = S.n;
+    std::vector<i64> cnt(n + 1, 0);
+    for (i32 s = 0; s < S.nsuper; s++) {
+        const i32 c = S.ncols(s), r = S.nrows(s);
+        const i32 *rows = S.rows.data() + S.rowptr[s];
+        for (i32 j = 0; j < c; j++) {
+            const i32 b = S.perm[S.sfirst[s] + j];
+            cnt[b + 1] += r - j;                       // column b gets rows i >= j
+            for (i32 i = j + 1; i < r; i++) cnt[S.perm[rows[i]] + 1]++;  // mirrored entry
+        }
+    }
+    h->zcolptr.assign(n + 1, 0);
+    for (i64 j = 0; j < n; j++) h->zcolptr[j + 1] = h->zcolptr[j] + cnt[j + 1];
+    const i64 nz = h->zcolptr[n];
+    std::vector<std::pair<i64, i64>> ent((size_t)nz);  // (row, offset), bucketed by column
+    std::vector<i64> w(h->zcolptr.begin(), h->zcolptr.end() - 1);
+    for (i32 s = 0; s < S.nsuper; s++) {
+        const i32 c = S.ncols(s), r = S.nrows(s);
+        const i32 *rows = S.rows.data() + S.rowptr[s];
+        for (i32 j = 0; j < c; j++) {
+            const i32 b = S.perm[S.sfirst[s] + j];
+            for (i32 i = j; i < r; i++) {
+                const i32 a = S.perm[rows[i]];
+                const i64 off = S.panelptr[s] + (i64)j * S.ld[s] + i;
+                ent[w[b]++] = {a, off};
+                if (i != j) ent[w[a]++] = {b, off};
+            }
+        }
+    }
+    h->zrow.resize(nz);
+    h->zoff.resize(nz);
+    for (i64 j = 0; j < n; j++) {
+        std::sort(ent.begin() + h->zcolptr[j], ent.begin() + h->zcolptr[j + 1]);
+        for (i64 p = h->zcolptr[j]; p < h->zcolptr[j + 1]; p++) { h->zrow[p] = ent[p].first; h->zoff[p] = ent[p].second; }
+    }
+    h->zpat_built = true;
+}
+
+extern "C" int32_t gmrfx_selinv_nnz(gmrfx_handle *h, int64_t *nnz) {
+    return guarded(h, [&]() -> int32_t {
+        if (!nnz) throw std::invalid_argument("nnz is null");
+        *nnz = 2 * h->S.nnz_l_stored - h->S.n;
+        return GMRFX_OK;
+    });
+}
+
+extern "C" int32_t gmrfx_selinv_csc(gmrfx_handle *h, int32_t base, int64_t *colptr, int64_t *rowval, double *nzval) {
+    return guarded(h, [&]() -> int32_t {
+        if (int32_t e = need_device(h, true)) return e;
+        if (!colptr || !rowval || !nzval) throw std::invalid_argument("null output");
+        if (base != 0 && base != 1) throw std::invalid_argument("index_base must be 0 or 1");
+        h->D->selinv_compute();
+        build_zpattern(h);
+        const i64 n = h->S.n, nz = h->zcolptr[n];
+        for (i64 j = 0; j <= n; j++) colptr[j] = h->zcolptr[j] + base;
+        for (i64 p = 0; p < nz; p++) rowval[p] = h->zrow[p] + base;
+        h->D->gather_z((const long long *)h->zoff.data(), nz, nzval);
+        return GMRFX_OK;
+    });
+}
+
+extern "C" int32_t gmrfx_selinv_extract(gmrfx_handle *h, int64_t ncol, const int64_t *colptr, const int64_t *rowval,
+                                        int32_t base, double *out) {
+    return guarded(h, [&]() -> int32_t {
+        if (int32_t e = need_device(h, true)) return e;
+        const Symbolic &S = h->S;
+        if (ncol != S.n) throw std::invalid_argument("pattern must have n columns");
+        if (!colptr || !rowval || !out) throw std::invalid_argument("null argument");
+        if (base != 0 && base != 1) throw std::invalid_argument("index_base must be 0 or 1");
+        h->D->selinv_compute();
+        const i64 nz = colptr[ncol] - base;
+        std::vector<long long> off((size_t)nz);
+        for (i64 j = 0; j < ncol; j++)
+            for (i64 p = colptr[j] - base; p < colptr[j + 1] - base; p++) {
+                i64 i = rowval[p] - base;
+                if (i < 0 || i >= S.n) throw std::invalid_argument("rowval out of range");
+                i32 a = S.iperm[i], b = S.iperm[j];
+                if (a < b) std::swap(a, b);
+                const i32 s = S.col2super[b];
+                const i32 *rows = S.rows.data() + S.rowptr[s];
+                const i32 r = S.nrows(s);
+                const i32 *it = std::lower_bound(rows, rows + r, a);
+                off[p] = (it != rows + r && *it == a) ? (long long)(S.panelptr[s] + (i64)(b - S.sfirst[s]) * S.ld[s] + (it - rows)) : -1;
+            }
+        h->D->gather_z(off.data(), nz, out);
+        return GMRFX_OK;
+    });
+}
+
+extern "C" int32_t gmrfx_get_perm(const gmrfx_handle *h, int32_t base, int64_t *perm) {
+    if (!h || !perm) return GMRFX_ERR_INVALID_ARG;
+    for (i64 k = 0; k < h->S.n; k++) perm[k] = (i64)h->S.perm[k] + base;
+    return GMRFX_OK;
+}
+
+extern "C" int32_t gmrfx_get_stats(const gmrfx_handle *h, gmrfx_stats *out, int32_t struct_size) {
+    if (!h || !out || struct_size <= 0) return GMRFX_ERR_INVALID_ARG;
+    gmrfx_stats st;
+    std::memset(&st, 0, sizeof(st));
+    const Symbolic &S = h->S;
+    st.n = S.n; st.nnz_q_tri = S.nnz_q_tri; st.nnz_l = S.nnz_l_true; st.nnz_l_stored = S.nnz_l_stored;
+    st.nsuper = S.nsuper; st.nlevels = S.nlevels; st.max_cols = S.max_cols; st.max_rows = S.max_rows;
+    st.sum_rows = S.sum_rows; st.n_small_fronts = S.n_small; st.n_big_fronts = S.n_big;
+    st.factor_flops = S.flops;
+    st.bytes_factor = 8.0 * (double)S.panelptr[S.nsuper];
+    st.bytes_cb_arena = 8.0 * (double)S.cb_arena;
+    st.ms_symbolic = S.ms_symbolic;
+    st.fail_col = -1;
+    if (h->D) {
+        const Device &D = *h->D;
+        st.bytes_device_total = D.bytes_total;
+        st.ms_factor = D.ms_factor; st.ms_solve = D.ms_solve; st.ms_solve_fwd = D.ms_fwd; st.ms_solve_bwd = D.ms_bwd;
+        st.ms_solve_perm = D.ms_perm; st.ms_backward_solve = D.ms_bsolve; st.ms_logdet = D.ms_logdet; st.ms_selinv = D.ms_selinv;
+        st.last_nrhs = D.last_nrhs;
+        if (D.factorized) st.fail_col = const_cast<Device &>(D).fail_col();
+    }
+    std::memcpy(out, &st, std::min<size_t>((size_t)struct_size, sizeof(st)));
+    return GMRFX_OK;
+}
+
+extern "C" int32_t gmrfx_symbolic_sizes(const gmrfx_handle *h, int64_t *sizes) {
+    if (!h || !sizes) return GMRFX_ERR_INVALID_ARG;
+    const Symbolic &S = h->S;
+    sizes[0] = S.nsuper; sizes[1] = S.sum_rows; sizes[2] = S.panelptr[S.nsuper]; sizes[3] = S.nlevels;
+    sizes[4] = S.cb_arena; sizes[5] = (int64_t)S.qsrc.size(); sizes[6] = 0; sizes[7] = 0;
+    return GMRFX_OK;
+}
+
+extern "C" int32_t gmrfx_symbolic_get(const gmrfx_handle *h, int64_t *super_first, int64_t *super_parent,
+                                      int64_t *row_ptr, int64_t *rows, int64_t *rel, int64_t *panel_ptr,
+                                      int64_t *panel_ld, int64_t *level, int64_t *q_src, int64_t *q_dst) {
+    if (!h) return GMRFX_ERR_INVALID_ARG;
+    const Symbolic &S = h->S;
+    const i32 ns = S.nsuper;
+    if (super_first) for (i32 s = 0; s <= ns; s++) super_first[s] = S.sfirst[s];
+    if (super_parent) for (i32 s = 0; s < ns; s++) super_parent[s] = S.sparent[s];
+    if (row_ptr) for (i32 s = 0; s <= ns; s++) row_ptr[s] = S.rowptr[s];
+    if (rows) for (i64 k = 0; k < S.sum_rows; k++) rows[k] = S.rows[k];
+    if (rel) for (i64 k = 0; k < S.sum_rows; k++) rel[k] = S.rel[k];
+    if (panel_ptr) for (i32 s = 0; s <= ns; s++) panel_ptr[s] = S.panelptr[s];
+    if (panel_ld) for (i32 s = 0; s < ns; s++) panel_ld[s] = S.ld[s];
+    if (level) for (i32 s = 0; s < ns; s++) level[s] = S.level[s];
+    if (q_src) for (size_t k = 0; k < S.qsrc.size(); k++) q_src[k] = S.qsrc[k];
+    if (q_dst) for (size_t k = 0; k < S.qdst.size(); k++) q_dst[k] = S.qdst[k];
+    return GMRFX_OK;
+}
+
+extern "C" int32_t gmrfx_get_factor_values(gmrfx_handle *h, double *out) {
+    return guarded(h, [&]() -> int32_t {
+        if (int32_t e = need_device(h, true)) return e;
+        if (!out) throw std::invalid_argument("out is null");
+        h->D->copy_factor(out);
+        return GMRFX_OK;
+    });
+}

@@ -1,0 +1,258 @@
+// ordering.cpp -- fill-reducing nested-dissection ordering (host).
+//
+// The reference delegates ordering to CHOLMOD's AMD or to a user-supplied permutation /
+// CliqueTrees algorithm (src/workspace/backend.jl:73-153). This backend computes its own
+// nested dissection (the ordering that exposes the separator-tree parallelism the GPU
+// schedule needs) and reports it through gmrfx_get_perm so CHOLMOD can factor the identical
+// P Q P'. Two bisectors:
+//   * geometric (mesh node coordinates supplied): median cut along the longest axis;
+//   * graph-based (no coordinates): BFS level structure from a pseudo-peripheral node.
+// In both, the vertex separator is the smaller one-sided boundary of the cut, thinned so that
+// every separator vertex touches both sides. Leaves (<= nd_leaf vertices) are ordered by a
+// halo-aware minimum-degree on bit masks.
+#include <algorithm>
+#include <bitset>
+#include <cmath>
+#include <numeric>
+#include <stdexcept>
+
+#include "symbolic.h"
+
+namespace gmrfx {
+
+void build_graph(i64 n, const i64 *colptr, const i64 *rowval, int base, Graph &G) {
+    G.n = n;
+    std::vector<i64> deg(n + 1, 0);
+    i64 nnz = colptr[n] - base;
+    for (i64 j = 0; j < n; j++)
+        for (i64 p = colptr[j] - base; p < colptr[j + 1] - base; p++) {
+            i64 i = rowval[p] - base;
+            if (i < 0 || i >= n) throw std::invalid_argument("rowval out of range");
+            if (i != j) { deg[i + 1]++; deg[j + 1]++; }
+        }
+    (void)nnz;
+    std::vector<i64> ptr(n + 1, 0);
+    for (i64 i = 0; i < n; i++) ptr[i + 1] = ptr[i] + deg[i + 1];
+    std::vector<i32> tmp(ptr[n]);
+    std::vector<i64> w(ptr.begin(), ptr.end() - 1);
+    for (i64 j = 0; j < n; j++)
+        for (i64 p = colptr[j] - base; p < colptr[j + 1] - base; p++) {
+            i64 i = rowval[p] - base;
+            if (i != j) { tmp[w[i]++] = (i32)j; tmp[w[j]++] = (i32)i; }
+        }
+    // sort + unique each list (both triangles stored => every edge appears twice)
+    G.xadj.assign(n + 1, 0);
+    i64 out = 0;
+    for (i64 i = 0; i < n; i++) {
+        std::sort(tmp.begin() + ptr[i], tmp.begin() + ptr[i + 1]);
+        i64 start = out;
+        for (i64 p = ptr[i]; p < ptr[i + 1]; p++)
+            if (out == start || tmp[out - 1] != tmp[p]) tmp[out++] = tmp[p];
+        G.xadj[i + 1] = out;
+    }
+    tmp.resize(out);
+    tmp.shrink_to_fit();
+    G.adj.swap(tmp);
+}
+
+namespace {
+
+struct ND {
+    const Graph &G;
+    const double *xy;
+    int dim;
+    int leaf;
+    std::vector<i32> label;   // region id of each vertex; -1 once ordered/separator
+    std::vector<i32> &perm;
+    i32 next_id = 1;
+    std::vector<i32> dist, queue;  // BFS scratch
+
+    ND(const Graph &g, const SymOptions &o, std::vector<i32> &p)
+        : G(g), xy(o.coords), dim(o.coords ? o.coord_dim : 0), leaf(o.nd_leaf > 0 ? o.nd_leaf : 64),
+          label(g.n, 0), perm(p) {
+        if (leaf > 64) leaf = 64;
+        dist.assign(g.n, -1);
+        queue.reserve(1024);
+    }
+
+    // ---- leaf ordering: minimum degree with a fixed halo --------------------------------
+    void order_leaf(i32 *v, i64 cnt, i64 pos) {
+        if (cnt <= 2) { for (i64 k = 0; k < cnt; k++) { perm[pos + k] = v[k]; label[v[k]] = -1; } return; }
+        constexpr int W = 192;
+        using Mask = std::bitset<W>;
+        std::vector<Mask> adj(cnt);
+        // local numbering: leaf vertices 0..cnt-1, halo cnt..W-1
+        std::vector<i32> halo;
+        i32 myid = label[v[0]];
+        for (i64 k = 0; k < cnt; k++) dist[v[k]] = (i32)k;  // borrow dist[] as local index
+        for (i64 k = 0; k < cnt; k++)
+            for (i64 p = G.xadj[v[k]]; p < G.xadj[v[k] + 1]; p++) {
+                i32 w = G.adj[p];
+                if (label[w] == myid) { adj[k].set(dist[w]); continue; }
+                // already-ordered separator vertex of an ancestor: part of the halo
+                auto it = std::find(halo.begin(), halo.end(), w);
+                int h;
+                if (it == halo.end()) {
+                    if ((int)(cnt + halo.size()) >= W) continue;
+                    halo.push_back(w);
+                    h = (int)(cnt + halo.size() - 1);
+                } else h = (int)(cnt + (it - halo.begin()));
+                adj[k].set(h);
+            }
+        Mask alive;
+        for (i64 k = 0; k < cnt; k++) alive.set(k);
+        for (i64 step = 0; step < cnt; step++) {
+            int best = -1; size_t bestdeg = ~size_t(0);
+            for (i64 k = 0; k < cnt; k++)
+                if (alive[k]) {
+                    size_t d = adj[k].count();
+                    if (d < bestdeg) { bestdeg = d; best = (int)k; }
+                }
+            alive.reset(best);
+            Mask nb = adj[best];
+            for (i64 k = 0; k < cnt; k++)
+                if (alive[k] && nb[k]) { adj[k] |= nb; adj[k].reset(k); adj[k].reset(best); }
+            perm[pos + step] = v[best];
+        }
+        for (i64 k = 0; k < cnt; k++) { dist[v[k]] = -1; label[v[k]] = -1; }
+    }
+
+    // Given v[0:cnt) labelled idA / idB, pick the smaller one-sided boundary as separator,
+    // thin it, and partition v into [A' | B' | S]. Returns sizes.
+    void split(i32 *v, i64 cnt, i32 idA, i32 idB, i64 &nA, i64 &nB, i64 &nS) {
+        i64 ba = 0, bb = 0;
+        for (i64 k = 0; k < cnt; k++) {
+            i32 u = v[k]; i32 other = label[u] == idA ? idB : idA; bool b = false;
+            for (i64 p = G.xadj[u]; p < G.xadj[u + 1]; p++) if (label[G.adj[p]] == other) { b = true; break; }
+            if (b) { if (label[u] == idA) ba++; else bb++; }
+        }
+        i32 from = (ba <= bb) ? idA : idB, other = (ba <= bb) ? idB : idA;
+        const i32 idS = next_id++;
+        for (i64 k = 0; k < cnt; k++) {
+            i32 u = v[k];
+            if (label[u] != from) continue;
+            for (i64 p = G.xadj[u]; p < G.xadj[u + 1]; p++) if (label[G.adj[p]] == other) { label[u] = idS; break; }
+        }
+        // thinning: a separator vertex with no neighbour left on `from`'s side can join `other`
+        // only if it has no neighbour in `from`; (it always touches `other`). Move those.
+        for (i64 k = 0; k < cnt; k++) {
+            i32 u = v[k];
+            if (label[u] != idS) continue;
+            bool touches_from = false;
+            for (i64 p = G.xadj[u]; p < G.xadj[u + 1]; p++) if (label[G.adj[p]] == from) { touches_from = true; break; }
+            if (!touches_from) label[u] = other;
+        }
+        // stable 3-way partition
+        std::vector<i32> tmp(v, v + cnt);
+        nA = nB = nS = 0;
+        for (i64 k = 0; k < cnt; k++) if (label[tmp[k]] == idA) nA++; else if (label[tmp[k]] == idB) nB++; else nS++;
+        i64 a = 0, b = nA, s = nA + nB;
+        for (i64 k = 0; k < cnt; k++) {
+            i32 u = tmp[k];
+            if (label[u] == idA) v[a++] = u; else if (label[u] == idB) v[b++] = u; else v[s++] = u;
+        }
+    }
+
+    bool bisect_geometric(i32 *v, i64 cnt, i32 idA, i32 idB) {
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        for (i64 k = 0; k < cnt; k++)
+            for (int d = 0; d < dim; d++) {
+                double c = xy[(i64)v[k] * dim + d];
+                lo[d] = std::min(lo[d], c); hi[d] = std::max(hi[d], c);
+            }
+        int ax = 0;
+        for (int d = 1; d < dim; d++) if (hi[d] - lo[d] > hi[ax] - lo[ax]) ax = d;
+        if (!(hi[ax] > lo[ax])) return false;
+        i64 mid = cnt / 2;
+        std::nth_element(v, v + mid, v + cnt, [&](i32 a, i32 b) {
+            double ca = xy[(i64)a * dim + ax], cb = xy[(i64)b * dim + ax];
+            return ca < cb || (ca == cb && a < b);
+        });
+        double thr = xy[(i64)v[mid] * dim + ax];
+        // keep ties on one side for a clean cut, unless that empties a side
+        i64 nlow = 0;
+        for (i64 k = 0; k < cnt; k++) if (xy[(i64)v[k] * dim + ax] < thr) nlow++;
+        bool by_value = nlow >= cnt / 4;
+        for (i64 k = 0; k < cnt; k++) {
+            bool inA = by_value ? (xy[(i64)v[k] * dim + ax] < thr) : (k < mid);
+            label[v[k]] = inA ? idA : idB;
+        }
+        return true;
+    }
+
+    // BFS inside region `id` from root; fills queue (visit order) and dist. Returns #visited.
+    i64 bfs(i32 root, i32 id) {
+        queue.clear();
+        queue.push_back(root);
+        dist[root] = 0;
+        for (size_t h = 0; h < queue.size(); h++) {
+            i32 u = queue[h];
+            for (i64 p = G.xadj[u]; p < G.xadj[u + 1]; p++) {
+                i32 w = G.adj[p];
+                if (label[w] == id && dist[w] < 0) { dist[w] = dist[u] + 1; queue.push_back(w); }
+            }
+        }
+        return (i64)queue.size();
+    }
+    void clear_bfs() { for (i32 u : queue) dist[u] = -1; }
+
+    // Graph bisection: returns false if the region is disconnected-and-handled (A = one
+    // component, B = rest) -- still a valid labelling with an empty separator.
+    void bisect_graph(i32 *v, i64 cnt, i32 id, i32 idA, i32 idB) {
+        i32 root = v[0];
+        i64 vis = bfs(root, id);
+        if (vis < cnt) {  // disconnected: component vs rest
+            for (i32 u : queue) label[u] = idA;
+            clear_bfs();
+            for (i64 k = 0; k < cnt; k++) if (label[v[k]] == id) label[v[k]] = idB;
+            return;
+        }
+        // pseudo-peripheral root: repeat BFS from the farthest, lowest-degree vertex
+        for (int it = 0; it < 3; it++) {
+            i32 far = queue.back();
+            i32 ecc = dist[far];
+            clear_bfs();
+            bfs(far, id);
+            root = far;
+            if (dist[queue.back()] <= ecc) break;
+        }
+        // queue is in BFS order from root: first half (by count, cut at a level boundary) is A
+        i64 half = cnt / 2;
+        i32 cutlevel = dist[queue[half]];
+        if (cutlevel == 0) cutlevel = 1;
+        for (i32 u : queue) label[u] = dist[u] < cutlevel ? idA : idB;
+        clear_bfs();
+    }
+
+    void run(i32 *v, i64 cnt, i64 pos) {
+        if (cnt <= leaf) { order_leaf(v, cnt, pos); return; }
+        i32 id = label[v[0]];
+        i32 idA = next_id++, idB = next_id++;
+        bool ok = false;
+        if (dim > 0) ok = bisect_geometric(v, cnt, idA, idB);
+        if (!ok) bisect_graph(v, cnt, id, idA, idB);
+        i64 nA, nB, nS;
+        split(v, cnt, idA, idB, nA, nB, nS);
+        if (nA == 0 || nB == 0) {
+            // degenerate (e.g. clique): no useful separator -> order as one block
+            for (i64 k = 0; k < cnt; k++) { perm[pos + k] = v[k]; label[v[k]] = -1; }
+            return;
+        }
+        for (i64 k = 0; k < nS; k++) { perm[pos + nA + nB + k] = v[nA + nB + k]; label[v[nA + nB + k]] = -1; }
+        run(v, nA, pos);
+        run(v + nA, nB, pos + nA);
+    }
+};
+
+}  // namespace
+
+void nested_dissection(const Graph &G, const SymOptions &opt, std::vector<i32> &perm) {
+    i64 n = G.n;
+    perm.assign(n, -1);
+    std::vector<i32> verts(n);
+    std::iota(verts.begin(), verts.end(), 0);
+    ND nd(G, opt, perm);
+    nd.run(verts.data(), n, 0);
+}
+
+}  // namespace gmrfx

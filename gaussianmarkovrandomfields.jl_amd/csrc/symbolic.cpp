@@ -1,0 +1,447 @@
+// symbolic.cpp -- elimination tree, column counts, supernodes, row structures, assembly maps
+// and level schedule. See symbolic.h. Algorithms restated from the literature:
+// elimination tree with path compression (Liu 1990), skeleton/least-common-ancestor column
+// counts (Gilbert, Ng & Peyton 1994), relaxed supernode amalgamation (Ashcraft & Grimes 1989).
+#include "symbolic.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <numeric>
+#include <stdexcept>
+
+namespace gmrfx {
+namespace {
+
+// Strict upper pattern of P A P' by column: for new column k the rows a < k, from graph G.
+void permuted_upper(const Graph &G, const std::vector<i32> &perm, const std::vector<i32> &iperm,
+                    std::vector<i64> &up, std::vector<i32> &ui) {
+    i64 n = G.n;
+    up.assign(n + 1, 0);
+    for (i64 k = 0; k < n; k++) {
+        i32 v = perm[k];
+        i64 c = 0;
+        for (i64 p = G.xadj[v]; p < G.xadj[v + 1]; p++) if (iperm[G.adj[p]] < k) c++;
+        up[k + 1] = up[k] + c;
+    }
+    ui.resize(up[n]);
+    for (i64 k = 0; k < n; k++) {
+        i32 v = perm[k];
+        i64 q = up[k];
+        for (i64 p = G.xadj[v]; p < G.xadj[v + 1]; p++) {
+            i32 a = iperm[G.adj[p]];
+            if (a < k) ui[q++] = a;
+        }
+        std::sort(ui.begin() + up[k], ui.begin() + up[k + 1]);
+    }
+}
+
+void etree(i64 n, const std::vector<i64> &up, const std::vector<i32> &ui, std::vector<i32> &parent) {
+    parent.assign(n, -1);
+    std::vector<i32> anc(n, -1);
+    for (i64 k = 0; k < n; k++)
+        for (i64 p = up[k]; p < up[k + 1]; p++) {
+            i32 i = ui[p];
+            while (i != -1 && i < k) {
+                i32 nx = anc[i];
+                anc[i] = (i32)k;
+                if (nx == -1) parent[i] = (i32)k;
+                i = nx;
+            }
+        }
+}
+
+// Postorder of a forest given parent[]; children visited in increasing index order.
+void postorder(i64 n, const std::vector<i32> &parent, std::vector<i32> &post) {
+    std::vector<i32> head(n, -1), next(n, -1);
+    for (i64 j = n - 1; j >= 0; j--)
+        if (parent[j] != -1) { next[j] = head[parent[j]]; head[parent[j]] = (i32)j; }
+    post.resize(n);
+    std::vector<i32> stack;
+    stack.reserve(64);
+    i64 k = 0;
+    for (i64 r = 0; r < n; r++) {
+        if (parent[r] != -1) continue;
+        stack.push_back((i32)r);
+        while (!stack.empty()) {
+            i32 p = stack.back();
+            i32 c = head[p];
+            if (c == -1) { stack.pop_back(); post[k++] = p; }
+            else { head[p] = next[c]; stack.push_back(c); }
+        }
+    }
+}
+
+// Column counts of L for a postordered tree (node index == postorder rank).
+// `up` holds, per column k, rows a<k: by symmetry these are the entries (k, a) of the lower
+// triangle, i.e. column a has row k. We need for each column j its lower rows i>j: build the
+// transpose on the fly.
+void colcounts(i64 n, const std::vector<i64> &up, const std::vector<i32> &ui,
+               const std::vector<i32> &parent, std::vector<i32> &cc) {
+    // lower pattern by column (rows i > j), rows ascending
+    std::vector<i64> lp(n + 1, 0);
+    for (i64 k = 0; k < n; k++) for (i64 p = up[k]; p < up[k + 1]; p++) lp[ui[p] + 1]++;
+    for (i64 j = 0; j < n; j++) lp[j + 1] += lp[j];
+    std::vector<i32> li(lp[n]);
+    { std::vector<i64> w(lp.begin(), lp.end() - 1);
+      for (i64 k = 0; k < n; k++) for (i64 p = up[k]; p < up[k + 1]; p++) li[w[ui[p]]++] = (i32)k; }
+    std::vector<i32> first(n, -1), maxfirst(n, -1), prevleaf(n, -1), ancestor(n);
+    std::vector<i64> delta(n, 0);
+    for (i64 k = 0; k < n; k++) {
+        i64 j = k;
+        delta[j] = (first[j] == -1) ? 1 : 0;
+        for (; j != -1 && first[j] == -1; j = parent[j]) first[j] = (i32)k;
+    }
+    for (i64 i = 0; i < n; i++) ancestor[i] = (i32)i;
+    for (i64 j = 0; j < n; j++) {
+        if (parent[j] != -1) delta[parent[j]]--;
+        for (i64 p = lp[j]; p < lp[j + 1]; p++) {
+            i32 i = li[p];
+            if (first[j] <= maxfirst[i]) continue;  // j is not a leaf of row subtree i
+            maxfirst[i] = first[j];
+            i32 jprev = prevleaf[i];
+            prevleaf[i] = (i32)j;
+            if (jprev == -1) { delta[j]++; continue; }  // first leaf
+            i32 q = jprev;
+            while (q != ancestor[q]) q = ancestor[q];
+            for (i32 s = jprev; s != q;) { i32 sp = ancestor[s]; ancestor[s] = q; s = sp; }
+            delta[j]++;
+            delta[q]--;
+        }
+        if (parent[j] != -1) ancestor[j] = parent[j];
+    }
+    std::vector<i64> c(delta);
+    for (i64 j = 0; j < n; j++) if (parent[j] != -1) c[parent[j]] += c[j];
+    cc.resize(n);
+    for (i64 j = 0; j < n; j++) cc[j] = (i32)c[j];
+}
+
+}  // namespace
+
+void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *user_perm,
+             const SymOptions &opt, Symbolic &S) {
+    auto t0 = std::chrono::steady_clock::now();
+    if (n <= 0) throw std::invalid_argument("n must be positive");
+    if (n >= (i64)2147483000) throw std::invalid_argument("n too large for 32-bit node indices");
+    if (base != 0 && base != 1) throw std::invalid_argument("index_base must be 0 or 1");
+    if (colptr[0] != base) throw std::invalid_argument("colptr[0] must equal index_base");
+    for (i64 j = 0; j < n; j++) if (colptr[j + 1] < colptr[j]) throw std::invalid_argument("colptr must be non-decreasing");
+    S = Symbolic();
+    S.n = n;
+    S.nnz_in = colptr[n] - base;
+
+    Graph G;
+    build_graph(n, colptr, rowval, base, G);
+
+    // ---- ordering ------------------------------------------------------------------------
+    std::vector<i32> perm(n);
+    if (user_perm) {
+        std::vector<uint8_t> seen(n, 0);
+        for (i64 k = 0; k < n; k++) {
+            i64 v = user_perm[k] - base;
+            if (v < 0 || v >= n || seen[v]) throw std::invalid_argument("perm is not a permutation");
+            seen[v] = 1;
+            perm[k] = (i32)v;
+        }
+    } else if (opt.ordering == 1) {
+        std::iota(perm.begin(), perm.end(), 0);
+    } else {
+        nested_dissection(G, opt, perm);
+    }
+    std::vector<i32> iperm(n);
+    for (i64 k = 0; k < n; k++) iperm[perm[k]] = (i32)k;
+
+    // ---- etree + postorder (the final order is the caller's/ND order composed with an
+    //      etree postorder: an equivalent reordering, same fill) -----------------------------
+    std::vector<i64> up; std::vector<i32> ui, parent;
+    permuted_upper(G, perm, iperm, up, ui);
+    etree(n, up, ui, parent);
+    {
+        std::vector<i32> post;
+        postorder(n, parent, post);
+        bool ident = true;
+        for (i64 k = 0; k < n; k++) if (post[k] != k) { ident = false; break; }
+        if (!ident) {
+            std::vector<i32> np(n);
+            for (i64 k = 0; k < n; k++) np[k] = perm[post[k]];
+            perm.swap(np);
+            for (i64 k = 0; k < n; k++) iperm[perm[k]] = (i32)k;
+            permuted_upper(G, perm, iperm, up, ui);
+            etree(n, up, ui, parent);
+        }
+    }
+    std::vector<i32> cc;
+    colcounts(n, up, ui, parent, cc);
+    for (i64 j = 0; j < n; j++) S.nnz_l_true += cc[j];
+
+    // ---- supernodes: maximal chains with nested structure, then relaxed amalgamation -------
+    std::vector<i32> sfirst;  // start column of each supernode
+    std::vector<i32> nchild(n, 0);
+    for (i64 j = 0; j < n; j++) if (parent[j] != -1) nchild[parent[j]]++;
+    sfirst.push_back(0);
+    for (i64 j = 1; j < n; j++) {
+        bool join = parent[j - 1] == j && cc[j - 1] == cc[j] + 1;
+        if (!join) sfirst.push_back((i32)j);
+    }
+    i32 ns0 = (i32)sfirst.size();
+    sfirst.push_back((i32)n);
+    // supernodal parent: supernode of parent[last column]
+    std::vector<i32> c2s(n);
+    for (i32 s = 0; s < ns0; s++) for (i32 j = sfirst[s]; j < sfirst[s + 1]; j++) c2s[j] = s;
+    std::vector<i32> sp0(ns0);
+    for (i32 s = 0; s < ns0; s++) { i32 pj = parent[sfirst[s + 1] - 1]; sp0[s] = pj == -1 ? -1 : c2s[pj]; }
+
+    // relaxed amalgamation (contiguous child -> parent merges only)
+    const int relax_cols = opt.relax_cols > 0 ? opt.relax_cols : 32;
+    const double relax_zeros = opt.relax_zeros > 0 ? opt.relax_zeros : 0.15;
+    struct SN { i32 first, last1; i64 r; double nnz; i32 parent; bool alive; };
+    std::vector<SN> sn(ns0);
+    for (i32 s = 0; s < ns0; s++) {
+        i64 c = sfirst[s + 1] - sfirst[s], r = cc[sfirst[s]];
+        sn[s] = {sfirst[s], sfirst[s + 1], r, (double)(r * c - c * (c - 1) / 2), sp0[s], true};
+    }
+    // merged_into[s]: representative after merges (child merged into parent => parent's id)
+    std::vector<i32> rep(ns0);
+    std::iota(rep.begin(), rep.end(), 0);
+    auto find = [&](i32 s) { while (rep[s] != s) { rep[s] = rep[rep[s]]; s = rep[s]; } return s; };
+    for (i32 p = 0; p < ns0; p++) {
+        // p is final up to merges of its trailing children; try to absorb the supernode that
+        // ends right before p's (current) first column while it is p's child.
+        for (;;) {
+            i32 f = sn[p].first;
+            if (f == 0) break;
+            i32 d = find(c2s[f - 1]);
+            if (d == p || !sn[d].alive) break;
+            i32 dp = sn[d].parent == -1 ? -1 : find(sn[d].parent);
+            if (dp != p) break;
+            i64 cd = sn[d].last1 - sn[d].first, cp = sn[p].last1 - sn[p].first;
+            i64 c = cd + cp, r = cd + sn[p].r;
+            double total = (double)(r * c - c * (c - 1) / 2);
+            double nnz = sn[d].nnz + sn[p].nnz;
+            double z = (total - nnz) / total;
+            bool merge = (c <= 4) || (c <= relax_cols && z <= 0.8 * 0.5) || (z <= relax_zeros && c <= 4 * relax_cols) ||
+                         (z <= 0.02);
+            if (!merge) break;
+            sn[p].first = sn[d].first;
+            sn[p].r = r;
+            sn[p].nnz = nnz;
+            sn[d].alive = false;
+            rep[d] = p;
+        }
+    }
+    // compact
+    std::vector<i32> newid(ns0, -1);
+    S.sfirst.clear();
+    for (i32 s = 0; s < ns0; s++) if (sn[s].alive) { newid[s] = (i32)S.sfirst.size(); S.sfirst.push_back(sn[s].first); }
+    S.nsuper = (i32)S.sfirst.size();
+    S.sfirst.push_back((i32)n);
+    S.sparent.resize(S.nsuper);
+    S.col2super.resize(n);
+    for (i32 s = 0; s < ns0; s++) if (sn[s].alive) {
+        i32 t = newid[s];
+        S.sparent[t] = sn[s].parent == -1 ? -1 : newid[find(sn[s].parent)];
+        for (i32 j = sn[s].first; j < sn[s].last1; j++) S.col2super[j] = t;
+    }
+    const i32 ns = S.nsuper;
+    std::vector<i64> snr(ns);  // predicted row counts (column counts / amalgamation bookkeeping)
+    for (i32 s = 0; s < ns0; s++) if (sn[s].alive) snr[newid[s]] = sn[s].r;
+
+    // children lists
+    S.childptr.assign(ns + 1, 0);
+    for (i32 s = 0; s < ns; s++) if (S.sparent[s] != -1) S.childptr[S.sparent[s] + 1]++;
+    for (i32 s = 0; s < ns; s++) S.childptr[s + 1] += S.childptr[s];
+    S.children.resize(S.childptr[ns]);
+    { std::vector<i64> w(S.childptr.begin(), S.childptr.end() - 1);
+      for (i32 s = 0; s < ns; s++) if (S.sparent[s] != -1) S.children[w[S.sparent[s]]++] = s; }
+
+    // ---- row structures: own columns, A-rows of own columns, children's trailing rows -------
+    // lower pattern by column of P A P'
+    std::vector<i64> lp(n + 1, 0);
+    for (i64 k = 0; k < n; k++) for (i64 p = up[k]; p < up[k + 1]; p++) lp[ui[p] + 1]++;
+    for (i64 j = 0; j < n; j++) lp[j + 1] += lp[j];
+    std::vector<i32> li(lp[n]);
+    { std::vector<i64> w(lp.begin(), lp.end() - 1);
+      for (i64 k = 0; k < n; k++) for (i64 p = up[k]; p < up[k + 1]; p++) li[w[ui[p]]++] = (i32)k; }
+    S.nnz_q_tri = lp[n] + n;
+
+    S.rowptr.assign(ns + 1, 0);
+    S.rows.clear();
+    S.rows.reserve((size_t)(S.nnz_l_true / 8 + n));
+    std::vector<i32> mark(n, -1);
+    for (i32 s = 0; s < ns; s++) {
+        i32 f = S.sfirst[s], l1 = S.sfirst[s + 1];
+        i64 start = (i64)S.rows.size();
+        for (i32 j = f; j < l1; j++) { S.rows.push_back(j); mark[j] = s; }
+        i64 tail = (i64)S.rows.size();
+        for (i32 j = f; j < l1; j++)
+            for (i64 p = lp[j]; p < lp[j + 1]; p++) {
+                i32 i = li[p];
+                if (i >= l1 && mark[i] != s) { mark[i] = s; S.rows.push_back(i); }
+            }
+        for (i64 q = S.childptr[s]; q < S.childptr[s + 1]; q++) {
+            i32 d = S.children[q];
+            i32 cd = S.sfirst[d + 1] - S.sfirst[d];
+            for (i64 p = S.rowptr[d] + cd; p < S.rowptr[d + 1]; p++) {
+                i32 i = S.rows[p];
+                if (i >= l1 && mark[i] != s) { mark[i] = s; S.rows.push_back(i); }
+            }
+        }
+        std::sort(S.rows.begin() + tail, S.rows.end());
+        S.rowptr[s + 1] = (i64)S.rows.size();
+        if ((i64)S.rows.size() - start != snr[s]) throw std::runtime_error("internal: supernode row count disagrees with column counts");
+    }
+    S.sum_rows = (i64)S.rows.size();
+
+    // consistency: first trailing row's supernode must be the parent
+    for (i32 s = 0; s < ns; s++) {
+        i32 c = S.ncols(s), r = S.nrows(s);
+        i32 want = r > c ? S.col2super[S.rows[S.rowptr[s] + c]] : -1;
+        if (want != S.sparent[s]) throw std::runtime_error("internal: supernodal etree inconsistent");
+    }
+
+    // ---- relative indices child -> parent -----------------------------------------------------
+    S.rel.assign(S.sum_rows, -1);
+    for (i32 s = 0; s < ns; s++) {
+        i32 p = S.sparent[s];
+        if (p == -1) continue;
+        i32 c = S.ncols(s);
+        i64 a = S.rowptr[s] + c, ae = S.rowptr[s + 1];
+        i64 b = S.rowptr[p], be = S.rowptr[p + 1];
+        for (; a < ae; a++) {
+            while (b < be && S.rows[b] < S.rows[a]) b++;
+            if (b == be || S.rows[b] != S.rows[a]) throw std::runtime_error("internal: child rows not contained in parent");
+            S.rel[a] = (i32)(b - S.rowptr[p]);
+        }
+    }
+
+    // ---- storage layout -------------------------------------------------------------------
+    S.panelptr.assign(ns + 1, 0);
+    S.ld.resize(ns);
+    S.cbptr.assign(ns, 0);
+    i64 off = 0, cb = 0;
+    S.max_cols = S.max_rows = 0;
+    S.flops = 0;
+    for (i32 s = 0; s < ns; s++) {
+        i64 c = S.ncols(s), r = S.nrows(s);
+        i64 ld = (r + 1) & ~i64(1);
+        S.ld[s] = (i32)ld;
+        S.panelptr[s] = off;
+        off += ld * c;
+        off = (off + 15) & ~i64(15);  // 128-byte aligned panels
+        S.cbptr[s] = cb;
+        i64 m = r - c;
+        cb += m * m;
+        cb = (cb + 15) & ~i64(15);
+        S.max_cols = std::max<i32>(S.max_cols, (i32)c);
+        S.max_rows = std::max<i32>(S.max_rows, (i32)r);
+        S.nnz_l_stored += r * c - c * (c - 1) / 2;
+        double dc = (double)c, dm = (double)m;
+        S.flops += dc * dc * dc / 3.0 + dc * dc * dm + dc * dm * dm;
+    }
+    S.panelptr[ns] = off;
+    S.cb_arena = cb;
+
+    S.diagoff.resize(n);
+    for (i32 s = 0; s < ns; s++) {
+        i32 c = S.ncols(s);
+        for (i32 j = 0; j < c; j++) S.diagoff[S.sfirst[s] + j] = S.panelptr[s] + (i64)j * S.ld[s] + j;
+    }
+
+    // ---- levels --------------------------------------------------------------------------
+    S.level.assign(ns, 0);
+    for (i32 s = 0; s < ns; s++) {
+        i32 p = S.sparent[s];
+        if (p != -1) S.level[p] = std::max(S.level[p], S.level[s] + 1);
+    }
+    S.nlevels = 0;
+    for (i32 s = 0; s < ns; s++) S.nlevels = std::max(S.nlevels, S.level[s] + 1);
+    S.small_rows = opt.small_front_rows > 0 ? opt.small_front_rows : 0;
+    S.is_small.resize(ns);
+    for (i32 s = 0; s < ns; s++) S.is_small[s] = S.nrows(s) <= S.small_rows;
+    S.levelptr.assign(S.nlevels + 1, 0);
+    for (i32 s = 0; s < ns; s++) S.levelptr[S.level[s] + 1]++;
+    for (i32 l = 0; l < S.nlevels; l++) S.levelptr[l + 1] += S.levelptr[l];
+    S.levellist.resize(ns);
+    { std::vector<i64> w(S.levelptr.begin(), S.levelptr.end() - 1);
+      for (i32 s = 0; s < ns; s++) S.levellist[w[S.level[s]]++] = s; }
+    S.level_nsmall.assign(S.nlevels, 0);
+    for (i32 l = 0; l < S.nlevels; l++) {
+        auto b = S.levellist.begin() + S.levelptr[l], e = S.levellist.begin() + S.levelptr[l + 1];
+        std::stable_sort(b, e, [&](i32 x, i32 y) {
+            if (S.is_small[x] != S.is_small[y]) return S.is_small[x] > S.is_small[y];
+            if (S.is_small[x]) return x < y;
+            return S.ncols(x) != S.ncols(y) ? S.ncols(x) > S.ncols(y) : x < y;
+        });
+        i32 k = 0;
+        for (auto it = b; it != e; ++it) if (S.is_small[*it]) k++;
+        S.level_nsmall[l] = k;
+        S.n_small += k;
+        S.n_big += (e - b) - k;
+    }
+
+    // ---- Q scatter map -------------------------------------------------------------------
+    // Which stored triangle defines Q: if both strict triangles are present use opt.uplo,
+    // otherwise whatever is stored.
+    bool has_up = false, has_lo = false;
+    for (i64 j = 0; j < n && !(has_up && has_lo); j++)
+        for (i64 p = colptr[j] - base; p < colptr[j + 1] - base; p++) {
+            i64 i = rowval[p] - base;
+            if (i < j) has_up = true; else if (i > j) has_lo = true;
+        }
+    int use = (has_up && has_lo) ? (opt.uplo == 0 ? 0 : 1) : (has_up ? 0 : 1);  // 0 upper, 1 lower
+    // count per destination supernode
+    S.qptr.assign(ns + 1, 0);
+    for (i64 j = 0; j < n; j++)
+        for (i64 p = colptr[j] - base; p < colptr[j + 1] - base; p++) {
+            i64 i = rowval[p] - base;
+            if ((use == 0 && i > j) || (use == 1 && i < j)) continue;
+            i32 a = iperm[i], b = iperm[j];
+            S.qptr[S.col2super[std::min(a, b)] + 1]++;
+        }
+    for (i32 s = 0; s < ns; s++) S.qptr[s + 1] += S.qptr[s];
+    i64 nq = S.qptr[ns];
+    S.qsrc.resize(nq);
+    S.qdst.resize(nq);
+    {
+        // position of a row inside its supernode: built per supernode into `pos`
+        std::vector<i64> w(S.qptr.begin(), S.qptr.end() - 1);
+        // first pass: store (src, packed (a,b)) grouped by supernode
+        std::vector<i32> ra(nq), rb(nq);
+        for (i64 j = 0; j < n; j++)
+            for (i64 p = colptr[j] - base; p < colptr[j + 1] - base; p++) {
+                i64 i = rowval[p] - base;
+                if ((use == 0 && i > j) || (use == 1 && i < j)) continue;
+                i32 a = iperm[i], b = iperm[j];
+                if (a < b) std::swap(a, b);
+                i64 q = w[S.col2super[b]]++;
+                S.qsrc[q] = p;
+                ra[q] = a; rb[q] = b;
+            }
+        std::vector<i32> pos(n, -1);
+        for (i32 s = 0; s < ns; s++) {
+            i64 r0 = S.rowptr[s], r1 = S.rowptr[s + 1];
+            for (i64 k = r0; k < r1; k++) pos[S.rows[k]] = (i32)(k - r0);
+            for (i64 q = S.qptr[s]; q < S.qptr[s + 1]; q++) {
+                i32 pr = pos[ra[q]];
+                if (pr < 0) throw std::runtime_error("internal: Q entry outside supernode structure");
+                S.qdst[q] = S.panelptr[s] + (i64)(rb[q] - S.sfirst[s]) * S.ld[s] + pr;
+            }
+            for (i64 k = r0; k < r1; k++) pos[S.rows[k]] = -1;
+        }
+        // sort each supernode's list by destination (column-major inside the panel)
+        std::vector<std::pair<i64, i64>> tmp;
+        for (i32 s = 0; s < ns; s++) {
+            i64 a = S.qptr[s], b = S.qptr[s + 1];
+            tmp.resize(b - a);
+            for (i64 q = a; q < b; q++) tmp[q - a] = {S.qdst[q], S.qsrc[q]};
+            std::sort(tmp.begin(), tmp.end());
+            for (i64 q = a; q < b; q++) { S.qdst[q] = tmp[q - a].first; S.qsrc[q] = tmp[q - a].second; }
+        }
+    }
+
+    S.perm.swap(perm);
+    S.iperm.swap(iperm);
+    S.ms_symbolic = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+}  // namespace gmrfx

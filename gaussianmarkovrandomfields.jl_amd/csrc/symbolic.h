@@ -1,0 +1,85 @@
+// symbolic.h -- host-side symbolic analysis for the multifrontal supernodal Cholesky.
+// Replaces the analyse phase CHOLMOD runs inside `cholesky(Q; perm)` for the reference
+// (src/workspace/backend.jl:147-153): ordering, elimination tree, column counts, supernodes,
+// row structures, assembly maps and the level schedule the HIP kernels execute.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace gmrfx {
+
+using i32 = int32_t;
+using i64 = int64_t;
+
+struct SymOptions {
+    int uplo = 0;            // 0 upper defines Q when both triangles stored, 1 lower
+    int ordering = 0;        // 0 auto ND, 1 natural
+    int nd_leaf = 0;         // 0 = default
+    int relax_cols = 0;      // 0 = default
+    double relax_zeros = 0;  // 0 = default
+    int coord_dim = 0;
+    const double *coords = nullptr;
+    int small_front_rows = 0;  // fronts with r <= this go to the fused LDS kernels (0 = default)
+};
+
+// Symmetric adjacency structure without self loops.
+struct Graph {
+    i64 n = 0;
+    std::vector<i64> xadj;
+    std::vector<i32> adj;
+};
+
+struct Symbolic {
+    i64 n = 0;
+    i64 nnz_in = 0;               // entries in the caller's CSC
+    std::vector<i32> perm, iperm; // perm[k] = original index of pivot k; iperm = inverse
+    // supernodes (indices in the permuted ordering)
+    i32 nsuper = 0;
+    std::vector<i32> sfirst;      // nsuper+1
+    std::vector<i32> sparent;     // nsuper, -1 for roots
+    std::vector<i32> col2super;   // n
+    std::vector<i64> rowptr;      // nsuper+1
+    std::vector<i32> rows;        // sum_rows; first c_s entries of a supernode are its own columns
+    std::vector<i32> rel;         // sum_rows; for k >= c_s: index of rows[k] in the parent's row list
+    std::vector<i64> panelptr;    // nsuper+1, offsets in doubles into the factor storage
+    std::vector<i32> ld;          // nsuper, leading dimension of the panel (>= r_s)
+    std::vector<i64> cbptr;       // nsuper, offset in doubles of the (r-c)x(r-c) contribution block
+    i64 cb_arena = 0;             // doubles
+    // supernodal tree
+    std::vector<i64> childptr;    // nsuper+1
+    std::vector<i32> children;    // children lists (ascending)
+    std::vector<i32> level;       // 0 = leaves
+    i32 nlevels = 0;
+    std::vector<i64> levelptr;    // nlevels+1
+    std::vector<i32> levellist;   // supernodes by level; inside a level: small fronts first,
+                                  // then big fronts by decreasing column count
+    std::vector<i32> level_nsmall;// per level: number of small fronts (prefix of the level's list)
+    std::vector<uint8_t> is_small;// per supernode
+    int small_rows = 0;
+    // Q scatter map, sorted by destination
+    std::vector<i64> qsrc;        // index into caller's nzval
+    std::vector<i64> qdst;        // offset in factor storage
+    std::vector<i64> qptr;        // nsuper+1: range of (qsrc,qdst) per destination supernode
+    // diag offsets (for logdet / selinv diag): offset of L_kk in factor storage
+    std::vector<i64> diagoff;     // n
+    // statistics
+    i64 nnz_l_true = 0, nnz_l_stored = 0, nnz_q_tri = 0, sum_rows = 0;
+    i32 max_cols = 0, max_rows = 0;
+    i64 n_small = 0, n_big = 0;
+    double flops = 0;
+    double ms_symbolic = 0;
+
+    i32 ncols(i32 s) const { return sfirst[s + 1] - sfirst[s]; }
+    i32 nrows(i32 s) const { return (i32)(rowptr[s + 1] - rowptr[s]); }
+};
+
+// Throws std::runtime_error / std::invalid_argument with a message on bad input.
+void analyze(i64 n, const i64 *colptr, const i64 *rowval, int index_base, const i64 *user_perm,
+             const SymOptions &opt, Symbolic &S);
+
+// ordering.cpp
+void build_graph(i64 n, const i64 *colptr, const i64 *rowval, int index_base, Graph &G);
+void nested_dissection(const Graph &G, const SymOptions &opt, std::vector<i32> &perm);
+
+}  // namespace gmrfx

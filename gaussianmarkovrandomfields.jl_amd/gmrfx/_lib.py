@@ -1,0 +1,116 @@
+"""ctypes binding of libgmrfx.so -- mirrors 1:1 the `ccall`s of the Julia shim
+(julia/GMRFX.jl). No compute happens in Python."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBPATH = os.environ.get("GMRFX_LIB", os.path.join(os.path.dirname(_HERE), "libgmrfx.so"))
+
+GMRFX_OK = 0
+ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_FACTORIZED, ERR_NOT_POSDEF, ERR_ALLOC = 1, 2, 3, 4, 5, 6
+
+
+class GmrfxOpts(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32), ("uplo", C.c_int32), ("ordering", C.c_int32), ("device", C.c_int32),
+        ("symbolic_only", C.c_int32), ("check_posdef", C.c_int32), ("nd_leaf", C.c_int32),
+        ("relax_cols", C.c_int32), ("relax_zeros", C.c_double), ("coord_dim", C.c_int32),
+        ("reserved0", C.c_int32), ("coords", C.c_void_p),
+    ]
+
+
+class GmrfxStats(C.Structure):
+    _fields_ = [(k, C.c_int64) for k in (
+        "n", "nnz_q_tri", "nnz_l", "nnz_l_stored", "nsuper", "nlevels", "max_cols", "max_rows", "sum_rows",
+        "n_small_fronts", "n_big_fronts")] + [(k, C.c_double) for k in (
+        "factor_flops", "bytes_factor", "bytes_cb_arena", "bytes_device_total", "ms_symbolic", "ms_factor",
+        "ms_solve", "ms_solve_fwd", "ms_solve_bwd", "ms_solve_perm", "ms_backward_solve", "ms_logdet",
+        "ms_selinv")] + [("last_nrhs", C.c_int64), ("fail_col", C.c_int64)]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class GmrfxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"gmrfx error {code}: {msg}")
+        self.code = code
+
+
+class NoDeviceError(GmrfxError):
+    pass
+
+
+class PosDefException(GmrfxError):
+    pass
+
+
+_lib = None
+EXPORTS = [
+    "gmrfx_last_create_error", "gmrfx_last_error", "gmrfx_create", "gmrfx_destroy", "gmrfx_clone",
+    "gmrfx_refactorize", "gmrfx_refactorize_dev", "gmrfx_solve", "gmrfx_solve_dev", "gmrfx_backward_solve",
+    "gmrfx_backward_solve_dev", "gmrfx_logdet", "gmrfx_selinv_compute", "gmrfx_selinv_diag", "gmrfx_selinv_nnz",
+    "gmrfx_selinv_csc", "gmrfx_selinv_extract", "gmrfx_get_perm", "gmrfx_get_stats", "gmrfx_symbolic_sizes",
+    "gmrfx_symbolic_get", "gmrfx_get_factor_values",
+]
+
+
+def lib():
+    """Load libgmrfx.so; fails loudly if it has not been built (no fallback of any kind)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIBPATH):
+            raise ImportError(f"{_LIBPATH} not found: build it with `make -C {os.path.dirname(_HERE)}` "
+                              "(or __graft_entry__.build()); there is no non-HIP fallback")
+        L = C.CDLL(_LIBPATH)
+        vp, i64, i32, dbl = C.c_void_p, C.c_int64, C.c_int32, C.c_double
+        L.gmrfx_last_create_error.restype = C.c_char_p
+        L.gmrfx_last_error.restype = C.c_char_p
+        L.gmrfx_last_error.argtypes = [vp]
+        L.gmrfx_create.argtypes = [i64, vp, vp, i32, vp, C.POINTER(GmrfxOpts), C.POINTER(vp)]
+        L.gmrfx_destroy.argtypes = [vp]
+        L.gmrfx_destroy.restype = None
+        L.gmrfx_clone.argtypes = [vp, C.POINTER(vp)]
+        L.gmrfx_refactorize.argtypes = [vp, vp, C.POINTER(i64)]
+        L.gmrfx_refactorize_dev.argtypes = [vp, vp, C.POINTER(i64)]
+        for nm in ("gmrfx_solve", "gmrfx_solve_dev", "gmrfx_backward_solve", "gmrfx_backward_solve_dev"):
+            getattr(L, nm).argtypes = [vp, vp, i64, i64, vp, i64]
+        L.gmrfx_logdet.argtypes = [vp, C.POINTER(dbl)]
+        L.gmrfx_selinv_compute.argtypes = [vp]
+        L.gmrfx_selinv_diag.argtypes = [vp, vp]
+        L.gmrfx_selinv_nnz.argtypes = [vp, C.POINTER(i64)]
+        L.gmrfx_selinv_csc.argtypes = [vp, i32, vp, vp, vp]
+        L.gmrfx_selinv_extract.argtypes = [vp, i64, vp, vp, i32, vp]
+        L.gmrfx_get_perm.argtypes = [vp, i32, vp]
+        L.gmrfx_get_stats.argtypes = [vp, C.POINTER(GmrfxStats), i32]
+        L.gmrfx_symbolic_sizes.argtypes = [vp, vp]
+        L.gmrfx_symbolic_get.argtypes = [vp] + [vp] * 10
+        L.gmrfx_get_factor_values.argtypes = [vp, vp]
+        for nm in EXPORTS[2:]:
+            if nm != "gmrfx_destroy":
+                getattr(L, nm).restype = i32
+        _lib = L
+    return _lib
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def check(code, handle=None):
+    if code == GMRFX_OK:
+        return
+    L = lib()
+    msg = (L.gmrfx_last_error(handle) if handle else L.gmrfx_last_create_error()) or b""
+    msg = msg.decode("utf-8", "replace")
+    if code == ERR_INVALID_ARG:
+        raise ValueError(f"gmrfx: {msg}")      # Julia: ArgumentError / DimensionMismatch
+    if code == ERR_NO_DEVICE:
+        raise NoDeviceError(code, msg)
+    if code == ERR_NOT_POSDEF:
+        raise PosDefException(code, msg)
+    raise GmrfxError(code, msg)

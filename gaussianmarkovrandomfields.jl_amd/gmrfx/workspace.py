@@ -1,0 +1,132 @@
+"""GMRFWorkspace / WorkspacePool -- mirror of src/workspace/gmrf_workspace.jl:31-302 and
+src/workspace/workspace_pool.jl:42-119 on top of MI355XBackend: owns a Q buffer with a fixed
+pattern, lazy validity flags, the logdet cache; every numeric result comes from the backend."""
+from __future__ import annotations
+
+import queue
+from contextlib import contextmanager
+
+import numpy as np
+import scipy.sparse as sp
+
+from .backend import MI355XBackend, _as_csc
+
+
+class GMRFWorkspace:
+    def __init__(self, Q, backend_type=MI355XBackend, **backend_kwargs):
+        Q = _as_csc(Q)
+        self.Q = Q.copy()
+        self.backend = backend_type(Q, **backend_kwargs)
+        self.numeric_valid = True      # ctor factorizes (gmrf_workspace.jl:72-84)
+        self.selinv_valid = False
+        self.logdet_valid = False
+        self.logdet_cache = 0.0
+        self.next_version = 1
+        self.loaded_version = 0
+
+    def dimension(self) -> int:
+        return self.Q.shape[0]
+
+    def _invalidate(self):
+        self.numeric_valid = False
+        self.selinv_valid = False
+        self.logdet_valid = False
+
+    def update_precision(self, Q_new) -> None:
+        Q_new = _as_csc(Q_new)
+        same = (Q_new.shape == self.Q.shape and np.array_equal(Q_new.indptr, self.Q.indptr)
+                and np.array_equal(Q_new.indices, self.Q.indices))
+        if not same:
+            raise ValueError("Sparsity pattern mismatch: Q_new has different colptr/rowval. "
+                             "GMRFWorkspace requires the same sparsity pattern across updates.")
+        self.Q.data[:] = Q_new.data
+        self._invalidate()
+        self.loaded_version = 0
+
+    def update_precision_values(self, nzval) -> None:
+        nzval = np.asarray(nzval, dtype=np.float64)
+        if nzval.shape[0] != self.Q.data.shape[0]:
+            raise ValueError(f"nzval length {nzval.shape[0]} does not match workspace Q nzval length {self.Q.data.shape[0]}")
+        self.Q.data[:] = nzval
+        self._invalidate()
+        self.loaded_version = 0
+
+    def ensure_numeric(self) -> None:
+        if not self.numeric_valid:
+            self.backend.refactorize(self.Q)
+            self.numeric_valid = True
+            self.selinv_valid = False
+            self.logdet_valid = False
+
+    def ensure_selinv(self) -> None:
+        if not self.selinv_valid:
+            self.ensure_numeric()
+            self.backend.compute_selinv()
+            self.selinv_valid = True
+
+    def workspace_solve(self, b):
+        self.ensure_numeric()
+        return self.backend.backend_solve(b)
+
+    def logdet(self) -> float:
+        if not self.logdet_valid:
+            self.ensure_numeric()
+            self.logdet_cache = self.backend.compute_logdet()
+            self.logdet_valid = True
+        return self.logdet_cache
+
+    def logdet_cov(self) -> float:
+        return -self.logdet()
+
+    def selinv(self) -> sp.csc_matrix:
+        self.ensure_selinv()
+        return self.backend.get_selinv()
+
+    def selinv_diag(self) -> np.ndarray:
+        self.ensure_selinv()
+        return self.backend.get_selinv_diag()
+
+    def selinv_dot(self, B) -> float:
+        self.ensure_selinv()
+        return self.backend.selinv_dot(B)
+
+    def selinv_extract_at(self, B) -> sp.csc_matrix:
+        self.ensure_selinv()
+        return self.backend.selinv_extract_at(B)
+
+    def backward_solve(self, x):
+        self.ensure_numeric()
+        return self.backend.backend_backward_solve(x)
+
+
+class WorkspacePool:
+    """N independent workspaces handed out through a queue (workspace_pool.jl:42-119). Distinct
+    handles own distinct HIP streams, so checkouts may be used from different threads."""
+
+    def __init__(self, Q, size: int = 2, **kw):
+        first = GMRFWorkspace(Q, **kw)
+        perm = first.backend.ordering_permutation()
+        kw2 = dict(kw)
+        kw2["ordering"] = perm        # resolve the ordering once, share it (backend.jl:86-88)
+        kw2.pop("coords", None)
+        self._all = [first] + [GMRFWorkspace(Q, **kw2) for _ in range(size - 1)]
+        self._q = queue.Queue()
+        for w in self._all:
+            self._q.put(w)
+
+    def checkout(self) -> GMRFWorkspace:
+        return self._q.get()
+
+    def checkin(self, ws: GMRFWorkspace) -> None:
+        self._q.put(ws)
+
+    @contextmanager
+    def with_workspace(self):
+        ws = self.checkout()
+        try:
+            yield ws
+        finally:
+            self.checkin(ws)
+
+    def __len__(self):
+        return len(self._all)

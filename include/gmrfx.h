@@ -1,0 +1,156 @@
+/*
+ * gmrfx.h -- C ABI of libgmrfx.so, the MI355X-native sparse-Cholesky / triangular-solve /
+ * selected-inverse backend for GaussianMarkovRandomFields.jl's GMRF precision-matrix path.
+ *
+ * Every entry point replaces one call the reference makes into CHOLMOD / SelectedInversion.jl
+ * behind its two solver seams (file:line relative to the reference repository):
+ *
+ *   seam B  WorkspaceBackend protocol            src/workspace/backend.jl:8-30
+ *   seam A  LinearSolve algorithm + GMRF hooks   src/solvers/{selinv,backward_solve,logdet}.jl,
+ *                                                ext/GaussianMarkovRandomFieldsPardiso.jl:10-80
+ *
+ * Conventions: plain C types only; int64 indices (Julia `Int`); `index_base` 0 or 1; dense
+ * blocks are column-major with explicit leading dimension; every array is caller-owned and
+ * only read/written during the call (the library copies what it keeps). A handle owns one HIP
+ * stream; a handle is not re-entrant, distinct handles may be used from different threads
+ * (the WorkspacePool contract, src/workspace/workspace_pool.jl:15-20). No callbacks, no
+ * global mutable state except a thread-local error string for failed gmrfx_create calls.
+ *
+ * All numeric work runs on the GPU. There is no CPU fallback: without a usable HIP device the
+ * numeric entry points return GMRFX_ERR_NO_DEVICE.
+ */
+#ifndef GMRFX_H
+#define GMRFX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gmrfx_handle gmrfx_handle;
+
+enum {
+    GMRFX_OK = 0,
+    GMRFX_ERR_INVALID_ARG = 1,   /* -> Julia ArgumentError / DimensionMismatch */
+    GMRFX_ERR_NO_DEVICE = 2,     /* no HIP device or handle created symbolic_only */
+    GMRFX_ERR_HIP = 3,           /* HIP runtime error, text in gmrfx_last_error */
+    GMRFX_ERR_NOT_FACTORIZED = 4,/* numeric op before the first gmrfx_refactorize */
+    GMRFX_ERR_NOT_POSDEF = 5,    /* only from gmrfx_refactorize when opts.check_posdef != 0 */
+    GMRFX_ERR_ALLOC = 6
+};
+
+enum { GMRFX_UPLO_UPPER = 0, GMRFX_UPLO_LOWER = 1 };
+enum { GMRFX_ORDER_AUTO = 0, GMRFX_ORDER_NATURAL = 1 };
+
+typedef struct gmrfx_opts {
+    int32_t struct_size;    /* = sizeof(gmrfx_opts); lets the struct grow compatibly */
+    int32_t uplo;           /* which stored triangle defines Q when both are present.
+                               GMRFX_UPLO_UPPER mirrors Symmetric(ws.Q) (default :U),
+                               src/workspace/gmrf_workspace.jl:176 */
+    int32_t ordering;       /* used when perm == NULL: AUTO = nested dissection (geometric if
+                               coords != NULL, graph-based otherwise), NATURAL = identity */
+    int32_t device;         /* HIP device ordinal; -1 = current device */
+    int32_t symbolic_only;  /* 1: host symbolic analysis only (ordering, supernodes, stats,
+                               gmrfx_get_perm); numeric entry points fail loudly */
+    int32_t check_posdef;   /* 0: seam-B behaviour, never fail on indefiniteness
+                               (cholesky!(...; check=false), src/workspace/backend.jl:184);
+                               1: seam-A behaviour, return GMRFX_ERR_NOT_POSDEF */
+    int32_t nd_leaf;        /* nested-dissection leaf size (0 = default) */
+    int32_t relax_cols;     /* supernode amalgamation: merge while width <= relax_cols ... */
+    double  relax_zeros;    /* ... or added explicit-zero fraction <= relax_zeros (0 = default) */
+    int32_t coord_dim;      /* 0, 2 or 3 */
+    int32_t reserved0;
+    const double *coords;   /* optional n x coord_dim row-major node coordinates (mesh nodes),
+                               enables geometric nested dissection; NULL otherwise */
+} gmrfx_opts;
+
+typedef struct gmrfx_stats {
+    int64_t n, nnz_q_tri, nnz_l, nnz_l_stored; /* true fill / fill incl. amalgamation zeros */
+    int64_t nsuper, nlevels, max_cols, max_rows, sum_rows;
+    int64_t n_small_fronts, n_big_fronts;
+    double  factor_flops;          /* sum_s c^3/3 + c^2 (r-c) + c (r-c)^2                  */
+    double  bytes_factor, bytes_cb_arena, bytes_device_total;
+    double  ms_symbolic;           /* host wall time of gmrfx_create's analysis             */
+    /* GPU times of the most recent call of each kind, HIP events on the handle's stream    */
+    double  ms_factor, ms_solve, ms_solve_fwd, ms_solve_bwd, ms_solve_perm, ms_backward_solve,
+            ms_logdet, ms_selinv;
+    int64_t last_nrhs;
+    int64_t fail_col;              /* -1, or first (permuted, 0-based) non-positive pivot   */
+} gmrfx_stats;
+
+/* Message for the most recent failed gmrfx_create on this thread. */
+const char *gmrfx_last_create_error(void);
+/* Message for the most recent failure on this handle. */
+const char *gmrfx_last_error(const gmrfx_handle *h);
+
+/* Symbolic analysis (+ device upload). Replaces `cholesky(Q; perm=...)`'s analyse phase:
+ * CHOLMODBackend ctor src/workspace/backend.jl:147-153, ordering_permutation :73-133.
+ * colptr/rowval: CSC pattern of Q, either one triangle or both (both is what ws.Q holds).
+ * perm (nullable): user elimination order, perm[k] = index (index_base-based) of the k-th
+ * pivot. The pattern is fixed for the life of the handle; nzval passed later must follow the
+ * same CSC order (the workspace guarantees it: gmrf_workspace.jl:131-143). */
+int32_t gmrfx_create(int64_t n, const int64_t *colptr, const int64_t *rowval, int32_t index_base,
+                     const int64_t *perm, const gmrfx_opts *opts, gmrfx_handle **out);
+void    gmrfx_destroy(gmrfx_handle *h);
+/* deepcopy(cache) at the start of Newton loops: arithmetic/condition/gaussian_approximation.jl:103-109 */
+int32_t gmrfx_clone(const gmrfx_handle *h, gmrfx_handle **out);
+
+/* Numeric refactorisation on the fixed pattern. Replaces
+ * `_copy_sparse_values!` + `cholesky!(F, S; check=false)`: src/workspace/backend.jl:165-189.
+ * Drops the selected-inverse cache. info (nullable) <- 0, or 1 + first failing pivot column
+ * in the elimination order. */
+int32_t gmrfx_refactorize(gmrfx_handle *h, const double *nzval, int64_t *info);
+int32_t gmrfx_refactorize_dev(gmrfx_handle *h, const double *d_nzval, int64_t *info);
+
+/* Q X = B. Replaces `F \ b` / `F \ B`: src/workspace/backend.jl:191-209. */
+int32_t gmrfx_solve(gmrfx_handle *h, const double *B, int64_t ldb, int64_t nrhs, double *X, int64_t ldx);
+int32_t gmrfx_solve_dev(gmrfx_handle *h, const double *d_B, int64_t ldb, int64_t nrhs, double *d_X, int64_t ldx);
+
+/* X = P' L^-T Z (sampling). Replaces `F.UP \ z`: src/workspace/backend.jl:281-284,
+ * src/solvers/backward_solve.jl:50-60. Batched over nrhs samples (the reference loops). */
+int32_t gmrfx_backward_solve(gmrfx_handle *h, const double *Z, int64_t ldz, int64_t nrhs, double *X, int64_t ldx);
+int32_t gmrfx_backward_solve_dev(gmrfx_handle *h, const double *d_Z, int64_t ldz, int64_t nrhs, double *d_X, int64_t ldx);
+
+/* +log det Q = 2 sum log L_jj. Replaces `logdet(F)`: src/workspace/backend.jl:211-213
+ * (seam A negates: src/solvers/logdet.jl:27-31). */
+int32_t gmrfx_logdet(gmrfx_handle *h, double *out);
+
+/* Takahashi selected inverse; computed lazily once per refactorisation and cached on the
+ * device. Replaces SelectedInversion.selinv / selinv_diag: src/workspace/backend.jl:215-257,
+ * src/solvers/selinv.jl:70-125. */
+int32_t gmrfx_selinv_compute(gmrfx_handle *h);
+int32_t gmrfx_selinv_diag(gmrfx_handle *h, double *out /* n, original ordering */);
+/* Full selected inverse, original ordering, both triangles, rows sorted: the pattern of
+ * (L+L') de-permuted (a superset of pattern(Q)). Two-call protocol: nnz, then fill. */
+int32_t gmrfx_selinv_nnz(gmrfx_handle *h, int64_t *nnz);
+int32_t gmrfx_selinv_csc(gmrfx_handle *h, int32_t index_base, int64_t *colptr, int64_t *rowval, double *nzval);
+/* Sigma on a caller pattern, 0.0 outside the factor pattern. Replaces
+ * SelectedInversion.selinv_extract(Z, B): src/workspace/backend.jl:275-279. */
+int32_t gmrfx_selinv_extract(gmrfx_handle *h, int64_t ncol, const int64_t *colptr, const int64_t *rowval,
+                             int32_t index_base, double *out_nzval);
+
+/* Elimination order actually used (index_base-based), so CHOLMOD can be run on the identical
+ * P Q P' (`CHOLMODBackend(Q; ordering = perm)`, src/workspace/backend.jl:147-149). */
+int32_t gmrfx_get_perm(const gmrfx_handle *h, int32_t index_base, int64_t *perm);
+int32_t gmrfx_get_stats(const gmrfx_handle *h, gmrfx_stats *out, int32_t struct_size);
+
+/* Symbolic structure, for tests and for tools that want the supernodal layout.
+ * sizes[0..7] = {nsuper, sum_rows, nnz_l_stored, n_levels, cb_arena, nnz_q_used, 0, 0}. */
+int32_t gmrfx_symbolic_sizes(const gmrfx_handle *h, int64_t *sizes);
+/* Any pointer may be NULL. super_first: nsuper+1; super_parent: nsuper; row_ptr: nsuper+1;
+ * rows: sum_rows (permuted indices); rel: sum_rows (position in parent's row list for the
+ * rows below the diagonal block, -1 elsewhere); panel_ptr: nsuper+1 (offset in doubles);
+ * panel_ld: nsuper; level: nsuper; q_src/q_dst: nnz_q_used (index into nzval -> offset in
+ * panel storage). */
+int32_t gmrfx_symbolic_get(const gmrfx_handle *h, int64_t *super_first, int64_t *super_parent,
+                           int64_t *row_ptr, int64_t *rows, int64_t *rel, int64_t *panel_ptr,
+                           int64_t *panel_ld, int64_t *level, int64_t *q_src, int64_t *q_dst);
+/* Copy the numeric factor panels (nnz_l_stored doubles) to the host: tests compare them
+ * with the oracle's L (unique for a given permutation). */
+int32_t gmrfx_get_factor_values(gmrfx_handle *h, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GMRFX_H */

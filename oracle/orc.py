@@ -1,0 +1,119 @@
+"""ctypes binding of the CPU oracle (oracle/gmrf_oracle.c). TEST INFRASTRUCTURE ONLY:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- never by the
+product package."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import scipy.sparse as sp
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "liborc.so"])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liborc.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.orc_factorize.restype = C.c_void_p
+        L.orc_factorize.argtypes = [C.c_int64, i64p, i64p, f64p, C.c_int, C.c_void_p]
+        L.orc_free.argtypes = [C.c_void_p]
+        for name in ("orc_n", "orc_nnz_L", "orc_fail_col", "orc_selinv_nnz"):
+            getattr(L, name).restype = C.c_int64
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.orc_get_L.argtypes = [C.c_void_p, i64p, i64p, f64p]
+        L.orc_get_parent.argtypes = [C.c_void_p, i64p]
+        L.orc_solve.argtypes = [C.c_void_p, f64p, C.c_int64, C.c_int64, f64p, C.c_int64]
+        L.orc_backward_solve.argtypes = [C.c_void_p, f64p, C.c_int64, C.c_int64, f64p, C.c_int64]
+        L.orc_logdet.restype = C.c_double
+        L.orc_logdet.argtypes = [C.c_void_p]
+        L.orc_selinv_diag.argtypes = [C.c_void_p, f64p]
+        L.orc_selinv_csc.argtypes = [C.c_void_p, i64p, i64p, f64p]
+        _LIB = L
+    return _LIB
+
+
+class OracleFactor:
+    """cholesky(Symmetric(Q); perm) + the operations the reference calls on it."""
+
+    def __init__(self, Q: sp.spmatrix, perm=None, uplo: str = "U"):
+        Q = sp.csc_matrix(Q)
+        Q.sort_indices()
+        self.n = Q.shape[0]
+        Ap = np.ascontiguousarray(Q.indptr, dtype=np.int64)
+        Ai = np.ascontiguousarray(Q.indices, dtype=np.int64)
+        Ax = np.ascontiguousarray(Q.data, dtype=np.float64)
+        pp = None
+        if perm is not None:
+            self._perm = np.ascontiguousarray(perm, dtype=np.int64)
+            pp = self._perm.ctypes.data_as(C.c_void_p)
+        self._h = lib().orc_factorize(self.n, Ap, Ai, Ax, ord(uplo), pp)
+        if not self._h:
+            raise ValueError("invalid permutation")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_free(self._h)
+            self._h = None
+
+    @property
+    def nnz_L(self):
+        return lib().orc_nnz_L(self._h)
+
+    @property
+    def fail_col(self):
+        return lib().orc_fail_col(self._h)
+
+    def L(self) -> sp.csc_matrix:
+        nz = self.nnz_L
+        Lp = np.empty(self.n + 1, np.int64); Li = np.empty(nz, np.int64); Lx = np.empty(nz)
+        lib().orc_get_L(self._h, Lp, Li, Lx)
+        return sp.csc_matrix((Lx, Li, Lp), shape=(self.n, self.n))
+
+    def parent(self):
+        p = np.empty(self.n, np.int64)
+        lib().orc_get_parent(self._h, p)
+        return p
+
+    def solve(self, B):
+        B = np.asarray(B, dtype=np.float64)
+        vec = B.ndim == 1
+        Bf = np.asfortranarray(B.reshape(self.n, -1))
+        X = np.empty_like(Bf, order="F")
+        lib().orc_solve(self._h, Bf.T.reshape(-1), self.n, Bf.shape[1], X.T.reshape(-1), self.n)
+        return X[:, 0].copy() if vec else X
+
+    def backward_solve(self, Z):
+        Z = np.asarray(Z, dtype=np.float64)
+        vec = Z.ndim == 1
+        Zf = np.asfortranarray(Z.reshape(self.n, -1))
+        X = np.empty_like(Zf, order="F")
+        lib().orc_backward_solve(self._h, Zf.T.reshape(-1), self.n, Zf.shape[1], X.T.reshape(-1), self.n)
+        return X[:, 0].copy() if vec else X
+
+    def logdet(self) -> float:
+        return lib().orc_logdet(self._h)
+
+    def selinv_diag(self):
+        out = np.empty(self.n)
+        lib().orc_selinv_diag(self._h, out)
+        return out
+
+    def selinv(self) -> sp.csc_matrix:
+        nz = lib().orc_selinv_nnz(self._h)
+        Zp = np.empty(self.n + 1, np.int64); Zi = np.empty(nz, np.int64); Zv = np.empty(nz)
+        lib().orc_selinv_csc(self._h, Zp, Zi, Zv)
+        return sp.csc_matrix((Zv, Zi, Zp), shape=(self.n, self.n))
