@@ -8,7 +8,8 @@ namespace gmrfx {
 
 constexpr int NB = 64;       // block-column width of the dense partial factorisation / sweeps
 constexpr int ASM_CW = 16;   // front columns owned by one assembly workgroup
-constexpr int FWD_RB = 32;   // front rows owned by one forward-assembly workgroup
+constexpr int FWD_RB = 32;    // front rows owned by one forward-assembly workgroup
+constexpr int TRSM_ROWS = 32; // rows of a front handled by one k_trsm / k_sel_yhat workgroup
 
 void launch_assemble(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_rows,
                      const double *nzval, double *L, double *CB);

@@ -130,46 +130,49 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int *__restrict__
     }
 }
 
-// Rows below the diagonal block: X * D' = A, one thread per row, the row lives in registers.
+// Rows below the diagonal block: X * D' = A. A workgroup owns 64 rows; the 64 x w row block
+// sits in LDS (transposed: R[k][i], conflict-free), thread (i, g) updates the columns k = g mod 4
+// of row i in a column sweep (one barrier per column). The diagonal of D holds reciprocals.
 __global__ __launch_bounds__(256) void k_trsm(DevSym S, const int *__restrict__ list, int kb,
                                               double *__restrict__ L) {
-    __shared__ double D[NB * (NB + 1)];
-    __shared__ double Dinv[NB];
+    __shared__ double D[NB * NB];
+    __shared__ double R[NB * TRSM_ROWS];
     const int s = list[blockIdx.y];
     const int c = S.sfirst[s + 1] - S.sfirst[s];
     const int r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
     if (kb >= c) return;
     const int w = min(NB, c - kb);
-    const int row0 = kb + w + blockIdx.x * 256;
+    const int row0 = kb + w + blockIdx.x * TRSM_ROWS;
     if (row0 >= r) return;
+    const int nrow = min(TRSM_ROWS, r - row0);
     const int ld = S.ld[s];
     double *Pp = L + S.panelptr[s];
     const double *Dg = Pp + kb + (long long)kb * ld;
+    double *A = Pp + row0 + (long long)kb * ld;
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        const int i = idx % NB, j = idx / NB;
+    for (int idx = tid; idx < w * w; idx += 256) {
+        const int i = idx % w, j = idx / w;
         double v = 0.0;
-        if (i < w && j < w && i >= j) v = Dg[i + (long long)j * ld];
-        D[i + j * (NB + 1)] = v;
+        if (i >= j) v = Dg[i + (long long)j * ld];
+        if (i == j) v = 1.0 / v;
+        D[i + j * NB] = v;
+    }
+    for (int idx = tid; idx < w * TRSM_ROWS; idx += 256) {
+        const int i = idx % TRSM_ROWS, k = idx / TRSM_ROWS;
+        R[k * TRSM_ROWS + i] = (i < nrow) ? A[i + (long long)k * ld] : 0.0;
+    }
+    const int i = tid % TRSM_ROWS, g = tid / TRSM_ROWS;
+    constexpr int G = 256 / TRSM_ROWS;
+    for (int q = 0; q < w; q++) {
+        __syncthreads();
+        const double xq = R[q * TRSM_ROWS + i] * D[q + q * NB];
+        for (int k = q + 1 + g; k < w; k += G) R[k * TRSM_ROWS + i] -= xq * D[k + q * NB];
     }
     __syncthreads();
-    if (tid < NB) Dinv[tid] = (tid < w) ? 1.0 / D[tid + tid * (NB + 1)] : 1.0;
-    __syncthreads();
-    const int i = row0 + tid;
-    if (i >= r) return;
-    double *A = Pp + i + (long long)kb * ld;
-    double a[NB];
-#pragma unroll
-    for (int k = 0; k < NB; k++) a[k] = (k < w) ? A[(long long)k * ld] : 0.0;
-#pragma unroll
-    for (int q = 0; q < NB; q++) {
-        const double xq = a[q] * Dinv[q];
-        a[q] = xq;
-#pragma unroll
-        for (int k = q + 1; k < NB; k++) a[k] -= xq * D[k + q * (NB + 1)];
+    for (int idx = tid; idx < w * TRSM_ROWS; idx += 256) {
+        const int ii = idx % TRSM_ROWS, k = idx / TRSM_ROWS;
+        if (ii < nrow) A[ii + (long long)k * ld] = R[k * TRSM_ROWS + ii] * D[k + k * NB];
     }
-#pragma unroll
-    for (int k = 0; k < NB; k++) if (k < w) A[(long long)k * ld] = a[k];
 }
 
 // C[i,j] -= sum_k A[i,k] * B[j,k]  on 64x64 tiles (4 waves x 32x32), FP64 MFMA, operands read
@@ -528,7 +531,7 @@ void launch_potrf(hipStream_t st, const DevSym &S, const int *list, int nactive,
 }
 void launch_trsm(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int max_rows_below, double *L) {
     if (nactive <= 0 || max_rows_below <= 0) return;
-    hipLaunchKernelGGL(k_trsm, dim3(cdiv(max_rows_below, 256), nactive), dim3(256), 0, st, S, list, kb, L);
+    hipLaunchKernelGGL(k_trsm, dim3(cdiv(max_rows_below, TRSM_ROWS), nactive), dim3(256), 0, st, S, list, kb, L);
 }
 void launch_gemm_nt(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int mode, int maxM,
                     int maxN, double *L, double *CB) {

@@ -49,48 +49,52 @@ __global__ __launch_bounds__(256) void k_sel_gather(DevSym S, const int *__restr
     }
 }
 
-// Yh[i, 0:w] = L[i, kb:kb+w] D^-1 for the rows below block-column kb; one thread per row.
+// Yh[i, 0:w] = L[i, kb:kb+w] D^-1 for the rows below block-column kb (row block in LDS, column
+// sweep from the right; same structure as k_trsm).
 __global__ __launch_bounds__(256) void k_sel_yhat(DevSym S, const int *__restrict__ list, int kb,
                                                   const double *__restrict__ L, double *__restrict__ Yh,
                                                   const long long *__restrict__ yoff) {
-    __shared__ double D[NB * (NB + 1)];
-    __shared__ double Dinv[NB];
+    __shared__ double D[NB * NB];
+    __shared__ double R[NB * TRSM_ROWS];
     const int s = list[blockIdx.y];
     const int c = S.sfirst[s + 1] - S.sfirst[s];
     const int r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
     if (kb >= c) return;
     const int w = min(NB, c - kb);
-    const int row0 = kb + w + blockIdx.x * 256;
+    const int row0 = kb + w + blockIdx.x * TRSM_ROWS;
     if (row0 >= r) return;
+    const int nrow = min(TRSM_ROWS, r - row0);
     const int ld = S.ld[s];
     const double *Pp = L + S.panelptr[s];
     const double *Dg = Pp + kb + (long long)kb * ld;
+    const double *A = Pp + row0 + (long long)kb * ld;
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        const int i = idx % NB, j = idx / NB;
+    for (int idx = tid; idx < w * w; idx += 256) {
+        const int i = idx % w, j = idx / w;
         double v = 0.0;
-        if (i < w && j < w && i >= j) v = Dg[i + (long long)j * ld];
-        D[i + j * (NB + 1)] = v;
+        if (i >= j) v = Dg[i + (long long)j * ld];
+        if (i == j) v = 1.0 / v;
+        D[i + j * NB] = v;
+    }
+    for (int idx = tid; idx < w * TRSM_ROWS; idx += 256) {
+        const int i = idx % TRSM_ROWS, k = idx / TRSM_ROWS;
+        R[k * TRSM_ROWS + i] = (i < nrow) ? A[i + (long long)k * ld] : 0.0;
+    }
+    const int i = tid % TRSM_ROWS, g = tid / TRSM_ROWS;
+    constexpr int G = 256 / TRSM_ROWS;
+    // y D = l  =>  y_q = (l_q - sum_{k>q} y_k D[k][q]) / D[q][q], q descending; equivalently
+    // after fixing y_q, subtract y_q D[q][k] from every l_k with k < q.
+    for (int q = w - 1; q >= 0; q--) {
+        __syncthreads();
+        const double xq = R[q * TRSM_ROWS + i] * D[q + q * NB];
+        for (int k = g; k < q; k += G) R[k * TRSM_ROWS + i] -= xq * D[q + k * NB];
     }
     __syncthreads();
-    if (tid < NB) Dinv[tid] = (tid < w) ? 1.0 / D[tid + tid * (NB + 1)] : 1.0;
-    __syncthreads();
-    const int i = row0 + tid;
-    if (i >= r) return;
-    const double *A = Pp + i + (long long)kb * ld;
-    double a[NB];
-#pragma unroll
-    for (int k = 0; k < NB; k++) a[k] = (k < w) ? A[(long long)k * ld] : 0.0;
-#pragma unroll
-    for (int q = NB - 1; q >= 0; q--) {
-        const double xq = a[q] * Dinv[q];
-        a[q] = xq;
-#pragma unroll
-        for (int k = 0; k < q; k++) a[k] -= xq * D[q + k * (NB + 1)];
+    double *Y = Yh + yoff[s] + row0;
+    for (int idx = tid; idx < w * TRSM_ROWS; idx += 256) {
+        const int ii = idx % TRSM_ROWS, k = idx / TRSM_ROWS;
+        if (ii < nrow) Y[ii + (long long)k * r] = R[k * TRSM_ROWS + ii] * D[k + k * NB];
     }
-    double *Y = Yh + yoff[s] + i;
-#pragma unroll
-    for (int k = 0; k < NB; k++) if (k < w) Y[(long long)k * r] = a[k];
 }
 
 __device__ __forceinline__ double zf_sym(const double *Zp, const double *ZBs, int ld, int c, int m, int i, int q) {
@@ -231,7 +235,7 @@ void launch_sel_gather(hipStream_t st, const DevSym &S, const int *list, int nfr
 void launch_sel_yhat(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int max_rows_below,
                      const double *L, double *Yh, const long long *yoff) {
     if (nactive <= 0 || max_rows_below <= 0) return;
-    hipLaunchKernelGGL(k_sel_yhat, dim3(cdiv(max_rows_below, 256), nactive), dim3(256), 0, st, S, list, kb, L, Yh, yoff);
+    hipLaunchKernelGGL(k_sel_yhat, dim3(cdiv(max_rows_below, TRSM_ROWS), nactive), dim3(256), 0, st, S, list, kb, L, Yh, yoff);
 }
 void launch_sel_symm(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int max_rows_below,
                      double *Z, const double *ZB, const double *Yh, const long long *yoff) {

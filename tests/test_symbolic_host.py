@@ -1,0 +1,120 @@
+"""CPU tests of the host logic of libgmrfx.so: ordering, supernodes, assembly maps, schedule.
+The numeric results here come from tests/mf_hostsim.py (numpy walk over the exported symbolic
+structure), checked against the oracle; the GPU kernels are tested in test_gpu_parity.py."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import gmrfx
+import orc
+from gmrfx import spde
+from mf_hostsim import HostSim
+
+
+def _cases():
+    m = spde.grid_mesh_2d(24, 24, jitter=0.25)
+    yield "matern24_graph", spde.matern_precision(m, 0, 0.3), {}
+    yield "matern24_coords", spde.matern_precision(m, 0, 0.3), {"coords": m.points}
+    yield "matern_a3", spde.matern_precision(spde.grid_mesh_2d(17, 17), 1, 0.3), {}
+    yield "rand60", spde.random_spd_precision(60), {}
+    yield "rand300", spde.random_spd_precision(300, 0.02), {}
+    m3 = spde.grid_mesh_3d(7, 7, 7)
+    yield "matern3d", spde.matern_precision(m3, 0, 0.5), {"coords": m3.points}
+    yield "natural", spde.matern_precision(spde.grid_mesh_2d(12, 12), 0, 0.3), {"ordering": "natural"}
+    yield "tiny", sp.csc_matrix(np.array([[4.0, 1, 0], [1, 3, 0], [0, 0, 2]])), {}
+    yield "scalar", sp.csc_matrix(np.array([[2.5]])), {}
+
+
+@pytest.mark.parametrize("name,Q,kw", list(_cases()), ids=[c[0] for c in _cases()])
+def test_symbolic_structure_and_hostsim(name, Q, kw):
+    n = Q.shape[0]
+    b = gmrfx.MI355XBackend(Q, symbolic_only=True, **kw)
+    perm = b.ordering_permutation()
+    assert sorted(perm.tolist()) == list(range(n))            # integer work: exact
+    st = b.stats()
+    F = orc.OracleFactor(Q, perm)
+    assert st["nnz_l"] == F.nnz_L                              # column counts exact
+    sy = b.symbolic()
+    # supernode partition covers 0..n, rows sorted, own columns first, rel consistent
+    assert sy.super_first[0] == 0 and sy.super_first[-1] == n
+    Lo = F.L()
+    for s in range(len(sy.super_parent)):
+        rows = sy.rows[sy.row_ptr[s]:sy.row_ptr[s + 1]]
+        c = sy.super_first[s + 1] - sy.super_first[s]
+        assert np.array_equal(rows[:c], np.arange(sy.super_first[s], sy.super_first[s + 1]))
+        assert np.all(np.diff(rows) > 0)
+        p = sy.super_parent[s]
+        rel = sy.rel[sy.row_ptr[s] + c:sy.row_ptr[s + 1]]
+        if len(rows) > c:
+            prow = sy.rows[sy.row_ptr[p]:sy.row_ptr[p + 1]]
+            assert np.array_equal(prow[rel], rows[c:])
+            assert sy.level[p] > sy.level[s]
+        else:
+            assert p == -1
+        # the supernode structure contains the true pattern of every one of its columns
+        for j in range(c):
+            col = sy.super_first[s] + j
+            true_rows = Lo.indices[Lo.indptr[col]:Lo.indptr[col + 1]]
+            assert np.all(np.isin(true_rows, rows[j:]))
+    # numeric walk == oracle
+    hs = HostSim(sy, n, np.asarray(Q.data, dtype=float)).factor()
+    Ld = hs.dense_from_panels(hs.L)
+    assert np.allclose(Ld, Lo.toarray(), rtol=1e-10, atol=1e-12)
+    rng = np.random.default_rng(1)
+    B = rng.standard_normal((n, 3))
+    X = np.empty_like(B)
+    X[perm] = hs.solve(B[perm])
+    assert np.allclose(X, F.solve(B), rtol=1e-9, atol=1e-12)
+    Xb = np.empty_like(B)
+    Xb[perm] = hs.solve(B, mode=1)
+    assert np.allclose(Xb, F.backward_solve(B), rtol=1e-9, atol=1e-12)
+    assert np.isclose(hs.logdet(), F.logdet(), rtol=1e-12)
+    Z = hs.dense_from_panels(hs.selinv())
+    Zo = F.selinv().toarray()[np.ix_(perm, perm)]
+    mask = np.tril(Zo != 0)
+    assert np.allclose(Z[mask], Zo[mask], rtol=1e-8, atol=1e-12)
+
+
+def test_user_permutation_is_respected_up_to_postorder():
+    Q = spde.matern_precision(spde.grid_mesh_2d(10, 10), 0, 0.3)
+    rng = np.random.default_rng(0)
+    p = rng.permutation(100)
+    b = gmrfx.MI355XBackend(Q, ordering=p, symbolic_only=True)
+    # same fill as the user's order (postordering never changes nnz(L))
+    assert b.stats()["nnz_l"] == orc.OracleFactor(Q, p).nnz_L
+
+
+def test_invalid_inputs_raise():
+    Q = spde.random_spd_precision(20)
+    with pytest.raises(ValueError):
+        gmrfx.MI355XBackend(Q, ordering=np.zeros(20, dtype=np.int64), symbolic_only=True)
+    with pytest.raises(ValueError):
+        gmrfx.MI355XBackend(sp.csc_matrix(np.ones((3, 4))), symbolic_only=True)
+    with pytest.raises(ValueError):
+        gmrfx.MI355XBackend(Q, ordering="bogus", symbolic_only=True)
+
+
+def test_one_triangle_input_equals_full_input():
+    Q = spde.matern_precision(spde.grid_mesh_2d(9, 9, jitter=0.2), 0, 0.4)
+    full = gmrfx.MI355XBackend(Q, symbolic_only=True)
+    up = gmrfx.MI355XBackend(sp.triu(Q, format="csc"), ordering=full.ordering_permutation(), symbolic_only=True)
+    lo = gmrfx.MI355XBackend(sp.tril(Q, format="csc"), ordering=full.ordering_permutation(), symbolic_only=True)
+    assert full.stats()["nnz_l"] == up.stats()["nnz_l"] == lo.stats()["nnz_l"]
+    for bk, M in ((full, Q), (up, sp.triu(Q, format="csc")), (lo, sp.tril(Q, format="csc"))):
+        sy = bk.symbolic()
+        hs = HostSim(sy, Q.shape[0], np.asarray(M.data, float)).factor()
+        assert np.isclose(hs.logdet(), np.linalg.slogdet(Q.toarray())[1], rtol=1e-12)
+
+
+def test_numeric_calls_fail_loudly_without_device():
+    """Symbolic-only handles (and GPU-less boxes) must refuse numeric work: no CPU fallback."""
+    Q = spde.random_spd_precision(20)
+    b = gmrfx.MI355XBackend(Q, symbolic_only=True)
+    with pytest.raises(gmrfx.NoDeviceError):
+        b.refactorize(Q)
+    with pytest.raises(gmrfx.NoDeviceError):
+        b.backend_solve(np.ones(20))
+    with pytest.raises(gmrfx.NoDeviceError):
+        b.compute_logdet()
+    with pytest.raises(gmrfx.NoDeviceError):
+        b.get_selinv_diag()
