@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path on MI355X.
+
+Metric (BASELINE.json): factor + solve(64 RHS) throughput in DoF/s on the 1M-node 2-D Matérn
+(nu=1 => smoothness=0, alpha=2) SPDE precision; a "step" = one numeric refactorisation on the
+fixed pattern (update_precision_values! -> ensure_numeric!) followed by one 64-RHS solve
+(workspace_solve(ws, B)), with nzval and B already resident in HBM. Symbolic analysis is
+excluded from the step and reported separately.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--grid G] [--nrhs R]
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); the path is run as
+independent replicas (one workspace per GPU, the reference's WorkspacePool pattern), no
+data-path collective, scaling = weak. Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "gaussianmarkovrandomfields.jl_amd"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+FP64_MFMA_PEAK_TF = 78.6   # v_mfma_f64_16x16x4_f64: 32 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz
+
+
+def cpu_baseline(nrhs: int, grid: int = 300):
+    """Oracle (single-thread C port of the CHOLMOD-path algorithm) on a bounded sample."""
+    import numpy as np
+    import orc
+    from gmrfx import spde
+    import gmrfx
+    mesh = spde.grid_mesh_2d(grid, grid, jitter=0.25, seed=0)
+    Q = spde.matern_precision(mesh, smoothness=0, range_=0.2)
+    n = Q.shape[0]
+    perm = gmrfx.MI355XBackend(Q, coords=mesh.points, symbolic_only=True).ordering_permutation()
+    B = np.random.default_rng(1).standard_normal((n, nrhs))
+    t0 = time.perf_counter()
+    F = orc.OracleFactor(Q, perm)          # symbolic (cheap) + numeric factorisation
+    t1 = time.perf_counter()
+    F.solve(B)
+    t2 = time.perf_counter()
+    return {"value": n / (t2 - t0), "unit": "DoF/s", "cores": 1, "kind": "port",
+            "sample": f"{grid}x{grid}-node mesh (n={n}), same generator/params/ordering; oracle simplicial LL' "
+                      f"{t1 - t0:.2f}s + {nrhs} column solves {t2 - t1:.2f}s, 1 thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--grid", type=int, default=1000, help="nodes per side of the 2-D mesh (cfg 2: 1000)")
+    ap.add_argument("--nrhs", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extras", action="store_true", help="also time selinv-diag and 256-sample rand (cfg 3)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import gmrfx
+    from gmrfx import spde
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libgmrfx has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    mesh = spde.grid_mesh_2d(args.grid, args.grid, jitter=0.25, seed=0)
+    Q = spde.matern_precision(mesh, smoothness=0, range_=0.2)   # range = 0.1 * domain width (2.0)
+    n = Q.shape[0]
+    be = gmrfx.MI355XBackend(Q, coords=mesh.points, device=local_rank, factorize=False)
+    st0 = be.stats()
+
+    dev = torch.device("cuda", local_rank)
+    d_nz = torch.from_numpy(np.ascontiguousarray(Q.data)).to(dev)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    Bh = torch.randn((args.nrhs, n), generator=g, dtype=torch.float64)   # row j = column j of the n x nrhs B
+    d_B = Bh.to(dev)
+    d_X = torch.empty_like(d_B)
+    torch.cuda.synchronize()
+
+    def step():
+        be.refactorize_dev(d_nz.data_ptr())
+        be.solve_dev(d_B.data_ptr(), n, args.nrhs, d_X.data_ptr(), n)
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    t_factor, t_solve, t_fwd, t_bwd, t_perm = [], [], [], [], []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        s = be.stats()
+        t_factor.append(s["ms_factor"]); t_solve.append(s["ms_solve"])
+        t_fwd.append(s["ms_solve_fwd"]); t_bwd.append(s["ms_solve_bwd"]); t_perm.append(s["ms_solve_perm"])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- untimed correctness evidence on this very run -------------------------------------
+    X = d_X.cpu().numpy().T            # n x nrhs
+    Bn = Bh.numpy().T
+    resid = float(np.linalg.norm(Q @ X - Bn) / np.linalg.norm(Bn))
+    logdet = be.compute_logdet()
+    st = be.stats()
+
+    extras = {}
+    if args.extras and rank == 0:
+        be.selinv_compute_dev()
+        extras["ms_selinv"] = be.stats()["ms_selinv"]
+        d_Z = torch.randn((256, n), generator=torch.Generator(device="cpu").manual_seed(2), dtype=torch.float64).to(dev)
+        d_S = torch.empty_like(d_Z)
+        torch.cuda.synchronize()
+        be.backward_solve_dev(d_Z.data_ptr(), n, 256, d_S.data_ptr(), n)
+        extras["ms_rand256"] = be.stats()["ms_backward_solve"]
+
+    if rank == 0:
+        ms_step = 1e3 * elapsed / args.steps
+        med = lambda v: float(np.median(v))
+        mf, ms_, mfw, mbw = med(t_factor), med(t_solve), med(t_fwd), med(t_bwd)
+        # algorithmic bytes of one triangular sweep: 8 nnz(L) + 4 sum_s r_s + 2*8*n*nrhs
+        nnzl = st["nnz_l_stored"]
+        bytes_sweep = 8.0 * nnzl + 4.0 * st["sum_rows"] + 16.0 * n * args.nrhs
+        sweep_ms = 0.5 * (mfw + mbw)
+        sweep_gbs = bytes_sweep / (sweep_ms * 1e-3) / 1e9
+        factor_tf = st["factor_flops"] / (mf * 1e-3) / 1e12
+        dominant_is_factor = mf >= (mfw + mbw)
+        roof_factor = {"bound": "mfma", "achieved": factor_tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                       "frac": factor_tf / FP64_MFMA_PEAK_TF, "traffic": None,
+                       "kernel": "numeric factorisation (all fronts)", "ms": mf, "flops": st["factor_flops"]}
+        roof_sweep = {"bound": "hbm", "achieved": sweep_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": sweep_gbs / HBM_PEAK_GBS, "traffic": None,
+                      "kernel": "triangular sweep (mean of forward and backward)", "ms": sweep_ms, "bytes": bytes_sweep}
+        out = {
+            "metric": "factor+solve(64 RHS) throughput", "value": world * n / (elapsed / args.steps), "unit": "DoF/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"cfg2: {args.grid}x{args.grid}-node jittered P1 mesh, 2-D Matern nu=1 (alpha=2), "
+                                   f"refactorize + {args.nrhs}-RHS solve per step, inputs resident in HBM",
+                       "n": n, "nnz_Q": int(Q.nnz), "nnz_L": int(st["nnz_l"]), "nnz_L_stored": int(nnzl),
+                       "nrhs": args.nrhs, "parallelism": "1 workspace per GPU (replicas)" if world > 1 else "1 GPU",
+                       "ordering": "own geometric nested dissection"},
+            "roofline": roof_factor if dominant_is_factor else roof_sweep,
+            "roofline_factor": roof_factor, "roofline_sweep": roof_sweep,
+            "phases_ms": {"factor": mf, "solve": ms_, "solve_fwd": mfw, "solve_bwd": mbw, "solve_perm": med(t_perm),
+                          "symbolic_host": st0["ms_symbolic"], **extras},
+            "logpdf_per_s": 1e3 / (mf + st["ms_logdet"] + 0.1),
+            "check": {"rel_residual": resid, "logdet": logdet, "fail_col": st["fail_col"]},
+            "supernodes": int(st["nsuper"]), "levels": int(st["nlevels"]),
+            "hbm_bytes_allocated": st["bytes_device_total"],
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.nrhs)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
