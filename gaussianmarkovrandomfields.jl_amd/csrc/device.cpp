@@ -105,6 +105,7 @@ void Device::upload(const Symbolic &S) {
         L.first = (int)S.levelptr[l];
         L.count = (int)(S.levelptr[l + 1] - S.levelptr[l]);
         L.nsmall = S.level_nsmall[l];
+        L.nsmall96 = S.level_nsmall96[l];
         L.max_rows = L.max_cols = 0;
         int max_trail = 0;
         for (int k = L.nsmall; k < L.count; k++) {
@@ -152,6 +153,8 @@ void Device::factor_levels() {
     const int big = INT_MAX;
     HC(hipMemcpyAsync(d_info_, &big, sizeof(int), hipMemcpyHostToDevice, stream));
     for (auto &L : levels_) {
+        launch_factor_small(stream, ds_, d_levellist_ + L.first, L.nsmall96, 96, d_nz_, d_L_, d_cb_, d_info_);
+        launch_factor_small(stream, ds_, d_levellist_ + L.first + L.nsmall96, L.nsmall - L.nsmall96, 128, d_nz_, d_L_, d_cb_, d_info_);
         const int *list = d_levellist_ + L.first + L.nsmall;
         const int nf = L.count - L.nsmall;
         launch_assemble(stream, ds_, list, nf, L.max_rows, d_nz_, d_L_, d_cb_);
@@ -159,7 +162,7 @@ void Device::factor_levels() {
         for (int b = 0; b < nblk; b++) {
             const int kb = b * NB;
             launch_potrf(stream, ds_, list, L.active[b], kb, d_L_, d_info_);
-            launch_trsm(stream, ds_, list, L.active[b], kb, L.max_rows - kb - 1, d_L_);
+            launch_trsm(stream, ds_, list, L.active[b], kb, 0, L.max_rows - kb - 1, d_L_, nullptr, nullptr);
             if (b + 1 < nblk)
                 launch_gemm_nt(stream, ds_, list, L.active[b + 1], kb, 0, L.max_rows - kb - NB, L.max_cols - kb - NB, d_L_, d_cb_);
         }
@@ -209,6 +212,8 @@ void Device::ensure_rhs_capacity(long long nrhs) {
 
 void Device::forward(int nr, int ldx) {
     for (auto &L : levels_) {
+        launch_fwd_small(stream, ds_, d_levellist_ + L.first, L.nsmall96, 96, d_L_, d_X_, d_W_, nr, ldx);
+        launch_fwd_small(stream, ds_, d_levellist_ + L.first + L.nsmall96, L.nsmall - L.nsmall96, 128, d_L_, d_X_, d_W_, nr, ldx);
         const int *list = d_levellist_ + L.first + L.nsmall;
         const int nf = L.count - L.nsmall;
         launch_fwd_assemble(stream, ds_, list, nf, L.max_rows, d_X_, d_W_, nr, ldx);
@@ -226,6 +231,8 @@ void Device::backward(int nr, int ldx) {
         auto &L = levels_[l];
         const int *list = d_levellist_ + L.first + L.nsmall;
         const int nf = L.count - L.nsmall;
+        launch_bwd_small(stream, ds_, d_levellist_ + L.first, L.nsmall96, 96, d_L_, d_X_, nr, ldx);
+        launch_bwd_small(stream, ds_, d_levellist_ + L.first + L.nsmall96, L.nsmall - L.nsmall96, 128, d_L_, d_X_, nr, ldx);
         if (level_max_trail(L) > 0) launch_bwd_gemm(stream, ds_, list, nf, 0, 0, L.max_cols, d_L_, d_X_, nr, ldx);
         const int nblk = level_nblk(L);
         for (int b = nblk - 1; b >= 0; b--) {
@@ -311,7 +318,7 @@ void Device::selinv_compute() {
         long long mx = 0;
         for (auto &L : levels_) {
             long long off = 0;
-            for (int k = L.nsmall; k < L.count; k++) {
+            for (int k = 0; k < L.count; k++) {
                 i32 s = S.levellist[L.first + k];
                 yoff[s] = off;
                 off += (long long)S.nrows(s) * NB;
@@ -333,9 +340,17 @@ void Device::selinv_compute() {
         const int nblk = level_nblk(L);
         for (int b = nblk - 1; b >= 0; b--) {
             const int kb = b * NB;
-            launch_sel_yhat(stream, ds_, list, L.active[b], kb, L.max_rows - kb - 1, d_L_, d_tmp_, d_yoff);
+            launch_trsm(stream, ds_, list, L.active[b], kb, 1, L.max_rows - kb - 1, d_L_, d_tmp_, d_yoff);
             launch_sel_symm(stream, ds_, list, L.active[b], kb, L.max_rows - kb - 1, d_Z_, d_cb_, d_tmp_, d_yoff);
             launch_sel_diag(stream, ds_, list, L.active[b], kb, d_L_, d_Z_, d_tmp_, d_yoff);
+        }
+        // small fronts of the level (<= 128 rows, <= 64 columns: one block step) on the same kernels
+        if (L.nsmall > 0) {
+            const int *sl = d_levellist_ + L.first;
+            launch_sel_gather(stream, ds_, sl, L.nsmall, 128, d_Z_, d_cb_);
+            launch_trsm(stream, ds_, sl, L.nsmall, 0, 1, 128, d_L_, d_tmp_, d_yoff);
+            launch_sel_symm(stream, ds_, sl, L.nsmall, 0, 128, d_Z_, d_cb_, d_tmp_, d_yoff);
+            launch_sel_diag(stream, ds_, sl, L.nsmall, 0, d_L_, d_Z_, d_tmp_, d_yoff);
         }
     }
     HC(hipEventRecord(ev_[1], stream));

@@ -88,12 +88,19 @@ __global__ __launch_bounds__(256) void k_assemble(DevSym S, const int *__restric
     }
 }
 
-// Cholesky of the NB x NB diagonal block at block-column kb of every active front.
-// One workgroup per front; LDL'-style right-looking updates need one barrier per column, the
-// square roots are applied when the block is written back.
+// Cholesky of the NB x NB diagonal block D at block-column kb of every active front, AND its
+// inverse, in one right-looking sweep. One workgroup per front; thread (tx,ty) keeps the 4x4
+// elements (tx+16a, ty+16b) of D and of M (M starts as I and receives the same row operations,
+// so that M = Ltilde^-1 with D = Ltilde diag(d) Ltilde'). Per column j the owners publish column j
+// of D and row j of M through double-buffered LDS vectors: ONE barrier per column.
+// Output: lower triangle + diagonal of the panel block = L; strict UPPER triangle = (L^-1)'
+// (i.e. P[c + i*ld] = Linv[i][c], c < i); diag(L^-1) = 1/diag(L) is implicit. The inverse turns
+// the panel TRSM and the diagonal solves of the sweeps into small MFMA GEMMs.
 __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int *__restrict__ list, int kb,
                                                double *__restrict__ L, int *__restrict__ info) {
-    __shared__ double D[NB * (NB + 1)];
+    __shared__ double colbuf[2][NB];
+    __shared__ double rowbuf[2][NB];
+    __shared__ double dsave[NB];
     const int s = list[blockIdx.x];
     const int c = S.sfirst[s + 1] - S.sfirst[s];
     if (kb >= c) return;
@@ -101,78 +108,158 @@ __global__ __launch_bounds__(256) void k_potrf(DevSym S, const int *__restrict__
     const int ld = S.ld[s];
     double *P = L + S.panelptr[s] + kb + (long long)kb * ld;
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < w * w; idx += 256) {
-        const int i = idx % w, j = idx / w;
-        D[i + j * (NB + 1)] = (i >= j) ? P[i + (long long)j * ld] : 0.0;
-    }
     const int tx = tid & 15, ty = tid >> 4;
+    double e[4][4], m[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int i = tx + 16 * a, k = ty + 16 * b;
+            e[a][b] = (i < w && k < w && i >= k) ? P[i + (long long)k * ld] : ((i == k) ? 1.0 : 0.0);
+            m[a][b] = (i == k) ? 1.0 : 0.0;
+        }
+    if (tid < NB) dsave[tid] = 1.0;
     for (int j = 0; j < w; j++) {
+        const int buf = j & 1, jb = j >> 4, jt = j & 15;
+        if (ty == jt) {
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+                if (b == jb) {
+#pragma unroll
+                    for (int a = 0; a < 4; a++) colbuf[buf][tx + 16 * a] = e[a][b];
+                }
+        }
+        if (tx == jt) {
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+                if (a == jb) {
+#pragma unroll
+                    for (int b = 0; b < 4; b++) rowbuf[buf][ty + 16 * b] = m[a][b];
+                }
+        }
         __syncthreads();
-        const double dj = D[j + j * (NB + 1)];
-        const double inv = 1.0 / dj;
-        for (int k = j + 1 + ty; k < w; k += 16) {
-            const double wk = D[k + j * (NB + 1)] * inv;
-            for (int i = k + tx; i < w; i += 16) D[i + k * (NB + 1)] -= D[i + j * (NB + 1)] * wk;
+        const double d = colbuf[buf][j];
+        const double inv = 1.0 / d;
+        if (tid == 0) dsave[j] = d;
+        double ck[4], rj[4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) { ck[b] = colbuf[buf][ty + 16 * b]; rj[b] = rowbuf[buf][ty + 16 * b]; }
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            const int i = tx + 16 * a;
+            if (i > j) {
+                const double li = colbuf[buf][i] * inv;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const int k = ty + 16 * b;
+                    if (k > j && k <= i) e[a][b] -= li * ck[b];
+                    m[a][b] -= li * rj[b];
+                }
+            }
         }
     }
     __syncthreads();
-    for (int idx = tid; idx < w * w; idx += 256) {
-        const int i = idx % w, j = idx / w;
-        if (i < j) continue;
-        const double dj = D[j + j * (NB + 1)];
-        const double sq = sqrt(dj);
-        if (i == j) {
-            if (!(dj > 0.0)) atomicMin(info, S.sfirst[s] + kb + j);
-            P[i + (long long)j * ld] = sq;
-        } else {
-            P[i + (long long)j * ld] = D[i + j * (NB + 1)] / sq;
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int i = tx + 16 * a, k = ty + 16 * b;
+            if (i >= w || k >= w) continue;
+            if (i > k) {
+                P[i + (long long)k * ld] = e[a][b] / sqrt(dsave[k]);            // L[i][k]
+                P[k + (long long)i * ld] = m[a][b] / sqrt(dsave[i]);            // Linv[i][k] -> upper (k, i)
+            } else if (i == k) {
+                const double dj = dsave[k];
+                if (!(dj > 0.0)) atomicMin(info, S.sfirst[s] + kb + k);
+                P[i + (long long)k * ld] = sqrt(dj);
+            }
         }
+}
+
+// Stage the inverse of the diagonal block into LDS as a full w x w lower-triangular matrix
+// Ti[k*NB + q] = Linv[k][q] (zero above the diagonal, reciprocal on it).
+__device__ __forceinline__ void stage_linv(const double *__restrict__ Dg, int ld, int w, double *Ti, int tid) {
+    // 16 independent clamped loads per thread. Every use of the loaded value is unconditional
+    // arithmetic (mask multiply / reciprocal), so the compiler cannot sink a load under a
+    // branch and the 16 loads issue back to back.
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+        const int idx = tid + 256 * u;
+        const int q = idx % NB, k = idx / NB;   // element Linv[k][q], stored at (q, k) for q < k
+        const int qq = min(q, w - 1), kk = min(k, w - 1);
+        v[u] = Dg[min(qq, kk) + (long long)max(qq, kk) * ld];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+        const int idx = tid + 256 * u;
+        const int q = idx % NB, k = idx / NB;
+        const double mk = (k < w && q < k) ? 1.0 : 0.0;
+        double x = v[u] * mk;
+        if (q == k && k < w) x = 1.0 / v[u];
+        Ti[k * NB + q] = x;
     }
 }
 
-// Rows below the diagonal block: X * D' = A. A workgroup owns 64 rows; the 64 x w row block
-// sits in LDS (transposed: R[k][i], conflict-free), thread (i, g) updates the columns k = g mod 4
-// of row i in a column sweep (one barrier per column). The diagonal of D holds reciprocals.
-__global__ __launch_bounds__(256) void k_trsm(DevSym S, const int *__restrict__ list, int kb,
-                                              double *__restrict__ L) {
-    __shared__ double D[NB * NB];
-    __shared__ double R[NB * TRSM_ROWS];
+// Panel rows below the diagonal block as a GEMM with the inverted block (FP64 MFMA):
+//   mode 0 (factorisation):      A[i, blk] <- A[i, blk] * Linv'      (in place, = L21 rows)
+//   mode 1 (selected inversion): Yh[i, :]  <- L[i, blk] * Linv
+// One wave owns 16 rows (reads all of them before it writes), a workgroup 64 rows.
+__global__ __launch_bounds__(256) void k_trsm(DevSym S, const int *__restrict__ list, int kb, int mode,
+                                              double *__restrict__ L, double *__restrict__ Yh,
+                                              const long long *__restrict__ yoff) {
+    __shared__ double Ti[NB * NB];
     const int s = list[blockIdx.y];
     const int c = S.sfirst[s + 1] - S.sfirst[s];
     const int r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
     if (kb >= c) return;
     const int w = min(NB, c - kb);
-    const int row0 = kb + w + blockIdx.x * TRSM_ROWS;
+    const int row0 = kb + w + blockIdx.x * 64;
     if (row0 >= r) return;
-    const int nrow = min(TRSM_ROWS, r - row0);
     const int ld = S.ld[s];
     double *Pp = L + S.panelptr[s];
-    const double *Dg = Pp + kb + (long long)kb * ld;
-    double *A = Pp + row0 + (long long)kb * ld;
-    const int tid = threadIdx.x;
-    for (int idx = tid; idx < w * w; idx += 256) {
-        const int i = idx % w, j = idx / w;
-        double v = 0.0;
-        if (i >= j) v = Dg[i + (long long)j * ld];
-        if (i == j) v = 1.0 / v;
-        D[i + j * NB] = v;
-    }
-    for (int idx = tid; idx < w * TRSM_ROWS; idx += 256) {
-        const int i = idx % TRSM_ROWS, k = idx / TRSM_ROWS;
-        R[k * TRSM_ROWS + i] = (i < nrow) ? A[i + (long long)k * ld] : 0.0;
-    }
-    const int i = tid % TRSM_ROWS, g = tid / TRSM_ROWS;
-    constexpr int G = 256 / TRSM_ROWS;
-    for (int q = 0; q < w; q++) {
-        __syncthreads();
-        const double xq = R[q * TRSM_ROWS + i] * D[q + q * NB];
-        for (int k = q + 1 + g; k < w; k += G) R[k * TRSM_ROWS + i] -= xq * D[k + q * NB];
-    }
+    stage_linv(Pp + kb + (long long)kb * ld, ld, w, Ti, threadIdx.x);
     __syncthreads();
-    for (int idx = tid; idx < w * TRSM_ROWS; idx += 256) {
-        const int ii = idx % TRSM_ROWS, k = idx / TRSM_ROWS;
-        if (ii < nrow) A[ii + (long long)k * ld] = R[k * TRSM_ROWS + ii] * D[k + k * NB];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lm = lane & 15, lk = lane >> 4;
+    const int i0 = row0 + wave * 16;
+    if (i0 >= r) return;
+    const int i = i0 + lm;
+    const double *A = Pp + (long long)kb * ld;
+    d4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+    {
+        const double *pa = A + min(i, r - 1);
+        double bv[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const int q = 4 * u + lk;
+            bv[u] = pa[(long long)min(q, w - 1) * ld];   // B[kk=q][n=i]; Ti is zero for q >= w, rows >= r never stored
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const int q = 4 * u + lk;
+            if (4 * u < w) {
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const int k = t * 16 + lm;                                    // A[m=k][kk=q]
+                    const double av = mode == 0 ? Ti[k * NB + q] : Ti[q * NB + k];
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[u], acc[t], 0, 0, 0);
+                }
+            }
+        }
     }
+    if (i >= r) return;
+    double *out = mode == 0 ? Pp + (long long)kb * ld : Yh + yoff[s];
+    const int ldo = mode == 0 ? ld : r;
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+            const int k = t * 16 + lk + 4 * rr;
+            if (k < w) out[i + (long long)k * ldo] = acc[t][rr];
+        }
 }
 
 // C[i,j] -= sum_k A[i,k] * B[j,k]  on 64x64 tiles (4 waves x 32x32), FP64 MFMA, operands read
@@ -214,24 +301,58 @@ __global__ __launch_bounds__(256) void k_gemm_nt(DevSym S, const int *__restrict
     for (int a = 0; a < 2; a++)
 #pragma unroll
         for (int b = 0; b < 2; b++) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
-    for (int k0 = 0; k0 < K; k0 += 4) {
-        const int kk = k0 + lk;
-        double av[2], bv[2];
+    // Operand rows are clamped (always-valid addresses, values masked afterwards) so that the
+    // loads of a whole batch of KU k-steps issue back to back; the next batch is fetched into
+    // a second register set before the current batch's MFMAs (software double buffering).
+    constexpr int KU = 4;
+    const double *pa[2], *pb[2];
 #pragma unroll
-        for (int a = 0; a < 2; a++) {
-            const int i = i0 + a * 16 + lm;
-            av[a] = (i < M && kk < K) ? A[i + (long long)kk * ld] : 0.0;
+    for (int a = 0; a < 2; a++) pa[a] = A + min(i0 + a * 16 + lm, M - 1);
+#pragma unroll
+    for (int b = 0; b < 2; b++) pb[b] = A + min(j0 + b * 16 + lm, N - 1);
+    double ca[KU][2], cb[KU][2];
+    // full batches: no masking at all, so the prefetch of batch k+1 really overlaps the MFMAs of
+    // batch k (nothing consumes the loaded registers before the MFMAs that need them)
+    auto fetch = [&](int k0, double (&xa)[KU][2], double (&xb)[KU][2]) {
+#pragma unroll
+        for (int u = 0; u < KU; u++) {
+            const long long off = (long long)(k0 + 4 * u + lk) * ld;
+#pragma unroll
+            for (int a = 0; a < 2; a++) xa[u][a] = pa[a][off];
+#pragma unroll
+            for (int b = 0; b < 2; b++) xb[u][b] = pb[b][off];
         }
+    };
+    auto mma = [&](double (&xa)[KU][2], double (&xb)[KU][2]) {
 #pragma unroll
-        for (int b = 0; b < 2; b++) {
-            const int j = j0 + b * 16 + lm;
-            bv[b] = (j < N && kk < K) ? A[j + (long long)kk * ld] : 0.0;
+        for (int u = 0; u < KU; u++)
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++)
+                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[u][b], xa[u][a], acc[a][b], 0, 0, 0);
+    };
+    const int kfull = K / (4 * KU) * (4 * KU);
+    // single-buffered batches: latency is hidden by the other resident waves (4-5 per SIMD at
+    // this register budget); hipcc turns a register double-buffer into vmcnt(0) at the loop head
+    // anyway, which defeats the overlap.
+    for (int k0 = 0; k0 < kfull; k0 += 4 * KU) {
+        fetch(k0, ca, cb);
+        mma(ca, cb);
+    }
+    if (kfull < K) {   // masked tail (k beyond K contributes 0 via an arithmetic mask on one operand;
+                       // a select would let the compiler sink the load under a branch)
+#pragma unroll
+        for (int u = 0; u < KU; u++) {
+            const int kk = kfull + 4 * u + lk;
+            const long long off = (long long)min(kk, K - 1) * ld;
+            const double mk = kk < K ? 1.0 : 0.0;
+#pragma unroll
+            for (int a = 0; a < 2; a++) ca[u][a] = pa[a][off] * mk;
+#pragma unroll
+            for (int b = 0; b < 2; b++) cb[u][b] = pb[b][off];
         }
-#pragma unroll
-        for (int a = 0; a < 2; a++)
-#pragma unroll
-            for (int b = 0; b < 2; b++)
-                acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[b], av[a], acc[a][b], 0, 0, 0);
+        mma(ca, cb);
     }
     // D[m][n]: m (rows of the first operand = C's column) = lk + 4*reg, n = lm = C's row
 #pragma unroll
@@ -291,53 +412,70 @@ __global__ __launch_bounds__(256) void k_fwd_assemble(DevSym S, const int *__res
     }
 }
 
-// Solve with the diagonal block of block-column kb. trans = 0: D y = b (forward);
-// trans = 1: D' x = y (backward). One workgroup per front.
+// Diagonal-block solve of block-column kb as a product with the inverted block (FP64 MFMA):
+// trans = 0: y = Linv b (forward), trans = 1: x = Linv' y (backward). One workgroup per front;
+// wave t produces rows 16t..16t+15 for up to 64 right-hand sides.
 __global__ __launch_bounds__(256) void k_solve_diag(DevSym S, const int *__restrict__ list, int kb, int trans,
                                                     const double *__restrict__ L, double *__restrict__ X, int nr,
                                                     int ldx) {
-    __shared__ double D[NB * NB];
-    __shared__ double Y[NB * 64];
+    __shared__ double Ti[NB * NB];
+    __shared__ double Bs[NB * 64];
     const int s = list[blockIdx.x];
     const int c = S.sfirst[s + 1] - S.sfirst[s];
     if (kb >= c) return;
     const int w = min(NB, c - kb);
     const int ld = S.ld[s];
-    const double *Dg = L + S.panelptr[s] + kb + (long long)kb * ld;
-    double *Xb = X + (long long)(S.sfirst[s] + kb) * ldx;
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < w * w; idx += 256) {
-        const int i = idx % w, j = idx / w;
-        D[i + j * NB] = (i >= j) ? Dg[i + (long long)j * ld] : 0.0;
-    }
-    for (int idx = tid; idx < w * nr; idx += 256) {
-        const int k = idx / nr, j = idx % nr;
-        Y[k * 64 + j] = Xb[(long long)k * ldx + j];
-    }
-    int npad = 1;
-    while (npad < nr) npad <<= 1;
-    const int j = tid & (npad - 1), g = tid / npad, G = 256 / npad;
-    if (!trans) {
-        for (int k = 0; k < w; k++) {
-            __syncthreads();
-            if (j < nr) {
-                const double yk = Y[k * 64 + j] / D[k + k * NB];
-                for (int i = k + 1 + g; i < w; i += G) Y[i * 64 + j] -= D[i + k * NB] * yk;
-            }
+    stage_linv(L + S.panelptr[s] + kb + (long long)kb * ld, ld, w, Ti, tid);
+    double *Xb = X + (long long)(S.sfirst[s] + kb) * ldx;
+    {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const int idx = tid + 256 * u;
+            const int k = idx >> 6, j = idx & 63;
+            v[u] = Xb[(long long)min(k, w - 1) * ldx + min(j, nr - 1)];
         }
-    } else {
-        for (int k = w - 1; k >= 0; k--) {
-            __syncthreads();
-            if (j < nr) {
-                const double xk = Y[k * 64 + j] / D[k + k * NB];
-                for (int i = g; i < k; i += G) Y[i * 64 + j] -= D[k + i * NB] * xk;
-            }
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const int idx = tid + 256 * u;
+            const int k = idx >> 6, j = idx & 63;
+            Bs[idx] = v[u];   // rows k >= w meet zero columns of Ti; columns j >= nr are never stored
         }
     }
     __syncthreads();
-    for (int idx = tid; idx < w * nr; idx += 256) {
-        const int k = idx / nr, jj = idx % nr;
-        Xb[(long long)k * ldx + jj] = Y[k * 64 + jj] / D[k + k * NB];
+    const int wave = tid >> 6, lane = tid & 63;
+    const int lm = lane & 15, lk = lane >> 4;
+    const int k0 = wave * 16;
+    if (k0 >= w) return;
+    const int nt = (nr + 15) >> 4;
+    d4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+    // forward needs q <= k (q < k0+16); backward needs q >= k (q >= k0)
+    const int qlo = trans ? k0 : 0, qhi = trans ? w : min(w, k0 + 16);
+    for (int q0 = qlo; q0 < qhi; q0 += 4) {
+        const int q = q0 + lk;
+        const int k = k0 + lm;
+        const double av = trans ? Ti[q * NB + k] : Ti[k * NB + q];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            if (t < nt) {
+                const double bv = Bs[q * 64 + t * 16 + lm];
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        if (t < nt) {
+            const int j = t * 16 + lm;
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                const int k = k0 + lk + 4 * rr;
+                if (k < w && j < nr) Xb[(long long)k * ldx + j] = acc[t][rr];
+            }
+        }
     }
 }
 
@@ -366,17 +504,25 @@ __global__ __launch_bounds__(256) void k_fwd_update(DevSym S, const int *__restr
     d4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
-    for (int k0 = 0; k0 < w; k0 += 4) {
-        const int kk = k0 + lk;
+    {
         const int i = i0 + lm;
-        const double a = (i < r && kk < w) ? P[i + (long long)(kb + kk) * ld] : 0.0;
+        const double *pa = P + min(i, r - 1) + (long long)kb * ld;
+        constexpr int KU = 4;
+        for (int k0 = 0; k0 < w; k0 += 4 * KU) {
+            double av[KU], bv[KU][4];
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            if (t < nt) {
-                const int j = t * 16 + lm;
-                const double b = (kk < w && j < nr) ? Yb[(long long)kk * ldx + j] : 0.0;
-                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+            for (int u = 0; u < KU; u++) {
+                const int kk = k0 + 4 * u + lk;
+                const int kc = min(kk, w - 1);
+                av[u] = pa[(long long)kc * ld] * (kk < w ? 1.0 : 0.0);
+#pragma unroll
+                for (int t = 0; t < 4; t++) bv[u][t] = Yb[(long long)kc * ldx + min(t * 16 + lm, nr - 1)];
             }
+#pragma unroll
+            for (int u = 0; u < KU; u++)
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    if (t < nt) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u][t], acc[t], 0, 0, 0);
         }
     }
 #pragma unroll
@@ -419,18 +565,26 @@ __global__ __launch_bounds__(256) void k_bwd_gemm(DevSym S, const int *__restric
     d4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
-    for (int k0 = q0; k0 < q1; k0 += 4) {
-        const int q = k0 + lk;
+    {
         const int col = i0 + lm;
-        const double a = (q < q1 && col < nout) ? P[q + (long long)col * ld] : 0.0;
-        const long long xr = (q < q1) ? rows[q] : 0;
+        const double *pa = P + (long long)min(col, nout - 1) * ld;
+        constexpr int KU = 4;
+        for (int k0 = q0; k0 < q1; k0 += 4 * KU) {
+            double av[KU], bv[KU][4];
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            if (t < nt) {
-                const int j = t * 16 + lm;
-                const double b = (q < q1 && j < nr) ? X[xr * ldx + j] : 0.0;
-                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+            for (int u = 0; u < KU; u++) {
+                const int q = k0 + 4 * u + lk;
+                const int qc = min(q, q1 - 1);
+                av[u] = pa[qc] * (q < q1 ? 1.0 : 0.0);
+                const long long xr = rows[qc];
+#pragma unroll
+                for (int t = 0; t < 4; t++) bv[u][t] = X[xr * ldx + min(t * 16 + lm, nr - 1)];
             }
+#pragma unroll
+            for (int u = 0; u < KU; u++)
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    if (t < nt) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u][t], acc[t], 0, 0, 0);
         }
     }
 #pragma unroll
@@ -529,9 +683,10 @@ void launch_potrf(hipStream_t st, const DevSym &S, const int *list, int nactive,
     if (nactive <= 0) return;
     hipLaunchKernelGGL(k_potrf, dim3(nactive), dim3(256), 0, st, S, list, kb, L, info);
 }
-void launch_trsm(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int max_rows_below, double *L) {
+void launch_trsm(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int mode, int max_rows_below,
+                 double *L, double *Yh, const long long *yoff) {
     if (nactive <= 0 || max_rows_below <= 0) return;
-    hipLaunchKernelGGL(k_trsm, dim3(cdiv(max_rows_below, TRSM_ROWS), nactive), dim3(256), 0, st, S, list, kb, L);
+    hipLaunchKernelGGL(k_trsm, dim3(cdiv(max_rows_below, 64), nactive), dim3(256), 0, st, S, list, kb, mode, L, Yh, yoff);
 }
 void launch_gemm_nt(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int mode, int maxM,
                     int maxN, double *L, double *CB) {

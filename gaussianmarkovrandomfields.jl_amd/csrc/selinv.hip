@@ -49,54 +49,6 @@ __global__ __launch_bounds__(256) void k_sel_gather(DevSym S, const int *__restr
     }
 }
 
-// Yh[i, 0:w] = L[i, kb:kb+w] D^-1 for the rows below block-column kb (row block in LDS, column
-// sweep from the right; same structure as k_trsm).
-__global__ __launch_bounds__(256) void k_sel_yhat(DevSym S, const int *__restrict__ list, int kb,
-                                                  const double *__restrict__ L, double *__restrict__ Yh,
-                                                  const long long *__restrict__ yoff) {
-    __shared__ double D[NB * NB];
-    __shared__ double R[NB * TRSM_ROWS];
-    const int s = list[blockIdx.y];
-    const int c = S.sfirst[s + 1] - S.sfirst[s];
-    const int r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
-    if (kb >= c) return;
-    const int w = min(NB, c - kb);
-    const int row0 = kb + w + blockIdx.x * TRSM_ROWS;
-    if (row0 >= r) return;
-    const int nrow = min(TRSM_ROWS, r - row0);
-    const int ld = S.ld[s];
-    const double *Pp = L + S.panelptr[s];
-    const double *Dg = Pp + kb + (long long)kb * ld;
-    const double *A = Pp + row0 + (long long)kb * ld;
-    const int tid = threadIdx.x;
-    for (int idx = tid; idx < w * w; idx += 256) {
-        const int i = idx % w, j = idx / w;
-        double v = 0.0;
-        if (i >= j) v = Dg[i + (long long)j * ld];
-        if (i == j) v = 1.0 / v;
-        D[i + j * NB] = v;
-    }
-    for (int idx = tid; idx < w * TRSM_ROWS; idx += 256) {
-        const int i = idx % TRSM_ROWS, k = idx / TRSM_ROWS;
-        R[k * TRSM_ROWS + i] = (i < nrow) ? A[i + (long long)k * ld] : 0.0;
-    }
-    const int i = tid % TRSM_ROWS, g = tid / TRSM_ROWS;
-    constexpr int G = 256 / TRSM_ROWS;
-    // y D = l  =>  y_q = (l_q - sum_{k>q} y_k D[k][q]) / D[q][q], q descending; equivalently
-    // after fixing y_q, subtract y_q D[q][k] from every l_k with k < q.
-    for (int q = w - 1; q >= 0; q--) {
-        __syncthreads();
-        const double xq = R[q * TRSM_ROWS + i] * D[q + q * NB];
-        for (int k = g; k < q; k += G) R[k * TRSM_ROWS + i] -= xq * D[q + k * NB];
-    }
-    __syncthreads();
-    double *Y = Yh + yoff[s] + row0;
-    for (int idx = tid; idx < w * TRSM_ROWS; idx += 256) {
-        const int ii = idx % TRSM_ROWS, k = idx / TRSM_ROWS;
-        if (ii < nrow) Y[ii + (long long)k * r] = R[k * TRSM_ROWS + ii] * D[k + k * NB];
-    }
-}
-
 __device__ __forceinline__ double zf_sym(const double *Zp, const double *ZBs, int ld, int c, int m, int i, int q) {
     const int a = max(i, q), b = min(i, q);
     return (b < c) ? Zp[a + (long long)b * ld] : ZBs[(a - c) + (long long)(b - c) * m];
@@ -158,7 +110,7 @@ __global__ __launch_bounds__(256) void k_sel_symm(DevSym S, const int *__restric
 __global__ __launch_bounds__(256) void k_sel_diag(DevSym S, const int *__restrict__ list, int kb,
                                                   const double *__restrict__ L, double *__restrict__ Z,
                                                   const double *__restrict__ Yh, const long long *__restrict__ yoff) {
-    __shared__ double D[NB * NB];   // diagonal block (lower); later reused for G = Yh' Znew
+    __shared__ double D[NB * NB];   // G = Yh' Znew
     __shared__ double T[NB * NB];   // T[j + i*NB] = (D^-1)[i][j]  (transposed inverse)
     const int s = list[blockIdx.x];
     const int c = S.sfirst[s + 1] - S.sfirst[s];
@@ -171,12 +123,16 @@ __global__ __launch_bounds__(256) void k_sel_diag(DevSym S, const int *__restric
     double *Zp = Z + S.panelptr[s];
     const double *Y = Yh + yoff[s];
     const int tid = threadIdx.x;
+    // T[j + i*NB] = Linv[i][j]: strict lower part is stored in the strict upper triangle of the
+    // factor's diagonal block by k_potrf, the diagonal is the reciprocal of L's.
     for (int idx = tid; idx < NB * NB; idx += 256) {
-        const int i = idx % NB, j = idx / NB;
+        const int j = idx % NB, i = idx / NB;
         double v = 0.0;
-        if (i < w && j < w && i >= j) v = Dg[i + (long long)j * ld];
-        D[i + j * NB] = v;
-        T[idx] = 0.0;
+        if (i < w && j < w) {
+            if (j < i) v = Dg[j + (long long)i * ld];
+            else if (j == i) v = 1.0 / Dg[i + (long long)i * ld];
+        }
+        T[idx] = v;
     }
     // G = Yh' * Znew (K = rows below), kept in registers; wave t owns tile-row t (16 x 64)
     const int wave = tid >> 6, lane = tid & 63;
@@ -199,17 +155,7 @@ __global__ __launch_bounds__(256) void k_sel_diag(DevSym S, const int *__restric
         }
     }
     __syncthreads();
-    // invert the lower-triangular D: thread j solves D x = e_j and stores x transposed
-    if (tid < w) {
-        const int j = tid;
-        for (int i = j; i < w; i++) {
-            double v = (i == j) ? 1.0 : 0.0;
-            for (int k = j; k < i; k++) v -= D[i + k * NB] * T[j + k * NB];
-            T[j + i * NB] = v / D[i + i * NB];
-        }
-    }
-    __syncthreads();
-    // D is dead: store G there. D[m][n] of the MFMA -> G[a0 + lk + 4*rr][t*16 + lm]
+    // store G in LDS. D[m][n] of the MFMA -> G[a0 + lk + 4*rr][t*16 + lm]
 #pragma unroll
     for (int t = 0; t < 4; t++)
 #pragma unroll
@@ -231,11 +177,6 @@ void launch_sel_gather(hipStream_t st, const DevSym &S, const int *list, int nfr
                        const double *Z, double *ZB) {
     if (nfronts <= 0 || max_trail <= 0) return;
     hipLaunchKernelGGL(k_sel_gather, dim3(cdiv(max_trail, 16), nfronts), dim3(256), 0, st, S, list, Z, ZB);
-}
-void launch_sel_yhat(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int max_rows_below,
-                     const double *L, double *Yh, const long long *yoff) {
-    if (nactive <= 0 || max_rows_below <= 0) return;
-    hipLaunchKernelGGL(k_sel_yhat, dim3(cdiv(max_rows_below, TRSM_ROWS), nactive), dim3(256), 0, st, S, list, kb, L, Yh, yoff);
 }
 void launch_sel_symm(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int max_rows_below,
                      double *Z, const double *ZB, const double *Yh, const long long *yoff) {

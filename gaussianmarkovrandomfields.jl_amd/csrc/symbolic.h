@@ -20,7 +20,7 @@ struct SymOptions {
     double relax_zeros = 0;  // 0 = default
     int coord_dim = 0;
     const double *coords = nullptr;
-    int small_front_rows = 0;  // fronts with r <= this go to the fused LDS kernels (0 = default)
+    int small_front_rows = -1; // fronts with r <= this (and <= 64 columns) use the fused LDS kernels; -1 = default (128), 0 = off
 };
 
 // Symmetric adjacency structure without self loops.
@@ -55,6 +55,7 @@ struct Symbolic {
     std::vector<i32> levellist;   // supernodes by level; inside a level: small fronts first,
                                   // then big fronts by decreasing column count
     std::vector<i32> level_nsmall;// per level: number of small fronts (prefix of the level's list)
+    std::vector<i32> level_nsmall96;// per level: how many of those have r <= 96 (they come first)
     std::vector<uint8_t> is_small;// per supernode
     int small_rows = 0;
     // Q scatter map, sorted by destination

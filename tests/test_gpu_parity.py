@@ -254,3 +254,23 @@ def test_residual_property_256():
     assert relerr(ws.selinv_diag(), F.selinv_diag()) < 1e-8
     # tr(Q^-1 Q) = n
     assert abs(ws.selinv_dot(Q) - Q.shape[0]) < 1e-8 * Q.shape[0]
+
+
+@pytest.mark.parametrize("name", ["rand400", "matern64_coords", "cfg1_alpha3_65x65", "matern3d_10", "natural_chain"])
+def test_generic_path_matches_fused_small_front_path(name, monkeypatch):
+    """The fused small-front kernels (default) and the generic level-batched kernels
+    (GMRFX_SMALL_ROWS=0) must both agree with the oracle."""
+    Q, kw = next((sp.csc_matrix(q), k) for n, q, k in CASES if n == name)
+    monkeypatch.setenv("GMRFX_SMALL_ROWS", "0")
+    ws = gmrfx.GMRFWorkspace(Q, **kw)
+    assert ws.backend.stats()["n_small_fronts"] == 0
+    F = orc.OracleFactor(Q, ws.backend.ordering_permutation())
+    assert abs(ws.backend.factor_csc() - F.L()).max() <= 1e-10 * abs(F.L()).max()
+    B = np.random.default_rng(0).standard_normal((Q.shape[0], 64))
+    assert relerr(ws.workspace_solve(B), F.solve(B)) < 1e-10
+    assert relerr(ws.backward_solve(B), F.backward_solve(B)) < 1e-10
+    assert relerr(ws.selinv_diag(), F.selinv_diag()) < 1e-8
+    monkeypatch.setenv("GMRFX_SMALL_ROWS", "96")
+    ws96 = gmrfx.GMRFWorkspace(Q, **kw)
+    assert relerr(ws96.workspace_solve(B), F.solve(B)) < 1e-10
+    assert relerr(ws96.selinv_diag(), F.selinv_diag()) < 1e-8
