@@ -1,0 +1,208 @@
+# GMRFX.jl -- thin ccall layer over libgmrfx.so (include/gmrfx.h), and the two plug-ins that attach
+# it to GaussianMarkovRandomFields.jl:
+#   * seam B: `MI355XBackend <: WorkspaceBackend`            (src/workspace/backend.jl:8-30)
+#   * seam A: `MI355XCholesky` LinearSolve algorithm + hooks  (ext/GaussianMarkovRandomFieldsPardiso.jl:10-80)
+# NOTE: this image has no Julia; the file is exercised 1:1 by the Python ctypes mirror
+# (gmrfx/_lib.py, gmrfx/backend.py, gmrfx/workspace.py) which the test-suite runs. Keep both in sync.
+module GMRFX
+
+using LinearAlgebra, SparseArrays
+import GaussianMarkovRandomFields as G
+import GaussianMarkovRandomFields: WorkspaceBackend, refactorize!, backend_solve, compute_logdet,
+    compute_selinv!, get_selinv, get_selinv_diag, backend_backward_solve, selinv_dot, selinv_extract_at,
+    GMRFWorkspace
+
+const LIB = get(ENV, "GMRFX_LIB", joinpath(@__DIR__, "..", "libgmrfx.so"))
+
+Base.@kwdef struct Opts            # mirrors gmrfx_opts
+    struct_size::Int32 = 0
+    uplo::Int32 = 0
+    ordering::Int32 = 0
+    device::Int32 = -1
+    symbolic_only::Int32 = 0
+    check_posdef::Int32 = 0
+    nd_leaf::Int32 = 0
+    relax_cols::Int32 = 0
+    relax_zeros::Float64 = 0.0
+    coord_dim::Int32 = 0
+    reserved0::Int32 = 0
+    coords::Ptr{Float64} = C_NULL
+end
+
+mutable struct Handle
+    ptr::Ptr{Cvoid}
+    function Handle(p)
+        h = new(p)
+        finalizer(x -> (x.ptr == C_NULL || ccall((:gmrfx_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.ptr); x.ptr = C_NULL), h)
+        return h
+    end
+end
+
+function check(code::Int32, h::Union{Handle, Nothing} = nothing)
+    code == 0 && return nothing
+    msg = h === nothing ? unsafe_string(ccall((:gmrfx_last_create_error, LIB), Cstring, ())) :
+        unsafe_string(ccall((:gmrfx_last_error, LIB), Cstring, (Ptr{Cvoid},), h.ptr))
+    code == 1 && throw(ArgumentError(msg))
+    code == 5 && throw(PosDefException(1))
+    error("gmrfx error $code: $msg")
+end
+
+function create(Q::SparseMatrixCSC{Float64, Int}; ordering = nothing, coords = nothing, device = -1,
+        check_posdef = false)
+    n = size(Q, 1)
+    perm = ordering isa AbstractVector ? Vector{Int}(ordering) : nothing
+    C = coords === nothing ? nothing : Matrix{Float64}(transpose(coords))     # dim x n == n x dim row-major
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve Q perm C begin
+        o = Opts(struct_size = sizeof(Opts), device = device, check_posdef = check_posdef,
+            ordering = ordering === :natural ? 1 : 0,
+            coord_dim = C === nothing ? 0 : size(C, 1), coords = C === nothing ? C_NULL : pointer(C))
+        check(ccall((:gmrfx_create, LIB), Int32,
+            (Int64, Ptr{Int64}, Ptr{Int64}, Int32, Ptr{Int64}, Ref{Opts}, Ref{Ptr{Cvoid}}),
+            n, SparseArrays.getcolptr(Q), rowvals(Q), 1, perm === nothing ? C_NULL : pointer(perm), Ref(o), out))
+    end
+    return Handle(out[])
+end
+
+# ---------------------------------------------------------------------------------- seam B
+mutable struct MI355XBackend <: WorkspaceBackend
+    h::Handle
+    n::Int
+    selinv_cache::Union{Nothing, SparseMatrixCSC{Float64, Int}}
+    selinv_diag_cache::Union{Nothing, Vector{Float64}}
+end
+
+function MI355XBackend(Q::Symmetric{Float64, <:SparseMatrixCSC{Float64}}; ordering = nothing, coords = nothing, device = -1)
+    A = parent(Q)                                   # both triangles stored; uplo=:U defines Q
+    b = MI355XBackend(create(A; ordering, coords, device), size(A, 1), nothing, nothing)
+    refactorize!(b, Q)
+    return b
+end
+
+function refactorize!(b::MI355XBackend, Q::Symmetric)
+    nz = nonzeros(parent(Q))
+    info = Ref{Int64}(0)
+    GC.@preserve nz check(ccall((:gmrfx_refactorize, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ref{Int64}), b.h.ptr, nz, info), b.h)
+    b.selinv_cache = nothing
+    b.selinv_diag_cache = nothing
+    return nothing                                  # never throws on indefiniteness (backend.jl:184)
+end
+
+function backend_solve(b::MI355XBackend, rhs::AbstractVector)
+    B = Vector{Float64}(rhs); X = similar(B)
+    GC.@preserve B X check(ccall((:gmrfx_solve, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64),
+        b.h.ptr, B, b.n, 1, X, b.n), b.h)
+    return X
+end
+function backend_solve(b::MI355XBackend, RHS::Matrix{Float64})
+    X = similar(RHS)
+    GC.@preserve RHS X check(ccall((:gmrfx_solve, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64),
+        b.h.ptr, RHS, stride(RHS, 2), size(RHS, 2), X, stride(X, 2)), b.h)
+    return X
+end
+
+function compute_logdet(b::MI355XBackend)
+    out = Ref{Float64}(0)
+    check(ccall((:gmrfx_logdet, LIB), Int32, (Ptr{Cvoid}, Ref{Float64}), b.h.ptr, out), b.h)
+    return out[]
+end
+
+compute_selinv!(b::MI355XBackend) = nothing         # lazy, like CHOLMODBackend (backend.jl:215-221)
+
+function get_selinv(b::MI355XBackend)
+    if b.selinv_cache === nothing
+        nnzr = Ref{Int64}(0)
+        check(ccall((:gmrfx_selinv_nnz, LIB), Int32, (Ptr{Cvoid}, Ref{Int64}), b.h.ptr, nnzr), b.h)
+        colptr = Vector{Int}(undef, b.n + 1); rv = Vector{Int}(undef, nnzr[]); nz = Vector{Float64}(undef, nnzr[])
+        GC.@preserve colptr rv nz check(ccall((:gmrfx_selinv_csc, LIB), Int32,
+            (Ptr{Cvoid}, Int32, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}), b.h.ptr, 1, colptr, rv, nz), b.h)
+        b.selinv_cache = SparseMatrixCSC(b.n, b.n, colptr, rv, nz)
+    end
+    return b.selinv_cache
+end
+
+function get_selinv_diag(b::MI355XBackend)
+    if b.selinv_diag_cache === nothing
+        d = Vector{Float64}(undef, b.n)
+        GC.@preserve d check(ccall((:gmrfx_selinv_diag, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}), b.h.ptr, d), b.h)
+        b.selinv_diag_cache = d
+    end
+    return b.selinv_diag_cache
+end
+
+function selinv_extract_at(b::MI355XBackend, B::SparseMatrixCSC)
+    out = Vector{Float64}(undef, nnz(B))
+    cp = Vector{Int}(SparseArrays.getcolptr(B)); rv = Vector{Int}(rowvals(B))
+    GC.@preserve cp rv out check(ccall((:gmrfx_selinv_extract, LIB), Int32,
+        (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int64}, Int32, Ptr{Float64}), b.h.ptr, b.n, cp, rv, 1, out), b.h)
+    return SparseMatrixCSC(size(B)..., cp, rv, out)
+end
+# values of Sigma are gathered on the GPU; the contraction stays in Julia so B may carry Duals
+selinv_dot(b::MI355XBackend, B::SparseMatrixCSC) = dot(nonzeros(selinv_extract_at(b, B)), nonzeros(B))
+
+function backend_backward_solve(b::MI355XBackend, x::AbstractVector)
+    Z = Vector{Float64}(x); X = similar(Z)          # copies views (backend.jl:282-283)
+    GC.@preserve Z X check(ccall((:gmrfx_backward_solve, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64),
+        b.h.ptr, Z, b.n, 1, X, b.n), b.h)
+    return X
+end
+# batched sampling: k samples in one sweep instead of the reference's k single-RHS solves (src/gmrf.jl:271-281)
+function backend_backward_solve(b::MI355XBackend, Zm::Matrix{Float64})
+    X = similar(Zm)
+    GC.@preserve Zm X check(ccall((:gmrfx_backward_solve, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64),
+        b.h.ptr, Zm, stride(Zm, 2), size(Zm, 2), X, stride(X, 2)), b.h)
+    return X
+end
+
+ordering_permutation(b::MI355XBackend) = (p = Vector{Int}(undef, b.n);
+    ccall((:gmrfx_get_perm, LIB), Int32, (Ptr{Cvoid}, Int32, Ptr{Int64}), b.h.ptr, 1, p); p)
+
+# selector, like GMRFWorkspace(Q, CliqueTreesBackend; alg) (src/workspace/cliquetrees_backend.jl:132-150)
+function G.GMRFWorkspace(Q::SparseMatrixCSC{Float64}, ::Type{MI355XBackend}; kwargs...)
+    n = size(Q, 1)
+    n == size(Q, 2) || throw(ArgumentError("Q must be square"))
+    backend = MI355XBackend(Symmetric(Q); kwargs...)
+    return GMRFWorkspace{Float64, MI355XBackend}(copy(Q), backend, zeros(n), zeros(n), true, false, false, 0.0, 1, 0)
+end
+
+function Base.deepcopy_internal(b::MI355XBackend, ::IdDict)   # deepcopy(cache) in Newton loops
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:gmrfx_clone, LIB), Int32, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}), b.h.ptr, out))
+    return MI355XBackend(Handle(out[]), b.n, nothing, nothing)
+end
+
+# ---------------------------------------------------------------------------------- seam A
+# LinearSolve algorithm: cacheval = MI355XBackend; GMRF-side hooks exactly as the Pardiso extension.
+import LinearSolve, SciMLBase
+struct MI355XCholesky <: LinearSolve.AbstractFactorization
+    ordering::Any
+end
+MI355XCholesky() = MI355XCholesky(nothing)
+LinearSolve.init_cacheval(::MI355XCholesky, A, b, u, Pl, Pr, maxiters, abstol, reltol, verbose, assumptions) = nothing
+function SciMLBase.solve!(cache::LinearSolve.LinearCache, alg::MI355XCholesky; kwargs...)
+    A = cache.A isa Symmetric ? parent(cache.A) : cache.A
+    if cache.isfresh
+        be = cache.cacheval
+        if be === nothing
+            h = create(A; ordering = alg.ordering, check_posdef = true)     # seam A throws PosDefException
+            be = MI355XBackend(h, size(A, 1), nothing, nothing)
+        end
+        refactorize!(be, Symmetric(A))
+        cache.cacheval = be
+        cache.isfresh = false
+    end
+    cache.u .= backend_solve(cache.cacheval, cache.b)
+    return SciMLBase.build_linear_solution(alg, cache.u, nothing, cache)
+end
+G.supports_selinv(::MI355XCholesky) = Val{true}()
+G.supports_backward_solve(::MI355XCholesky) = Val{true}()
+G._selinv_diag_impl(cache, ::MI355XCholesky) = get_selinv_diag(cache.cacheval)
+G._selinv_impl(cache, ::MI355XCholesky) = Symmetric(get_selinv(cache.cacheval))
+G._backward_solve_impl(cache, x, ::MI355XCholesky) = backend_backward_solve(cache.cacheval, x)
+G._logdet_cov_impl(cache, ::MI355XCholesky) = -compute_logdet(cache.cacheval)       # note the sign (logdet.jl:30)
+G.prepare_for_linsolve(A::SparseMatrixCSC, ::MI355XCholesky) = Symmetric(A)
+G.configure_algorithm(alg::MI355XCholesky) = alg
+G.algorithm_applicable(::MI355XCholesky, A) = A isa Union{SparseMatrixCSC, Symmetric{<:Any, <:SparseMatrixCSC}}
+
+export MI355XBackend, MI355XCholesky, ordering_permutation
+end # module

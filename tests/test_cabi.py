@@ -1,0 +1,60 @@
+"""CPU: libgmrfx.so loads and exports every symbol include/gmrfx.h declares; struct layouts of
+the ctypes mirror match sizeof on the C side is implied by struct_size round-trips."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+from gmrfx import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "gmrfx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gmrfx_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported():
+    L = _lib.lib()
+    syms = declared_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in include/gmrfx.h but not exported"
+    assert sorted(_lib.EXPORTS) == syms
+
+
+def test_stats_struct_roundtrip_and_symbolic_only_handle():
+    import scipy.sparse as sp
+    Q = sp.csc_matrix(np.array([[4.0, 1, 0], [1, 3, 1], [0, 1, 5]]))
+    opts = _lib.GmrfxOpts()
+    opts.struct_size = C.sizeof(_lib.GmrfxOpts)
+    opts.symbolic_only = 1
+    opts.device = -1
+    h = C.c_void_p()
+    colptr = np.ascontiguousarray(Q.indptr, dtype=np.int64) + 1       # 1-based, as Julia passes it
+    rowval = np.ascontiguousarray(Q.indices, dtype=np.int64) + 1
+    rc = _lib.lib().gmrfx_create(3, _lib.ptr(colptr), _lib.ptr(rowval), 1, None, C.byref(opts), C.byref(h))
+    assert rc == 0, _lib.lib().gmrfx_last_create_error()
+    st = _lib.GmrfxStats()
+    assert _lib.lib().gmrfx_get_stats(h, C.byref(st), C.sizeof(_lib.GmrfxStats)) == 0
+    assert st.n == 3 and st.nnz_l >= 5 and st.fail_col == -1
+    perm = np.zeros(3, np.int64)
+    assert _lib.lib().gmrfx_get_perm(h, 1, _lib.ptr(perm)) == 0
+    assert sorted(perm.tolist()) == [1, 2, 3]
+    # numeric entry points refuse to run without a device: no CPU fallback
+    out = C.c_double()
+    assert _lib.lib().gmrfx_logdet(h, C.byref(out)) == _lib.ERR_NO_DEVICE
+    assert b"GPU-only" in _lib.lib().gmrfx_last_error(h)
+    _lib.lib().gmrfx_destroy(h)
+
+
+def test_bad_arguments_are_reported_not_crashed():
+    h = C.c_void_p()
+    colptr = np.array([0, 1, 5], dtype=np.int64)     # rowval out of range
+    rowval = np.array([0, 7, 1, 1, 1], dtype=np.int64)
+    rc = _lib.lib().gmrfx_create(2, _lib.ptr(colptr), _lib.ptr(rowval), 0, None, None, C.byref(h))
+    assert rc == _lib.ERR_INVALID_ARG and h.value is None
+    assert b"range" in _lib.lib().gmrfx_last_create_error()

@@ -1,0 +1,96 @@
+"""CPU: the oracle against (a) the committed golden fixtures, (b) the dense identities the
+reference's own tests use (test/workspace/test_gmrf_workspace.jl:26-83, test/test_gmrf.jl:64-76),
+(c) scipy SuperLU as an independent sparse solver."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+import orc
+from gmrfx import spde
+
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+def load(path):
+    g = np.load(path)
+    n = int(g["n"])
+    Q = sp.csc_matrix((g["nzval"], g["rowval"], g["colptr"]), shape=(n, n))
+    return g, Q
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[:-4] for p in GOLD])
+def test_oracle_matches_golden(path):
+    g, Q = load(path)
+    F = orc.OracleFactor(Q, g["perm"])
+    assert np.array_equal(np.diff(F.L().indptr), g["L_colcount"])          # integer work: exact
+    assert np.allclose(F.L().diagonal(), g["L_diag"], rtol=1e-11)
+    assert np.allclose(F.solve(g["B"]), g["X"], rtol=1e-10, atol=1e-13)
+    assert np.allclose(F.backward_solve(g["Z"]), g["Xb"], rtol=1e-10, atol=1e-13)
+    assert np.isclose(F.logdet(), float(g["logdet"]), rtol=1e-12)
+    assert np.allclose(F.selinv_diag(), g["selinv_diag"], rtol=1e-9)
+    Z = F.selinv()
+    assert np.allclose(np.asarray(Z[Q.nonzero()]).ravel(), g["Qinv_on_pattern"], rtol=1e-8, atol=1e-13)
+
+
+@pytest.mark.parametrize("n", [20, 100, 400])
+def test_oracle_dense_identities_reference_fixture(n):
+    """`Q = S S' + n I` (test_gmrf_workspace.jl:8-13) at the reference's sizes."""
+    Q = spde.random_spd_precision(n, 0.3 if n < 400 else 0.02)
+    D = Q.toarray()
+    Qi = np.linalg.inv(D)
+    F = orc.OracleFactor(Q)                      # identity permutation
+    b = np.random.default_rng(n).standard_normal(n)
+    assert np.allclose(F.solve(b), np.linalg.solve(D, b), rtol=1e-10)
+    assert np.isclose(F.logdet(), np.linalg.slogdet(D)[1], rtol=1e-10)
+    assert np.allclose(F.selinv_diag(), np.diag(Qi), rtol=1e-8)
+    Z = F.selinv().tocoo()
+    assert np.allclose(Z.data, Qi[Z.row, Z.col], rtol=1e-6, atol=1e-14)
+    assert np.isclose((F.selinv().multiply(Q)).sum(), n, rtol=1e-8)      # tr(Q^-1 Q) = n
+    # uplo handling: only the selected triangle defines Q
+    Qu = sp.triu(Q, format="csc")
+    assert np.isclose(orc.OracleFactor(Qu, uplo="U").logdet(), F.logdet(), rtol=1e-13)
+    assert np.isclose(orc.OracleFactor(sp.tril(Q, format="csc"), uplo="L").logdet(), F.logdet(), rtol=1e-13)
+
+
+def test_oracle_vs_superlu_medium():
+    m = spde.grid_mesh_2d(60, 60, jitter=0.25)
+    Q = spde.matern_precision(m, 0, 0.2)
+    F = orc.OracleFactor(Q, np.random.default_rng(0).permutation(m.n))
+    lu = spla.splu(Q, permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
+    B = np.random.default_rng(1).standard_normal((m.n, 4))
+    assert np.allclose(F.solve(B), lu.solve(B), rtol=1e-9, atol=1e-12)
+    assert np.isclose(F.logdet(), np.log(np.abs(lu.U.diagonal())).sum() + np.log(np.abs(lu.L.diagonal())).sum(), rtol=1e-11)
+
+
+def test_backward_solve_is_a_sampler():
+    """cov(P' L^-T z) = Q^-1 in ORIGINAL ordering (test_gmrf_workspace.jl:85-100)."""
+    Q = spde.random_spd_precision(20)
+    F = orc.OracleFactor(Q, np.random.default_rng(3).permutation(20))
+    S = F.backward_solve(np.random.default_rng(123).standard_normal((20, 50000)))
+    assert np.allclose((S * S).mean(axis=1), np.diag(np.linalg.inv(Q.toarray())), rtol=0.1)
+
+
+def test_indefinite_is_flagged_not_fatal():
+    Q = spde.random_spd_precision(15).tolil()
+    Q.setdiag(-1.0)
+    F = orc.OracleFactor(sp.csc_matrix(Q))
+    assert F.fail_col >= 0
+
+
+def test_matern_generator_matches_reference_formulas():
+    """Appendix A of SURVEY.md: variance ~ 1 in the interior, pattern sizes, explicit zeros kept."""
+    m = spde.grid_mesh_2d(41, 41)
+    Q = spde.matern_precision(m, smoothness=0, range_=0.3)       # nu = 1, alpha = 2: 19-point pattern
+    assert np.diff(Q.indptr).max() == 19 and (Q.data == 0).sum() > 0
+    var = orc.OracleFactor(Q).selinv_diag().reshape(41, 41)
+    assert abs(var[20, 20] - 1.0) < 0.1                           # sigma^2 = 1 away from the boundary
+    assert np.diff(spde.matern_precision(m, 1, 0.3).indptr).max() == 37   # alpha = 3
+    with pytest.raises(ValueError):
+        spde.smoothness_to_nu(-1, 2)
+    # 3-D nu=1 (alpha = 5/2) is not expressible, as in the reference (Integer(alpha) throws)
+    import math
+    assert spde.smoothness_to_nu(0, 3) == 0.5 and math.isclose(spde.range_to_kappa(2.0, 1.0), math.sqrt(8) / 2)
