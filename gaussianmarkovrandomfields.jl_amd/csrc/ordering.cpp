@@ -117,39 +117,106 @@ struct ND {
         for (i64 k = 0; k < cnt; k++) { dist[v[k]] = -1; label[v[k]] = -1; }
     }
 
-    // Given v[0:cnt) labelled idA / idB, pick the smaller one-sided boundary as separator,
-    // thin it, and partition v into [A' | B' | S]. Returns sizes.
+    // Given v[0:cnt) labelled idA / idB: the vertex separator is a MINIMUM VERTEX COVER of the
+    // bipartite graph formed by the cut edges (Hopcroft-Karp maximum matching + Koenig's
+    // construction) -- the smallest separator this edge cut admits; for the 2-ring stencils of
+    // alpha=2 SPDE precisions on jittered meshes it is ~1/3 smaller than a one-sided boundary.
+    // Partitions v into [A' | B' | S]. Returns sizes.
+    std::vector<i32> lidx;   // scratch: local index of a boundary vertex (size n, -1 = none)
     void split(i32 *v, i64 cnt, i32 idA, i32 idB, i64 &nA, i64 &nB, i64 &nS) {
-        i64 ba = 0, bb = 0;
+        if (lidx.empty()) lidx.assign(G.n, -1);
+        std::vector<i32> Lv, Rv;   // boundary vertices of A (left) and B (right)
         for (i64 k = 0; k < cnt; k++) {
-            i32 u = v[k]; i32 other = label[u] == idA ? idB : idA; bool b = false;
-            for (i64 p = G.xadj[u]; p < G.xadj[u + 1]; p++) if (label[G.adj[p]] == other) { b = true; break; }
-            if (b) { if (label[u] == idA) ba++; else bb++; }
+            i32 u = v[k]; i32 other = label[u] == idA ? idB : idA;
+            for (i64 p = G.xadj[u]; p < G.xadj[u + 1]; p++)
+                if (label[G.adj[p]] == other) {
+                    if (label[u] == idA) { lidx[u] = (i32)Lv.size(); Lv.push_back(u); }
+                    else { lidx[u] = (i32)Rv.size(); Rv.push_back(u); }
+                    break;
+                }
         }
-        i32 from = (ba <= bb) ? idA : idB, other = (ba <= bb) ? idB : idA;
+        const i32 nl = (i32)Lv.size(), nrr = (i32)Rv.size();
+        // adjacency L -> R (local indices)
+        std::vector<i64> lp(nl + 1, 0);
+        for (i32 a = 0; a < nl; a++) {
+            i64 c = 0;
+            for (i64 p = G.xadj[Lv[a]]; p < G.xadj[Lv[a] + 1]; p++) if (label[G.adj[p]] == idB) c++;
+            lp[a + 1] = lp[a] + c;
+        }
+        std::vector<i32> la(lp[nl]);
+        for (i32 a = 0; a < nl; a++) {
+            i64 q = lp[a];
+            for (i64 p = G.xadj[Lv[a]]; p < G.xadj[Lv[a] + 1]; p++) if (label[G.adj[p]] == idB) la[q++] = lidx[G.adj[p]];
+        }
+        // Hopcroft-Karp
+        std::vector<i32> ml(nl, -1), mr(nrr, -1), dist(nl), stack, it(nl);
+        const i32 INF = 0x7fffffff;
+        for (;;) {
+            // BFS from free left vertices
+            std::vector<i32> q;
+            for (i32 a = 0; a < nl; a++) { if (ml[a] < 0) { dist[a] = 0; q.push_back(a); } else dist[a] = INF; }
+            bool found = false;
+            for (size_t h = 0; h < q.size(); h++) {
+                i32 a = q[h];
+                for (i64 p = lp[a]; p < lp[a + 1]; p++) {
+                    i32 b2 = mr[la[p]];
+                    if (b2 < 0) found = true;
+                    else if (dist[b2] == INF) { dist[b2] = dist[a] + 1; q.push_back(b2); }
+                }
+            }
+            if (!found) break;
+            // DFS (iterative) along layered graph
+            for (i32 a = 0; a < nl; a++) it[a] = 0;
+            for (i32 root = 0; root < nl; root++) {
+                if (ml[root] >= 0) continue;
+                stack.clear();
+                stack.push_back(root);
+                while (!stack.empty()) {
+                    i32 a = stack.back();
+                    if (it[a] >= lp[a + 1] - lp[a]) { dist[a] = INF; stack.pop_back(); continue; }
+                    i32 r = la[lp[a] + it[a]++];
+                    i32 b2 = mr[r];
+                    if (b2 < 0) {
+                        // augment along the stack: each stack vertex takes the right vertex it just tried
+                        for (i32 t = (i32)stack.size() - 1; t >= 0; t--) {
+                            i32 x = stack[t];
+                            i32 rr = la[lp[x] + it[x] - 1];
+                            mr[rr] = x; ml[x] = rr;
+                        }
+                        stack.clear();
+                    } else if (dist[b2] == dist[a] + 1) {
+                        stack.push_back(b2);
+                    }
+                }
+            }
+        }
+        // Koenig: Z = reachable from free left vertices by alternating paths
+        std::vector<uint8_t> zl(nl, 0), zr(nrr, 0);
+        {
+            std::vector<i32> q;
+            for (i32 a = 0; a < nl; a++) if (ml[a] < 0) { zl[a] = 1; q.push_back(a); }
+            for (size_t h = 0; h < q.size(); h++) {
+                i32 a = q[h];
+                for (i64 p = lp[a]; p < lp[a + 1]; p++) {
+                    i32 r = la[p];
+                    if (zr[r]) continue;
+                    zr[r] = 1;
+                    i32 b2 = mr[r];
+                    if (b2 >= 0 && !zl[b2]) { zl[b2] = 1; q.push_back(b2); }
+                }
+            }
+        }
         const i32 idS = next_id++;
-        for (i64 k = 0; k < cnt; k++) {
-            i32 u = v[k];
-            if (label[u] != from) continue;
-            for (i64 p = G.xadj[u]; p < G.xadj[u + 1]; p++) if (label[G.adj[p]] == other) { label[u] = idS; break; }
-        }
-        // thinning: a separator vertex with no neighbour left on `from`'s side can join `other`
-        // only if it has no neighbour in `from`; (it always touches `other`). Move those.
-        for (i64 k = 0; k < cnt; k++) {
-            i32 u = v[k];
-            if (label[u] != idS) continue;
-            bool touches_from = false;
-            for (i64 p = G.xadj[u]; p < G.xadj[u + 1]; p++) if (label[G.adj[p]] == from) { touches_from = true; break; }
-            if (!touches_from) label[u] = other;
-        }
+        for (i32 a = 0; a < nl; a++) { if (!zl[a]) label[Lv[a]] = idS; lidx[Lv[a]] = -1; }
+        for (i32 r = 0; r < nrr; r++) { if (zr[r]) label[Rv[r]] = idS; lidx[Rv[r]] = -1; }
         // stable 3-way partition
         std::vector<i32> tmp(v, v + cnt);
         nA = nB = nS = 0;
         for (i64 k = 0; k < cnt; k++) if (label[tmp[k]] == idA) nA++; else if (label[tmp[k]] == idB) nB++; else nS++;
-        i64 a = 0, b = nA, s = nA + nB;
+        i64 a = 0, b = nA, sidx = nA + nB;
         for (i64 k = 0; k < cnt; k++) {
             i32 u = tmp[k];
-            if (label[u] == idA) v[a++] = u; else if (label[u] == idB) v[b++] = u; else v[s++] = u;
+            if (label[u] == idA) v[a++] = u; else if (label[u] == idB) v[b++] = u; else v[sidx++] = u;
         }
     }
 
@@ -163,20 +230,38 @@ struct ND {
         int ax = 0;
         for (int d = 1; d < dim; d++) if (hi[d] - lo[d] > hi[ax] - lo[ax]) ax = d;
         if (!(hi[ax] > lo[ax])) return false;
-        i64 mid = cnt / 2;
-        std::nth_element(v, v + mid, v + cnt, [&](i32 a, i32 b) {
+        // Sort along the axis, then slide the cut position inside the middle 20 % of the
+        // vertices and keep the position with the FEWEST CUT EDGES: on (jittered) structured
+        // meshes that snaps the cut into the gap between two grid lines, on unstructured meshes
+        // it picks the locally smoothest interface. The separator is then the minimum vertex
+        // cover of exactly that edge cut (split()).
+        auto less = [&](i32 a, i32 b) {
             double ca = xy[(i64)a * dim + ax], cb = xy[(i64)b * dim + ax];
             return ca < cb || (ca == cb && a < b);
-        });
-        double thr = xy[(i64)v[mid] * dim + ax];
-        // keep ties on one side for a clean cut, unless that empties a side
-        i64 nlow = 0;
-        for (i64 k = 0; k < cnt; k++) if (xy[(i64)v[k] * dim + ax] < thr) nlow++;
-        bool by_value = nlow >= cnt / 4;
-        for (i64 k = 0; k < cnt; k++) {
-            bool inA = by_value ? (xy[(i64)v[k] * dim + ax] < thr) : (k < mid);
-            label[v[k]] = inA ? idA : idB;
+        };
+        {   // only the sliding window needs to be sorted
+            const i64 wlo = std::max<i64>(1, (i64)(0.4 * cnt)), whi = std::min<i64>(cnt - 1, (i64)(0.6 * cnt) + 1);
+            std::nth_element(v, v + wlo, v + cnt, less);
+            std::nth_element(v + wlo, v + whi, v + cnt, less);
+            std::sort(v + wlo, v + whi, less);
         }
+        for (i64 k = 0; k < cnt; k++) label[v[k]] = idB;
+        const i64 klo = std::max<i64>(1, (i64)(0.4 * cnt)), khi = std::min<i64>(cnt - 1, (i64)(0.6 * cnt) + 1);
+        i64 cut = 0, best_cut = -1, best_k = cnt / 2;
+        for (i64 k = 0; k < khi; k++) {
+            const i32 u = v[k];
+            for (i64 p = G.xadj[u]; p < G.xadj[u + 1]; p++) {
+                const i32 lw = label[G.adj[p]];
+                if (lw == idB) cut++; else if (lw == idA) cut--;
+            }
+            label[u] = idA;
+            const i64 na = k + 1;
+            if (na >= klo) {
+                const i64 dmid = std::llabs(na - cnt / 2), bmid = std::llabs(best_k - cnt / 2);
+                if (best_cut < 0 || cut < best_cut || (cut == best_cut && dmid < bmid)) { best_cut = cut; best_k = na; }
+            }
+        }
+        for (i64 k = best_k; k < khi; k++) label[v[k]] = idB;
         return true;
     }
 
