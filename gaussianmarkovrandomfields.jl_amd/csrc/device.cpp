@@ -105,7 +105,7 @@ void Device::upload(const Symbolic &S) {
         L.first = (int)S.levelptr[l];
         L.count = (int)(S.levelptr[l + 1] - S.levelptr[l]);
         L.nsmall = S.level_nsmall[l];
-        L.nsmall96 = S.level_nsmall96[l];
+        for (int k = 0; k < 4; k++) L.ncls[k] = S.level_ncls[(size_t)l * 4 + k];
         L.max_rows = L.max_cols = 0;
         int max_trail = 0;
         for (int k = L.nsmall; k < L.count; k++) {
@@ -146,6 +146,7 @@ void Device::clone_from(const Device &o, const Symbolic &S) {
     }
 }
 
+static const int kClsRows[4] = {48, 64, 96, 128};
 static inline int level_max_trail(const LevelInfo &L) { return L.active.back(); }
 static inline int level_nblk(const LevelInfo &L) { return (int)L.active.size() - 2; }
 
@@ -153,15 +154,15 @@ void Device::factor_levels() {
     const int big = INT_MAX;
     HC(hipMemcpyAsync(d_info_, &big, sizeof(int), hipMemcpyHostToDevice, stream));
     for (auto &L : levels_) {
-        launch_factor_small(stream, ds_, d_levellist_ + L.first, L.nsmall96, 96, d_nz_, d_L_, d_cb_, d_info_);
-        launch_factor_small(stream, ds_, d_levellist_ + L.first + L.nsmall96, L.nsmall - L.nsmall96, 128, d_nz_, d_L_, d_cb_, d_info_);
+        for (int k = 0, off = 0; k < 4; off += L.ncls[k], k++)
+            launch_factor_small(stream, ds_, d_levellist_ + L.first + off, L.ncls[k], kClsRows[k], d_nz_, d_L_, d_cb_, d_info_);
         const int *list = d_levellist_ + L.first + L.nsmall;
         const int nf = L.count - L.nsmall;
         launch_assemble(stream, ds_, list, nf, L.max_rows, d_nz_, d_L_, d_cb_);
         const int nblk = level_nblk(L);
         for (int b = 0; b < nblk; b++) {
             const int kb = b * NB;
-            launch_potrf(stream, ds_, list, L.active[b], kb, d_L_, d_info_);
+            launch_potrf_lds(stream, ds_, list, L.active[b], kb, d_L_, d_info_);
             launch_trsm(stream, ds_, list, L.active[b], kb, 0, L.max_rows - kb - 1, d_L_, nullptr, nullptr);
             if (b + 1 < nblk)
                 launch_gemm_nt(stream, ds_, list, L.active[b + 1], kb, 0, L.max_rows - kb - NB, L.max_cols - kb - NB, d_L_, d_cb_);
@@ -212,8 +213,8 @@ void Device::ensure_rhs_capacity(long long nrhs) {
 
 void Device::forward(int nr, int ldx) {
     for (auto &L : levels_) {
-        launch_fwd_small(stream, ds_, d_levellist_ + L.first, L.nsmall96, 96, d_L_, d_X_, d_W_, nr, ldx);
-        launch_fwd_small(stream, ds_, d_levellist_ + L.first + L.nsmall96, L.nsmall - L.nsmall96, 128, d_L_, d_X_, d_W_, nr, ldx);
+        for (int k = 0, off = 0; k < 4; off += L.ncls[k], k++)
+            launch_fwd_small(stream, ds_, d_levellist_ + L.first + off, L.ncls[k], kClsRows[k], d_L_, d_X_, d_W_, nr, ldx);
         const int *list = d_levellist_ + L.first + L.nsmall;
         const int nf = L.count - L.nsmall;
         launch_fwd_assemble(stream, ds_, list, nf, L.max_rows, d_X_, d_W_, nr, ldx);
@@ -231,8 +232,8 @@ void Device::backward(int nr, int ldx) {
         auto &L = levels_[l];
         const int *list = d_levellist_ + L.first + L.nsmall;
         const int nf = L.count - L.nsmall;
-        launch_bwd_small(stream, ds_, d_levellist_ + L.first, L.nsmall96, 96, d_L_, d_X_, nr, ldx);
-        launch_bwd_small(stream, ds_, d_levellist_ + L.first + L.nsmall96, L.nsmall - L.nsmall96, 128, d_L_, d_X_, nr, ldx);
+        for (int k = 0, off = 0; k < 4; off += L.ncls[k], k++)
+            launch_bwd_small(stream, ds_, d_levellist_ + L.first + off, L.ncls[k], kClsRows[k], d_L_, d_X_, nr, ldx);
         if (level_max_trail(L) > 0) launch_bwd_gemm(stream, ds_, list, nf, 0, 0, L.max_cols, d_L_, d_X_, nr, ldx);
         const int nblk = level_nblk(L);
         for (int b = nblk - 1; b >= 0; b--) {

@@ -34,7 +34,7 @@ struct LevelInfo {
     int first;        // offset into levellist
     int count;        // fronts in level
     int nsmall;       // prefix handled by the fused small-front kernels
-    int nsmall96;     // of which r <= 96 (first)
+    int ncls[4];      // of which r <= 48 / 64 / 96 / 128 (in this order)
     int max_rows;     // over big fronts
     int max_cols;     // over big fronts (they are sorted by decreasing column count)
     std::vector<int> active;  // active[k] = number of big fronts with ncols > k*NB

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void k_assemble(DevSym S, const int *__restric
     const int tid = threadIdx.x;
     for (int col = col0; col < col1; col++) {
         if (col < c) { for (int i = tid; i < ld; i += 256) P[i + (long long)col * ld] = 0.0; }
-        else { for (int i = tid; i < m; i += 256) U[i + (long long)(col - c) * m] = 0.0; }
+        else { for (int i = (col - c) + tid; i < m; i += 256) U[i + (long long)(col - c) * m] = 0.0; }   // lower triangle only
     }
     __syncthreads();
     if (col0 < c) {
@@ -267,6 +267,7 @@ __global__ __launch_bounds__(256) void k_trsm(DevSym S, const int *__restrict__ 
 // the 16 lanes sharing a register index walk down a COLUMN of the column-major C.
 // mode 0: trailing update inside the panel after block-column kb; mode 1: contribution block
 // CB -= L21 L21' (K = all c columns).
+template <int TW>   // MFMA tiles per wave and dimension: wave tile 16*TW squared, workgroup tile twice that
 __global__ __launch_bounds__(256) void k_gemm_nt(DevSym S, const int *__restrict__ list, int kb, int mode,
                                                  double *__restrict__ L, double *__restrict__ CB) {
     const int s = list[blockIdx.z];
@@ -291,45 +292,46 @@ __global__ __launch_bounds__(256) void k_gemm_nt(DevSym S, const int *__restrict
         ldc = M;
     }
     const int bi = blockIdx.x, bj = blockIdx.y;
-    if (bj > bi || bi * 64 >= M || bj * 64 >= N) return;
+    constexpr int WT = 16 * TW, GT = 2 * WT;
+    if (bj > bi || bi * GT >= M || bj * GT >= N) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int i0 = bi * 64 + (wave & 1) * 32, j0 = bj * 64 + (wave >> 1) * 32;
-    if (i0 >= M || j0 >= N || j0 > i0 + 31) return;
+    const int i0 = bi * GT + (wave & 1) * WT, j0 = bj * GT + (wave >> 1) * WT;
+    if (i0 >= M || j0 >= N || j0 > i0 + WT - 1) return;
     const int lm = lane & 15, lk = lane >> 4;
-    d4 acc[2][2];
+    d4 acc[TW][TW];
 #pragma unroll
-    for (int a = 0; a < 2; a++)
+    for (int a = 0; a < TW; a++)
 #pragma unroll
-        for (int b = 0; b < 2; b++) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int b = 0; b < TW; b++) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
     // Operand rows are clamped (always-valid addresses, values masked afterwards) so that the
     // loads of a whole batch of KU k-steps issue back to back; the next batch is fetched into
     // a second register set before the current batch's MFMAs (software double buffering).
-    constexpr int KU = 4;
-    const double *pa[2], *pb[2];
+    constexpr int KU = TW == 2 ? 4 : 2;
+    const double *pa[TW], *pb[TW];
 #pragma unroll
-    for (int a = 0; a < 2; a++) pa[a] = A + min(i0 + a * 16 + lm, M - 1);
+    for (int a = 0; a < TW; a++) pa[a] = A + min(i0 + a * 16 + lm, M - 1);
 #pragma unroll
-    for (int b = 0; b < 2; b++) pb[b] = A + min(j0 + b * 16 + lm, N - 1);
-    double ca[KU][2], cb[KU][2];
+    for (int b = 0; b < TW; b++) pb[b] = A + min(j0 + b * 16 + lm, N - 1);
+    double ca[KU][TW], cb[KU][TW];
     // full batches: no masking at all, so the prefetch of batch k+1 really overlaps the MFMAs of
     // batch k (nothing consumes the loaded registers before the MFMAs that need them)
-    auto fetch = [&](int k0, double (&xa)[KU][2], double (&xb)[KU][2]) {
+    auto fetch = [&](int k0, double (&xa)[KU][TW], double (&xb)[KU][TW]) {
 #pragma unroll
         for (int u = 0; u < KU; u++) {
             const long long off = (long long)(k0 + 4 * u + lk) * ld;
 #pragma unroll
-            for (int a = 0; a < 2; a++) xa[u][a] = pa[a][off];
+            for (int a = 0; a < TW; a++) xa[u][a] = pa[a][off];
 #pragma unroll
-            for (int b = 0; b < 2; b++) xb[u][b] = pb[b][off];
+            for (int b = 0; b < TW; b++) xb[u][b] = pb[b][off];
         }
     };
-    auto mma = [&](double (&xa)[KU][2], double (&xb)[KU][2]) {
+    auto mma = [&](double (&xa)[KU][TW], double (&xb)[KU][TW]) {
 #pragma unroll
         for (int u = 0; u < KU; u++)
 #pragma unroll
-            for (int a = 0; a < 2; a++)
+            for (int a = 0; a < TW; a++)
 #pragma unroll
-                for (int b = 0; b < 2; b++)
+                for (int b = 0; b < TW; b++)
                     acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[u][b], xa[u][a], acc[a][b], 0, 0, 0);
     };
     const int kfull = K / (4 * KU) * (4 * KU);
@@ -348,17 +350,17 @@ __global__ __launch_bounds__(256) void k_gemm_nt(DevSym S, const int *__restrict
             const long long off = (long long)min(kk, K - 1) * ld;
             const double mk = kk < K ? 1.0 : 0.0;
 #pragma unroll
-            for (int a = 0; a < 2; a++) ca[u][a] = pa[a][off] * mk;
+            for (int a = 0; a < TW; a++) ca[u][a] = pa[a][off] * mk;
 #pragma unroll
-            for (int b = 0; b < 2; b++) cb[u][b] = pb[b][off];
+            for (int b = 0; b < TW; b++) cb[u][b] = pb[b][off];
         }
         mma(ca, cb);
     }
     // D[m][n]: m (rows of the first operand = C's column) = lk + 4*reg, n = lm = C's row
 #pragma unroll
-    for (int a = 0; a < 2; a++)
+    for (int a = 0; a < TW; a++)
 #pragma unroll
-        for (int b = 0; b < 2; b++)
+        for (int b = 0; b < TW; b++)
 #pragma unroll
             for (int rr = 0; rr < 4; rr++) {
                 const int i = i0 + a * 16 + lm;
@@ -691,7 +693,11 @@ void launch_trsm(hipStream_t st, const DevSym &S, const int *list, int nactive, 
 void launch_gemm_nt(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int mode, int maxM,
                     int maxN, double *L, double *CB) {
     if (nactive <= 0 || maxM <= 0 || maxN <= 0) return;
-    hipLaunchKernelGGL(k_gemm_nt, dim3(cdiv(maxM, 64), cdiv(maxN, 64), nactive), dim3(256), 0, st, S, list, kb, mode, L, CB);
+    // 64x64 workgroup tiles, operands straight from L2 at 3-4 waves per SIMD. Measured on MI355X: the
+    // sustained v_mfma_f64_16x16x4_f64 rate is 36.3 TFLOP/s (tools/micro/mfma64.hip), this kernel reaches
+    // ~27 TFLOP/s on the top-of-tree SYRKs; 128x128 tiles (register- or LDS-staged) were tried and lost
+    // to it because they drop to one wave per SIMD.
+    hipLaunchKernelGGL(k_gemm_nt<2>, dim3(cdiv(maxM, 64), cdiv(maxN, 64), nactive), dim3(256), 0, st, S, list, kb, mode, L, CB);
 }
 void launch_fwd_assemble(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_rows, double *X,
                          double *W, int nr, int ldx) {

@@ -22,57 +22,19 @@ namespace gmrfx {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+constexpr int lds_ldf(int R) { return R + 2; }                                   // = 2 (mod 4), odd half: conflict-free tile RMW
+constexpr int lds_ldp(int R) { return (R + 16) % 32 == 16 ? R + 16 : R + 32; }   // = 16 (mod 32): conflict-free operand reads
+constexpr int LDW = 80;                                                          // 64 columns, = 16 (mod 32)
+
+// Partial Cholesky (first c columns) of the r x r front held in LDS (F, column-major, leading
+// dimension lds_ldf(RMAX)), 4 columns per step, together with X = L11^-1 (stored transposed in
+// the strict upper triangle of F's c x c block). Must be called by all 256 threads.
 template <int RMAX>
-__global__ __launch_bounds__(256) void k_factor_small(DevSym S, const int *__restrict__ list,
-                                                      const double *__restrict__ nzval, double *__restrict__ L,
-                                                      double *__restrict__ CB, int *__restrict__ info) {
-    constexpr int LDF = RMAX + 2;    // = 2 (mod 32): conflict-free tile access with the column on the lanes
-    constexpr int LDP = RMAX + 16;   // = 16 (mod 32): conflict-free operand reads
-    __shared__ double F[LDF * RMAX];
-    __shared__ double Pn[4 * LDP];   // current panel, Pn[q][i] = L[i][j0+q] (0 outside the panel rows)
-    constexpr int LDW = 80;          // 64 columns, = 16 (mod 32)
-    __shared__ double Wn[4 * LDW];   // current rows of L11^-1, Wn[q][b] = X[j0+q][b] (0 for b > j0+q)
-    const int s = list[blockIdx.x];
-    const int first = S.sfirst[s];
-    const int c = S.sfirst[s + 1] - first;
-    const int r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
-    const int ld = S.ld[s];
-    const int m = r - c;
+__device__ __forceinline__ void lds_partial_cholesky(double *F, double *Pn, double *Wn, const int c, const int r,
+                                                      const int first, int *__restrict__ info) {
+    constexpr int LDF = lds_ldf(RMAX);
+    constexpr int LDP = lds_ldp(RMAX);
     const int tid = threadIdx.x;
-    double *P = L + S.panelptr[s];
-
-    // ---- assembly in LDS -----------------------------------------------------------------
-    for (int idx = tid; idx < LDF * RMAX; idx += 256) F[idx] = 0.0;
-    __syncthreads();
-    {
-        const long long q0 = S.qptr[s];
-        const int nq = (int)(S.qptr[s + 1] - q0);
-        for (int q = tid; q < nq; q += 256) {
-            const int rel = S.qdst[q0 + q];
-            const int col = rel / ld, row = rel - col * ld;
-            F[col * LDF + row] = nzval[S.qsrc[q0 + q]];
-        }
-    }
-    __syncthreads();
-    for (long long ch = S.childptr[s]; ch < S.childptr[s + 1]; ch++) {
-        const int d = S.children[ch];
-        const int cd = S.sfirst[d + 1] - S.sfirst[d];
-        const int md = (int)(S.rowptr[d + 1] - S.rowptr[d]) - cd;
-        const int *reld = S.rel + S.rowptr[d] + cd;
-        const double *Ud = CB + S.cbptr[d];
-        // 4 child columns at a time, 64 lanes down the column
-        const int lane = tid & 63, jj = tid >> 6;
-        for (int j0 = 0; j0 < md; j0 += 4) {
-            const int j = j0 + jj;
-            if (j < md) {
-                const int tc = reld[j];
-                for (int i = j + lane; i < md; i += 64) F[tc * LDF + reld[i]] += Ud[i + (long long)j * md];
-            }
-        }
-        __syncthreads();
-    }
-
-    // ---- partial factorisation, 4 columns per step -----------------------------------------------
     const int wave = tid >> 6, lane = tid & 63;
     const int lm = lane & 15, lk = lane >> 4;
     for (int j0 = 0; j0 < c; j0 += 4) {
@@ -84,17 +46,19 @@ __global__ __launch_bounds__(256) void k_factor_small(DevSym S, const int *__res
 #pragma unroll
             for (int b = 0; b <= a; b++)
                 dd[a][b] = (a < nbk) ? F[(j0 + b) * LDF + j0 + a] : ((a == b) ? 1.0 : 0.0);
+        // reciprocal pivots: one sqrt + one division per pivot, everything else multiplies (the
+        // dependent chain of this 4x4 factorisation is on the critical path of every panel step)
         const double p0 = dd[0][0];
-        const double l00 = sqrt(p0);
-        const double l10 = dd[1][0] / l00, l20 = dd[2][0] / l00, l30 = dd[3][0] / l00;
+        const double i00 = 1.0 / sqrt(p0);
+        const double l10 = dd[1][0] * i00, l20 = dd[2][0] * i00, l30 = dd[3][0] * i00;
         const double p1 = dd[1][1] - l10 * l10;
-        const double l11 = sqrt(p1);
-        const double l21 = (dd[2][1] - l20 * l10) / l11, l31 = (dd[3][1] - l30 * l10) / l11;
+        const double i11 = 1.0 / sqrt(p1);
+        const double l21 = (dd[2][1] - l20 * l10) * i11, l31 = (dd[3][1] - l30 * l10) * i11;
         const double p2 = dd[2][2] - l20 * l20 - l21 * l21;
-        const double l22 = sqrt(p2);
-        const double l32 = (dd[3][2] - l30 * l20 - l31 * l21) / l22;
+        const double i22 = 1.0 / sqrt(p2);
+        const double l32 = (dd[3][2] - l30 * l20 - l31 * l21) * i22;
         const double p3 = dd[3][3] - l30 * l30 - l31 * l31 - l32 * l32;
-        const double l33 = sqrt(p3);
+        const double i33 = 1.0 / sqrt(p3);
         if (tid == 0) {
             int bad = -1;
             if (!(p3 > 0.0) && nbk > 3) bad = 3;
@@ -116,10 +80,10 @@ __global__ __launch_bounds__(256) void k_factor_small(DevSym S, const int *__res
 #pragma unroll
                 for (int k = 0; k < 4; k++) p[k] = (k < nbk) ? F[(j0 + k) * LDF + i] : 0.0;
                 const int a = i - j0;   // position inside the diagonal block if < 4
-                x[0] = p[0] / l00;
-                x[1] = (a >= 1) ? (p[1] - x[0] * l10) / l11 : 0.0;
-                x[2] = (a >= 2) ? (p[2] - x[0] * l20 - x[1] * l21) / l22 : 0.0;
-                x[3] = (a >= 3) ? (p[3] - x[0] * l30 - x[1] * l31 - x[2] * l32) / l33 : 0.0;
+                x[0] = p[0] * i00;
+                x[1] = (a >= 1) ? (p[1] - x[0] * l10) * i11 : 0.0;
+                x[2] = (a >= 2) ? (p[2] - x[0] * l20 - x[1] * l21) * i22 : 0.0;
+                x[3] = (a >= 3) ? (p[3] - x[0] * l30 - x[1] * l31 - x[2] * l32) * i33 : 0.0;
 #pragma unroll
                 for (int k = 0; k < 4; k++) if (k >= nbk) x[k] = 0.0;
             }
@@ -139,10 +103,10 @@ __global__ __launch_bounds__(256) void k_factor_small(DevSym S, const int *__res
                     }
                     mv[a] = v;
                 }
-                wv[0] = mv[0] / l00;
-                wv[1] = (mv[1] - l10 * wv[0]) / l11;
-                wv[2] = (mv[2] - l20 * wv[0] - l21 * wv[1]) / l22;
-                wv[3] = (mv[3] - l30 * wv[0] - l31 * wv[1] - l32 * wv[2]) / l33;
+                wv[0] = mv[0] * i00;
+                wv[1] = (mv[1] - l10 * wv[0]) * i11;
+                wv[2] = (mv[2] - l20 * wv[0] - l21 * wv[1]) * i22;
+                wv[3] = (mv[3] - l30 * wv[0] - l31 * wv[1] - l32 * wv[2]) * i33;
 #pragma unroll
                 for (int a = 0; a < 4; a++) if (a >= nbk || b > j0 + a) wv[a] = 0.0;
             }
@@ -218,6 +182,60 @@ __global__ __launch_bounds__(256) void k_factor_small(DevSym S, const int *__res
         __syncthreads();
     }
 
+}
+
+template <int RMAX>
+__global__ __launch_bounds__(256, (RMAX <= 64 ? 4 : (RMAX <= 96 ? 2 : 1))) void k_factor_small(DevSym S, const int *__restrict__ list,
+                                                      const double *__restrict__ nzval, double *__restrict__ L,
+                                                      double *__restrict__ CB, int *__restrict__ info) {
+    constexpr int LDF = lds_ldf(RMAX);
+    constexpr int LDP = lds_ldp(RMAX);
+    __shared__ double F[LDF * RMAX];
+    __shared__ double Pn[4 * LDP];   // current panel, Pn[q][i] = L[i][j0+q] (0 outside the panel rows)
+    __shared__ double Wn[4 * LDW];   // current rows of L11^-1, Wn[q][b] = X[j0+q][b] (0 for b > j0+q)
+    const int s = list[blockIdx.x];
+    const int first = S.sfirst[s];
+    const int c = S.sfirst[s + 1] - first;
+    const int r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
+    const int ld = S.ld[s];
+    const int m = r - c;
+    const int tid = threadIdx.x;
+    double *P = L + S.panelptr[s];
+
+    // ---- assembly in LDS -----------------------------------------------------------------
+    for (int idx = tid; idx < LDF * RMAX; idx += 256) F[idx] = 0.0;
+    __syncthreads();
+    {
+        const long long q0 = S.qptr[s];
+        const int nq = (int)(S.qptr[s + 1] - q0);
+        for (int q = tid; q < nq; q += 256) {
+            const int rel = S.qdst[q0 + q];
+            const int col = rel / ld, row = rel - col * ld;
+            F[col * LDF + row] = nzval[S.qsrc[q0 + q]];
+        }
+    }
+    __syncthreads();
+    for (long long ch = S.childptr[s]; ch < S.childptr[s + 1]; ch++) {
+        const int d = S.children[ch];
+        const int cd = S.sfirst[d + 1] - S.sfirst[d];
+        const int md = (int)(S.rowptr[d + 1] - S.rowptr[d]) - cd;
+        const int *reld = S.rel + S.rowptr[d] + cd;
+        const double *Ud = CB + S.cbptr[d];
+        // 4 child columns at a time, 64 lanes down the column
+        const int lane = tid & 63, jj = tid >> 6;
+        for (int j0 = 0; j0 < md; j0 += 4) {
+            const int j = j0 + jj;
+            if (j < md) {
+                const int tc = reld[j];
+                for (int i = j + lane; i < md; i += 64) F[tc * LDF + reld[i]] += Ud[i + (long long)j * md];
+            }
+        }
+        __syncthreads();
+    }
+
+    lds_partial_cholesky<RMAX>(F, Pn, Wn, c, r, first, info);
+    const int wave = tid >> 6, lane = tid & 63;
+
     // ---- write-out: panel (L lower + (L11^-1)' strict upper of the diagonal block), CB (lower) ---
     for (int j = wave; j < c; j += 4) {
         double *dst = P + (long long)j * ld;
@@ -250,7 +268,7 @@ __device__ __forceinline__ double linv_elem(const double *__restrict__ P, int ld
 }
 
 template <int RMAX>
-__global__ __launch_bounds__(256) void k_fwd_small(DevSym S, const int *__restrict__ list,
+__global__ __launch_bounds__(256, (RMAX <= 64 ? 4 : 2)) void k_fwd_small(DevSym S, const int *__restrict__ list,
                                                    const double *__restrict__ L, double *__restrict__ X,
                                                    double *__restrict__ W, int nr, int ldx) {
     __shared__ double fv[RMAX * LDV];
@@ -267,6 +285,7 @@ __global__ __launch_bounds__(256) void k_fwd_small(DevSym S, const int *__restri
     const double jm = j < nr ? 1.0 : 0.0;
     // own rows <- b ; trailing rows <- 0
     // (rows r..RMAX-1 are zeroed too: masked MFMA k-steps still multiply 0 by whatever is there)
+#pragma unroll 8
     for (int i = g; i < RMAX; i += 4) {
         double v = 0.0;
         if (i < c) v = X[(long long)(first + i) * ldx + jc] * jm;
@@ -279,6 +298,7 @@ __global__ __launch_bounds__(256) void k_fwd_small(DevSym S, const int *__restri
         const int md = (int)(S.rowptr[d + 1] - S.rowptr[d]) - cd;
         const int *reld = S.rel + S.rowptr[d] + cd;
         const double *Wd = W + S.wptr[d] * ldx;
+#pragma unroll 4
         for (int a = g; a < md; a += 4) fv[reld[a] * LDV + j] += Wd[(long long)a * ldx + jc] * jm;
         __syncthreads();
     }
@@ -293,6 +313,7 @@ __global__ __launch_bounds__(256) void k_fwd_small(DevSym S, const int *__restri
         for (int t = 0; t < 4; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
         if (k0 < c) {
             const int qhi = min(c, k0 + 16);
+#pragma unroll 1
             for (int q0 = 0; q0 < qhi; q0 += 16) {
                 double av[4];
 #pragma unroll
@@ -327,21 +348,23 @@ __global__ __launch_bounds__(256) void k_fwd_small(DevSym S, const int *__restri
     }
     // ---- W_s = (children's contributions) - L21 y --------------------------------------------
     const int ntile = (r - c + 15) >> 4;
+#pragma unroll 1
     for (int it = wave; it < ntile; it += 4) {
         const int i0 = c + it * 16;
         const double *pa = P + min(i0 + lm, r - 1);
         d4 acc[4];
 #pragma unroll
         for (int t = 0; t < 4; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
-        for (int q0 = 0; q0 < c; q0 += 32) {
-            double av[8];
+#pragma unroll 1
+        for (int q0 = 0; q0 < c; q0 += 16) {
+            double av[4];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < 4; u++) {
                 const int q = q0 + 4 * u + lk;
                 av[u] = pa[(long long)min(q, c - 1) * ld] * (q < c ? 1.0 : 0.0);
             }
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < 4; u++) {
                 const int q = min(q0 + 4 * u + lk, RMAX - 1);
                 if (q0 + 4 * u < c) {
 #pragma unroll
@@ -365,7 +388,7 @@ __global__ __launch_bounds__(256) void k_fwd_small(DevSym S, const int *__restri
 }
 
 template <int RMAX>
-__global__ __launch_bounds__(256) void k_bwd_small(DevSym S, const int *__restrict__ list,
+__global__ __launch_bounds__(256, (RMAX <= 64 ? 4 : 2)) void k_bwd_small(DevSym S, const int *__restrict__ list,
                                                    const double *__restrict__ L, double *__restrict__ X, int nr,
                                                    int ldx) {
     __shared__ double fv[RMAX * LDV];
@@ -381,6 +404,7 @@ __global__ __launch_bounds__(256) void k_bwd_small(DevSym S, const int *__restri
         const int j = tid & 63, g = tid >> 6;
         const int jc = min(j, nr - 1);
         const double jm = j < nr ? 1.0 : 0.0;
+#pragma unroll 8
         for (int i = g; i < RMAX; i += 4) fv[i * LDV + j] = (i < r) ? X[(long long)rows[i] * ldx + jc] * jm : 0.0;
     }
     __syncthreads();
@@ -394,15 +418,16 @@ __global__ __launch_bounds__(256) void k_bwd_small(DevSym S, const int *__restri
         d4 acc[4];
 #pragma unroll
         for (int t = 0; t < 4; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
-        for (int q0 = c; q0 < r; q0 += 32) {
-            double av[8];
+#pragma unroll 1
+        for (int q0 = c; q0 < r; q0 += 16) {
+            double av[4];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < 4; u++) {
                 const int q = q0 + 4 * u + lk;
                 av[u] = pa[min(q, r - 1)] * (q < r ? 1.0 : 0.0);
             }
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < 4; u++) {
                 const int q = min(q0 + 4 * u + lk, RMAX - 1);
                 if (q0 + 4 * u < r) {
 #pragma unroll
@@ -428,6 +453,7 @@ __global__ __launch_bounds__(256) void k_bwd_small(DevSym S, const int *__restri
         d4 acc[4];
 #pragma unroll
         for (int t = 0; t < 4; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
         for (int q0 = k0; q0 < c; q0 += 16) {
             double av[4];
 #pragma unroll
@@ -454,25 +480,70 @@ __global__ __launch_bounds__(256) void k_bwd_small(DevSym S, const int *__restri
     }
 }
 
+// 64 x 64 diagonal block of a big front: factor + inverse with the same LDS machinery
+// (16 panel steps of 4 columns instead of 64 single-column steps).
+__global__ __launch_bounds__(256) void k_potrf_lds(DevSym S, const int *__restrict__ list, int kb,
+                                                   double *__restrict__ L, int *__restrict__ info) {
+    constexpr int LDF = lds_ldf(64);
+    __shared__ double F[LDF * 64];
+    __shared__ double Pn[4 * lds_ldp(64)];
+    __shared__ double Wn[4 * LDW];
+    const int s = list[blockIdx.x];
+    const int c = S.sfirst[s + 1] - S.sfirst[s];
+    if (kb >= c) return;
+    const int w = min(NB, c - kb);
+    const int ld = S.ld[s];
+    double *P = L + S.panelptr[s] + kb + (long long)kb * ld;
+    const int tid = threadIdx.x;
+    // 16 unconditional loads per thread (column j = idx / 64, row i = idx % 64), lower part kept
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+        const int idx = tid + 256 * u;
+        const int i = idx & 63, j = idx >> 6;
+        v[u] = P[min(i, w - 1) + (long long)min(j, w - 1) * ld];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+        const int idx = tid + 256 * u;
+        const int i = idx & 63, j = idx >> 6;
+        F[j * LDF + i] = v[u] * ((i < w && j < w && i >= j) ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    lds_partial_cholesky<64>(F, Pn, Wn, w, w, S.sfirst[s] + kb, info);
+    for (int idx = tid; idx < 64 * 64; idx += 256) {
+        const int i = idx & 63, j = idx >> 6;
+        if (i < w && j < w) P[i + (long long)j * ld] = F[j * LDF + i];
+    }
+}
+void launch_potrf_lds(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, double *L, int *info) {
+    if (nactive <= 0) return;
+    hipLaunchKernelGGL(k_potrf_lds, dim3(nactive), dim3(256), 0, st, S, list, kb, L, info);
+}
+
 void launch_factor_small(hipStream_t st, const DevSym &S, const int *list, int nfronts, int rmax,
                          const double *nzval, double *L, double *CB, int *info) {
     if (nfronts <= 0) return;
-    if (rmax <= 96)
-        hipLaunchKernelGGL(k_factor_small<96>, dim3(nfronts), dim3(256), 0, st, S, list, nzval, L, CB, info);
-    else
-        hipLaunchKernelGGL(k_factor_small<128>, dim3(nfronts), dim3(256), 0, st, S, list, nzval, L, CB, info);
+    if (rmax <= 48) hipLaunchKernelGGL(k_factor_small<48>, dim3(nfronts), dim3(256), 0, st, S, list, nzval, L, CB, info);
+    else if (rmax <= 64) hipLaunchKernelGGL(k_factor_small<64>, dim3(nfronts), dim3(256), 0, st, S, list, nzval, L, CB, info);
+    else if (rmax <= 96) hipLaunchKernelGGL(k_factor_small<96>, dim3(nfronts), dim3(256), 0, st, S, list, nzval, L, CB, info);
+    else hipLaunchKernelGGL(k_factor_small<128>, dim3(nfronts), dim3(256), 0, st, S, list, nzval, L, CB, info);
 }
 
 void launch_fwd_small(hipStream_t st, const DevSym &S, const int *list, int nfronts, int rmax, const double *L,
                       double *X, double *W, int nr, int ldx) {
     if (nfronts <= 0) return;
-    if (rmax <= 96) hipLaunchKernelGGL(k_fwd_small<96>, dim3(nfronts), dim3(256), 0, st, S, list, L, X, W, nr, ldx);
+    if (rmax <= 48) hipLaunchKernelGGL(k_fwd_small<48>, dim3(nfronts), dim3(256), 0, st, S, list, L, X, W, nr, ldx);
+    else if (rmax <= 64) hipLaunchKernelGGL(k_fwd_small<64>, dim3(nfronts), dim3(256), 0, st, S, list, L, X, W, nr, ldx);
+    else if (rmax <= 96) hipLaunchKernelGGL(k_fwd_small<96>, dim3(nfronts), dim3(256), 0, st, S, list, L, X, W, nr, ldx);
     else hipLaunchKernelGGL(k_fwd_small<128>, dim3(nfronts), dim3(256), 0, st, S, list, L, X, W, nr, ldx);
 }
 void launch_bwd_small(hipStream_t st, const DevSym &S, const int *list, int nfronts, int rmax, const double *L,
                       double *X, int nr, int ldx) {
     if (nfronts <= 0) return;
-    if (rmax <= 96) hipLaunchKernelGGL(k_bwd_small<96>, dim3(nfronts), dim3(256), 0, st, S, list, L, X, nr, ldx);
+    if (rmax <= 48) hipLaunchKernelGGL(k_bwd_small<48>, dim3(nfronts), dim3(256), 0, st, S, list, L, X, nr, ldx);
+    else if (rmax <= 64) hipLaunchKernelGGL(k_bwd_small<64>, dim3(nfronts), dim3(256), 0, st, S, list, L, X, nr, ldx);
+    else if (rmax <= 96) hipLaunchKernelGGL(k_bwd_small<96>, dim3(nfronts), dim3(256), 0, st, S, list, L, X, nr, ldx);
     else hipLaunchKernelGGL(k_bwd_small<128>, dim3(nfronts), dim3(256), 0, st, S, list, L, X, nr, ldx);
 }
 

@@ -358,13 +358,13 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
     // small fronts (fused LDS kernels, small.hip): r <= 96 or r <= 128 rows and <= 64 columns
     S.small_rows = opt.small_front_rows >= 0 ? opt.small_front_rows : 128;
     S.is_small.resize(ns);
+    static const int kClsRows[4] = {48, 64, 96, 128};
     auto cls = [&](i32 s) -> int {
-        if (S.ncols(s) > 64) return 2;
-        if (S.nrows(s) <= std::min(96, S.small_rows)) return 0;
-        if (S.nrows(s) <= std::min(128, S.small_rows)) return 1;
-        return 2;
+        if (S.ncols(s) > 64) return 4;
+        for (int k = 0; k < 4; k++) if (S.nrows(s) <= std::min(kClsRows[k], S.small_rows)) return k;
+        return 4;
     };
-    for (i32 s = 0; s < ns; s++) S.is_small[s] = cls(s) < 2;
+    for (i32 s = 0; s < ns; s++) S.is_small[s] = cls(s) < 4;
     S.levelptr.assign(S.nlevels + 1, 0);
     for (i32 s = 0; s < ns; s++) S.levelptr[S.level[s] + 1]++;
     for (i32 l = 0; l < S.nlevels; l++) S.levelptr[l + 1] += S.levelptr[l];
@@ -372,19 +372,18 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
     { std::vector<i64> w(S.levelptr.begin(), S.levelptr.end() - 1);
       for (i32 s = 0; s < ns; s++) S.levellist[w[S.level[s]]++] = s; }
     S.level_nsmall.assign(S.nlevels, 0);
-    S.level_nsmall96.assign(S.nlevels, 0);
+    S.level_ncls.assign((size_t)S.nlevels * 4, 0);
     for (i32 l = 0; l < S.nlevels; l++) {
         auto b = S.levellist.begin() + S.levelptr[l], e = S.levellist.begin() + S.levelptr[l + 1];
         std::stable_sort(b, e, [&](i32 x, i32 y) {
             const int cx = cls(x), cy = cls(y);
             if (cx != cy) return cx < cy;
-            if (cx < 2) return x < y;
+            if (cx < 4) return x < y;
             return S.ncols(x) != S.ncols(y) ? S.ncols(x) > S.ncols(y) : x < y;
         });
-        i32 k = 0, k96 = 0;
-        for (auto it = b; it != e; ++it) { if (cls(*it) < 2) k++; if (cls(*it) == 0) k96++; }
+        i32 k = 0;
+        for (auto it = b; it != e; ++it) { const int cc = cls(*it); if (cc < 4) { k++; S.level_ncls[(size_t)l * 4 + cc]++; } }
         S.level_nsmall[l] = k;
-        S.level_nsmall96[l] = k96;
         S.n_small += k;
         S.n_big += (e - b) - k;
     }

@@ -55,7 +55,7 @@ struct Symbolic {
     std::vector<i32> levellist;   // supernodes by level; inside a level: small fronts first,
                                   // then big fronts by decreasing column count
     std::vector<i32> level_nsmall;// per level: number of small fronts (prefix of the level's list)
-    std::vector<i32> level_nsmall96;// per level: how many of those have r <= 96 (they come first)
+    std::vector<i32> level_ncls;  // per level x 4: small fronts with r <= 48 / 64 / 96 / 128 (in this order in the list)
     std::vector<uint8_t> is_small;// per supernode
     int small_rows = 0;
     // Q scatter map, sorted by destination

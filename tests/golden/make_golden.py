@@ -54,7 +54,8 @@ def make(name, Q, perm, seed):
     np.savez_compressed(
         os.path.join(HERE, name + ".npz"), n=n, colptr=Q.indptr.astype(np.int64), rowval=Q.indices.astype(np.int64),
         nzval=Q.data, perm=np.asarray(perm, dtype=np.int64), B=B, X=X, Z=Zs, Xb=Xb, logdet=logdet,
-        selinv_diag=np.diag(Dinv).copy(), Qinv_on_pattern=Dinv[Q.nonzero()].copy(), L_colcount=colcount,
+        selinv_diag=np.diag(Dinv).copy(),
+        Qinv_on_pattern=Dinv[Q.indices, np.repeat(np.arange(n), np.diff(Q.indptr))].copy(), L_colcount=colcount,
         L_diag=np.diag(Lp).copy())
     print(f"{name}: n={n} nnz={Q.nnz} nnz(L)={colcount.sum()} logdet={logdet:.12g}")
 
