@@ -126,6 +126,33 @@ void Device::upload(const Symbolic &S) {
         L.active.push_back(max_trail);  // stash: last element = max trailing rows of the level
     }
 
+    // fronts with more than one 64-column block, by decreasing width: dense-inverse stages
+    {
+        std::vector<int> il;
+        for (i32 s = 0; s < ns; s++) if (S.ncols(s) > NB) il.push_back(s);
+        std::sort(il.begin(), il.end(), [&](int a, int b) { return S.ncols(a) != S.ncols(b) ? S.ncols(a) > S.ncols(b) : a < b; });
+        inv_maxc_ = il.empty() ? 0 : S.ncols(il[0]);
+        const int *p; up(p, il); d_invlist_ = const_cast<int *>(p);
+        long long tmax = 0;
+        for (int B = NB; B < inv_maxc_; B *= 2) {
+            int na = 0;
+            std::vector<long long> off;
+            long long acc = 0;
+            for (int s : il) {
+                if (S.ncols(s) <= B) break;
+                off.push_back(acc);
+                acc += (long long)((S.ncols(s) + 2 * B - 1) / (2 * B)) * B * B;
+                na++;
+            }
+            inv_nact_.push_back(na);
+            const long long *lq; up(lq, off); d_inv_toff_.push_back(const_cast<long long *>(lq));
+            HC(hipStreamSynchronize(stream));
+            tmax = std::max(tmax, acc);
+        }
+        d_invT_ = dalloc<double>((size_t)std::max<long long>(tmax, 1));
+        HC(hipStreamSynchronize(stream));
+    }
+
     l_size_ = S.panelptr[ns];
     d_L_ = dalloc<double>((size_t)l_size_);
     d_cb_ = dalloc<double>((size_t)S.cb_arena);
@@ -171,6 +198,16 @@ void Device::factor_levels() {
     }
 }
 
+void Device::invert_diag_blocks() {
+    int stage = 0;
+    for (int B = NB; B < inv_maxc_; B *= 2, stage++) {
+        const int na = inv_nact_[stage];
+        if (na <= 0) break;
+        launch_inv_stage(stream, ds_, d_invlist_, na, B, inv_maxc_, 1, d_L_, d_invT_, d_inv_toff_[stage]);
+        launch_inv_stage(stream, ds_, d_invlist_, na, B, inv_maxc_, 2, d_L_, d_invT_, d_inv_toff_[stage]);
+    }
+}
+
 void Device::refactorize(const double *nzval, bool on_device) {
     HC(hipSetDevice(device));
     const double *src = nzval;
@@ -185,6 +222,7 @@ void Device::refactorize(const double *nzval, bool on_device) {
     (void)src;
     HC(hipEventRecord(ev_[0], stream));
     factor_levels();
+    invert_diag_blocks();
     HC(hipEventRecord(ev_[1], stream));
     HC(hipStreamSynchronize(stream));
     HC(hipGetLastError());
@@ -206,6 +244,7 @@ void Device::ensure_rhs_capacity(long long nrhs) {
     if (chunk > rhs_cap_) {
         // (old buffers stay in allocs_ until destruction; capacity only ever grows to 64)
         d_X_ = dalloc<double>((size_t)S_->n * 64);
+        d_X2_ = dalloc<double>((size_t)S_->n * 64);
         d_W_ = dalloc<double>((size_t)std::max<long long>(sum_trail_, 1) * 64);
         rhs_cap_ = 64;
     }
@@ -218,12 +257,11 @@ void Device::forward(int nr, int ldx) {
         const int *list = d_levellist_ + L.first + L.nsmall;
         const int nf = L.count - L.nsmall;
         launch_fwd_assemble(stream, ds_, list, nf, L.max_rows, d_X_, d_W_, nr, ldx);
-        const int nblk = level_nblk(L);
-        for (int b = 0; b < nblk; b++) {
-            const int kb = b * NB;
-            launch_solve_diag(stream, ds_, list, L.active[b], kb, 0, d_L_, d_X_, nr, ldx);
-            launch_fwd_update(stream, ds_, list, L.active[b], kb, L.max_rows - kb - 1, d_L_, d_X_, d_W_, nr, ldx);
-        }
+        // y = L11^-1 b as one triangular product per front (dense inverse, inverse.hip), then the
+        // trailing update W -= L21 y with K = all columns of the front
+        launch_xmul(stream, ds_, list, nf, L.max_cols, 0, d_L_, d_X_, d_X2_, nr, ldx);
+        launch_copy_own(stream, ds_, list, nf, L.max_cols, d_X2_, d_X_, nr, ldx);
+        launch_fwd_update(stream, ds_, list, nf, 0, INT_MAX, level_max_trail(L), d_L_, d_X_, d_W_, nr, ldx);
     }
 }
 
@@ -235,12 +273,8 @@ void Device::backward(int nr, int ldx) {
         for (int k = 0, off = 0; k < 4; off += L.ncls[k], k++)
             launch_bwd_small(stream, ds_, d_levellist_ + L.first + off, L.ncls[k], kClsRows[k], d_L_, d_X_, nr, ldx);
         if (level_max_trail(L) > 0) launch_bwd_gemm(stream, ds_, list, nf, 0, 0, L.max_cols, d_L_, d_X_, nr, ldx);
-        const int nblk = level_nblk(L);
-        for (int b = nblk - 1; b >= 0; b--) {
-            const int kb = b * NB;
-            launch_solve_diag(stream, ds_, list, L.active[b], kb, 1, d_L_, d_X_, nr, ldx);
-            if (kb > 0) launch_bwd_gemm(stream, ds_, list, L.active[b], kb, 1, kb, d_L_, d_X_, nr, ldx);
-        }
+        launch_xmul(stream, ds_, list, nf, L.max_cols, 1, d_L_, d_X_, d_X2_, nr, ldx);
+        launch_copy_own(stream, ds_, list, nf, L.max_cols, d_X2_, d_X_, nr, ldx);
     }
 }
 

@@ -82,7 +82,14 @@ private:
     std::vector<LevelInfo> levels_;
     int *d_levellist_ = nullptr;
     double *d_L_ = nullptr, *d_Z_ = nullptr, *d_cb_ = nullptr, *d_nz_ = nullptr;
-    double *d_X_ = nullptr, *d_W_ = nullptr, *d_io_ = nullptr, *d_tmp_ = nullptr, *d_part_ = nullptr;
+    double *d_X_ = nullptr, *d_X2_ = nullptr, *d_W_ = nullptr, *d_io_ = nullptr, *d_tmp_ = nullptr, *d_part_ = nullptr;
+    // dense-inverse stages (inverse.hip)
+    int *d_invlist_ = nullptr;
+    std::vector<int> inv_nact_;            // per stage: fronts with more than 64<<stage columns
+    std::vector<long long *> d_inv_toff_;   // per stage: offsets of the T buffers
+    double *d_invT_ = nullptr;
+    int inv_maxc_ = 0;
+    void invert_diag_blocks();
     long long rhs_cap_ = 0, io_cap_ = 0, tmp_cap_ = 0;
     int *d_info_ = nullptr;
     hipEvent_t ev_[8] = {};

@@ -1,0 +1,236 @@
+// inverse.hip -- dense inverse X = L11^-1 of the diagonal block of every big front, and the
+// sweep kernels that use it.
+//
+// Why: with 64-column blocks the triangular sweeps of the top separator fronts are a chain of
+// ~c/64 dependent (diagonal solve, update) launch pairs per level and direction -- ~120 latency-
+// bound steps of 30-40 us each on the 1M-node benchmark. L11 of a separator front is well
+// conditioned (cond ~ 1e2 on SPDE precisions), so its explicit inverse turns the whole diagonal
+// solve of a level into ONE triangular matrix product that parallelises over row tiles.
+//
+// Storage: X[k][q] (k > q) lives at P[q + k*ld], i.e. transposed in the strict upper triangle of
+// the c x c diagonal block of the panel, which the factorisation never touches (the 64 x 64
+// diagonal sub-blocks are already filled by k_potrf_lds); diag(X) = 1/diag(L) stays implicit.
+//
+// Construction by recursive doubling, B = 64, 128, 256, ...: for every aligned pair of blocks
+//   [ A  0 ]^-1   [ A^-1           0   ]
+//   [ Bm C ]    = [ -C^-1 Bm A^-1  C^-1 ]        T' = (Bm A^-1)'  (phase 1),  X10 = -C^-1 T (phase 2)
+// all pairs of all fronts of a stage run in the same two launches (FP64 MFMA, 64x64 tiles).
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace gmrfx {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// X[k][q] for 0 <= k,q < c (0 above the diagonal). Unconditional clamped load + arithmetic mask.
+__device__ __forceinline__ double xinv_elem(const double *__restrict__ P, int ld, int c, int k, int q) {
+    const int kk = min(max(k, 0), c - 1), qq = min(max(q, 0), c - 1);
+    const double v = P[min(kk, qq) + (long long)max(kk, qq) * ld];
+    const bool in = k >= 0 && q >= 0 && k < c && q < c;
+    double x = v * ((in && q < k) ? 1.0 : 0.0);
+    if (in && k == q) x = 1.0 / v;
+    return x;
+}
+
+// One 64x64 output tile per workgroup (4 waves x 32x32). phase 1: T'[j][i] = sum_q Bm[i][q] Ainv[q][j];
+// phase 2: X10[i][j] = - sum_q Cinv[i][q] T[q][j], written transposed into the upper triangle.
+// blockIdx = (tile, pair, front).
+__global__ __launch_bounds__(256) void k_inv_stage(DevSym S, const int *__restrict__ list, int B, int phase,
+                                                   double *__restrict__ L, double *__restrict__ T,
+                                                   const long long *__restrict__ toff) {
+    const int s = list[blockIdx.z];
+    const int c = S.sfirst[s + 1] - S.sfirst[s];
+    const int o = 2 * B * blockIdx.y;          // first column of block A
+    if (o + B >= c) return;                     // no C block
+    const int nC = min(B, c - o - B);           // rows of C (and of Bm)
+    const int ld = S.ld[s];
+    double *P = L + S.panelptr[s];
+    double *Tp = T + toff[blockIdx.z] + (long long)blockIdx.y * B * B;   // T' stored [j + i*B]
+    const int ntj = B >> 6;                      // tiles along j (columns of A)
+    const int ti = blockIdx.x / ntj, tj = blockIdx.x % ntj;
+    if (ti * 64 >= nC) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lm = lane & 15, lk = lane >> 4;
+    const int i0 = ti * 64 + (wave & 1) * 32, j0 = tj * 64 + (wave >> 1) * 32;
+    if (i0 >= nC) return;
+    d4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+    constexpr int KU = 4;
+    if (phase == 1) {
+        // D[m][n]: m = i (rows of Bm), n = j.  A_mfma[m=i][q] = Bm[i][q] = P[(o+B+i) + (o+q)*ld]
+        //                                      B_mfma[q][n=j] = Ainv[q][j] (q >= j) = X[o+q][o+j]
+        const double *Ablk = P + o + (long long)o * ld;   // origin of block A inside the panel
+        for (int q0 = (j0 & ~15); q0 < B; q0 += 4 * KU) {
+            double av[KU][2], bv[KU][2];
+#pragma unroll
+            for (int u = 0; u < KU; u++) {
+                const int q = q0 + 4 * u + lk;
+#pragma unroll
+                for (int a = 0; a < 2; a++) {
+                    const int i = min(i0 + a * 16 + lm, nC - 1);
+                    av[u][a] = P[(o + B + i) + (long long)(o + min(q, B - 1)) * ld] * (q < B ? 1.0 : 0.0);
+                }
+#pragma unroll
+                for (int b = 0; b < 2; b++) bv[u][b] = xinv_elem(Ablk, ld, B, q, j0 + b * 16 + lm);
+            }
+#pragma unroll
+            for (int u = 0; u < KU; u++)
+#pragma unroll
+                for (int a = 0; a < 2; a++)
+#pragma unroll
+                    for (int b = 0; b < 2; b++)
+                        acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][a], bv[u][b], acc[a][b], 0, 0, 0);
+        }
+        // D[m = i][n = j] -> T'[j + i*B], j on the lanes (contiguous)
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) {
+                    const int i = i0 + a * 16 + lk + 4 * rr, j = j0 + b * 16 + lm;
+                    if (i < nC) Tp[j + (long long)i * B] = acc[a][b][rr];
+                }
+    } else {
+        // D[m][n]: m = i (rows of C), n = j.  A_mfma[m=i][q] = Cinv[i][q] (q <= i) = X[o+B+i][o+B+q]
+        //                                      B_mfma[q][n=j] = T[q][j] = T'[j + q*B]
+        const double *Cblk = P + (o + B) + (long long)(o + B) * ld;
+        const int qhi = min(nC, i0 + 32);
+        for (int q0 = 0; q0 < qhi; q0 += 4 * KU) {
+            double av[KU][2], bv[KU][2];
+#pragma unroll
+            for (int u = 0; u < KU; u++) {
+                const int q = q0 + 4 * u + lk;
+#pragma unroll
+                for (int a = 0; a < 2; a++) av[u][a] = xinv_elem(Cblk, ld, nC, i0 + a * 16 + lm, q);
+#pragma unroll
+                for (int b = 0; b < 2; b++) bv[u][b] = Tp[(j0 + b * 16 + lm) + (long long)min(q, nC - 1) * B];
+            }
+#pragma unroll
+            for (int u = 0; u < KU; u++)
+#pragma unroll
+                for (int a = 0; a < 2; a++)
+#pragma unroll
+                    for (int b = 0; b < 2; b++)
+                        acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][a], bv[u][b], acc[a][b], 0, 0, 0);
+        }
+        // X10[i][j] = -acc, stored at upper (row o+j, col o+B+i): j on the lanes (contiguous)
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) {
+                    const int i = i0 + a * 16 + lk + 4 * rr, j = j0 + b * 16 + lm;
+                    if (i < nC) P[(o + j) + (long long)(o + B + i) * ld] = -acc[a][b][rr];
+                }
+    }
+}
+
+// Diagonal solve of a whole big front as a triangular product with X = L11^-1:
+//   trans = 0: Y[k] = sum_{q <= k} X[k][q] b[q]        (forward)
+//   trans = 1: Y[k] = sum_{q >= k} X[q][k] b[q]        (backward)
+// b = rows first..first+c of Xin (row-major, ldx), result goes to the same rows of Xout (it cannot
+// be written in place: other workgroups still need b). One wave = 16 rows x up to 64 RHS.
+__global__ __launch_bounds__(256) void k_xmul(DevSym S, const int *__restrict__ list, int trans,
+                                              const double *__restrict__ L, const double *__restrict__ Xin,
+                                              double *__restrict__ Xout, int nr, int ldx) {
+    const int s = list[blockIdx.y];
+    const int c = S.sfirst[s + 1] - S.sfirst[s];
+    __shared__ double red[3 * 64 * 16];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int k0 = blockIdx.x * 16;      // one 16-row tile per workgroup, the 4 waves split the K range
+    if (k0 >= c) return;
+    const int ld = S.ld[s];
+    const int first = S.sfirst[s];
+    const double *P = L + S.panelptr[s];
+    const double *Bb = Xin + (long long)first * ldx;
+    const int lm = lane & 15, lk = lane >> 4;
+    const int nt = (nr + 15) >> 4;
+    d4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+    const int qlo = trans ? k0 : 0, qhi = trans ? c : min(c, k0 + 16);
+    constexpr int KU = 4;
+    for (int q0 = qlo + wave * 4 * KU; q0 < qhi; q0 += 16 * KU) {
+        double av[KU], bv[KU][4];
+#pragma unroll
+        for (int u = 0; u < KU; u++) {
+            const int q = q0 + 4 * u + lk;
+            av[u] = trans ? xinv_elem(P, ld, c, q, k0 + lm) : xinv_elem(P, ld, c, k0 + lm, q);
+#pragma unroll
+            for (int t = 0; t < 4; t++) bv[u][t] = Bb[(long long)min(q, c - 1) * ldx + min(t * 16 + lm, nr - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < KU; u++)
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+                if (t < nt) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u][t], acc[t], 0, 0, 0);
+    }
+    // reduce the 4 partial tiles (same code as splitk_reduce in kernels.hip)
+    if (wave > 0) {
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) red[((wave - 1) * 16 + t * 4 + rr) * 64 + lane] = acc[t][rr];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; w++)
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) acc[t][rr] += red[(w * 16 + t * 4 + rr) * 64 + lane];
+    double *Yb = Xout + (long long)first * ldx;
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+        if (t < nt) {
+            const int j = t * 16 + lm;
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                const int k = k0 + lk + 4 * rr;
+                if (k < c && j < nr) Yb[(long long)k * ldx + j] = acc[t][rr];
+            }
+        }
+}
+
+// Xdst[own rows of the listed fronts] = Xsrc[same rows]
+__global__ __launch_bounds__(256) void k_copy_own(DevSym S, const int *__restrict__ list,
+                                                  const double *__restrict__ Xsrc, double *__restrict__ Xdst, int nr,
+                                                  int ldx) {
+    const int s = list[blockIdx.y];
+    const int c = S.sfirst[s + 1] - S.sfirst[s];
+    const long long base = (long long)S.sfirst[s] * ldx;
+    const long long cnt = (long long)c * ldx;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < cnt; i += (long long)gridDim.x * 256) {
+        if ((int)(i % ldx) < nr) Xdst[base + i] = Xsrc[base + i];
+    }
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+void launch_inv_stage(hipStream_t st, const DevSym &S, const int *list, int nactive, int B, int max_c, int phase,
+                      double *L, double *T, const long long *toff) {
+    if (nactive <= 0) return;
+    const int npair = cdiv(max_c, 2 * B);
+    const int ntile = (B / 64) * (B / 64);
+    hipLaunchKernelGGL(k_inv_stage, dim3(ntile, npair, nactive), dim3(256), 0, st, S, list, B, phase, L, T, toff);
+}
+void launch_xmul(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_c, int trans, const double *L,
+                 const double *Xin, double *Xout, int nr, int ldx) {
+    if (nfronts <= 0 || max_c <= 0) return;
+    hipLaunchKernelGGL(k_xmul, dim3(cdiv(max_c, 16), nfronts), dim3(256), 0, st, S, list, trans, L, Xin, Xout, nr, ldx);
+}
+void launch_copy_own(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_c, const double *Xsrc,
+                     double *Xdst, int nr, int ldx) {
+    if (nfronts <= 0 || max_c <= 0) return;
+    const int nb = std::max(1, std::min(64, cdiv(max_c * ldx, 256)));
+    hipLaunchKernelGGL(k_copy_own, dim3(nb, nfronts), dim3(256), 0, st, S, list, Xsrc, Xdst, nr, ldx);
+}
+
+}  // namespace gmrfx

@@ -21,8 +21,46 @@ void launch_fwd_assemble(hipStream_t st, const DevSym &S, const int *list, int n
                          double *W, int nr, int ldx);
 void launch_solve_diag(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int trans,
                        const double *L, double *X, int nr, int ldx);
-void launch_fwd_update(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int max_rows_below,
+void launch_fwd_update(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int wblk, int max_rows_below,
                        const double *L, double *X, double *W, int nr, int ldx);
+#ifdef __HIPCC__
+typedef double gmrfx_d4 __attribute__((ext_vector_type(4)));
+// Split-K reduction for the long-K sweep kernels: the 4 waves of a workgroup hold partial sums of
+// the SAME (16*NA) x 64 output tile (NA row tiles x 4 rhs tiles each; every wave swept a quarter of
+// the K range). After the call wave w owns the total of row tile w in acc[w][*].
+// `red` needs 3*16*64 doubles of LDS. Must be called by all 256 threads.
+template <int NA>
+__device__ __forceinline__ void splitk_reduce4(gmrfx_d4 (&acc)[NA][4], double *red, int wave, int lane) {
+#pragma unroll
+    for (int a = 0; a < NA; a++) {
+        __syncthreads();
+        if (wave != a) {
+            const int slot = wave < a ? wave : wave - 1;
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) red[(slot * 16 + t * 4 + rr) * 64 + lane] = acc[a][t][rr];
+        }
+        __syncthreads();
+        if (wave == a) {
+#pragma unroll
+            for (int sl = 0; sl < 3; sl++)
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+#pragma unroll
+                    for (int rr = 0; rr < 4; rr++) acc[a][t][rr] += red[(sl * 16 + t * 4 + rr) * 64 + lane];
+        }
+    }
+}
+#endif
+
+// inverse.hip -- dense L11^-1 of big fronts (recursive doubling) and the sweeps that use it
+void launch_inv_stage(hipStream_t st, const DevSym &S, const int *list, int nactive, int B, int max_c, int phase,
+                      double *L, double *T, const long long *toff);
+void launch_xmul(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_c, int trans, const double *L,
+                 const double *Xin, double *Xout, int nr, int ldx);
+void launch_copy_own(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_c, const double *Xsrc,
+                     double *Xdst, int nr, int ldx);
 void launch_bwd_gemm(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int mode, int max_out,
                      const double *L, double *X, int nr, int ldx);
 void launch_permute(hipStream_t st, const int *perm, int n, double *Bc, long long ldb, double *X, int nr, int ldx, int dir);

@@ -19,7 +19,7 @@
 
 namespace gmrfx {
 
-typedef double d4 __attribute__((ext_vector_type(4)));
+typedef gmrfx_d4 d4;
 
 __device__ __forceinline__ int lower_bound_i32(const int *a, int n, int v) {
     int lo = 0, hi = n;
@@ -485,14 +485,14 @@ __global__ __launch_bounds__(256) void k_solve_diag(DevSym S, const int *__restr
 // the block. T is X for the front's own rows and W_s for its trailing rows. One wave = 16 rows
 // x up to 64 right-hand sides (4 MFMA tiles); the result tile has the right-hand-side index on
 // the lanes, i.e. contiguous in the row-major X/W.
-__global__ __launch_bounds__(256) void k_fwd_update(DevSym S, const int *__restrict__ list, int kb,
+__global__ __launch_bounds__(256) void k_fwd_update(DevSym S, const int *__restrict__ list, int kb, int wblk,
                                                     const double *__restrict__ L, double *__restrict__ X,
                                                     double *__restrict__ W, int nr, int ldx) {
     const int s = list[blockIdx.y];
     const int c = S.sfirst[s + 1] - S.sfirst[s];
     const int r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
     if (kb >= c) return;
-    const int w = min(NB, c - kb);
+    const int w = min(wblk, c - kb);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i0 = kb + w + (blockIdx.x * 4 + wave) * 16;
     if (i0 >= r) return;
@@ -537,6 +537,76 @@ __global__ __launch_bounds__(256) void k_fwd_update(DevSym S, const int *__restr
                 if (i < r && j < nr) {
                     double *dst = (i < c) ? X + (long long)(first + i) * ldx + j : Ws + (long long)(i - c) * ldx + j;
                     *dst -= acc[t][rr];
+                }
+            }
+        }
+    }
+}
+
+// Long-K variant (dense-inverse sweeps: K = all c columns of a big front): a workgroup owns 32
+// trailing rows x 64 right-hand sides, every wave sweeps a quarter of the K range for the WHOLE
+// tile (16 MFMA tiles per k-step from 4 + 4 operand loads; 512-B contiguous panel segments per
+// column), the partial tiles are summed through LDS and each wave writes one row tile.
+__global__ __launch_bounds__(256) void k_fwd_update_longk(DevSym S, const int *__restrict__ list,
+                                                         const double *__restrict__ L, double *__restrict__ X,
+                                                         double *__restrict__ W, int nr, int ldx) {
+    __shared__ double red[3 * 16 * 64];
+    const int s = list[blockIdx.y];
+    const int c = S.sfirst[s + 1] - S.sfirst[s];
+    const int r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
+    const int i0 = c + blockIdx.x * 32;
+    if (i0 >= r) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lm = lane & 15, lk = lane >> 4;
+    const int ld = S.ld[s];
+    const double *P = L + S.panelptr[s];
+    const double *Yb = X + (long long)S.sfirst[s] * ldx;
+    double *Ws = W + S.wptr[s] * ldx;
+    const int nt = (nr + 15) >> 4;
+    constexpr int NA = 2;   // row tiles per workgroup (32 rows): 64 accumulator VGPRs, 3 waves/SIMD
+    d4 acc[NA][4];
+#pragma unroll
+    for (int a = 0; a < NA; a++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc[a][t] = (d4){0.0, 0.0, 0.0, 0.0};
+    const double *pa[NA];
+#pragma unroll
+    for (int a = 0; a < NA; a++) pa[a] = P + min(i0 + a * 16 + lm, r - 1);
+    const int jc[4] = {min(lm, nr - 1), min(16 + lm, nr - 1), min(32 + lm, nr - 1), min(48 + lm, nr - 1)};
+    constexpr int KU = 4;
+    for (int k0 = wave * 4 * KU; k0 < c; k0 += 16 * KU) {
+        double av[KU][NA], bv[KU][4];
+#pragma unroll
+        for (int u = 0; u < KU; u++) {
+            const int kk = k0 + 4 * u + lk;
+            const int kc = min(kk, c - 1);
+            const double mk = kk < c ? 1.0 : 0.0;
+#pragma unroll
+            for (int a = 0; a < NA; a++) av[u][a] = pa[a][(long long)kc * ld] * mk;
+#pragma unroll
+            for (int t = 0; t < 4; t++) bv[u][t] = Yb[(long long)kc * ldx + jc[t]];
+        }
+#pragma unroll
+        for (int u = 0; u < KU; u++)
+#pragma unroll
+            for (int a = 0; a < NA; a++)
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    if (t < nt) acc[a][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][a], bv[u][t], acc[a][t], 0, 0, 0);
+    }
+    splitk_reduce4<NA>(acc, red, wave, lane);
+    // wave w owns row tile w
+#pragma unroll
+    for (int a = 0; a < NA; a++) {
+        if (a != wave) continue;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            if (t < nt) {
+                const int j = t * 16 + lm;
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) {
+                    const int i = i0 + a * 16 + lk + 4 * rr;
+                    if (i < r && j < nr) Ws[(long long)(i - c) * ldx + j] -= acc[a][t][rr];
                 }
             }
         }
@@ -597,6 +667,74 @@ __global__ __launch_bounds__(256) void k_bwd_gemm(DevSym S, const int *__restric
             for (int rr = 0; rr < 4; rr++) {
                 const int col = i0 + lk + 4 * rr;
                 if (col < nout && j < nr) X[(long long)(first + col) * ldx + j] -= acc[t][rr];
+            }
+        }
+    }
+}
+
+// Long-K variant of mode 0 (own columns -= L21' * x_R over ALL trailing rows of a big front): a
+// workgroup owns 64 own columns x 64 right-hand sides, its waves split the trailing rows.
+__global__ __launch_bounds__(256) void k_bwd_gemm_longk(DevSym S, const int *__restrict__ list,
+                                                       const double *__restrict__ L, double *__restrict__ X, int nr,
+                                                       int ldx) {
+    __shared__ double red[3 * 16 * 64];
+    const int s = list[blockIdx.y];
+    const int c = S.sfirst[s + 1] - S.sfirst[s];
+    const int r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
+    const int i0 = blockIdx.x * 32;
+    if (i0 >= c || r <= c) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lm = lane & 15, lk = lane >> 4;
+    const int ld = S.ld[s];
+    const int first = S.sfirst[s];
+    const double *P = L + S.panelptr[s];
+    const int *rows = S.rows + S.rowptr[s];
+    const int nt = (nr + 15) >> 4;
+    constexpr int NA = 2;   // row tiles per workgroup (32 rows): 64 accumulator VGPRs, 3 waves/SIMD
+    d4 acc[NA][4];
+#pragma unroll
+    for (int a = 0; a < NA; a++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc[a][t] = (d4){0.0, 0.0, 0.0, 0.0};
+    const double *pa[NA];
+#pragma unroll
+    for (int a = 0; a < NA; a++) pa[a] = P + (long long)min(i0 + a * 16 + lm, c - 1) * ld;
+    const int jc[4] = {min(lm, nr - 1), min(16 + lm, nr - 1), min(32 + lm, nr - 1), min(48 + lm, nr - 1)};
+    constexpr int KU = 4;
+    for (int k0 = c + wave * 4 * KU; k0 < r; k0 += 16 * KU) {
+        double av[KU][NA], bv[KU][4];
+#pragma unroll
+        for (int u = 0; u < KU; u++) {
+            const int q = k0 + 4 * u + lk;
+            const int qc = min(q, r - 1);
+            const double mk = q < r ? 1.0 : 0.0;
+#pragma unroll
+            for (int a = 0; a < NA; a++) av[u][a] = pa[a][qc] * mk;
+            const long long xr = rows[qc];
+#pragma unroll
+            for (int t = 0; t < 4; t++) bv[u][t] = X[xr * ldx + jc[t]];
+        }
+#pragma unroll
+        for (int u = 0; u < KU; u++)
+#pragma unroll
+            for (int a = 0; a < NA; a++)
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    if (t < nt) acc[a][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][a], bv[u][t], acc[a][t], 0, 0, 0);
+    }
+    splitk_reduce4<NA>(acc, red, wave, lane);
+#pragma unroll
+    for (int a = 0; a < NA; a++) {
+        if (a != wave) continue;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            if (t < nt) {
+                const int j = t * 16 + lm;
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) {
+                    const int col = i0 + a * 16 + lk + 4 * rr;
+                    if (col < c && j < nr) X[(long long)(first + col) * ldx + j] -= acc[a][t][rr];
+                }
             }
         }
     }
@@ -709,15 +847,22 @@ void launch_solve_diag(hipStream_t st, const DevSym &S, const int *list, int nac
     if (nactive <= 0) return;
     hipLaunchKernelGGL(k_solve_diag, dim3(nactive), dim3(256), 0, st, S, list, kb, trans, L, X, nr, ldx);
 }
-void launch_fwd_update(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int max_rows_below,
+void launch_fwd_update(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int wblk, int max_rows_below,
                        const double *L, double *X, double *W, int nr, int ldx) {
     if (nactive <= 0 || max_rows_below <= 0) return;
-    hipLaunchKernelGGL(k_fwd_update, dim3(cdiv(max_rows_below, 64), nactive), dim3(256), 0, st, S, list, kb, L, X, W, nr, ldx);
+    // long K (dense-inverse sweeps of the big fronts, kb = 0, all columns): waves split K
+    if (wblk > 4 * NB)
+        hipLaunchKernelGGL(k_fwd_update_longk, dim3(cdiv(max_rows_below, 32), nactive), dim3(256), 0, st, S, list, L, X, W, nr, ldx);
+    else
+        hipLaunchKernelGGL(k_fwd_update, dim3(cdiv(max_rows_below, 64), nactive), dim3(256), 0, st, S, list, kb, wblk, L, X, W, nr, ldx);
 }
 void launch_bwd_gemm(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int mode, int max_out,
                      const double *L, double *X, int nr, int ldx) {
     if (nactive <= 0 || max_out <= 0) return;
-    hipLaunchKernelGGL(k_bwd_gemm, dim3(cdiv(max_out, 64), nactive), dim3(256), 0, st, S, list, kb, mode, L, X, nr, ldx);
+    if (mode == 0)
+        hipLaunchKernelGGL(k_bwd_gemm_longk, dim3(cdiv(max_out, 32), nactive), dim3(256), 0, st, S, list, L, X, nr, ldx);
+    else
+        hipLaunchKernelGGL(k_bwd_gemm, dim3(cdiv(max_out, 64), nactive), dim3(256), 0, st, S, list, kb, mode, L, X, nr, ldx);
 }
 void launch_permute(hipStream_t st, const int *perm, int n, double *Bc, long long ldb, double *X, int nr, int ldx, int dir) {
     hipLaunchKernelGGL(k_permute, dim3(cdiv(n, 64)), dim3(256), 0, st, perm, n, Bc, ldb, X, nr, ldx, dir);
