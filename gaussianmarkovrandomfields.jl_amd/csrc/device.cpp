@@ -345,8 +345,7 @@ void Device::selinv_compute() {
     if (selinv_valid) return;
     const Symbolic &S = *S_;
     if (!d_Z_) d_Z_ = dalloc<double>((size_t)l_size_);
-    // Yh workspace: per level sum of r * NB; per-supernode offsets
-    static_assert(sizeof(long long) == 8, "");
+    // workspaces: small fronts: Yh = r x 64 per front; big fronts: Yt and Z21t = (r-c) x c each
     long long *d_yoff = nullptr;
     {
         std::vector<long long> yoff(S.nsuper, 0);
@@ -356,7 +355,7 @@ void Device::selinv_compute() {
             for (int k = 0; k < L.count; k++) {
                 i32 s = S.levellist[L.first + k];
                 yoff[s] = off;
-                off += (long long)S.nrows(s) * NB;
+                off += k < L.nsmall ? (long long)S.nrows(s) * NB : 2LL * (S.nrows(s) - S.ncols(s)) * S.ncols(s);
             }
             mx = std::max(mx, off);
         }
@@ -371,15 +370,13 @@ void Device::selinv_compute() {
         auto &L = levels_[l];
         const int *list = d_levellist_ + L.first + L.nsmall;
         const int nf = L.count - L.nsmall;
+        // big fronts: whole-front step through the dense inverse (selinv.hip, k_sel_dense).
+        // Yt lives at d_tmp_ + yoff[s], Z21t right behind it (offset (r-c)*c): pass both bases.
         launch_sel_gather(stream, ds_, list, nf, level_max_trail(L), d_Z_, d_cb_);
-        const int nblk = level_nblk(L);
-        for (int b = nblk - 1; b >= 0; b--) {
-            const int kb = b * NB;
-            launch_trsm(stream, ds_, list, L.active[b], kb, 1, L.max_rows - kb - 1, d_L_, d_tmp_, d_yoff);
-            launch_sel_symm(stream, ds_, list, L.active[b], kb, L.max_rows - kb - 1, d_Z_, d_cb_, d_tmp_, d_yoff);
-            launch_sel_diag(stream, ds_, list, L.active[b], kb, d_L_, d_Z_, d_tmp_, d_yoff);
-        }
-        // small fronts of the level (<= 128 rows, <= 64 columns: one block step) on the same kernels
+        for (int phase = 0; phase < 3; phase++)
+            launch_sel_dense(stream, ds_, list, nf, phase, L.max_cols, level_max_trail(L), d_L_, d_Z_, d_cb_, d_tmp_,
+                             d_tmp_, d_yoff);
+        // small fronts of the level (<= 128 rows, <= 64 columns: one block step)
         if (L.nsmall > 0) {
             const int *sl = d_levellist_ + L.first;
             launch_sel_gather(stream, ds_, sl, L.nsmall, 128, d_Z_, d_cb_);

@@ -21,17 +21,7 @@
 
 namespace gmrfx {
 
-typedef double d4 __attribute__((ext_vector_type(4)));
-
-// X[k][q] for 0 <= k,q < c (0 above the diagonal). Unconditional clamped load + arithmetic mask.
-__device__ __forceinline__ double xinv_elem(const double *__restrict__ P, int ld, int c, int k, int q) {
-    const int kk = min(max(k, 0), c - 1), qq = min(max(q, 0), c - 1);
-    const double v = P[min(kk, qq) + (long long)max(kk, qq) * ld];
-    const bool in = k >= 0 && q >= 0 && k < c && q < c;
-    double x = v * ((in && q < k) ? 1.0 : 0.0);
-    if (in && k == q) x = 1.0 / v;
-    return x;
-}
+typedef gmrfx_d4 d4;
 
 // One 64x64 output tile per workgroup (4 waves x 32x32). phase 1: T'[j][i] = sum_q Bm[i][q] Ainv[q][j];
 // phase 2: X10[i][j] = - sum_q Cinv[i][q] T[q][j], written transposed into the upper triangle.

@@ -25,6 +25,44 @@ void launch_fwd_update(hipStream_t st, const DevSym &S, const int *list, int nac
                        const double *L, double *X, double *W, int nr, int ldx);
 #ifdef __HIPCC__
 typedef double gmrfx_d4 __attribute__((ext_vector_type(4)));
+// X[k][q] of the dense inverse X = L11^-1 of a big front (0 above the diagonal): strict lower part
+// stored transposed in the strict upper triangle of the panel's diagonal block, diag = 1/L's.
+// Unconditional clamped load + arithmetic mask (see inverse.hip).
+__device__ __forceinline__ double xinv_elem(const double *__restrict__ P, int ld, int c, int k, int q) {
+    const int kk = min(max(k, 0), c - 1), qq = min(max(q, 0), c - 1);
+    const double v = P[min(kk, qq) + (long long)max(kk, qq) * ld];
+    const bool in = k >= 0 && q >= 0 && k < c && q < c;
+    double x = v * ((in && q < k) ? 1.0 : 0.0);
+    if (in && k == q) x = 1.0 / v;
+    return x;
+}
+// 32x32 (2x2 MFMA tiles) wave-level product  acc[a][b] += sum_{q in [qlo,qhi)} fa(m0+16a+lm, q) * fb(q, n0+16b+lm)
+// with operand accessors that must be safe (clamped) for any index and return 0 outside.
+template <class FA, class FB>
+__device__ __forceinline__ void wave_gemm_32x32(gmrfx_d4 (&acc)[2][2], int m0, int n0, int qlo, int qhi, FA fa, FB fb,
+                                                int lm, int lk) {
+    constexpr int KU = 4;
+    for (int q0 = qlo & ~3; q0 < qhi; q0 += 4 * KU) {
+        double av[KU][2], bv[KU][2];
+#pragma unroll
+        for (int u = 0; u < KU; u++) {
+            const int q = q0 + 4 * u + lk;
+            const double mk = (q >= qlo && q < qhi) ? 1.0 : 0.0;
+#pragma unroll
+            for (int a = 0; a < 2; a++) av[u][a] = fa(m0 + a * 16 + lm, q) * mk;
+#pragma unroll
+            for (int b = 0; b < 2; b++) bv[u][b] = fb(q, n0 + b * 16 + lm);
+        }
+#pragma unroll
+        for (int u = 0; u < KU; u++)
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++)
+                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][a], bv[u][b], acc[a][b], 0, 0, 0);
+    }
+}
+
 // Split-K reduction for the long-K sweep kernels: the 4 waves of a workgroup hold partial sums of
 // the SAME (16*NA) x 64 output tile (NA row tiles x 4 rhs tiles each; every wave swept a quarter of
 // the K range). After the call wave w owns the total of row tile w in acc[w][*].
@@ -84,5 +122,9 @@ void launch_sel_symm(hipStream_t st, const DevSym &S, const int *list, int nacti
                      double *Z, const double *ZB, const double *Yh, const long long *yoff);
 void launch_sel_diag(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, const double *L,
                      double *Z, const double *Yh, const long long *yoff);
+// whole-front Takahashi step for big fronts through the dense inverse X = L11^-1:
+// phase 0: Yt = (L21 X)', phase 1: Z21 = -Z22 Y, phase 2: Z11 = X'X - Y' Z21
+void launch_sel_dense(hipStream_t st, const DevSym &S, const int *list, int nfronts, int phase, int max_c, int max_trail,
+                      const double *L, double *Z, const double *ZB, double *Yt, double *Z21t, const long long *woff);
 
 }  // namespace gmrfx

@@ -17,7 +17,7 @@
 
 namespace gmrfx {
 
-typedef double d4 __attribute__((ext_vector_type(4)));
+typedef gmrfx_d4 d4;
 
 // ZB_s[i,j] = Zf_parent(rel[i], rel[j]) for i >= j.
 __global__ __launch_bounds__(256) void k_sel_gather(DevSym S, const int *__restrict__ list,
@@ -171,6 +171,100 @@ __global__ __launch_bounds__(256) void k_sel_diag(DevSym S, const int *__restric
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Big fronts: one Takahashi step for the WHOLE front through the dense inverse X = L11^-1
+// (inverse.hip) -- three batched GEMM launches per level instead of 3 per 64-column block:
+//   phase 0   Yt[k][i]  = sum_{q>=k} L21[i][q] X[q][k]            (Y = L21 X, stored transposed)
+//   phase 1   Z21[i][k] = - sum_q Z22[i][q] Y[q][k]               (also kept transposed in Z21t)
+//   phase 2   Z11[a][b] = sum_{k>=a} X[k][a] X[k][b] - sum_q Y[q][a] Z21[q][b],  a >= b
+// 64x64 output tiles, 4 waves x 32x32, FP64 MFMA; operand orientations chosen so that all but
+// one operand stream (the upper half of the symmetric Z22) are contiguous along the lanes.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sel_dense(DevSym S, const int *__restrict__ list, int phase,
+                                                   const double *__restrict__ L, double *__restrict__ Z,
+                                                   const double *__restrict__ ZB, double *__restrict__ Yt,
+                                                   double *__restrict__ Z21t, const long long *__restrict__ woff) {
+    const int s = list[blockIdx.z];
+    const int c = S.sfirst[s + 1] - S.sfirst[s];
+    const int r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
+    const int m = r - c;
+    const int ld = S.ld[s];
+    const double *P = L + S.panelptr[s];
+    double *Zp = Z + S.panelptr[s];
+    const double *ZBs = ZB + S.cbptr[s];
+    double *Y = Yt + woff[s];        // Yt[k + i*c]
+    double *Zt = Z21t + woff[s] + (long long)m * c;   // Z21t[k + i*c], right behind Yt in the same slab
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lm = lane & 15, lk = lane >> 4;
+    const int M = phase == 0 ? m : c;        // extent of the MFMA "m" index
+    const int N = phase == 1 ? m : c;        // extent of the MFMA "n" index (on the lanes)
+    if (m == 0 && phase < 2) return;
+    const int bm = blockIdx.x, bn = blockIdx.y;
+    if (bm * 64 >= M || bn * 64 >= N) return;
+    if (phase == 2 && bn < bm) return;       // a-tile >= b-tile only
+    const int m0 = bm * 64 + (wave & 1) * 32, n0 = bn * 64 + (wave >> 1) * 32;
+    if (m0 >= M || n0 >= N) return;
+    d4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+    if (phase == 0) {
+        // m = i (row of L21), n = k
+        auto fa = [&](int i, int q) { return P[(c + min(i, m - 1)) + (long long)min(max(q, 0), c - 1) * ld]; };
+        auto fb = [&](int q, int k) { return xinv_elem(P, ld, c, q, k); };
+        wave_gemm_32x32(acc, m0, n0, n0, c, fa, fb, lm, lk);
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) {
+                    const int i = m0 + a * 16 + lk + 4 * rr, k = n0 + b * 16 + lm;
+                    if (i < m && k < c) Y[k + (long long)i * c] = acc[a][b][rr];
+                }
+    } else if (phase == 1) {
+        // m = k, n = i
+        auto fa = [&](int k, int q) { return Y[min(k, c - 1) + (long long)min(max(q, 0), m - 1) * c]; };
+        auto fb = [&](int q, int i) {
+            const int qq = min(max(q, 0), m - 1), ii = min(i, m - 1);
+            return ZBs[max(ii, qq) + (long long)min(ii, qq) * m];
+        };
+        wave_gemm_32x32(acc, m0, n0, 0, m, fa, fb, lm, lk);
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) {
+                    const int k = m0 + a * 16 + lk + 4 * rr, i = n0 + b * 16 + lm;
+                    if (k < c && i < m) {
+                        Zp[(c + i) + (long long)k * ld] = -acc[a][b][rr];
+                        Zt[k + (long long)i * c] = -acc[a][b][rr];
+                    }
+                }
+    } else {
+        // m = b, n = a (a >= b)
+        auto fa1 = [&](int b, int k) { return xinv_elem(P, ld, c, k, b); };
+        auto fb1 = [&](int k, int a) { return xinv_elem(P, ld, c, k, a); };
+        wave_gemm_32x32(acc, m0, n0, n0, c, fa1, fb1, lm, lk);
+        if (m > 0) {
+            auto fa2 = [&](int b, int q) { return -Zt[min(b, c - 1) + (long long)min(max(q, 0), m - 1) * c]; };
+            auto fb2 = [&](int q, int a) { return Y[min(a, c - 1) + (long long)min(max(q, 0), m - 1) * c]; };
+            wave_gemm_32x32(acc, m0, n0, 0, m, fa2, fb2, lm, lk);
+        }
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) {
+                    const int bb = m0 + a * 16 + lk + 4 * rr, aa = n0 + b * 16 + lm;
+                    if (aa < c && bb < c && aa >= bb) Zp[aa + (long long)bb * ld] = acc[a][b][rr];
+                }
+    }
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 void launch_sel_gather(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_trail,
@@ -187,6 +281,14 @@ void launch_sel_diag(hipStream_t st, const DevSym &S, const int *list, int nacti
                      double *Z, const double *Yh, const long long *yoff) {
     if (nactive <= 0) return;
     hipLaunchKernelGGL(k_sel_diag, dim3(nactive), dim3(256), 0, st, S, list, kb, L, Z, Yh, yoff);
+}
+
+void launch_sel_dense(hipStream_t st, const DevSym &S, const int *list, int nfronts, int phase, int max_c, int max_trail,
+                      const double *L, double *Z, const double *ZB, double *Yt, double *Z21t, const long long *woff) {
+    if (nfronts <= 0) return;
+    const int M = phase == 0 ? max_trail : max_c, N = phase == 1 ? max_trail : max_c;
+    if (M <= 0 || N <= 0) return;
+    hipLaunchKernelGGL(k_sel_dense, dim3(cdiv(M, 64), cdiv(N, 64), nfronts), dim3(256), 0, st, S, list, phase, L, Z, ZB, Yt, Z21t, woff);
 }
 
 }  // namespace gmrfx
