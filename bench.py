@@ -24,7 +24,8 @@ sys.path.insert(0, os.path.join(ROOT, "gaussianmarkovrandomfields.jl_amd"))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
-FP64_MFMA_PEAK_TF = 78.6   # v_mfma_f64_16x16x4_f64: 32 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz
+FP64_MFMA_PEAK_TF = 78.6   # datasheet FP64 matrix peak (32 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz)
+FP64_MFMA_MEASURED_TF = 36.3   # sustained v_mfma_f64_16x16x4_f64 on this part (tools/micro/mfma64.hip, 138 cycles/instr)
 
 
 def cpu_baseline(nrhs: int, grid: int = 300):
@@ -146,11 +147,23 @@ def main():
         sweep_gbs = bytes_sweep / (sweep_ms * 1e-3) / 1e9
         factor_tf = st["factor_flops"] / (mf * 1e-3) / 1e12
         dominant_is_factor = mf >= (mfw + mbw)
+        # HBM traffic from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
+        # runs, gfx950 FETCH_SIZE x2 correction): only valid for the workload they were collected on
+        pmc = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+                pj = json.load(fh)
+            if pj["workload"] == {"grid": args.grid, "nrhs": args.nrhs}:
+                pmc = pj
+        except Exception:
+            pmc = None
         roof_factor = {"bound": "mfma", "achieved": factor_tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                       "frac": factor_tf / FP64_MFMA_PEAK_TF, "traffic": None,
+                       "frac": factor_tf / FP64_MFMA_PEAK_TF, "traffic": pmc["factor"]["total_bytes"] if pmc else None,
+                       "peak_measured": FP64_MFMA_MEASURED_TF, "frac_of_measured_peak": factor_tf / FP64_MFMA_MEASURED_TF,
                        "kernel": "numeric factorisation (all fronts)", "ms": mf, "flops": st["factor_flops"]}
         roof_sweep = {"bound": "hbm", "achieved": sweep_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                      "frac": sweep_gbs / HBM_PEAK_GBS, "traffic": None,
+                      "frac": sweep_gbs / HBM_PEAK_GBS,
+                      "traffic": 0.5 * (pmc["sweep_forward"]["total_bytes"] + pmc["sweep_backward"]["total_bytes"]) if pmc else None,
                       "kernel": "triangular sweep (mean of forward and backward)", "ms": sweep_ms, "bytes": bytes_sweep}
         out = {
             "metric": "factor+solve(64 RHS) throughput", "value": world * n / (elapsed / args.steps), "unit": "DoF/s",

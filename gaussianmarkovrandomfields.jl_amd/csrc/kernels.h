@@ -18,7 +18,7 @@ void launch_trsm(hipStream_t st, const DevSym &S, const int *list, int nactive, 
 void launch_gemm_nt(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int mode, int maxM,
                     int maxN, double *L, double *CB);
 void launch_fwd_assemble(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_rows, double *X,
-                         double *W, int nr, int ldx);
+                         double *W, int nr, int ldx, int own_only);
 void launch_solve_diag(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int trans,
                        const double *L, double *X, int nr, int ldx);
 void launch_fwd_update(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int wblk, int max_rows_below,

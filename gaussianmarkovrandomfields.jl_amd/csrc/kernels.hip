@@ -375,17 +375,19 @@ __global__ __launch_bounds__(256) void k_gemm_nt(DevSym S, const int *__restrict
 
 // Forward: add the children's update vectors into this front's own rows of X and into W_s.
 __global__ __launch_bounds__(256) void k_fwd_assemble(DevSym S, const int *__restrict__ list, double *__restrict__ X,
-                                                      double *__restrict__ W, int nr, int ldx) {
+                                                      double *__restrict__ W, int nr, int ldx, int own_only) {
     const int s = list[blockIdx.y];
     const int c = S.sfirst[s + 1] - S.sfirst[s];
     const int r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
     const int i0 = blockIdx.x * FWD_RB;
-    if (i0 >= r) return;
-    const int i1 = min(i0 + FWD_RB, r);
+    // own_only: the trailing rows (W_s) are assembled inside k_fwd_update_longk, written once
+    const int rlim = own_only ? c : r;
+    if (i0 >= rlim) return;
+    const int i1 = min(i0 + FWD_RB, rlim);
     const int first = S.sfirst[s];
     double *Ws = W + S.wptr[s] * ldx;
     const int tid = threadIdx.x;
-    {
+    if (!own_only) {
         const int a = max(i0, c);
         const int cnt = (i1 - a) * nr;
         for (int idx = tid; idx < cnt; idx += 256) {
@@ -551,6 +553,7 @@ __global__ __launch_bounds__(256) void k_fwd_update_longk(DevSym S, const int *_
                                                          const double *__restrict__ L, double *__restrict__ X,
                                                          double *__restrict__ W, int nr, int ldx) {
     __shared__ double red[3 * 16 * 64];
+    __shared__ double Tl[32 * 64];   // children's contributions to this 32-row tile of W_s
     const int s = list[blockIdx.y];
     const int c = S.sfirst[s + 1] - S.sfirst[s];
     const int r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
@@ -563,6 +566,26 @@ __global__ __launch_bounds__(256) void k_fwd_update_longk(DevSym S, const int *_
     const double *Yb = X + (long long)S.sfirst[s] * ldx;
     double *Ws = W + S.wptr[s] * ldx;
     const int nt = (nr + 15) >> 4;
+    // ---- gather the children's update vectors for these rows into LDS (fixed child order, no
+    //      atomics): W_s is then written exactly once, with no zero-fill / read-modify-write passes
+    {
+        const int j = threadIdx.x & 63, g = threadIdx.x >> 6;
+        const int jcl = min(j, nr - 1);
+        const double jm = j < nr ? 1.0 : 0.0;
+        for (int i = g; i < 32; i += 4) Tl[i * 64 + j] = 0.0;
+        __syncthreads();
+        for (long long ch = S.childptr[s]; ch < S.childptr[s + 1]; ch++) {
+            const int d = S.children[ch];
+            const int cd = S.sfirst[d + 1] - S.sfirst[d];
+            const int md = (int)(S.rowptr[d + 1] - S.rowptr[d]) - cd;
+            const int *reld = S.rel + S.rowptr[d] + cd;
+            const double *Wd = W + S.wptr[d] * ldx;
+            const int a0 = lower_bound_i32(reld, md, i0);
+            const int a1 = lower_bound_i32(reld, md, i0 + 32);
+            for (int a = a0 + g; a < a1; a += 4) Tl[(reld[a] - i0) * 64 + j] += Wd[(long long)a * ldx + jcl] * jm;
+            __syncthreads();
+        }
+    }
     constexpr int NA = 2;   // row tiles per workgroup (32 rows): 64 accumulator VGPRs, 3 waves/SIMD
     d4 acc[NA][4];
 #pragma unroll
@@ -606,7 +629,7 @@ __global__ __launch_bounds__(256) void k_fwd_update_longk(DevSym S, const int *_
 #pragma unroll
                 for (int rr = 0; rr < 4; rr++) {
                     const int i = i0 + a * 16 + lk + 4 * rr;
-                    if (i < r && j < nr) Ws[(long long)(i - c) * ldx + j] -= acc[a][t][rr];
+                    if (i < r && j < nr) Ws[(long long)(i - c) * ldx + j] = Tl[(i - i0) * 64 + j] - acc[a][t][rr];
                 }
             }
         }
@@ -838,9 +861,9 @@ void launch_gemm_nt(hipStream_t st, const DevSym &S, const int *list, int nactiv
     hipLaunchKernelGGL(k_gemm_nt<2>, dim3(cdiv(maxM, 64), cdiv(maxN, 64), nactive), dim3(256), 0, st, S, list, kb, mode, L, CB);
 }
 void launch_fwd_assemble(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_rows, double *X,
-                         double *W, int nr, int ldx) {
-    if (nfronts <= 0) return;
-    hipLaunchKernelGGL(k_fwd_assemble, dim3(cdiv(max_rows, FWD_RB), nfronts), dim3(256), 0, st, S, list, X, W, nr, ldx);
+                         double *W, int nr, int ldx, int own_only) {
+    if (nfronts <= 0 || max_rows <= 0) return;
+    hipLaunchKernelGGL(k_fwd_assemble, dim3(cdiv(max_rows, FWD_RB), nfronts), dim3(256), 0, st, S, list, X, W, nr, ldx, own_only);
 }
 void launch_solve_diag(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int trans,
                        const double *L, double *X, int nr, int ldx) {
