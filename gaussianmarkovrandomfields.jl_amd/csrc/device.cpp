@@ -185,7 +185,7 @@ void Device::factor_levels() {
             launch_factor_small(stream, ds_, d_levellist_ + L.first + off, L.ncls[k], kClsRows[k], d_nz_, d_L_, d_cb_, d_info_);
         const int *list = d_levellist_ + L.first + L.nsmall;
         const int nf = L.count - L.nsmall;
-        launch_assemble(stream, ds_, list, nf, L.max_rows, d_nz_, d_L_, d_cb_);
+        launch_assemble(stream, ds_, list, nf, L.max_cols, d_nz_, d_L_, d_cb_);
         const int nblk = level_nblk(L);
         for (int b = 0; b < nblk; b++) {
             const int kb = b * NB;
@@ -194,7 +194,7 @@ void Device::factor_levels() {
             if (b + 1 < nblk)
                 launch_gemm_nt(stream, ds_, list, L.active[b + 1], kb, 0, L.max_rows - kb - NB, L.max_cols - kb - NB, d_L_, d_cb_);
         }
-        launch_gemm_nt(stream, ds_, list, nf, 0, 1, level_max_trail(L), level_max_trail(L), d_L_, d_cb_);
+        launch_syrk_cb(stream, ds_, list, nf, level_max_trail(L), d_L_, d_cb_);
     }
 }
 

@@ -10,8 +10,9 @@ constexpr int NB = 64;       // block-column width of the dense partial factoris
 constexpr int ASM_CW = 16;   // front columns owned by one assembly workgroup
 constexpr int FWD_RB = 32;    // front rows owned by one forward-assembly workgroup
 
-void launch_assemble(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_rows,
+void launch_assemble(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols,
                      const double *nzval, double *L, double *CB);
+void launch_syrk_cb(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_trail, const double *L, double *CB);
 void launch_potrf(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, double *L, int *info);
 void launch_trsm(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int mode, int max_rows_below,
                  double *L, double *Yh, const long long *yoff);

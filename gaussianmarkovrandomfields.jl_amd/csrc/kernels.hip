@@ -41,29 +41,26 @@ __device__ __forceinline__ int lower_bound_i32(const int *a, int n, int v) {
 __global__ __launch_bounds__(256) void k_assemble(DevSym S, const int *__restrict__ list,
                                                   const double *__restrict__ nzval, double *__restrict__ L,
                                                   double *__restrict__ CB) {
+    // PANEL part of the front only (front-local columns < c). The contribution-block part is
+    // assembled inside k_syrk_cb (children gathered into an LDS tile, CB written exactly once).
     const int s = list[blockIdx.y];
     const int c = S.sfirst[s + 1] - S.sfirst[s];
-    const int r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
     const int col0 = blockIdx.x * ASM_CW;
-    if (col0 >= r) return;
-    const int col1 = min(col0 + ASM_CW, r);
+    if (col0 >= c) return;
+    const int col1 = min(col0 + ASM_CW, c);
     const int ld = S.ld[s];
-    const int m = r - c;
     double *P = L + S.panelptr[s];
-    double *U = CB + S.cbptr[s];
     const int tid = threadIdx.x;
-    for (int col = col0; col < col1; col++) {
-        if (col < c) { for (int i = tid; i < ld; i += 256) P[i + (long long)col * ld] = 0.0; }
-        else { for (int i = (col - c) + tid; i < m; i += 256) U[i + (long long)(col - c) * m] = 0.0; }   // lower triangle only
-    }
+    for (int col = col0; col < col1; col++)
+        for (int i = tid; i < ld; i += 256) P[i + (long long)col * ld] = 0.0;
     __syncthreads();
-    if (col0 < c) {
+    {
         const long long q0 = S.qptr[s];
         const int nq = (int)(S.qptr[s + 1] - q0);
         const int *qd = S.qdst + q0;
         const int *qs = S.qsrc + q0;
         const int lo = lower_bound_i32(qd, nq, col0 * ld);
-        const int hi = lower_bound_i32(qd, nq, min(col1, c) * ld);
+        const int hi = lower_bound_i32(qd, nq, col1 * ld);
         for (int q = lo + tid; q < hi; q += 256) P[qd[q]] = nzval[qs[q]];
     }
     __syncthreads();
@@ -77,12 +74,7 @@ __global__ __launch_bounds__(256) void k_assemble(DevSym S, const int *__restric
         const int j1 = lower_bound_i32(reld, md, col1);
         for (int j = j0; j < j1; j++) {
             const int tc = reld[j];
-            for (int i = j + tid; i < md; i += 256) {
-                const int ti = reld[i];
-                const double v = Ud[i + (long long)j * md];
-                if (tc < c) P[ti + (long long)tc * ld] += v;
-                else U[(ti - c) + (long long)(tc - c) * m] += v;
-            }
+            for (int i = j + tid; i < md; i += 256) P[reld[i] + (long long)tc * ld] += Ud[i + (long long)j * md];
         }
         __syncthreads();
     }
@@ -366,6 +358,68 @@ __global__ __launch_bounds__(256) void k_gemm_nt(DevSym S, const int *__restrict
                 const int i = i0 + a * 16 + lm;
                 const int j = j0 + b * 16 + lk + 4 * rr;
                 if (i < M && j < N && i >= j) C[i + (long long)j * ldc] -= acc[a][b][rr];
+            }
+}
+
+// Contribution block of a big front, written ONCE:  CB = (extend-add of the children's CBs) - L21 L21'.
+// One workgroup per 64x64 lower tile: the children's entries that fall into the tile are gathered
+// into an LDS tile (fixed child order, no atomics), the product runs on the FP64 MFMA, the
+// epilogue stores LDS tile minus accumulators. No zero-fill, no read-modify-write of CB in HBM.
+__global__ __launch_bounds__(256) void k_syrk_cb(DevSym S, const int *__restrict__ list, const double *__restrict__ L,
+                                                 double *__restrict__ CB) {
+    __shared__ double Tl[64 * 65];
+    const int s = list[blockIdx.z];
+    const int c = S.sfirst[s + 1] - S.sfirst[s];
+    const int r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
+    const int m = r - c;
+    const int bi = blockIdx.x, bj = blockIdx.y;
+    if (bj > bi || bi * 64 >= m) return;
+    const int ld = S.ld[s];
+    const double *A = L + S.panelptr[s] + c;
+    double *C = CB + S.cbptr[s];
+    const int tid = threadIdx.x;
+    const int ti0 = bi * 64, tj0 = bj * 64;      // tile origin inside CB
+    for (int idx = tid; idx < 64 * 65; idx += 256) Tl[idx] = 0.0;
+    __syncthreads();
+    for (long long ch = S.childptr[s]; ch < S.childptr[s + 1]; ch++) {
+        const int d = S.children[ch];
+        const int cd = S.sfirst[d + 1] - S.sfirst[d];
+        const int md = (int)(S.rowptr[d + 1] - S.rowptr[d]) - cd;
+        const int *reld = S.rel + S.rowptr[d] + cd;
+        const double *Ud = CB + S.cbptr[d];
+        // child rows/cols whose parent position falls into this tile (rel is increasing)
+        const int a0 = lower_bound_i32(reld, md, c + ti0), a1 = lower_bound_i32(reld, md, c + ti0 + 64);
+        const int b0 = lower_bound_i32(reld, md, c + tj0), b1 = lower_bound_i32(reld, md, c + tj0 + 64);
+        const int la = tid & 63, lb = tid >> 6;
+        const int a = a0 + la;
+        if (a < a1) {
+            const int ti = reld[a] - c - ti0;
+            for (int b = b0 + lb; b < b1; b += 4)
+                if (a >= b) Tl[ti + (reld[b] - c - tj0) * 65] += Ud[a + (long long)b * md];
+        }
+        __syncthreads();
+    }
+    const int wave = tid >> 6, lane = tid & 63;
+    const int i0 = ti0 + (wave & 1) * 32, j0 = tj0 + (wave >> 1) * 32;
+    if (i0 >= m || j0 >= m || j0 > i0 + 31) return;
+    const int lm = lane & 15, lk = lane >> 4;
+    d4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+    auto fa = [&](int j, int q) { return A[min(j, m - 1) + (long long)min(max(q, 0), c - 1) * ld]; };
+    auto fb = [&](int q, int i) { return A[min(i, m - 1) + (long long)min(max(q, 0), c - 1) * ld]; };
+    // D[m_ = j][n = i] = sum_q L21[j][q] L21[i][q]: rows i on the lanes (contiguous in column-major CB)
+    wave_gemm_32x32(acc, j0, i0, 0, c, fa, fb, lm, lk);
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                const int j = j0 + a * 16 + lk + 4 * rr, i = i0 + b * 16 + lm;
+                if (i < m && j < m && i >= j) C[i + (long long)j * m] = Tl[(i - ti0) + (j - tj0) * 65] - acc[a][b][rr];
             }
 }
 
@@ -837,10 +891,14 @@ __global__ __launch_bounds__(256) void k_gather_diag(const double *__restrict__ 
 // ------------------------------------------------------------------------------------------
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-void launch_assemble(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_rows,
+void launch_assemble(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols,
                      const double *nzval, double *L, double *CB) {
     if (nfronts <= 0) return;
-    hipLaunchKernelGGL(k_assemble, dim3(cdiv(max_rows, ASM_CW), nfronts), dim3(256), 0, st, S, list, nzval, L, CB);
+    hipLaunchKernelGGL(k_assemble, dim3(cdiv(max_cols, ASM_CW), nfronts), dim3(256), 0, st, S, list, nzval, L, CB);
+}
+void launch_syrk_cb(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_trail, const double *L, double *CB) {
+    if (nfronts <= 0 || max_trail <= 0) return;
+    hipLaunchKernelGGL(k_syrk_cb, dim3(cdiv(max_trail, 64), cdiv(max_trail, 64), nfronts), dim3(256), 0, st, S, list, L, CB);
 }
 void launch_potrf(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, double *L, int *info) {
     if (nactive <= 0) return;
