@@ -228,13 +228,28 @@ __global__ __launch_bounds__(256, (RMAX <= 64 ? 4 : (RMAX <= 96 ? 2 : 1))) void 
         const int md = (int)(S.rowptr[d + 1] - S.rowptr[d]) - cd;
         const int *reld = S.rel + S.rowptr[d] + cd;
         const double *Ud = CB + S.cbptr[d];
-        // 4 child columns at a time, 64 lanes down the column
+        // relative indices of the child once into LDS (Pn is free during assembly), then the
+        // child's lower triangle in batches of 8 columns per thread: 8 independent loads in flight
+        int *relL = reinterpret_cast<int *>(Pn);
+        for (int k = tid; k < md; k += 256) relL[k] = reld[k];
+        __syncthreads();
         const int lane = tid & 63, jj = tid >> 6;
-        for (int j0 = 0; j0 < md; j0 += 4) {
-            const int j = j0 + jj;
-            if (j < md) {
-                const int tc = reld[j];
-                for (int i = j + lane; i < md; i += 64) F[tc * LDF + reld[i]] += Ud[i + (long long)j * md];
+        for (int ib = 0; ib < md; ib += 64) {
+            const int i = ib + lane;
+            const int ic = min(i, md - 1);
+            const int ti = relL[ic];
+            for (int j0 = 0; j0 < md; j0 += 32) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int j = min(j0 + jj + 4 * u, md - 1);
+                    v[u] = Ud[max(ic, j) + (long long)min(ic, j) * md];     // always a valid lower entry
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int j = j0 + jj + 4 * u;
+                    if (i < md && j < md && i >= j) F[relL[j] * LDF + ti] += v[u];
+                }
             }
         }
         __syncthreads();
@@ -290,13 +305,17 @@ __global__ __launch_bounds__(256, (RMAX <= 64 ? 4 : 2)) void k_fwd_small(DevSym 
     const int j = tid & 63, g = tid >> 6;
     const int jc = min(j, nr - 1);
     const double jm = j < nr ? 1.0 : 0.0;
-    // own rows <- b ; trailing rows <- 0
-    // (rows r..RMAX-1 are zeroed too: masked MFMA k-steps still multiply 0 by whatever is there)
-#pragma unroll 8
-    for (int i = g; i < RMAX; i += 4) {
-        double v = 0.0;
-        if (i < c) v = X[(long long)(first + i) * ldx + jc] * jm;
-        fv[i * LDV + j] = v;
+    // own rows <- b ; all other rows (trailing and r..RMAX-1) <- 0: masked MFMA k-steps still multiply
+    // 0 by whatever is there. Unconditional clamped loads, 8 in flight per thread.
+    for (int i0 = g; i0 < RMAX; i0 += 32) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = X[(long long)(first + min(i0 + 4 * u, c - 1)) * ldx + jc];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = i0 + 4 * u;
+            if (i < RMAX) fv[i * LDV + j] = (i < c) ? v[u] * jm : 0.0;
+        }
     }
     __syncthreads();
     for (long long ch = S.childptr[s]; ch < S.childptr[s + 1]; ch++) {
@@ -305,8 +324,17 @@ __global__ __launch_bounds__(256, (RMAX <= 64 ? 4 : 2)) void k_fwd_small(DevSym 
         const int md = (int)(S.rowptr[d + 1] - S.rowptr[d]) - cd;
         const int *reld = S.rel + S.rowptr[d] + cd;
         const double *Wd = W + S.wptr[d] * ldx;
-#pragma unroll 4
-        for (int a = g; a < md; a += 4) fv[reld[a] * LDV + j] += Wd[(long long)a * ldx + jc] * jm;
+        for (int a0 = g; a0 < md; a0 += 32) {
+            double v[8]; int tr[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int a = min(a0 + 4 * u, md - 1);
+                tr[u] = reld[a];
+                v[u] = Wd[(long long)a * ldx + jc] * jm;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) if (a0 + 4 * u < md) fv[tr[u] * LDV + j] += v[u];
+        }
         __syncthreads();
     }
     const int wave = tid >> 6, lane = tid & 63;
@@ -399,6 +427,7 @@ __global__ __launch_bounds__(256, (RMAX <= 64 ? 4 : 2)) void k_bwd_small(DevSym 
                                                    const double *__restrict__ L, double *__restrict__ X, int nr,
                                                    int ldx) {
     __shared__ double fv[RMAX * LDV];
+    __shared__ int rowsL[RMAX];
     const int s = list[blockIdx.x];
     const int first = S.sfirst[s];
     const int c = S.sfirst[s + 1] - first;
@@ -411,8 +440,18 @@ __global__ __launch_bounds__(256, (RMAX <= 64 ? 4 : 2)) void k_bwd_small(DevSym 
         const int j = tid & 63, g = tid >> 6;
         const int jc = min(j, nr - 1);
         const double jm = j < nr ? 1.0 : 0.0;
-#pragma unroll 8
-        for (int i = g; i < RMAX; i += 4) fv[i * LDV + j] = (i < r) ? X[(long long)rows[i] * ldx + jc] * jm : 0.0;
+        for (int k = tid; k < RMAX; k += 256) rowsL[k] = rows[min(k, r - 1)];
+        __syncthreads();
+        for (int i0 = g; i0 < RMAX; i0 += 32) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = X[(long long)rowsL[min(i0 + 4 * u, RMAX - 1)] * ldx + jc];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i = i0 + 4 * u;
+                if (i < RMAX) fv[i * LDV + j] = (i < r) ? v[u] * jm : 0.0;
+            }
+        }
     }
     __syncthreads();
     const int wave = tid >> 6, lane = tid & 63;
