@@ -261,7 +261,7 @@ void Device::forward(int nr, int ldx) {
         // trailing update W -= L21 y with K = all columns of the front
         launch_xmul(stream, ds_, list, nf, L.max_cols, 0, d_L_, d_X_, d_X2_, nr, ldx);
         launch_copy_own(stream, ds_, list, nf, L.max_cols, d_X2_, d_X_, nr, ldx);
-        launch_fwd_update(stream, ds_, list, nf, 0, INT_MAX, level_max_trail(L), d_L_, d_X_, d_W_, nr, ldx);
+        launch_fwd_update(stream, ds_, list, nf, level_max_trail(L), d_L_, d_X_, d_W_, nr, ldx);
     }
 }
 
@@ -272,7 +272,7 @@ void Device::backward(int nr, int ldx) {
         const int nf = L.count - L.nsmall;
         for (int k = 0, off = 0; k < 4; off += L.ncls[k], k++)
             launch_bwd_small(stream, ds_, d_levellist_ + L.first + off, L.ncls[k], kClsRows[k], d_L_, d_X_, nr, ldx);
-        if (level_max_trail(L) > 0) launch_bwd_gemm(stream, ds_, list, nf, 0, 0, L.max_cols, d_L_, d_X_, nr, ldx);
+        if (level_max_trail(L) > 0) launch_bwd_gemm(stream, ds_, list, nf, L.max_cols, d_L_, d_X_, nr, ldx);
         launch_xmul(stream, ds_, list, nf, L.max_cols, 1, d_L_, d_X_, d_X2_, nr, ldx);
         launch_copy_own(stream, ds_, list, nf, L.max_cols, d_X2_, d_X_, nr, ldx);
     }

@@ -13,17 +13,14 @@ constexpr int FWD_RB = 32;    // front rows owned by one forward-assembly workgr
 void launch_assemble(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols,
                      const double *nzval, double *L, double *CB);
 void launch_syrk_cb(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_trail, const double *L, double *CB);
-void launch_potrf(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, double *L, int *info);
 void launch_trsm(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int mode, int max_rows_below,
                  double *L, double *Yh, const long long *yoff);
 void launch_gemm_nt(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int mode, int maxM,
                     int maxN, double *L, double *CB);
 void launch_fwd_assemble(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_rows, double *X,
                          double *W, int nr, int ldx, int own_only);
-void launch_solve_diag(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int trans,
-                       const double *L, double *X, int nr, int ldx);
-void launch_fwd_update(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int wblk, int max_rows_below,
-                       const double *L, double *X, double *W, int nr, int ldx);
+void launch_fwd_update(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_trail, const double *L,
+                       double *X, double *W, int nr, int ldx);
 #ifdef __HIPCC__
 typedef double gmrfx_d4 __attribute__((ext_vector_type(4)));
 // X[k][q] of the dense inverse X = L11^-1 of a big front (0 above the diagonal): strict lower part
@@ -100,8 +97,8 @@ void launch_xmul(hipStream_t st, const DevSym &S, const int *list, int nfronts, 
                  const double *Xin, double *Xout, int nr, int ldx);
 void launch_copy_own(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_c, const double *Xsrc,
                      double *Xdst, int nr, int ldx);
-void launch_bwd_gemm(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int mode, int max_out,
-                     const double *L, double *X, int nr, int ldx);
+void launch_bwd_gemm(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, const double *L,
+                     double *X, int nr, int ldx);
 void launch_permute(hipStream_t st, const int *perm, int n, double *Bc, long long ldb, double *X, int nr, int ldx, int dir);
 void launch_logdet(hipStream_t st, const double *L, const long long *diagoff, int n, double *part, int nparts, double *out);
 void launch_gather(hipStream_t st, const double *src, const long long *off, long long cnt, double *out);

@@ -80,94 +80,6 @@ __global__ __launch_bounds__(256) void k_assemble(DevSym S, const int *__restric
     }
 }
 
-// Cholesky of the NB x NB diagonal block D at block-column kb of every active front, AND its
-// inverse, in one right-looking sweep. One workgroup per front; thread (tx,ty) keeps the 4x4
-// elements (tx+16a, ty+16b) of D and of M (M starts as I and receives the same row operations,
-// so that M = Ltilde^-1 with D = Ltilde diag(d) Ltilde'). Per column j the owners publish column j
-// of D and row j of M through double-buffered LDS vectors: ONE barrier per column.
-// Output: lower triangle + diagonal of the panel block = L; strict UPPER triangle = (L^-1)'
-// (i.e. P[c + i*ld] = Linv[i][c], c < i); diag(L^-1) = 1/diag(L) is implicit. The inverse turns
-// the panel TRSM and the diagonal solves of the sweeps into small MFMA GEMMs.
-__global__ __launch_bounds__(256) void k_potrf(DevSym S, const int *__restrict__ list, int kb,
-                                               double *__restrict__ L, int *__restrict__ info) {
-    __shared__ double colbuf[2][NB];
-    __shared__ double rowbuf[2][NB];
-    __shared__ double dsave[NB];
-    const int s = list[blockIdx.x];
-    const int c = S.sfirst[s + 1] - S.sfirst[s];
-    if (kb >= c) return;
-    const int w = min(NB, c - kb);
-    const int ld = S.ld[s];
-    double *P = L + S.panelptr[s] + kb + (long long)kb * ld;
-    const int tid = threadIdx.x;
-    const int tx = tid & 15, ty = tid >> 4;
-    double e[4][4], m[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; a++)
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const int i = tx + 16 * a, k = ty + 16 * b;
-            e[a][b] = (i < w && k < w && i >= k) ? P[i + (long long)k * ld] : ((i == k) ? 1.0 : 0.0);
-            m[a][b] = (i == k) ? 1.0 : 0.0;
-        }
-    if (tid < NB) dsave[tid] = 1.0;
-    for (int j = 0; j < w; j++) {
-        const int buf = j & 1, jb = j >> 4, jt = j & 15;
-        if (ty == jt) {
-#pragma unroll
-            for (int b = 0; b < 4; b++)
-                if (b == jb) {
-#pragma unroll
-                    for (int a = 0; a < 4; a++) colbuf[buf][tx + 16 * a] = e[a][b];
-                }
-        }
-        if (tx == jt) {
-#pragma unroll
-            for (int a = 0; a < 4; a++)
-                if (a == jb) {
-#pragma unroll
-                    for (int b = 0; b < 4; b++) rowbuf[buf][ty + 16 * b] = m[a][b];
-                }
-        }
-        __syncthreads();
-        const double d = colbuf[buf][j];
-        const double inv = 1.0 / d;
-        if (tid == 0) dsave[j] = d;
-        double ck[4], rj[4];
-#pragma unroll
-        for (int b = 0; b < 4; b++) { ck[b] = colbuf[buf][ty + 16 * b]; rj[b] = rowbuf[buf][ty + 16 * b]; }
-#pragma unroll
-        for (int a = 0; a < 4; a++) {
-            const int i = tx + 16 * a;
-            if (i > j) {
-                const double li = colbuf[buf][i] * inv;
-#pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    const int k = ty + 16 * b;
-                    if (k > j && k <= i) e[a][b] -= li * ck[b];
-                    m[a][b] -= li * rj[b];
-                }
-            }
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int a = 0; a < 4; a++)
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const int i = tx + 16 * a, k = ty + 16 * b;
-            if (i >= w || k >= w) continue;
-            if (i > k) {
-                P[i + (long long)k * ld] = e[a][b] / sqrt(dsave[k]);            // L[i][k]
-                P[k + (long long)i * ld] = m[a][b] / sqrt(dsave[i]);            // Linv[i][k] -> upper (k, i)
-            } else if (i == k) {
-                const double dj = dsave[k];
-                if (!(dj > 0.0)) atomicMin(info, S.sfirst[s] + kb + k);
-                P[i + (long long)k * ld] = sqrt(dj);
-            }
-        }
-}
-
 // Stage the inverse of the diagonal block into LDS as a full w x w lower-triangular matrix
 // Ti[k*NB + q] = Linv[k][q] (zero above the diagonal, reciprocal on it).
 __device__ __forceinline__ void stage_linv(const double *__restrict__ Dg, int ld, int w, double *Ti, int tid) {
@@ -470,136 +382,8 @@ __global__ __launch_bounds__(256) void k_fwd_assemble(DevSym S, const int *__res
     }
 }
 
-// Diagonal-block solve of block-column kb as a product with the inverted block (FP64 MFMA):
-// trans = 0: y = Linv b (forward), trans = 1: x = Linv' y (backward). One workgroup per front;
-// wave t produces rows 16t..16t+15 for up to 64 right-hand sides.
-__global__ __launch_bounds__(256) void k_solve_diag(DevSym S, const int *__restrict__ list, int kb, int trans,
-                                                    const double *__restrict__ L, double *__restrict__ X, int nr,
-                                                    int ldx) {
-    __shared__ double Ti[NB * NB];
-    __shared__ double Bs[NB * 64];
-    const int s = list[blockIdx.x];
-    const int c = S.sfirst[s + 1] - S.sfirst[s];
-    if (kb >= c) return;
-    const int w = min(NB, c - kb);
-    const int ld = S.ld[s];
-    const int tid = threadIdx.x;
-    stage_linv(L + S.panelptr[s] + kb + (long long)kb * ld, ld, w, Ti, tid);
-    double *Xb = X + (long long)(S.sfirst[s] + kb) * ldx;
-    {
-        double v[16];
-#pragma unroll
-        for (int u = 0; u < 16; u++) {
-            const int idx = tid + 256 * u;
-            const int k = idx >> 6, j = idx & 63;
-            v[u] = Xb[(long long)min(k, w - 1) * ldx + min(j, nr - 1)];
-        }
-#pragma unroll
-        for (int u = 0; u < 16; u++) {
-            const int idx = tid + 256 * u;
-            const int k = idx >> 6, j = idx & 63;
-            Bs[idx] = v[u];   // rows k >= w meet zero columns of Ti; columns j >= nr are never stored
-        }
-    }
-    __syncthreads();
-    const int wave = tid >> 6, lane = tid & 63;
-    const int lm = lane & 15, lk = lane >> 4;
-    const int k0 = wave * 16;
-    if (k0 >= w) return;
-    const int nt = (nr + 15) >> 4;
-    d4 acc[4];
-#pragma unroll
-    for (int t = 0; t < 4; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
-    // forward needs q <= k (q < k0+16); backward needs q >= k (q >= k0)
-    const int qlo = trans ? k0 : 0, qhi = trans ? w : min(w, k0 + 16);
-    for (int q0 = qlo; q0 < qhi; q0 += 4) {
-        const int q = q0 + lk;
-        const int k = k0 + lm;
-        const double av = trans ? Ti[q * NB + k] : Ti[k * NB + q];
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            if (t < nt) {
-                const double bv = Bs[q * 64 + t * 16 + lm];
-                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
-            }
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-        if (t < nt) {
-            const int j = t * 16 + lm;
-#pragma unroll
-            for (int rr = 0; rr < 4; rr++) {
-                const int k = k0 + lk + 4 * rr;
-                if (k < w && j < nr) Xb[(long long)k * ldx + j] = acc[t][rr];
-            }
-        }
-    }
-}
-
-// Forward update after block-column kb: T[i,:] -= L[i, kb:kb+w] * y  for the front rows below
-// the block. T is X for the front's own rows and W_s for its trailing rows. One wave = 16 rows
-// x up to 64 right-hand sides (4 MFMA tiles); the result tile has the right-hand-side index on
-// the lanes, i.e. contiguous in the row-major X/W.
-__global__ __launch_bounds__(256) void k_fwd_update(DevSym S, const int *__restrict__ list, int kb, int wblk,
-                                                    const double *__restrict__ L, double *__restrict__ X,
-                                                    double *__restrict__ W, int nr, int ldx) {
-    const int s = list[blockIdx.y];
-    const int c = S.sfirst[s + 1] - S.sfirst[s];
-    const int r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
-    if (kb >= c) return;
-    const int w = min(wblk, c - kb);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int i0 = kb + w + (blockIdx.x * 4 + wave) * 16;
-    if (i0 >= r) return;
-    const int ld = S.ld[s];
-    const int first = S.sfirst[s];
-    const double *P = L + S.panelptr[s];
-    const double *Yb = X + (long long)(first + kb) * ldx;
-    double *Ws = W + S.wptr[s] * ldx;
-    const int lm = lane & 15, lk = lane >> 4;
-    const int nt = (nr + 15) >> 4;
-    d4 acc[4];
-#pragma unroll
-    for (int t = 0; t < 4; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
-    {
-        const int i = i0 + lm;
-        const double *pa = P + min(i, r - 1) + (long long)kb * ld;
-        constexpr int KU = 4;
-        for (int k0 = 0; k0 < w; k0 += 4 * KU) {
-            double av[KU], bv[KU][4];
-#pragma unroll
-            for (int u = 0; u < KU; u++) {
-                const int kk = k0 + 4 * u + lk;
-                const int kc = min(kk, w - 1);
-                av[u] = pa[(long long)kc * ld] * (kk < w ? 1.0 : 0.0);
-#pragma unroll
-                for (int t = 0; t < 4; t++) bv[u][t] = Yb[(long long)kc * ldx + min(t * 16 + lm, nr - 1)];
-            }
-#pragma unroll
-            for (int u = 0; u < KU; u++)
-#pragma unroll
-                for (int t = 0; t < 4; t++)
-                    if (t < nt) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u][t], acc[t], 0, 0, 0);
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-        if (t < nt) {
-            const int j = t * 16 + lm;
-#pragma unroll
-            for (int rr = 0; rr < 4; rr++) {
-                const int i = i0 + lk + 4 * rr;
-                if (i < r && j < nr) {
-                    double *dst = (i < c) ? X + (long long)(first + i) * ldx + j : Ws + (long long)(i - c) * ldx + j;
-                    *dst -= acc[t][rr];
-                }
-            }
-        }
-    }
-}
-
-// Long-K variant (dense-inverse sweeps: K = all c columns of a big front): a workgroup owns 32
+// Forward update of a big front after y = L11^-1 b: W_s = (children) - L21 y with K = all c columns.
+// A workgroup owns 32
 // trailing rows x 64 right-hand sides, every wave sweeps a quarter of the K range for the WHOLE
 // tile (16 MFMA tiles per k-step from 4 + 4 operand loads; 512-B contiguous panel segments per
 // column), the partial tiles are summed through LDS and each wave writes one row tile.
@@ -690,66 +474,7 @@ __global__ __launch_bounds__(256) void k_fwd_update_longk(DevSym S, const int *_
     }
 }
 
-// Backward update: X[own col i,:] -= sum_{q in [q0,q1)} L[q,i] * X[rows[q],:] for own columns
-// i < ncols_out. mode 0: q over the trailing rows [c,r) (gathered through rows[]), outputs
-// all c columns; mode 1: q over block-column kb's rows, outputs the columns left of it.
-__global__ __launch_bounds__(256) void k_bwd_gemm(DevSym S, const int *__restrict__ list, int kb, int mode,
-                                                  const double *__restrict__ L, double *__restrict__ X, int nr,
-                                                  int ldx) {
-    const int s = list[blockIdx.y];
-    const int c = S.sfirst[s + 1] - S.sfirst[s];
-    const int r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
-    int q0, q1, nout;
-    if (mode == 0) { q0 = c; q1 = r; nout = c; }
-    else { if (kb >= c) return; q0 = kb; q1 = min(kb + NB, c); nout = kb; }
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int i0 = (blockIdx.x * 4 + wave) * 16;
-    if (i0 >= nout || q0 >= q1) return;
-    const int ld = S.ld[s];
-    const int first = S.sfirst[s];
-    const double *P = L + S.panelptr[s];
-    const int *rows = S.rows + S.rowptr[s];
-    const int lm = lane & 15, lk = lane >> 4;
-    const int nt = (nr + 15) >> 4;
-    d4 acc[4];
-#pragma unroll
-    for (int t = 0; t < 4; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
-    {
-        const int col = i0 + lm;
-        const double *pa = P + (long long)min(col, nout - 1) * ld;
-        constexpr int KU = 4;
-        for (int k0 = q0; k0 < q1; k0 += 4 * KU) {
-            double av[KU], bv[KU][4];
-#pragma unroll
-            for (int u = 0; u < KU; u++) {
-                const int q = k0 + 4 * u + lk;
-                const int qc = min(q, q1 - 1);
-                av[u] = pa[qc] * (q < q1 ? 1.0 : 0.0);
-                const long long xr = rows[qc];
-#pragma unroll
-                for (int t = 0; t < 4; t++) bv[u][t] = X[xr * ldx + min(t * 16 + lm, nr - 1)];
-            }
-#pragma unroll
-            for (int u = 0; u < KU; u++)
-#pragma unroll
-                for (int t = 0; t < 4; t++)
-                    if (t < nt) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u][t], acc[t], 0, 0, 0);
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-        if (t < nt) {
-            const int j = t * 16 + lm;
-#pragma unroll
-            for (int rr = 0; rr < 4; rr++) {
-                const int col = i0 + lk + 4 * rr;
-                if (col < nout && j < nr) X[(long long)(first + col) * ldx + j] -= acc[t][rr];
-            }
-        }
-    }
-}
-
-// Long-K variant of mode 0 (own columns -= L21' * x_R over ALL trailing rows of a big front): a
+// Backward update of a big front: own columns -= L21' * x_R over ALL trailing rows: a
 // workgroup owns 64 own columns x 64 right-hand sides, its waves split the trailing rows.
 __global__ __launch_bounds__(256) void k_bwd_gemm_longk(DevSym S, const int *__restrict__ list,
                                                        const double *__restrict__ L, double *__restrict__ X, int nr,
@@ -900,10 +625,6 @@ void launch_syrk_cb(hipStream_t st, const DevSym &S, const int *list, int nfront
     if (nfronts <= 0 || max_trail <= 0) return;
     hipLaunchKernelGGL(k_syrk_cb, dim3(cdiv(max_trail, 64), cdiv(max_trail, 64), nfronts), dim3(256), 0, st, S, list, L, CB);
 }
-void launch_potrf(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, double *L, int *info) {
-    if (nactive <= 0) return;
-    hipLaunchKernelGGL(k_potrf, dim3(nactive), dim3(256), 0, st, S, list, kb, L, info);
-}
 void launch_trsm(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int mode, int max_rows_below,
                  double *L, double *Yh, const long long *yoff) {
     if (nactive <= 0 || max_rows_below <= 0) return;
@@ -923,27 +644,15 @@ void launch_fwd_assemble(hipStream_t st, const DevSym &S, const int *list, int n
     if (nfronts <= 0 || max_rows <= 0) return;
     hipLaunchKernelGGL(k_fwd_assemble, dim3(cdiv(max_rows, FWD_RB), nfronts), dim3(256), 0, st, S, list, X, W, nr, ldx, own_only);
 }
-void launch_solve_diag(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int trans,
-                       const double *L, double *X, int nr, int ldx) {
-    if (nactive <= 0) return;
-    hipLaunchKernelGGL(k_solve_diag, dim3(nactive), dim3(256), 0, st, S, list, kb, trans, L, X, nr, ldx);
+void launch_fwd_update(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_trail, const double *L,
+                       double *X, double *W, int nr, int ldx) {
+    if (nfronts <= 0 || max_trail <= 0) return;
+    hipLaunchKernelGGL(k_fwd_update_longk, dim3(cdiv(max_trail, 32), nfronts), dim3(256), 0, st, S, list, L, X, W, nr, ldx);
 }
-void launch_fwd_update(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int wblk, int max_rows_below,
-                       const double *L, double *X, double *W, int nr, int ldx) {
-    if (nactive <= 0 || max_rows_below <= 0) return;
-    // long K (dense-inverse sweeps of the big fronts, kb = 0, all columns): waves split K
-    if (wblk > 4 * NB)
-        hipLaunchKernelGGL(k_fwd_update_longk, dim3(cdiv(max_rows_below, 32), nactive), dim3(256), 0, st, S, list, L, X, W, nr, ldx);
-    else
-        hipLaunchKernelGGL(k_fwd_update, dim3(cdiv(max_rows_below, 64), nactive), dim3(256), 0, st, S, list, kb, wblk, L, X, W, nr, ldx);
-}
-void launch_bwd_gemm(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int mode, int max_out,
-                     const double *L, double *X, int nr, int ldx) {
-    if (nactive <= 0 || max_out <= 0) return;
-    if (mode == 0)
-        hipLaunchKernelGGL(k_bwd_gemm_longk, dim3(cdiv(max_out, 32), nactive), dim3(256), 0, st, S, list, L, X, nr, ldx);
-    else
-        hipLaunchKernelGGL(k_bwd_gemm, dim3(cdiv(max_out, 64), nactive), dim3(256), 0, st, S, list, kb, mode, L, X, nr, ldx);
+void launch_bwd_gemm(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, const double *L,
+                     double *X, int nr, int ldx) {
+    if (nfronts <= 0 || max_cols <= 0) return;
+    hipLaunchKernelGGL(k_bwd_gemm_longk, dim3(cdiv(max_cols, 32), nfronts), dim3(256), 0, st, S, list, L, X, nr, ldx);
 }
 void launch_permute(hipStream_t st, const int *perm, int n, double *Bc, long long ldb, double *X, int nr, int ldx, int dir) {
     hipLaunchKernelGGL(k_permute, dim3(cdiv(n, 64)), dim3(256), 0, st, perm, n, Bc, ldb, X, nr, ldx, dir);

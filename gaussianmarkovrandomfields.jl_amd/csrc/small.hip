@@ -290,7 +290,7 @@ __device__ __forceinline__ double linv_elem(const double *__restrict__ P, int ld
 }
 
 template <int RMAX>
-__global__ __launch_bounds__(256, (RMAX <= 64 ? 4 : 2)) void k_fwd_small(DevSym S, const int *__restrict__ list,
+__global__ __launch_bounds__(256, (RMAX <= 48 ? 4 : (RMAX <= 64 ? 3 : (RMAX <= 96 ? 2 : 1)))) void k_fwd_small(DevSym S, const int *__restrict__ list,
                                                    const double *__restrict__ L, double *__restrict__ X,
                                                    double *__restrict__ W, int nr, int ldx) {
     __shared__ double fv[RMAX * LDV];
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256, (RMAX <= 64 ? 4 : 2)) void k_fwd_small(DevSym 
 }
 
 template <int RMAX>
-__global__ __launch_bounds__(256, (RMAX <= 64 ? 4 : 2)) void k_bwd_small(DevSym S, const int *__restrict__ list,
+__global__ __launch_bounds__(256, (RMAX <= 48 ? 4 : (RMAX <= 64 ? 3 : (RMAX <= 96 ? 2 : 1)))) void k_bwd_small(DevSym S, const int *__restrict__ list,
                                                    const double *__restrict__ L, double *__restrict__ X, int nr,
                                                    int ldx) {
     __shared__ double fv[RMAX * LDV];

@@ -298,3 +298,53 @@ def test_hip_path_matches_golden_fixtures(path):
     # and its covariance identity is order-independent: x = P'L^-T z  =>  Q = (x-map)^-T (x-map)^-1
     Xb = ws.backward_solve(np.eye(n))
     assert np.allclose(Xb @ Xb.T, np.linalg.inv(Q.toarray()), rtol=1e-7, atol=1e-12)
+
+
+def test_full_size_properties_cfg2():
+    """BASELINE.json config 2 at FULL size (10^6 nodes): no oracle can follow here, so the check is
+    through size-independent properties: residual of the 64-RHS solve, bit-reproducibility of the
+    factorisation (no atomics anywhere), logdet scaling law, solve linearity, backward-solve
+    covariance identity on probe vectors, tr(Q^-1 Q) = n from the selected inverse."""
+    m = spde.grid_mesh_2d(1000, 1000, jitter=0.25, seed=0)
+    Q = spde.matern_precision(m, 0, 0.2)
+    n = Q.shape[0]
+    be = gmrfx.MI355XBackend(Q, coords=m.points)
+    assert be.last_info == 0
+    rng = np.random.default_rng(1)
+    B = rng.standard_normal((n, 64))
+    X = be.backend_solve(B)
+    assert np.linalg.norm(Q @ X - B) / np.linalg.norm(B) < 1e-9
+    ld1 = be.compute_logdet()
+    f1 = be.factor_values()
+    be.refactorize(Q)
+    assert np.array_equal(be.factor_values(), f1)            # deterministic, bit for bit
+    assert be.compute_logdet() == ld1
+    be.refactorize_values(Q.data * 2.0)
+    assert abs(be.compute_logdet() - (ld1 + n * np.log(2.0))) < 1e-10 * abs(ld1)
+    x2 = be.backend_solve(B[:, :2])
+    # (2Q)^-1 b = Q^-1 b / 2; the two factors round differently and cond(Q) ~ 1e8 here
+    assert np.linalg.norm(2.0 * x2 - X[:, :2]) / np.linalg.norm(X[:, :2]) < 1e-7
+    be.refactorize(Q)
+    # x = P' L^-T z  =>  Q x = P' L z' ... equivalently z'z = x' Q x for every probe z
+    Z = rng.standard_normal((n, 4))
+    S = be.backend_backward_solve(Z)
+    assert np.allclose(np.einsum("ij,ij->j", S, Q @ S), np.einsum("ij,ij->j", Z, Z), rtol=1e-9)
+    d = be.get_selinv_diag()
+    assert d.min() > 0
+    assert abs(be.selinv_dot(Q) - n) < 1e-7 * n
+    # diag(Q^-1) against 3 unit-vector solves
+    for k in (0, n // 2 + 17, n - 1):
+        e = np.zeros(n); e[k] = 1.0
+        assert abs(be.backend_solve(e)[k] - d[k]) < 1e-7 * d[k]
+
+
+def test_3d_medium_residual():
+    m3 = spde.grid_mesh_3d(28, 28, 28)
+    Q = spde.matern_precision(m3, 0, 0.5)
+    ws = gmrfx.GMRFWorkspace(Q, coords=m3.points)
+    B = np.random.default_rng(2).standard_normal((Q.shape[0], 8))
+    X = ws.workspace_solve(B)
+    assert np.linalg.norm(Q @ X - B) / np.linalg.norm(B) < 1e-10
+    F = orc.OracleFactor(Q, ws.backend.ordering_permutation())
+    assert abs(ws.logdet() - F.logdet()) < 1e-10 * abs(F.logdet())
+    assert relerr(ws.selinv_diag(), F.selinv_diag()) < 1e-8
