@@ -28,6 +28,9 @@ Device::~Device() {
     if (stream) { (void)hipStreamSynchronize(stream); }
     for (void *p : allocs_) (void)hipFree(p);
     for (auto &e : ev_) if (e) (void)hipEventDestroy(e);
+    if (ev_fact_) (void)hipEventDestroy(ev_fact_);
+    if (ev_inv_) (void)hipEventDestroy(ev_inv_);
+    if (stream2) (void)hipStreamDestroy(stream2);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -42,6 +45,9 @@ void Device::init(const Symbolic &S, int dev) {
     device = dev;
     HC(hipSetDevice(device));
     HC(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    HC(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+    HC(hipEventCreateWithFlags(&ev_fact_, hipEventDisableTiming));
+    HC(hipEventCreateWithFlags(&ev_inv_, hipEventDisableTiming));
     for (auto &ev : ev_) HC(hipEventCreate(&ev));
     upload(S);
 }
@@ -153,6 +159,9 @@ void Device::upload(const Symbolic &S) {
         HC(hipStreamSynchronize(stream));
     }
 
+    first_multiblock_level_ = S.nlevels;
+    for (i32 l = 0; l < S.nlevels; l++) if (levels_[l].max_cols > NB) { first_multiblock_level_ = l; break; }
+
     l_size_ = S.panelptr[ns];
     d_L_ = dalloc<double>((size_t)l_size_);
     d_cb_ = dalloc<double>((size_t)S.cb_arena);
@@ -170,6 +179,7 @@ void Device::clone_from(const Device &o, const Symbolic &S) {
         HC(hipMemcpyAsync(d_info_, o.d_info_, sizeof(int), hipMemcpyDeviceToDevice, stream));
         HC(hipStreamSynchronize(stream));
         factorized = true;
+        inverse_pending = true;   // the copy may predate the source's lazy inverse: recompute on demand
     }
 }
 
@@ -198,7 +208,21 @@ void Device::factor_levels() {
     }
 }
 
-void Device::invert_diag_blocks() {
+// The dense inverses are only needed by the sweeps and the selected inversion of the big
+// fronts, never by logdet: they are computed lazily (first solve / selinv after a
+// refactorisation) on a side stream, so that in a refactorise+solve step they overlap the
+// small-front levels at the bottom of the forward sweep.
+void Device::start_inverse_async() {
+    if (!inverse_pending) return;
+    HC(hipEventRecord(ev_fact_, stream));
+    HC(hipStreamWaitEvent(stream2, ev_fact_, 0));
+    invert_diag_blocks(stream2);
+    HC(hipEventRecord(ev_inv_, stream2));
+    inverse_pending = false;
+}
+void Device::wait_inverse() { HC(hipStreamWaitEvent(stream, ev_inv_, 0)); }
+
+void Device::invert_diag_blocks(hipStream_t stream) {
     int stage = 0;
     for (int B = NB; B < inv_maxc_; B *= 2, stage++) {
         const int na = inv_nact_[stage];
@@ -222,8 +246,8 @@ void Device::refactorize(const double *nzval, bool on_device) {
     (void)src;
     HC(hipEventRecord(ev_[0], stream));
     factor_levels();
-    invert_diag_blocks();
     HC(hipEventRecord(ev_[1], stream));
+    inverse_pending = true;
     HC(hipStreamSynchronize(stream));
     HC(hipGetLastError());
     float ms = 0;
@@ -251,7 +275,9 @@ void Device::ensure_rhs_capacity(long long nrhs) {
 }
 
 void Device::forward(int nr, int ldx) {
+    int lev = 0;
     for (auto &L : levels_) {
+        if (lev++ == first_multiblock_level_) wait_inverse();
         for (int k = 0, off = 0; k < 4; off += L.ncls[k], k++)
             launch_fwd_small(stream, ds_, d_levellist_ + L.first + off, L.ncls[k], kClsRows[k], d_L_, d_X_, d_W_, nr, ldx);
         const int *list = d_levellist_ + L.first + L.nsmall;
@@ -266,6 +292,7 @@ void Device::forward(int nr, int ldx) {
 }
 
 void Device::backward(int nr, int ldx) {
+    wait_inverse();   // (a no-op event wait once the forward sweep has passed it)
     for (int l = (int)levels_.size() - 1; l >= 0; l--) {
         auto &L = levels_[l];
         const int *list = d_levellist_ + L.first + L.nsmall;
@@ -283,6 +310,7 @@ void Device::solve(const double *B, long long ldb, long long nrhs, double *X, lo
     if (nrhs <= 0) return;
     const long long n = S_->n;
     ensure_rhs_capacity(nrhs);
+    start_inverse_async();
     const double *dB = B;
     double *dXo = X;
     long long ldin = ldb, ldout = ldx_out;
@@ -344,6 +372,8 @@ void Device::selinv_compute() {
     HC(hipSetDevice(device));
     if (selinv_valid) return;
     const Symbolic &S = *S_;
+    start_inverse_async();
+    wait_inverse();
     if (!d_Z_) d_Z_ = dalloc<double>((size_t)l_size_);
     // workspaces: small fronts: Yh = r x 64 per front; big fronts: Yt and Z21t = (r-c) x c each
     long long *d_yoff = nullptr;

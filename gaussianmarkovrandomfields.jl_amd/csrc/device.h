@@ -62,11 +62,14 @@ public:
     long long fail_col();
 
     bool factorized = false, selinv_valid = false;
+    bool inverse_pending = false;   // dense inverses of the big fronts are computed lazily, on a side stream
     double ms_factor = 0, ms_solve = 0, ms_fwd = 0, ms_bwd = 0, ms_perm = 0, ms_bsolve = 0, ms_logdet = 0, ms_selinv = 0;
     long long last_nrhs = 0;
     double bytes_total = 0;
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;  // side stream: dense-inverse stages overlap the leaf levels of the forward sweep
+    hipEvent_t ev_fact_ = nullptr, ev_inv_ = nullptr;
 
 private:
     void upload(const Symbolic &S);
@@ -89,7 +92,10 @@ private:
     std::vector<long long *> d_inv_toff_;   // per stage: offsets of the T buffers
     double *d_invT_ = nullptr;
     int inv_maxc_ = 0;
-    void invert_diag_blocks();
+    void invert_diag_blocks(hipStream_t st);
+    void start_inverse_async();
+    void wait_inverse();
+    int first_multiblock_level_ = 0;
     long long rhs_cap_ = 0, io_cap_ = 0, tmp_cap_ = 0;
     int *d_info_ = nullptr;
     hipEvent_t ev_[8] = {};
