@@ -101,6 +101,10 @@ void Device::upload(const Symbolic &S) {
     up(ip, S.perm); ds_.perm = ip;
     {
         const int *ll; up(ll, S.levellist); d_levellist_ = const_cast<int *>(ll);
+        const int *a; up(a, S.sub_first); d_sub_first_ = const_cast<int *>(a);
+        const int *b; up(b, S.sub_last); d_sub_last_ = const_cast<int *>(b);
+        for (int k = 0; k < 3; k++) nsub_cls_[k] = S.nsub_cls[k];
+        const int *sl; up(sl, S.sel_levellist); d_sel_levellist_ = const_cast<int *>(sl);
     }
     HC(hipStreamSynchronize(stream));
 
@@ -190,6 +194,10 @@ static inline int level_nblk(const LevelInfo &L) { return (int)L.active.size() -
 void Device::factor_levels() {
     const int big = INT_MAX;
     HC(hipMemcpyAsync(d_info_, &big, sizeof(int), hipMemcpyHostToDevice, stream));
+    // whole small subtrees first (one workgroup each), then the level schedule of everything above
+    for (int k = 0, off = 0; k < 3; off += nsub_cls_[k], k++)
+        launch_subtree(stream, ds_, 0, d_sub_first_ + off, d_sub_last_ + off, nsub_cls_[k], kClsRows[k], d_nz_, d_L_, d_cb_,
+                       d_info_, nullptr, nullptr, 0, 0);
     for (auto &L : levels_) {
         for (int k = 0, off = 0; k < 4; off += L.ncls[k], k++)
             launch_factor_small(stream, ds_, d_levellist_ + L.first + off, L.ncls[k], kClsRows[k], d_nz_, d_L_, d_cb_, d_info_);
@@ -275,6 +283,9 @@ void Device::ensure_rhs_capacity(long long nrhs) {
 }
 
 void Device::forward(int nr, int ldx) {
+    for (int k = 0, off = 0; k < 3; off += nsub_cls_[k], k++)
+        launch_subtree(stream, ds_, 1, d_sub_first_ + off, d_sub_last_ + off, nsub_cls_[k], kClsRows[k], nullptr, d_L_, nullptr,
+                       nullptr, d_X_, d_W_, nr, ldx);
     int lev = 0;
     for (auto &L : levels_) {
         if (lev++ == first_multiblock_level_) wait_inverse();
@@ -303,6 +314,9 @@ void Device::backward(int nr, int ldx) {
         launch_xmul(stream, ds_, list, nf, L.max_cols, 1, d_L_, d_X_, d_X2_, nr, ldx);
         launch_copy_own(stream, ds_, list, nf, L.max_cols, d_X2_, d_X_, nr, ldx);
     }
+    for (int k = 0, off = 0; k < 3; off += nsub_cls_[k], k++)
+        launch_subtree(stream, ds_, 2, d_sub_first_ + off, d_sub_last_ + off, nsub_cls_[k], kClsRows[k], nullptr, d_L_, nullptr,
+                       nullptr, d_X_, nullptr, nr, ldx);
 }
 
 void Device::solve(const double *B, long long ldb, long long nrhs, double *X, long long ldx_out, bool on_device, int mode) {
@@ -380,12 +394,13 @@ void Device::selinv_compute() {
     {
         std::vector<long long> yoff(S.nsuper, 0);
         long long mx = 0;
-        for (auto &L : levels_) {
+        for (i32 l = 0; l < S.nlevels; l++) {
             long long off = 0;
-            for (int k = 0; k < L.count; k++) {
-                i32 s = S.levellist[L.first + k];
+            const i64 lf = S.sel_levelptr[l], cnt = S.sel_levelptr[l + 1] - lf;
+            for (i64 k = 0; k < cnt; k++) {
+                i32 s = S.sel_levellist[lf + k];
                 yoff[s] = off;
-                off += k < L.nsmall ? (long long)S.nrows(s) * NB : 2LL * (S.nrows(s) - S.ncols(s)) * S.ncols(s);
+                off += k < S.sel_level_nsmall[l] ? (long long)S.nrows(s) * NB : 2LL * (S.nrows(s) - S.ncols(s)) * S.ncols(s);
             }
             mx = std::max(mx, off);
         }
@@ -398,8 +413,11 @@ void Device::selinv_compute() {
     HC(hipMemsetAsync(d_Z_, 0, (size_t)l_size_ * sizeof(double), stream));
     for (int l = (int)levels_.size() - 1; l >= 0; l--) {
         auto &L = levels_[l];
-        const int *list = d_levellist_ + L.first + L.nsmall;
-        const int nf = L.count - L.nsmall;
+        // all fronts of the level (subtree members included): small first, then big
+        const int sfirst = (int)S.sel_levelptr[l], scount = (int)(S.sel_levelptr[l + 1] - S.sel_levelptr[l]);
+        const int snsmall = S.sel_level_nsmall[l];
+        const int *list = d_sel_levellist_ + sfirst + snsmall;
+        const int nf = scount - snsmall;
         // big fronts: whole-front step through the dense inverse (selinv.hip, k_sel_dense).
         // Yt lives at d_tmp_ + yoff[s], Z21t right behind it (offset (r-c)*c): pass both bases.
         launch_sel_gather(stream, ds_, list, nf, level_max_trail(L), d_Z_, d_cb_);
@@ -407,12 +425,12 @@ void Device::selinv_compute() {
             launch_sel_dense(stream, ds_, list, nf, phase, L.max_cols, level_max_trail(L), d_L_, d_Z_, d_cb_, d_tmp_,
                              d_tmp_, d_yoff);
         // small fronts of the level (<= 128 rows, <= 64 columns: one block step)
-        if (L.nsmall > 0) {
-            const int *sl = d_levellist_ + L.first;
-            launch_sel_gather(stream, ds_, sl, L.nsmall, 128, d_Z_, d_cb_);
-            launch_trsm(stream, ds_, sl, L.nsmall, 0, 1, 128, d_L_, d_tmp_, d_yoff);
-            launch_sel_symm(stream, ds_, sl, L.nsmall, 0, 128, d_Z_, d_cb_, d_tmp_, d_yoff);
-            launch_sel_diag(stream, ds_, sl, L.nsmall, 0, d_L_, d_Z_, d_tmp_, d_yoff);
+        if (snsmall > 0) {
+            const int *sl = d_sel_levellist_ + sfirst;
+            launch_sel_gather(stream, ds_, sl, snsmall, 128, d_Z_, d_cb_);
+            launch_trsm(stream, ds_, sl, snsmall, 0, 1, 128, d_L_, d_tmp_, d_yoff);
+            launch_sel_symm(stream, ds_, sl, snsmall, 0, 128, d_Z_, d_cb_, d_tmp_, d_yoff);
+            launch_sel_diag(stream, ds_, sl, snsmall, 0, d_L_, d_Z_, d_tmp_, d_yoff);
         }
     }
     HC(hipEventRecord(ev_[1], stream));

@@ -82,6 +82,7 @@ extern "C" int32_t gmrfx_create(int64_t n, const int64_t *colptr, const int64_t 
         so.coords = h->opts.coords;
         if (so.coords && so.coord_dim != 2 && so.coord_dim != 3) throw std::invalid_argument("coord_dim must be 2 or 3");
         if (const char *e = std::getenv("GMRFX_SMALL_ROWS")) so.small_front_rows = std::atoi(e);   // tuning/testing knob
+        if (const char *e = std::getenv("GMRFX_SUBTREE_MAX")) so.subtree_max = std::atoi(e);       // 0 disables subtree tasks
         analyze(n, colptr, rowval, index_base, perm, so, h->S);
         h->opts.coords = nullptr;  // caller-owned, not kept
     } catch (const std::invalid_argument &e) {

@@ -192,15 +192,10 @@ __device__ __forceinline__ void lds_partial_cholesky(double *F, double *Pn, doub
 }
 
 template <int RMAX>
-__global__ __launch_bounds__(256, (RMAX <= 64 ? 4 : (RMAX <= 96 ? 2 : 1))) void k_factor_small(DevSym S, const int *__restrict__ list,
-                                                      const double *__restrict__ nzval, double *__restrict__ L,
-                                                      double *__restrict__ CB, int *__restrict__ info) {
+__device__ __forceinline__ void factor_small_front(const DevSym &S, const int s, const double *__restrict__ nzval,
+                                                   double *__restrict__ L, double *__restrict__ CB,
+                                                   int *__restrict__ info, double *F, double *Pn, double *Wn) {
     constexpr int LDF = lds_ldf(RMAX);
-    constexpr int LDP = lds_ldp(RMAX);
-    __shared__ double F[LDF * RMAX];
-    __shared__ double Pn[4 * LDP];   // current panel, Pn[q][i] = L[i][j0+q] (0 outside the panel rows)
-    __shared__ double Wn[4 * LDW];   // current rows of L11^-1, Wn[q][b] = X[j0+q][b] (0 for b > j0+q)
-    const int s = list[blockIdx.x];
     const int first = S.sfirst[s];
     const int c = S.sfirst[s + 1] - first;
     const int r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
@@ -270,6 +265,35 @@ __global__ __launch_bounds__(256, (RMAX <= 64 ? 4 : (RMAX <= 96 ? 2 : 1))) void 
     }
 }
 
+template <int RMAX>
+__global__ __launch_bounds__(256, (RMAX <= 64 ? 4 : (RMAX <= 96 ? 2 : 1))) void k_factor_small(DevSym S, const int *__restrict__ list,
+                                                      const double *__restrict__ nzval, double *__restrict__ L,
+                                                      double *__restrict__ CB, int *__restrict__ info) {
+    __shared__ double F[lds_ldf(RMAX) * RMAX];
+    __shared__ double Pn[4 * lds_ldp(RMAX)];   // current panel, Pn[q][i] = L[i][j0+q] (0 outside the panel rows)
+    __shared__ double Wn[4 * LDW];             // current rows of L11^-1, Wn[q][b] = X[j0+q][b] (0 for b > j0+q)
+    factor_small_front<RMAX>(S, list[blockIdx.x], nzval, L, CB, info, F, Pn, Wn);
+}
+
+// Subtree task: ONE workgroup factors a whole small subtree (supernode ids first..last are its
+// fronts in postorder), so the bottom levels of the tree cost one launch and a child's contribution
+// block is consumed by the same CU that produced it (L2-hot) instead of one launch per level.
+template <int RMAX>
+__global__ __launch_bounds__(256, (RMAX <= 64 ? 4 : 2)) void k_factor_subtree(DevSym S, const int *__restrict__ sub_first,
+                                                        const int *__restrict__ sub_last,
+                                                        const double *__restrict__ nzval, double *__restrict__ L,
+                                                        double *__restrict__ CB, int *__restrict__ info) {
+    __shared__ double F[lds_ldf(RMAX) * RMAX];
+    __shared__ double Pn[4 * lds_ldp(RMAX)];
+    __shared__ double Wn[4 * LDW];
+    const int s0 = sub_first[blockIdx.x], s1 = sub_last[blockIdx.x];
+    for (int s = s0; s <= s1; s++) {
+        factor_small_front<RMAX>(S, s, nzval, L, CB, info, F, Pn, Wn);
+        __threadfence_block();
+        __syncthreads();   // this front's CB (global) is visible to the wave that reads it for the parent
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Fused sweeps for small fronts. The front's slice of the right-hand sides (r rows x up to 64
 // columns) sits in LDS; the panel streams through the MFMA A operand straight from HBM (each
@@ -290,11 +314,9 @@ __device__ __forceinline__ double linv_elem(const double *__restrict__ P, int ld
 }
 
 template <int RMAX>
-__global__ __launch_bounds__(256, (RMAX <= 48 ? 4 : (RMAX <= 64 ? 3 : (RMAX <= 96 ? 2 : 1)))) void k_fwd_small(DevSym S, const int *__restrict__ list,
-                                                   const double *__restrict__ L, double *__restrict__ X,
-                                                   double *__restrict__ W, int nr, int ldx) {
-    __shared__ double fv[RMAX * LDV];
-    const int s = list[blockIdx.x];
+__device__ __forceinline__ void fwd_small_front(const DevSym &S, const int s, const double *__restrict__ L,
+                                                double *__restrict__ X, double *__restrict__ W, const int nr,
+                                                const int ldx, double *fv) {
     const int first = S.sfirst[s];
     const int c = S.sfirst[s + 1] - first;
     const int r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
@@ -423,12 +445,30 @@ __global__ __launch_bounds__(256, (RMAX <= 48 ? 4 : (RMAX <= 64 ? 3 : (RMAX <= 9
 }
 
 template <int RMAX>
-__global__ __launch_bounds__(256, (RMAX <= 48 ? 4 : (RMAX <= 64 ? 3 : (RMAX <= 96 ? 2 : 1)))) void k_bwd_small(DevSym S, const int *__restrict__ list,
-                                                   const double *__restrict__ L, double *__restrict__ X, int nr,
-                                                   int ldx) {
+__global__ __launch_bounds__(256, (RMAX <= 48 ? 4 : (RMAX <= 64 ? 3 : (RMAX <= 96 ? 2 : 1)))) void k_fwd_small(DevSym S, const int *__restrict__ list,
+                                                   const double *__restrict__ L, double *__restrict__ X,
+                                                   double *__restrict__ W, int nr, int ldx) {
     __shared__ double fv[RMAX * LDV];
-    __shared__ int rowsL[RMAX];
-    const int s = list[blockIdx.x];
+    fwd_small_front<RMAX>(S, list[blockIdx.x], L, X, W, nr, ldx, fv);
+}
+// forward sweep of a whole small subtree by one workgroup (fronts in postorder)
+template <int RMAX>
+__global__ __launch_bounds__(256, (RMAX <= 48 ? 4 : (RMAX <= 64 ? 3 : 2))) void k_fwd_subtree(DevSym S, const int *__restrict__ sub_first,
+                                                     const int *__restrict__ sub_last, const double *__restrict__ L,
+                                                     double *__restrict__ X, double *__restrict__ W, int nr, int ldx) {
+    __shared__ double fv[RMAX * LDV];
+    const int s0 = sub_first[blockIdx.x], s1 = sub_last[blockIdx.x];
+    for (int s = s0; s <= s1; s++) {
+        fwd_small_front<RMAX>(S, s, L, X, W, nr, ldx, fv);
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+template <int RMAX>
+__device__ __forceinline__ void bwd_small_front(const DevSym &S, const int s, const double *__restrict__ L,
+                                                double *__restrict__ X, const int nr, const int ldx, double *fv,
+                                                int *rowsL) {
     const int first = S.sfirst[s];
     const int c = S.sfirst[s + 1] - first;
     const int r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
@@ -526,6 +566,29 @@ __global__ __launch_bounds__(256, (RMAX <= 48 ? 4 : (RMAX <= 64 ? 3 : (RMAX <= 9
     }
 }
 
+template <int RMAX>
+__global__ __launch_bounds__(256, (RMAX <= 48 ? 4 : (RMAX <= 64 ? 3 : (RMAX <= 96 ? 2 : 1)))) void k_bwd_small(DevSym S, const int *__restrict__ list,
+                                                   const double *__restrict__ L, double *__restrict__ X, int nr,
+                                                   int ldx) {
+    __shared__ double fv[RMAX * LDV];
+    __shared__ int rowsL[RMAX];
+    bwd_small_front<RMAX>(S, list[blockIdx.x], L, X, nr, ldx, fv, rowsL);
+}
+// backward sweep of a whole small subtree by one workgroup (fronts in reverse postorder)
+template <int RMAX>
+__global__ __launch_bounds__(256, (RMAX <= 48 ? 4 : (RMAX <= 64 ? 3 : 2))) void k_bwd_subtree(DevSym S, const int *__restrict__ sub_first,
+                                                     const int *__restrict__ sub_last, const double *__restrict__ L,
+                                                     double *__restrict__ X, int nr, int ldx) {
+    __shared__ double fv[RMAX * LDV];
+    __shared__ int rowsL[RMAX];
+    const int s0 = sub_first[blockIdx.x], s1 = sub_last[blockIdx.x];
+    for (int s = s1; s >= s0; s--) {
+        bwd_small_front<RMAX>(S, s, L, X, nr, ldx, fv, rowsL);
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
 // 64 x 64 diagonal block of a big front: factor + inverse with the same LDS machinery
 // (16 panel steps of 4 columns instead of 64 single-column steps).
 __global__ __launch_bounds__(256) void k_potrf_lds(DevSym S, const int *__restrict__ list, int kb,
@@ -576,6 +639,21 @@ void launch_factor_small(hipStream_t st, const DevSym &S, const int *list, int n
     else hipLaunchKernelGGL(k_factor_small<128>, dim3(nfronts), dim3(256), 0, st, S, list, nzval, L, CB, info);
 }
 
+void launch_subtree(hipStream_t st, const DevSym &S, int phase, const int *sub_first, const int *sub_last, int ntasks,
+                    int rmax, const double *nzval, double *L, double *CB, int *info, double *X, double *W, int nr, int ldx) {
+    if (ntasks <= 0) return;
+    const dim3 g(ntasks), b(256);
+#define GMRFX_SUB(R)                                                                                                   \
+    do {                                                                                                               \
+        if (phase == 0) hipLaunchKernelGGL(k_factor_subtree<R>, g, b, 0, st, S, sub_first, sub_last, nzval, L, CB, info); \
+        else if (phase == 1) hipLaunchKernelGGL(k_fwd_subtree<R>, g, b, 0, st, S, sub_first, sub_last, L, X, W, nr, ldx);  \
+        else hipLaunchKernelGGL(k_bwd_subtree<R>, g, b, 0, st, S, sub_first, sub_last, L, X, nr, ldx);                    \
+    } while (0)
+    if (rmax <= 48) GMRFX_SUB(48);
+    else if (rmax <= 64) GMRFX_SUB(64);
+    else GMRFX_SUB(96);
+#undef GMRFX_SUB
+}
 void launch_fwd_small(hipStream_t st, const DevSym &S, const int *list, int nfronts, int rmax, const double *L,
                       double *X, double *W, int nr, int ldx) {
     if (nfronts <= 0) return;

@@ -365,12 +365,44 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
         return 4;
     };
     for (i32 s = 0; s < ns; s++) S.is_small[s] = cls(s) < 4;
+    // ---- subtree tasks ---------------------------------------------------------------------
+    // Supernodes are numbered in postorder, so the subtree of s is the id range [s-cnt+1, s].
+    S.in_subtree.assign(ns, 0);
+    {
+        const int submax = opt.subtree_max >= 0 ? opt.subtree_max : 24;
+        std::vector<i32> cnt(ns, 1), maxr(ns, 0);
+        std::vector<uint8_t> ok(ns, 0);
+        for (i32 s = 0; s < ns; s++) {
+            bool good = submax > 0 && cls(s) <= 2;
+            maxr[s] = S.nrows(s);
+            for (i64 q = S.childptr[s]; q < S.childptr[s + 1]; q++) {
+                const i32 d = S.children[q];
+                good = good && ok[d];
+                cnt[s] += cnt[d];
+                maxr[s] = std::max(maxr[s], maxr[d]);
+            }
+            ok[s] = good && cnt[s] <= submax;
+        }
+        std::vector<i32> roots[3];
+        for (i32 s = 0; s < ns; s++) {
+            if (!ok[s]) continue;
+            const i32 p = S.sparent[s];
+            if (p != -1 && ok[p]) continue;
+            const int k = maxr[s] <= 48 ? 0 : (maxr[s] <= 64 ? 1 : 2);
+            roots[k].push_back(s);
+            for (i32 t = s - cnt[s] + 1; t <= s; t++) S.in_subtree[t] = 1;
+        }
+        for (int k = 0; k < 3; k++) {
+            S.nsub_cls[k] = (i32)roots[k].size();
+            for (i32 s : roots[k]) { S.sub_first.push_back(s - cnt[s] + 1); S.sub_last.push_back(s); }
+        }
+    }
     S.levelptr.assign(S.nlevels + 1, 0);
-    for (i32 s = 0; s < ns; s++) S.levelptr[S.level[s] + 1]++;
+    for (i32 s = 0; s < ns; s++) if (!S.in_subtree[s]) S.levelptr[S.level[s] + 1]++;
     for (i32 l = 0; l < S.nlevels; l++) S.levelptr[l + 1] += S.levelptr[l];
-    S.levellist.resize(ns);
+    S.levellist.resize(S.levelptr[S.nlevels]);
     { std::vector<i64> w(S.levelptr.begin(), S.levelptr.end() - 1);
-      for (i32 s = 0; s < ns; s++) S.levellist[w[S.level[s]]++] = s; }
+      for (i32 s = 0; s < ns; s++) if (!S.in_subtree[s]) S.levellist[w[S.level[s]]++] = s; }
     S.level_nsmall.assign(S.nlevels, 0);
     S.level_ncls.assign((size_t)S.nlevels * 4, 0);
     for (i32 l = 0; l < S.nlevels; l++) {
@@ -386,6 +418,22 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
         S.level_nsmall[l] = k;
         S.n_small += k;
         S.n_big += (e - b) - k;
+    }
+    for (i32 s = 0; s < ns; s++) S.n_small += S.in_subtree[s];
+    // all-front level lists for the (top-down) selected inversion
+    S.sel_levelptr.assign(S.nlevels + 1, 0);
+    for (i32 s = 0; s < ns; s++) S.sel_levelptr[S.level[s] + 1]++;
+    for (i32 l = 0; l < S.nlevels; l++) S.sel_levelptr[l + 1] += S.sel_levelptr[l];
+    S.sel_levellist.resize(ns);
+    { std::vector<i64> w(S.sel_levelptr.begin(), S.sel_levelptr.end() - 1);
+      for (i32 s = 0; s < ns; s++) S.sel_levellist[w[S.level[s]]++] = s; }
+    S.sel_level_nsmall.assign(S.nlevels, 0);
+    for (i32 l = 0; l < S.nlevels; l++) {
+        auto b = S.sel_levellist.begin() + S.sel_levelptr[l], e = S.sel_levellist.begin() + S.sel_levelptr[l + 1];
+        std::stable_partition(b, e, [&](i32 x) { return cls(x) < 4; });
+        i32 k = 0;
+        for (auto it = b; it != e; ++it) if (cls(*it) < 4) k++;
+        S.sel_level_nsmall[l] = k;
     }
 
     // ---- Q scatter map -------------------------------------------------------------------

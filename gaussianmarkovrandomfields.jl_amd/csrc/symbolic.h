@@ -20,6 +20,7 @@ struct SymOptions {
     double relax_zeros = 0;  // 0 = default
     int coord_dim = 0;
     const double *coords = nullptr;
+    int subtree_max = -1;      // max fronts per subtree task; -1 = default (24), 0 = off
     int small_front_rows = -1; // fronts with r <= this (and <= 64 columns) use the fused LDS kernels; -1 = default (128), 0 = off
 };
 
@@ -57,6 +58,15 @@ struct Symbolic {
     std::vector<i32> level_nsmall;// per level: number of small fronts (prefix of the level's list)
     std::vector<i32> level_ncls;  // per level x 4: small fronts with r <= 48 / 64 / 96 / 128 (in this order in the list)
     std::vector<uint8_t> is_small;// per supernode
+    // subtree tasks: maximal all-small subtrees (<= 96 rows per front), each processed by ONE workgroup,
+    // fronts in postorder = contiguous supernode id range [sub_first, sub_last]; grouped by row class
+    std::vector<i32> sub_first, sub_last;
+    i32 nsub_cls[3] = {0, 0, 0};   // tasks whose largest front has <= 48 / 64 / 96 rows (in this order)
+    std::vector<uint8_t> in_subtree;
+    // level lists over ALL fronts (subtree members included) for the selected inversion: per level
+    // small fronts first, then big fronts
+    std::vector<i64> sel_levelptr;
+    std::vector<i32> sel_levellist, sel_level_nsmall;
     int small_rows = 0;
     // Q scatter map, sorted by destination
     std::vector<i64> qsrc;        // index into caller's nzval

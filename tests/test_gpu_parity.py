@@ -350,3 +350,17 @@ def test_3d_medium_residual():
     F = orc.OracleFactor(Q, ws.backend.ordering_permutation())
     assert abs(ws.logdet() - F.logdet()) < 1e-10 * abs(F.logdet())
     assert relerr(ws.selinv_diag(), F.selinv_diag()) < 1e-8
+
+
+@pytest.mark.parametrize("name", ["matern64_coords", "cfg1_alpha3_65x65", "matern3d_10", "rand400"])
+def test_subtree_tasks_on_and_off_agree(name, monkeypatch):
+    """Whole-subtree workgroup tasks (default) vs pure level scheduling (GMRFX_SUBTREE_MAX=0):
+    same factor bit for bit (same arithmetic per front), same answers."""
+    Q, kw = next((sp.csc_matrix(q), k) for n, q, k in CASES if n == name)
+    ws_on = gmrfx.GMRFWorkspace(Q, **kw)
+    monkeypatch.setenv("GMRFX_SUBTREE_MAX", "0")
+    ws_off = gmrfx.GMRFWorkspace(Q, **kw)
+    assert np.array_equal(ws_on.backend.factor_values(), ws_off.backend.factor_values())
+    B = np.random.default_rng(0).standard_normal((Q.shape[0], 64))
+    assert np.array_equal(ws_on.workspace_solve(B), ws_off.workspace_solve(B))
+    assert np.array_equal(ws_on.selinv_diag(), ws_off.selinv_diag())
