@@ -58,6 +58,9 @@ def main():
     ap.add_argument("--nrhs", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--extras", action="store_true", help="also time selinv-diag and 256-sample rand (cfg 3)")
+    ap.add_argument("--pool", type=int, default=0,
+                    help="extra: throughput of P independent workspaces driven concurrently on this GPU "
+                         "(the reference's WorkspacePool pattern; reported separately, never as `value`)")
     args = ap.parse_args()
 
     import numpy as np
@@ -135,6 +138,32 @@ def main():
         torch.cuda.synchronize()
         be.backward_solve_dev(d_Z.data_ptr(), n, 256, d_S.data_ptr(), n)
         extras["ms_rand256"] = be.stats()["ms_backward_solve"]
+
+    if args.pool > 1 and rank == 0:
+        # P independent handles (own HIP streams), one host thread each; ctypes drops the GIL in the calls
+        import threading
+        perm = be.ordering_permutation()
+        pool = [be] + [gmrfx.MI355XBackend(Q, ordering=perm, device=local_rank, factorize=False) for _ in range(args.pool - 1)]
+        bufs = [(d_B, d_X)] + [(d_B, torch.empty_like(d_B)) for _ in range(args.pool - 1)]
+        torch.cuda.synchronize()
+
+        def worker(b, bx, reps):
+            for _ in range(reps):
+                b.refactorize_dev(d_nz.data_ptr())
+                b.solve_dev(bx[0].data_ptr(), n, args.nrhs, bx[1].data_ptr(), n)
+
+        for reps in (1, args.steps):     # warm-up round, then the timed round
+            th = [threading.Thread(target=worker, args=(pool[i], bufs[i], reps)) for i in range(args.pool)]
+            torch.cuda.synchronize()
+            tp0 = time.perf_counter()
+            [t.start() for t in th]
+            [t.join() for t in th]
+            torch.cuda.synchronize()
+            tp = time.perf_counter() - tp0
+        extras["pool"] = {"workspaces": args.pool, "dof_per_s": args.pool * args.steps * n / tp,
+                          "ms_per_step_per_workspace": 1e3 * tp / args.steps}
+        for b in pool[1:]:
+            b.close()
 
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
