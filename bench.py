@@ -57,6 +57,9 @@ def main():
     ap.add_argument("--grid", type=int, default=1000, help="nodes per side of the 2-D mesh (cfg 2: 1000)")
     ap.add_argument("--nrhs", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="multi-process rehearsal on a box with ONE GPU: every rank uses cuda:0 and the "
+                         "process group runs on gloo (RCCL refuses two ranks on one device)")
     ap.add_argument("--extras", action="store_true", help="also time selinv-diag and 256-sample rand (cfg 3)")
     ap.add_argument("--pool", type=int, default=0,
                     help="extra: throughput of P independent workspaces driven concurrently on this GPU "
@@ -73,12 +76,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libgmrfx has no CPU path")
+    if args.rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     mesh = spde.grid_mesh_2d(args.grid, args.grid, jitter=0.25, seed=0)
     Q = spde.matern_precision(mesh, smoothness=0, range_=0.2)   # range = 0.1 * domain width (2.0)
@@ -118,7 +126,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
