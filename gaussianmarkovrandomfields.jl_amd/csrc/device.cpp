@@ -207,7 +207,7 @@ void Device::factor_levels() {
         const int nblk = level_nblk(L);
         for (int b = 0; b < nblk; b++) {
             const int kb = b * NB;
-            launch_potrf_lds(stream, ds_, list, L.active[b], kb, d_L_, d_info_);
+            launch_potrf64(stream, ds_, list, L.active[b], kb, d_L_, d_info_);
             launch_trsm(stream, ds_, list, L.active[b], kb, 0, L.max_rows - kb - 1, d_L_, nullptr, nullptr);
             if (b + 1 < nblk)
                 launch_gemm_nt(stream, ds_, list, L.active[b + 1], kb, 0, L.max_rows - kb - NB, L.max_cols - kb - NB, d_L_, d_cb_);

@@ -7,7 +7,7 @@
 namespace gmrfx {
 
 constexpr int NB = 64;       // block-column width of the dense partial factorisation / sweeps
-constexpr int ASM_CW = 16;   // front columns owned by one assembly workgroup
+constexpr int ASM_CW = 4;    // front columns owned by one assembly workgroup
 constexpr int FWD_RB = 32;    // front rows owned by one forward-assembly workgroup
 
 void launch_assemble(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols,
@@ -111,6 +111,7 @@ void launch_factor_small(hipStream_t st, const DevSym &S, const int *list, int n
 void launch_subtree(hipStream_t st, const DevSym &S, int phase, const int *sub_first, const int *sub_last, int ntasks,
                     int rmax, const double *nzval, double *L, double *CB, int *info, double *X, double *W, int nr, int ldx);
 void launch_potrf_lds(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, double *L, int *info);
+void launch_potrf64(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, double *L, int *info);   // potrf64.hip
 void launch_fwd_small(hipStream_t st, const DevSym &S, const int *list, int nfronts, int rmax, const double *L,
                       double *X, double *W, int nr, int ldx);
 void launch_bwd_small(hipStream_t st, const DevSym &S, const int *list, int nfronts, int rmax, const double *L,

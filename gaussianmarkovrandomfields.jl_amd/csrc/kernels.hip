@@ -51,6 +51,7 @@ __global__ __launch_bounds__(256) void k_assemble(DevSym S, const int *__restric
     const int ld = S.ld[s];
     double *P = L + S.panelptr[s];
     const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
     for (int col = col0; col < col1; col++)
         for (int i = tid; i < ld; i += 256) P[i + (long long)col * ld] = 0.0;
     __syncthreads();
@@ -72,9 +73,25 @@ __global__ __launch_bounds__(256) void k_assemble(DevSym S, const int *__restric
         const double *Ud = CB + S.cbptr[d];
         const int j0 = lower_bound_i32(reld, md, col0);
         const int j1 = lower_bound_i32(reld, md, col1);
-        for (int j = j0; j < j1; j++) {
+        // one child column per wave, four independent row chunks in flight per lane (the loop is a
+        // chain of dependent HBM round trips: rel -> P read-modify-write)
+        for (int j = j0 + wave; j < j1; j += 4) {
             const int tc = reld[j];
-            for (int i = j + tid; i < md; i += 256) P[reld[i] + (long long)tc * ld] += Ud[i + (long long)j * md];
+            double *Pc = P + (long long)tc * ld;
+            const double *Uc = Ud + (long long)j * md;
+            for (int i0 = j + lane; i0 < md; i0 += 256) {
+                int ri[4];
+                double u[4], pv[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) ri[q] = reld[min(i0 + 64 * q, md - 1)];
+#pragma unroll
+                for (int q = 0; q < 4; q++) u[q] = Uc[min(i0 + 64 * q, md - 1)];
+#pragma unroll
+                for (int q = 0; q < 4; q++) pv[q] = Pc[ri[q]];
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    if (i0 + 64 * q < md) Pc[ri[q]] = pv[q] + u[q];
+            }
         }
         __syncthreads();
     }

@@ -22,6 +22,16 @@ namespace gmrfx {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+// Phase-cycle instrumentation for tools/micro/potrf_prof.hip (compiled out of the library).
+#ifdef GMRFX_CYC
+__device__ long long g_cyc[4][16];
+#define CYC_DECL long long cyc_t = clock64(); const int cyc_w = (threadIdx.x & 63) == 0 ? (int)(threadIdx.x >> 6) : -1
+#define CYC_MARK(k) do { __builtin_amdgcn_sched_barrier(0); long long t_ = clock64(); if (cyc_w >= 0) g_cyc[cyc_w][k] += t_ - cyc_t; cyc_t = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define CYC_DECL
+#define CYC_MARK(k)
+#endif
+
 constexpr int lds_ldf(int R) { return R + 2; }                                   // = 2 (mod 4), odd half: conflict-free tile RMW
 constexpr int lds_ldp(int R) { return (R + 16) % 32 == 16 ? R + 16 : R + 32; }   // = 16 (mod 32): conflict-free operand reads
 constexpr int LDW = 80;                                                          // 64 columns, = 16 (mod 32)
@@ -31,13 +41,19 @@ constexpr int LDW = 80;                                                         
 // the strict upper triangle of F's c x c block). Must be called by all 256 threads.
 template <int RMAX>
 __device__ __forceinline__ void lds_partial_cholesky(double *F, double *Pn, double *Wn, const int c, const int r,
-                                                      const int first, int *__restrict__ info) {
+                                                      const int first, int *__restrict__ info,
+                                                      double *__restrict__ Pg, const int ldg) {
+    // Pg/ldg: the front's panel in HBM. L values and the rows of X = L11^-1 are written there AS
+    // SOON AS THEY ARE FINAL (coalesced), not kept in F: that removes one of the three barriers of
+    // a panel step (nothing is written to F between the reads of the step and its tile updates)
     constexpr int LDF = lds_ldf(RMAX);
     constexpr int LDP = lds_ldp(RMAX);
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int lm = lane & 15, lk = lane >> 4;
+    CYC_DECL;
     for (int j0 = 0; j0 < c; j0 += 4) {
+        CYC_MARK(0);
         const int nbk = min(4, c - j0);
         // 4x4 diagonal block (identity-padded) -> its Cholesky factor, redundantly per thread
         double dd[4][4];
@@ -66,6 +82,10 @@ __device__ __forceinline__ void lds_partial_cholesky(double *F, double *Pn, doub
         const double l32 = (dd[3][2] - l30 * l20 - l31 * l21) * i22;
         const double p3 = dd[3][3] - l30 * l30 - l31 * l31 - l32 * l32;
         const double i33 = rsqrt_nr(p3);
+#ifdef GMRFX_CYC
+        asm volatile("" ::"v"(i33));
+#endif
+        CYC_MARK(1);
         if (tid == 0) {
             int bad = -1;
             if (!(p3 > 0.0) && nbk > 3) bad = 3;
@@ -118,14 +138,16 @@ __device__ __forceinline__ void lds_partial_cholesky(double *F, double *Pn, doub
                 for (int a = 0; a < 4; a++) if (a >= nbk || b > j0 + a) wv[a] = 0.0;
             }
         }
-        __syncthreads();   // every read of the diagonal block / panel / M rows is done
+        CYC_MARK(2);
+        // Pn / Wn were last read by the previous step's tile updates (a barrier ago) and F is not
+        // written in this phase: no barrier needed before publishing the panel
         if (tid < RMAX) {
             const int i = tid;
 #pragma unroll
             for (int k = 0; k < 4; k++) Pn[k * LDP + i] = x[k];
             if (row_active) {
 #pragma unroll
-                for (int k = 0; k < 4; k++) if (k < nbk && i >= j0 + k) F[(j0 + k) * LDF + i] = x[k];
+                for (int k = 0; k < 4; k++) if (k < nbk && i >= j0 + k) Pg[i + (long long)(j0 + k) * ldg] = x[k];
             }
         } else if (tid >= 128 && tid < 128 + 64) {
             const int b = tid - 128;
@@ -133,10 +155,12 @@ __device__ __forceinline__ void lds_partial_cholesky(double *F, double *Pn, doub
             for (int a = 0; a < 4; a++) Wn[a * LDW + b] = wv[a];
             if (w_active) {
 #pragma unroll
-                for (int a = 0; a < 4; a++) if (a < nbk && b < j0 + a) F[(j0 + a) * LDF + b] = wv[a];   // X[j0+a][b] at F(b, j0+a)
+                for (int a = 0; a < 4; a++) if (a < nbk && b < j0 + a) Pg[b + (long long)(j0 + a) * ldg] = wv[a];   // X[j0+a][b]
             }
         }
+        CYC_MARK(3);
         __syncthreads();
+        CYC_MARK(4);
         // ---- rank-4 updates on 16x16 tiles ------------------------------------------------------
         const int jn = j0 + nbk;                 // first non-final column
         if (jn < r) {
@@ -163,6 +187,7 @@ __device__ __forceinline__ void lds_partial_cholesky(double *F, double *Pn, doub
                     if (row >= col) F[col * LDF + row] = cc[rr];                // lower part only
                 }
             }
+            CYC_MARK(5);
             // (b) M[i][b] -= sum_q L[i][j0+q] W[q][b] for jn <= i < c, b < jn; stored at F(b, i)
             if (jn < c) {
                 const int tihi = (c - 1) >> 4;                 // column tiles (index i) tlo..tihi
@@ -186,7 +211,9 @@ __device__ __forceinline__ void lds_partial_cholesky(double *F, double *Pn, doub
                 }
             }
         }
+        CYC_MARK(6);
         __syncthreads();
+        CYC_MARK(7);
     }
 
 }
@@ -250,14 +277,10 @@ __device__ __forceinline__ void factor_small_front(const DevSym &S, const int s,
         __syncthreads();
     }
 
-    lds_partial_cholesky<RMAX>(F, Pn, Wn, c, r, first, info);
+    lds_partial_cholesky<RMAX>(F, Pn, Wn, c, r, first, info, P, ld);
     const int wave = tid >> 6, lane = tid & 63;
 
-    // ---- write-out: panel (L lower + (L11^-1)' strict upper of the diagonal block), CB (lower) ---
-    for (int j = wave; j < c; j += 4) {
-        double *dst = P + (long long)j * ld;
-        for (int i = lane; i < r; i += 64) dst[i] = F[j * LDF + i];
-    }
+    // ---- write-out: the panel went to HBM column block by column block; only CB (lower) is left ---
     double *U = CB + S.cbptr[s];
     for (int j = wave; j < m; j += 4) {
         double *dst = U + (long long)j * m;
@@ -619,11 +642,7 @@ __global__ __launch_bounds__(256) void k_potrf_lds(DevSym S, const int *__restri
         F[j * LDF + i] = v[u] * ((i < w && j < w && i >= j) ? 1.0 : 0.0);
     }
     __syncthreads();
-    lds_partial_cholesky<64>(F, Pn, Wn, w, w, S.sfirst[s] + kb, info);
-    for (int idx = tid; idx < 64 * 64; idx += 256) {
-        const int i = idx & 63, j = idx >> 6;
-        if (i < w && j < w) P[i + (long long)j * ld] = F[j * LDF + i];
-    }
+    lds_partial_cholesky<64>(F, Pn, Wn, w, w, S.sfirst[s] + kb, info, P, ld);
 }
 void launch_potrf_lds(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, double *L, int *info) {
     if (nactive <= 0) return;
