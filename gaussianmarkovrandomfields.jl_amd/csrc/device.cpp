@@ -188,6 +188,7 @@ void Device::clone_from(const Device &o, const Symbolic &S) {
 }
 
 static const int kClsRows[4] = {48, 64, 96, 128};
+static const int OBK = 4;   // 64-column blocks per outer (256-column) block of the panel factorisation
 static inline int level_max_trail(const LevelInfo &L) { return L.active.back(); }
 static inline int level_nblk(const LevelInfo &L) { return (int)L.active.size() - 2; }
 
@@ -209,8 +210,15 @@ void Device::factor_levels() {
             const int kb = b * NB;
             launch_potrf64(stream, ds_, list, L.active[b], kb, d_L_, d_info_);
             launch_trsm(stream, ds_, list, L.active[b], kb, 0, L.max_rows - kb - 1, d_L_, nullptr, nullptr);
-            if (b + 1 < nblk)
-                launch_gemm_nt(stream, ds_, list, L.active[b + 1], kb, 0, L.max_rows - kb - NB, L.max_cols - kb - NB, d_L_, d_cb_);
+            // two-level blocking: K = 64 updates only inside the current 256-column block, the
+            // rest of the panel once per block with K = 256
+            const int J1 = (b / OBK + 1) * OBK;   // first 64-block of the next 256-column block
+            if (b + 1 < nblk && b + 1 < J1)
+                launch_gemm_nt(stream, ds_, list, L.active[b + 1], kb, NB, kb + NB, J1 * NB, L.max_rows - kb - NB,
+                               std::min(J1 * NB, L.max_cols) - kb - NB, d_L_);
+            if (b + 1 == J1 && J1 < nblk)
+                launch_gemm_nt(stream, ds_, list, L.active[J1], (J1 - OBK) * NB, OBK * NB, J1 * NB, INT_MAX,
+                               L.max_rows - J1 * NB, L.max_cols - J1 * NB, d_L_);
         }
         launch_syrk_cb(stream, ds_, list, nf, level_max_trail(L), d_L_, d_cb_);
     }

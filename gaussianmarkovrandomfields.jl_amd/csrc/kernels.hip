@@ -21,23 +21,40 @@ namespace gmrfx {
 
 typedef gmrfx_d4 d4;
 
-__device__ __forceinline__ int lower_bound_i32(const int *a, int n, int v) {
-    int lo = 0, hi = n;
-    while (lo < hi) {
-        int mid = (lo + hi) >> 1;
-        if (a[mid] < v) lo = mid + 1; else hi = mid;
+// Two lower bounds in the sorted array a[0..n) at once, by all 64 lanes of a wave together
+// (64-ary search: 2 rounds of one load each for n <= 4096 instead of 12 dependent loads each).
+// Must be called in wave-uniform control flow; the results are wave-uniform.
+__device__ __forceinline__ void wave_lower_bound2(const int *__restrict__ a, const int n, const int k0, const int k1,
+                                                  const int lane, int &r0, int &r1) {
+    int lo0 = 0, hi0 = n, lo1 = 0, hi1 = n;
+    while (lo0 < hi0 || lo1 < hi1) {
+        const int st0 = max((hi0 - lo0 + 63) >> 6, 1), st1 = max((hi1 - lo1 + 63) >> 6, 1);
+        const int x0 = lo0 + lane * st0, x1 = lo1 + lane * st1;
+        const int v0 = a[min(x0, n - 1)], v1 = a[min(x1, n - 1)];
+        const int c0 = __popcll(__ballot(x0 < hi0 && v0 < k0));
+        const int c1 = __popcll(__ballot(x1 < hi1 && v1 < k1));
+        if (lo0 < hi0) {
+            if (c0 == 0) hi0 = lo0;
+            else { const int nl = lo0 + (c0 - 1) * st0 + 1; hi0 = min(lo0 + c0 * st0, hi0); lo0 = nl; }
+        }
+        if (lo1 < hi1) {
+            if (c1 == 0) hi1 = lo1;
+            else { const int nl = lo1 + (c1 - 1) * st1 + 1; hi1 = min(lo1 + c1 * st1, hi1); lo1 = nl; }
+        }
     }
-    return lo;
+    r0 = lo0;
+    r1 = lo1;
 }
 
 // ------------------------------------------------------------------------------------------
 // Factorisation
 // ------------------------------------------------------------------------------------------
 
-// Zero the front, scatter Q's values, extend-add the children's contribution blocks.
-// Block (bx, f) owns front-local columns [bx*CW, bx*CW+CW) of front f: every target entry has
-// exactly one owner block, children are applied one after the other, so the sum order is
-// fixed and the result is bit-reproducible (no atomics).
+// Zero the panel, scatter Q's values, extend-add the children's contribution blocks.
+// ONE WAVE owns one front-local column (workgroup (bx, f) = columns 4 bx .. 4 bx + 3 of front f):
+// every target entry has exactly one owner, which applies the children one after the other, so
+// the sum order is fixed (bit-reproducible, no atomics) and no barrier is needed at all; the
+// kernel is a chain of dependent HBM round trips, kept short by the wave-wide searches.
 __global__ __launch_bounds__(256) void k_assemble(DevSym S, const int *__restrict__ list,
                                                   const double *__restrict__ nzval, double *__restrict__ L,
                                                   double *__restrict__ CB) {
@@ -45,55 +62,44 @@ __global__ __launch_bounds__(256) void k_assemble(DevSym S, const int *__restric
     // assembled inside k_syrk_cb (children gathered into an LDS tile, CB written exactly once).
     const int s = list[blockIdx.y];
     const int c = S.sfirst[s + 1] - S.sfirst[s];
-    const int col0 = blockIdx.x * ASM_CW;
-    if (col0 >= c) return;
-    const int col1 = min(col0 + ASM_CW, c);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tc = blockIdx.x * ASM_CW + wave;
+    if (tc >= c) return;
     const int ld = S.ld[s];
-    double *P = L + S.panelptr[s];
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
-    for (int col = col0; col < col1; col++)
-        for (int i = tid; i < ld; i += 256) P[i + (long long)col * ld] = 0.0;
-    __syncthreads();
+    double *Pc = L + S.panelptr[s] + (long long)tc * ld;
+    for (int i = lane; i < ld; i += 64) Pc[i] = 0.0;
     {
         const long long q0 = S.qptr[s];
         const int nq = (int)(S.qptr[s + 1] - q0);
         const int *qd = S.qdst + q0;
         const int *qs = S.qsrc + q0;
-        const int lo = lower_bound_i32(qd, nq, col0 * ld);
-        const int hi = lower_bound_i32(qd, nq, col1 * ld);
-        for (int q = lo + tid; q < hi; q += 256) P[qd[q]] = nzval[qs[q]];
+        int lo, hi;
+        wave_lower_bound2(qd, nq, tc * ld, (tc + 1) * ld, lane, lo, hi);
+        for (int q = lo + lane; q < hi; q += 64) Pc[qd[q] - tc * ld] = nzval[qs[q]];
     }
-    __syncthreads();
     for (long long ch = S.childptr[s]; ch < S.childptr[s + 1]; ch++) {
         const int d = S.children[ch];
         const int cd = S.sfirst[d + 1] - S.sfirst[d];
         const int md = (int)(S.rowptr[d + 1] - S.rowptr[d]) - cd;
         const int *reld = S.rel + S.rowptr[d] + cd;
-        const double *Ud = CB + S.cbptr[d];
-        const int j0 = lower_bound_i32(reld, md, col0);
-        const int j1 = lower_bound_i32(reld, md, col1);
-        // one child column per wave, four independent row chunks in flight per lane (the loop is a
-        // chain of dependent HBM round trips: rel -> P read-modify-write)
-        for (int j = j0 + wave; j < j1; j += 4) {
-            const int tc = reld[j];
-            double *Pc = P + (long long)tc * ld;
-            const double *Uc = Ud + (long long)j * md;
-            for (int i0 = j + lane; i0 < md; i0 += 256) {
-                int ri[4];
-                double u[4], pv[4];
+        int j, j1;
+        wave_lower_bound2(reld, md, tc, tc + 1, lane, j, j1);
+        if (j1 == j) continue;                    // this child has no row mapped to column tc
+        const double *Uc = CB + S.cbptr[d] + (long long)j * md;
+        // four independent row chunks in flight per lane (rel -> P read-modify-write chain)
+        for (int i0 = j + lane; i0 < md; i0 += 256) {
+            int ri[4];
+            double u[4], pv[4];
 #pragma unroll
-                for (int q = 0; q < 4; q++) ri[q] = reld[min(i0 + 64 * q, md - 1)];
+            for (int q = 0; q < 4; q++) ri[q] = reld[min(i0 + 64 * q, md - 1)];
 #pragma unroll
-                for (int q = 0; q < 4; q++) u[q] = Uc[min(i0 + 64 * q, md - 1)];
+            for (int q = 0; q < 4; q++) u[q] = Uc[min(i0 + 64 * q, md - 1)];
 #pragma unroll
-                for (int q = 0; q < 4; q++) pv[q] = Pc[ri[q]];
+            for (int q = 0; q < 4; q++) pv[q] = Pc[ri[q]];
 #pragma unroll
-                for (int q = 0; q < 4; q++)
-                    if (i0 + 64 * q < md) Pc[ri[q]] = pv[q] + u[q];
-            }
+            for (int q = 0; q < 4; q++)
+                if (i0 + 64 * q < md) Pc[ri[q]] = pv[q] + u[q];
         }
-        __syncthreads();
     }
 }
 
@@ -186,32 +192,24 @@ __global__ __launch_bounds__(256) void k_trsm(DevSym S, const int *__restrict__ 
 // C[i,j] -= sum_k A[i,k] * B[j,k]  on 64x64 tiles (4 waves x 32x32), FP64 MFMA, operands read
 // straight from HBM/L2. The MFMA is issued "transposed" (first operand = rows of B) so that
 // the 16 lanes sharing a register index walk down a COLUMN of the column-major C.
-// mode 0: trailing update inside the panel after block-column kb; mode 1: contribution block
+// Trailing update inside the panel (see the comment in the kernel); the contribution block is k_syrk_cb.
 // CB -= L21 L21' (K = all c columns).
 template <int TW>   // MFMA tiles per wave and dimension: wave tile 16*TW squared, workgroup tile twice that
-__global__ __launch_bounds__(256) void k_gemm_nt(DevSym S, const int *__restrict__ list, int kb, int mode,
-                                                 double *__restrict__ L, double *__restrict__ CB) {
+__global__ __launch_bounds__(256) void k_gemm_nt(DevSym S, const int *__restrict__ list, int k0, int K, int c0, int c1,
+                                                 double *__restrict__ L) {
+    // panel columns [c0, min(c1, c)) of the front, rows c0 .. r-1:  C -= A A'  with A = the K
+    // (finished) panel columns k0 .. k0+K-1 of those rows. Two-level blocking: K = 64 updates stay
+    // inside the current 256-column block, the rest of the panel is updated once per 256 columns
+    // with K = 256 (a quarter of the read-modify-write traffic of a flat right-looking sweep).
     const int s = list[blockIdx.z];
     const int c = S.sfirst[s + 1] - S.sfirst[s];
+    if (c0 >= c) return;
     const int r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
     const int ld = S.ld[s];
     double *P = L + S.panelptr[s];
-    int M, N, K, ldc;
-    const double *A;
-    double *C;
-    if (mode == 0) {
-        if (kb + NB >= c) return;
-        const int o = kb + NB;
-        M = r - o; N = c - o; K = NB;
-        A = P + o + (long long)kb * ld;
-        C = P + o + (long long)o * ld;
-        ldc = ld;
-    } else {
-        M = N = r - c; K = c;
-        A = P + c;
-        C = CB + S.cbptr[s];
-        ldc = M;
-    }
+    const int M = r - c0, N = min(c1, c) - c0, ldc = ld;
+    const double *A = P + c0 + (long long)k0 * ld;
+    double *C = P + c0 + (long long)c0 * ld;
     const int bi = blockIdx.x, bj = blockIdx.y;
     constexpr int WT = 16 * TW, GT = 2 * WT;
     if (bj > bi || bi * GT >= M || bj * GT >= N) return;
@@ -317,8 +315,9 @@ __global__ __launch_bounds__(256) void k_syrk_cb(DevSym S, const int *__restrict
         const int *reld = S.rel + S.rowptr[d] + cd;
         const double *Ud = CB + S.cbptr[d];
         // child rows/cols whose parent position falls into this tile (rel is increasing)
-        const int a0 = lower_bound_i32(reld, md, c + ti0), a1 = lower_bound_i32(reld, md, c + ti0 + 64);
-        const int b0 = lower_bound_i32(reld, md, c + tj0), b1 = lower_bound_i32(reld, md, c + tj0 + 64);
+        int a0, a1, b0, b1;
+        wave_lower_bound2(reld, md, c + ti0, c + ti0 + 64, tid & 63, a0, a1);
+        wave_lower_bound2(reld, md, c + tj0, c + tj0 + 64, tid & 63, b0, b1);
         const int la = tid & 63, lb = tid >> 6;
         const int a = a0 + la;
         if (a < a1) {
@@ -385,8 +384,8 @@ __global__ __launch_bounds__(256) void k_fwd_assemble(DevSym S, const int *__res
         const int md = (int)(S.rowptr[d + 1] - S.rowptr[d]) - cd;
         const int *reld = S.rel + S.rowptr[d] + cd;
         const double *Wd = W + S.wptr[d] * ldx;
-        const int a0 = lower_bound_i32(reld, md, i0);
-        const int a1 = lower_bound_i32(reld, md, i1);
+        int a0, a1;
+        wave_lower_bound2(reld, md, i0, i1, (int)(threadIdx.x & 63), a0, a1);
         const int cnt = (a1 - a0) * nr;
         for (int idx = tid; idx < cnt; idx += 256) {
             const int a = a0 + idx / nr, j = idx % nr;
@@ -435,8 +434,8 @@ __global__ __launch_bounds__(256) void k_fwd_update_longk(DevSym S, const int *_
             const int md = (int)(S.rowptr[d + 1] - S.rowptr[d]) - cd;
             const int *reld = S.rel + S.rowptr[d] + cd;
             const double *Wd = W + S.wptr[d] * ldx;
-            const int a0 = lower_bound_i32(reld, md, i0);
-            const int a1 = lower_bound_i32(reld, md, i0 + 32);
+            int a0, a1;
+            wave_lower_bound2(reld, md, i0, i0 + 32, (int)(threadIdx.x & 63), a0, a1);
             for (int a = a0 + g; a < a1; a += 4) Tl[(reld[a] - i0) * 64 + j] += Wd[(long long)a * ldx + jcl] * jm;
             __syncthreads();
         }
@@ -647,14 +646,14 @@ void launch_trsm(hipStream_t st, const DevSym &S, const int *list, int nactive, 
     if (nactive <= 0 || max_rows_below <= 0) return;
     hipLaunchKernelGGL(k_trsm, dim3(cdiv(max_rows_below, 64), nactive), dim3(256), 0, st, S, list, kb, mode, L, Yh, yoff);
 }
-void launch_gemm_nt(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int mode, int maxM,
-                    int maxN, double *L, double *CB) {
+void launch_gemm_nt(hipStream_t st, const DevSym &S, const int *list, int nactive, int k0, int K, int c0, int c1,
+                    int maxM, int maxN, double *L) {
     if (nactive <= 0 || maxM <= 0 || maxN <= 0) return;
     // 64x64 workgroup tiles, operands straight from L2 at 3-4 waves per SIMD. Measured on MI355X: the
     // sustained v_mfma_f64_16x16x4_f64 rate is 36.3 TFLOP/s (tools/micro/mfma64.hip), this kernel reaches
     // ~27 TFLOP/s on the top-of-tree SYRKs; 128x128 tiles (register- or LDS-staged) were tried and lost
     // to it because they drop to one wave per SIMD.
-    hipLaunchKernelGGL(k_gemm_nt<2>, dim3(cdiv(maxM, 64), cdiv(maxN, 64), nactive), dim3(256), 0, st, S, list, kb, mode, L, CB);
+    hipLaunchKernelGGL(k_gemm_nt<2>, dim3(cdiv(maxM, 64), cdiv(maxN, 64), nactive), dim3(256), 0, st, S, list, k0, K, c0, c1, L);
 }
 void launch_fwd_assemble(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_rows, double *X,
                          double *W, int nr, int ldx, int own_only) {
