@@ -132,16 +132,21 @@ __device__ __forceinline__ void stage_linv(const double *__restrict__ Dg, int ld
 //   mode 0 (factorisation):      A[i, blk] <- A[i, blk] * Linv'      (in place, = L21 rows)
 //   mode 1 (selected inversion): Yh[i, :]  <- L[i, blk] * Linv
 // One wave owns 16 rows (reads all of them before it writes), a workgroup 64 rows.
-__global__ __launch_bounds__(256) void k_trsm(DevSym S, const int *__restrict__ list, int kb, int mode,
+template <int MODE, int SPLIT>
+__global__ __launch_bounds__(256) void k_trsm(DevSym S, const int *__restrict__ list, int kb,
                                               double *__restrict__ L, double *__restrict__ Yh,
                                               const long long *__restrict__ yoff) {
+    // SPLIT = 0: a workgroup owns 64 rows, each wave 16 of them (all four 16-column tiles);
+    // SPLIT = 1 (latency variant for levels with a handful of fronts): a workgroup owns 16 rows
+    // and each wave ONE column tile of them -- four times the workgroups, a quarter of the MFMA
+    // chain per wave (a single CU sustains only ~0.14 TFLOP/s of FP64 MFMA).
     __shared__ double Ti[NB * NB];
     const int s = list[blockIdx.y];
     const int c = S.sfirst[s + 1] - S.sfirst[s];
     const int r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
     if (kb >= c) return;
     const int w = min(NB, c - kb);
-    const int row0 = kb + w + blockIdx.x * 64;
+    const int row0 = kb + w + blockIdx.x * (SPLIT ? 16 : 64);
     if (row0 >= r) return;
     const int ld = S.ld[s];
     double *Pp = L + S.panelptr[s];
@@ -149,44 +154,65 @@ __global__ __launch_bounds__(256) void k_trsm(DevSym S, const int *__restrict__ 
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int lm = lane & 15, lk = lane >> 4;
-    const int i0 = row0 + wave * 16;
+    const int i0 = SPLIT ? row0 : row0 + wave * 16;
     if (i0 >= r) return;
     const int i = i0 + lm;
     const double *A = Pp + (long long)kb * ld;
-    d4 acc[4];
+    const double *pa = A + min(i, r - 1);
+    double bv[16];
 #pragma unroll
-    for (int t = 0; t < 4; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
-    {
-        const double *pa = A + min(i, r - 1);
-        double bv[16];
+    for (int u = 0; u < 16; u++) {
+        const int q = 4 * u + lk;
+        bv[u] = pa[(long long)min(q, w - 1) * ld];   // B[kk=q][n=i]; Ti is zero for q >= w, rows >= r never stored
+    }
+    double *out = MODE == 0 ? Pp + (long long)kb * ld : Yh + yoff[s];
+    const int ldo = MODE == 0 ? ld : r;
+    // Linv is lower triangular: MODE 0 (A Linv') needs q <= k, MODE 1 (L Linv) needs q >= k
+    if (SPLIT) {
+        const int t = wave;
+        d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+        const int k = t * 16 + lm;
+        const int ulo = MODE == 0 ? 0 : 4 * t, uhi = MODE == 0 ? 4 * t + 4 : 16;
 #pragma unroll
         for (int u = 0; u < 16; u++) {
-            const int q = 4 * u + lk;
-            bv[u] = pa[(long long)min(q, w - 1) * ld];   // B[kk=q][n=i]; Ti is zero for q >= w, rows >= r never stored
+            const int q = 4 * u + lk;                                             // A[m=k][kk=q]
+            const double av = MODE == 0 ? Ti[k * NB + q] : Ti[q * NB + k];
+            if (u >= ulo && u < uhi && 4 * u < w) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[u], acc, 0, 0, 0);
         }
+        __syncthreads();   // in place: the other waves read the columns this wave overwrites
+        if (i >= r) return;
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+            const int kk = t * 16 + lk + 4 * rr;
+            if (kk < w) out[i + (long long)kk * ldo] = acc[rr];
+        }
+    } else {
+        d4 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int u = 0; u < 16; u++) {
             const int q = 4 * u + lk;
             if (4 * u < w) {
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
-                    const int k = t * 16 + lm;                                    // A[m=k][kk=q]
-                    const double av = mode == 0 ? Ti[k * NB + q] : Ti[q * NB + k];
-                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[u], acc[t], 0, 0, 0);
+                    if (MODE == 0 ? (u <= 4 * t + 3) : (u >= 4 * t)) {
+                        const int k = t * 16 + lm;                                    // A[m=k][kk=q]
+                        const double av = MODE == 0 ? Ti[k * NB + q] : Ti[q * NB + k];
+                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[u], acc[t], 0, 0, 0);
+                    }
                 }
             }
         }
+        if (i >= r) return;
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                const int k = t * 16 + lk + 4 * rr;
+                if (k < w) out[i + (long long)k * ldo] = acc[t][rr];
+            }
     }
-    if (i >= r) return;
-    double *out = mode == 0 ? Pp + (long long)kb * ld : Yh + yoff[s];
-    const int ldo = mode == 0 ? ld : r;
-#pragma unroll
-    for (int t = 0; t < 4; t++)
-#pragma unroll
-        for (int rr = 0; rr < 4; rr++) {
-            const int k = t * 16 + lk + 4 * rr;
-            if (k < w) out[i + (long long)k * ldo] = acc[t][rr];
-        }
 }
 
 // C[i,j] -= sum_k A[i,k] * B[j,k]  on 64x64 tiles (4 waves x 32x32), FP64 MFMA, operands read
@@ -225,7 +251,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(DevSym S, const int *__restrict
     // Operand rows are clamped (always-valid addresses, values masked afterwards) so that the
     // loads of a whole batch of KU k-steps issue back to back; the next batch is fetched into
     // a second register set before the current batch's MFMAs (software double buffering).
-    constexpr int KU = TW == 2 ? 4 : 2;
+    constexpr int KU = TW == 2 ? 4 : 8;
     const double *pa[TW], *pb[TW];
 #pragma unroll
     for (int a = 0; a < TW; a++) pa[a] = A + min(i0 + a * 16 + lm, M - 1);
@@ -644,7 +670,15 @@ void launch_syrk_cb(hipStream_t st, const DevSym &S, const int *list, int nfront
 void launch_trsm(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int mode, int max_rows_below,
                  double *L, double *Yh, const long long *yoff) {
     if (nactive <= 0 || max_rows_below <= 0) return;
-    hipLaunchKernelGGL(k_trsm, dim3(cdiv(max_rows_below, 64), nactive), dim3(256), 0, st, S, list, kb, mode, L, Yh, yoff);
+    const bool split = (long long)cdiv(max_rows_below, 64) * nactive <= 128;
+    const dim3 grid(cdiv(max_rows_below, split ? 16 : 64), nactive);
+    if (mode == 0) {
+        if (split) hipLaunchKernelGGL((k_trsm<0, 1>), grid, dim3(256), 0, st, S, list, kb, L, Yh, yoff);
+        else hipLaunchKernelGGL((k_trsm<0, 0>), grid, dim3(256), 0, st, S, list, kb, L, Yh, yoff);
+    } else {
+        if (split) hipLaunchKernelGGL((k_trsm<1, 1>), grid, dim3(256), 0, st, S, list, kb, L, Yh, yoff);
+        else hipLaunchKernelGGL((k_trsm<1, 0>), grid, dim3(256), 0, st, S, list, kb, L, Yh, yoff);
+    }
 }
 void launch_gemm_nt(hipStream_t st, const DevSym &S, const int *list, int nactive, int k0, int K, int c0, int c1,
                     int maxM, int maxN, double *L) {
@@ -653,7 +687,12 @@ void launch_gemm_nt(hipStream_t st, const DevSym &S, const int *list, int nactiv
     // sustained v_mfma_f64_16x16x4_f64 rate is 36.3 TFLOP/s (tools/micro/mfma64.hip), this kernel reaches
     // ~27 TFLOP/s on the top-of-tree SYRKs; 128x128 tiles (register- or LDS-staged) were tried and lost
     // to it because they drop to one wave per SIMD.
-    hipLaunchKernelGGL(k_gemm_nt<2>, dim3(cdiv(maxM, 64), cdiv(maxN, 64), nactive), dim3(256), 0, st, S, list, k0, K, c0, c1, L);
+    // Levels with a handful of fronts are latency bound: 32x32 workgroup tiles there (four times
+    // the workgroups, a quarter of the MFMA chain per wave).
+    if ((long long)cdiv(maxM, 64) * cdiv(maxN, 64) * nactive <= 256)
+        hipLaunchKernelGGL(k_gemm_nt<1>, dim3(cdiv(maxM, 32), cdiv(maxN, 32), nactive), dim3(256), 0, st, S, list, k0, K, c0, c1, L);
+    else
+        hipLaunchKernelGGL(k_gemm_nt<2>, dim3(cdiv(maxM, 64), cdiv(maxN, 64), nactive), dim3(256), 0, st, S, list, k0, K, c0, c1, L);
 }
 void launch_fwd_assemble(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_rows, double *X,
                          double *W, int nr, int ldx, int own_only) {
