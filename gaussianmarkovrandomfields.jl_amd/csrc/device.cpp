@@ -97,6 +97,34 @@ void Device::upload(const Symbolic &S) {
         up(lp, wptr); ds_.wptr = lp;
         HC(hipStreamSynchronize(stream));
     }
+    {
+        std::vector<long long> wptr(ns + 1, 0);
+        for (i32 s = 0; s < ns; s++) wptr[s + 1] = wptr[s] + (S.nrows(s) - S.ncols(s));
+        std::vector<EdgeRec> edges(S.children.size());
+        std::vector<int> etile;
+        for (i32 p = 0; p < ns; p++) {
+            const int cp = S.ncols(p), mp = S.nrows(p) - cp, nT = (mp + 31) / 32;
+            for (i64 ch = S.childptr[p]; ch < S.childptr[p + 1]; ch++) {
+                const i32 d = S.children[ch];
+                const int cd = S.ncols(d), md = S.nrows(d) - cd;
+                const i64 reloff = S.rowptr[d] + cd;
+                if (etile.size() + (size_t)nT + 1 >= (size_t)INT_MAX) throw std::runtime_error("edge tile table too large");
+                EdgeRec e{d, md, (int)etile.size(), 0, (long long)reloff, wptr[d], (long long)S.cbptr[d]};
+                int a = 0;
+                for (int T = 0; T <= nT; T++) {
+                    const int key = cp + 32 * T;
+                    while (a < md && S.rel[reloff + a] < key) a++;
+                    etile.push_back(a);
+                }
+                e.nown = etile[e.tptr];
+                edges[ch] = e;
+            }
+        }
+        const EdgeRec *ep; up(ep, edges); ds_.edge = ep;
+        if (etile.empty()) etile.push_back(0);
+        up(ip, etile); ds_.etile = ip;
+        HC(hipStreamSynchronize(stream));
+    }
     tmp64 = conv<long long>(S.diagoff); up(lp, tmp64); ds_.diagoff = lp; HC(hipStreamSynchronize(stream));
     up(ip, S.perm); ds_.perm = ip;
     {

@@ -9,6 +9,18 @@
 
 namespace gmrfx {
 
+// One record per (child -> parent) edge of the assembly tree, in childptr order: everything a
+// parent's workgroup needs to gather from that child, in ONE load instead of a chain of dependent
+// index loads (children[ch] -> sfirst/rowptr/cbptr/wptr[d] -> ...).
+struct EdgeRec {
+    int d, md;         // child supernode and its number of trailing rows
+    int tptr;          // offset of this edge's tile table in DevSym::etile
+    int nown;          // child rows that map into the parent's OWN columns (= etile[tptr])
+    long long reloff;  // offset of the child's trailing rows in DevSym::rel
+    long long woff;    // DevSym::wptr[d]
+    long long cboff;   // DevSym::cbptr[d]
+};
+
 // Pointers to the symbolic structure in HBM; passed to kernels by value.
 struct DevSym {
     int n, nsuper;
@@ -28,6 +40,11 @@ struct DevSym {
     const long long *wptr;      // nsuper+1: prefix sum of trailing rows (r-c)
     const long long *diagoff;   // n
     const int *perm;            // n
+    const EdgeRec *edge;        // one per child edge (same index as `children`)
+    // etile[tptr + T], T = 0 .. ceil((r_p - c_p) / 32): first trailing row a of the child whose
+    // position in the parent is >= c_p + 32 T (the child's rows falling into the parent's 32-row
+    // trailing tile T are [etile[T], etile[T+1]) -- no search at run time)
+    const int *etile;
 };
 
 struct LevelInfo {

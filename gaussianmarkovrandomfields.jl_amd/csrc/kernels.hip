@@ -78,14 +78,13 @@ __global__ __launch_bounds__(256) void k_assemble(DevSym S, const int *__restric
         for (int q = lo + lane; q < hi; q += 64) Pc[qd[q] - tc * ld] = nzval[qs[q]];
     }
     for (long long ch = S.childptr[s]; ch < S.childptr[s + 1]; ch++) {
-        const int d = S.children[ch];
-        const int cd = S.sfirst[d + 1] - S.sfirst[d];
-        const int md = (int)(S.rowptr[d + 1] - S.rowptr[d]) - cd;
-        const int *reld = S.rel + S.rowptr[d] + cd;
+        const EdgeRec er = S.edge[ch];
+        const int md = er.md;
+        const int *reld = S.rel + er.reloff;
         int j, j1;
-        wave_lower_bound2(reld, md, tc, tc + 1, lane, j, j1);
+        wave_lower_bound2(reld, er.nown, tc, tc + 1, lane, j, j1);   // only rows mapped into own columns
         if (j1 == j) continue;                    // this child has no row mapped to column tc
-        const double *Uc = CB + S.cbptr[d] + (long long)j * md;
+        const double *Uc = CB + er.cboff + (long long)j * md;
         // four independent row chunks in flight per lane (rel -> P read-modify-write chain)
         for (int i0 = j + lane; i0 < md; i0 += 256) {
             int ri[4];
@@ -334,24 +333,49 @@ __global__ __launch_bounds__(256) void k_syrk_cb(DevSym S, const int *__restrict
     const int ti0 = bi * 64, tj0 = bj * 64;      // tile origin inside CB
     for (int idx = tid; idx < 64 * 65; idx += 256) Tl[idx] = 0.0;
     __syncthreads();
-    for (long long ch = S.childptr[s]; ch < S.childptr[s + 1]; ch++) {
-        const int d = S.children[ch];
-        const int cd = S.sfirst[d + 1] - S.sfirst[d];
-        const int md = (int)(S.rowptr[d + 1] - S.rowptr[d]) - cd;
-        const int *reld = S.rel + S.rowptr[d] + cd;
-        const double *Ud = CB + S.cbptr[d];
-        // child rows/cols whose parent position falls into this tile (rel is increasing)
-        int a0, a1, b0, b1;
-        wave_lower_bound2(reld, md, c + ti0, c + ti0 + 64, tid & 63, a0, a1);
-        wave_lower_bound2(reld, md, c + tj0, c + tj0 + 64, tid & 63, b0, b1);
+    {
+        // Children two at a time: edge records and tile ranges of both first (two round trips for
+        // the pair), then 16 entries per thread and child with all loads in flight at once. The
+        // children are still ADDED one after the other (fixed order, bit-reproducible).
+        const long long ch0 = S.childptr[s], ch1 = S.childptr[s + 1];
+        const int nT = (m + 31) >> 5;
         const int la = tid & 63, lb = tid >> 6;
-        const int a = a0 + la;
-        if (a < a1) {
-            const int ti = reld[a] - c - ti0;
-            for (int b = b0 + lb; b < b1; b += 4)
-                if (a >= b) Tl[ti + (reld[b] - c - tj0) * 65] += Ud[a + (long long)b * md];
+        for (long long cb = ch0; cb < ch1; cb += 2) {
+            EdgeRec er[2];
+            int a0[2], a1[2], b0[2], b1[2];
+#pragma unroll
+            for (int q = 0; q < 2; q++) er[q] = S.edge[min(cb + q, ch1 - 1)];
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int *et = S.etile + er[q].tptr;
+                a0[q] = et[2 * bi]; a1[q] = et[min(2 * bi + 2, nT)];
+                b0[q] = et[2 * bj]; b1[q] = et[min(2 * bj + 2, nT)];
+            }
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                if (cb + q < ch1) {
+                    const int md = er[q].md;
+                    const int *reld = S.rel + er[q].reloff;
+                    const double *Ud = CB + er[q].cboff;
+                    const int a = a0[q] + la, ac = min(a, md - 1);
+                    const int ti = reld[ac] - c - ti0;
+                    int tb[16];
+                    double uv[16];
+#pragma unroll
+                    for (int u = 0; u < 16; u++) {
+                        const int b = min(b0[q] + lb + 4 * u, md - 1);
+                        tb[u] = reld[b];
+                        uv[u] = Ud[ac + (long long)b * md];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 16; u++) {
+                        const int b = b0[q] + lb + 4 * u;
+                        if (a < a1[q] && b < b1[q] && a >= b) Tl[ti + (tb[u] - c - tj0) * 65] += uv[u];
+                    }
+                    __syncthreads();
+                }
+            }
         }
-        __syncthreads();
     }
     const int wave = tid >> 6, lane = tid & 63;
     const int i0 = ti0 + (wave & 1) * 32, j0 = tj0 + (wave >> 1) * 32;
@@ -405,21 +429,33 @@ __global__ __launch_bounds__(256) void k_fwd_assemble(DevSym S, const int *__res
     }
     __syncthreads();
     for (long long ch = S.childptr[s]; ch < S.childptr[s + 1]; ch++) {
-        const int d = S.children[ch];
-        const int cd = S.sfirst[d + 1] - S.sfirst[d];
-        const int md = (int)(S.rowptr[d + 1] - S.rowptr[d]) - cd;
-        const int *reld = S.rel + S.rowptr[d] + cd;
-        const double *Wd = W + S.wptr[d] * ldx;
+        const EdgeRec er = S.edge[ch];
+        const int md = er.md;
+        const int *reld = S.rel + er.reloff;
+        const double *Wd = W + er.woff * ldx;
         int a0, a1;
         wave_lower_bound2(reld, md, i0, i1, (int)(threadIdx.x & 63), a0, a1);
-        const int cnt = (a1 - a0) * nr;
-        for (int idx = tid; idx < cnt; idx += 256) {
-            const int a = a0 + idx / nr, j = idx % nr;
-            const int ti = reld[a];
-            const double v = Wd[(long long)a * ldx + j];
-            if (ti < c) X[(long long)(first + ti) * ldx + j] += v;
-            else Ws[(long long)(ti - c) * ldx + j] += v;
+        const int cnt = (a1 - a0) * nr;    // <= FWD_RB * 64 = 8 entries per thread, loads batched
+        int tiv[8];
+        double v[8], xv[8];
+        double *dst[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int idx = min(tid + 256 * u, max(cnt - 1, 0));
+            const int a = min(a0 + idx / nr, md - 1), j = idx % nr;
+            tiv[u] = reld[a];
+            v[u] = Wd[(long long)a * ldx + j];
         }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int idx = min(tid + 256 * u, max(cnt - 1, 0));
+            const int j = idx % nr;
+            dst[u] = tiv[u] < c ? X + (long long)(first + tiv[u]) * ldx + j : Ws + (long long)(tiv[u] - c) * ldx + j;
+            xv[u] = *dst[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (tid + 256 * u < cnt) *dst[u] = xv[u] + v[u];
         __syncthreads();
     }
 }
@@ -454,16 +490,39 @@ __global__ __launch_bounds__(256) void k_fwd_update_longk(DevSym S, const int *_
         const double jm = j < nr ? 1.0 : 0.0;
         for (int i = g; i < 32; i += 4) Tl[i * 64 + j] = 0.0;
         __syncthreads();
-        for (long long ch = S.childptr[s]; ch < S.childptr[s + 1]; ch++) {
-            const int d = S.children[ch];
-            const int cd = S.sfirst[d + 1] - S.sfirst[d];
-            const int md = (int)(S.rowptr[d + 1] - S.rowptr[d]) - cd;
-            const int *reld = S.rel + S.rowptr[d] + cd;
-            const double *Wd = W + S.wptr[d] * ldx;
-            int a0, a1;
-            wave_lower_bound2(reld, md, i0, i0 + 32, (int)(threadIdx.x & 63), a0, a1);
-            for (int a = a0 + g; a < a1; a += 4) Tl[(reld[a] - i0) * 64 + j] += Wd[(long long)a * ldx + jcl] * jm;
-            __syncthreads();
+        // children two at a time (see k_syrk_cb): records + tile ranges first, then at most 32
+        // child rows per tile and child, all loads in flight at once; added in child order
+        const long long ch0 = S.childptr[s], ch1 = S.childptr[s + 1];
+        const int T = blockIdx.x;
+        for (long long cb = ch0; cb < ch1; cb += 2) {
+            EdgeRec er[2];
+            int a0[2], a1[2];
+#pragma unroll
+            for (int q = 0; q < 2; q++) er[q] = S.edge[min(cb + q, ch1 - 1)];
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                a0[q] = S.etile[er[q].tptr + T];
+                a1[q] = S.etile[er[q].tptr + T + 1];
+            }
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                if (cb + q < ch1) {
+                    const int *reld = S.rel + er[q].reloff;
+                    const double *Wd = W + er[q].woff * ldx;
+                    int tr[8];
+                    double wv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int a = min(a0[q] + g + 4 * u, er[q].md - 1);
+                        tr[u] = reld[a];
+                        wv[u] = Wd[(long long)a * ldx + jcl];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+                        if (a0[q] + g + 4 * u < a1[q]) Tl[(tr[u] - i0) * 64 + j] += wv[u] * jm;
+                    __syncthreads();
+                }
+            }
         }
     }
     constexpr int NA = 2;   // row tiles per workgroup (32 rows): 64 accumulator VGPRs, 3 waves/SIMD

@@ -245,11 +245,10 @@ __device__ __forceinline__ void factor_small_front(const DevSym &S, const int s,
     }
     __syncthreads();
     for (long long ch = S.childptr[s]; ch < S.childptr[s + 1]; ch++) {
-        const int d = S.children[ch];
-        const int cd = S.sfirst[d + 1] - S.sfirst[d];
-        const int md = (int)(S.rowptr[d + 1] - S.rowptr[d]) - cd;
-        const int *reld = S.rel + S.rowptr[d] + cd;
-        const double *Ud = CB + S.cbptr[d];
+        const EdgeRec er = S.edge[ch];
+        const int md = er.md;
+        const int *reld = S.rel + er.reloff;
+        const double *Ud = CB + er.cboff;
         // relative indices of the child once into LDS (Pn is free during assembly), then the
         // child's lower triangle in batches of 8 columns per thread: 8 independent loads in flight
         int *relL = reinterpret_cast<int *>(Pn);
@@ -364,11 +363,10 @@ __device__ __forceinline__ void fwd_small_front(const DevSym &S, const int s, co
     }
     __syncthreads();
     for (long long ch = S.childptr[s]; ch < S.childptr[s + 1]; ch++) {
-        const int d = S.children[ch];
-        const int cd = S.sfirst[d + 1] - S.sfirst[d];
-        const int md = (int)(S.rowptr[d + 1] - S.rowptr[d]) - cd;
-        const int *reld = S.rel + S.rowptr[d] + cd;
-        const double *Wd = W + S.wptr[d] * ldx;
+        const EdgeRec er = S.edge[ch];
+        const int md = er.md;
+        const int *reld = S.rel + er.reloff;
+        const double *Wd = W + er.woff * ldx;
         for (int a0 = g; a0 < md; a0 += 32) {
             double v[8]; int tr[8];
 #pragma unroll
