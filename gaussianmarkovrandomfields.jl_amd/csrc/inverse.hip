@@ -146,6 +146,7 @@ __global__ __launch_bounds__(256) void k_xmul(DevSym S, const int *__restrict__ 
     for (int t = 0; t < 4; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
     const int qlo = trans ? k0 : 0, qhi = trans ? c : min(c, k0 + 16);
     constexpr int KU = 4;
+#pragma unroll 1
     for (int q0 = qlo + wave * 4 * KU; q0 < qhi; q0 += 16 * KU) {
         double av[KU], bv[KU][4];
 #pragma unroll
@@ -159,27 +160,15 @@ __global__ __launch_bounds__(256) void k_xmul(DevSym S, const int *__restrict__ 
         for (int u = 0; u < KU; u++)
 #pragma unroll
             for (int t = 0; t < 4; t++)
-                if (t < nt) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u][t], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u][t], acc[t], 0, 0, 0);
     }
-    // reduce the 4 partial tiles (same code as splitk_reduce in kernels.hip)
-    if (wave > 0) {
-#pragma unroll
-        for (int t = 0; t < 4; t++)
-#pragma unroll
-            for (int rr = 0; rr < 4; rr++) red[((wave - 1) * 16 + t * 4 + rr) * 64 + lane] = acc[t][rr];
-    }
-    __syncthreads();
-    if (wave > 0) return;
-#pragma unroll
-    for (int w = 0; w < 3; w++)
-#pragma unroll
-        for (int t = 0; t < 4; t++)
-#pragma unroll
-            for (int rr = 0; rr < 4; rr++) acc[t][rr] += red[(w * 16 + t * 4 + rr) * 64 + lane];
+    // distributed split-K reduction: wave w ends up with the complete 16 x 16 tile of RHS block w
+    d4 (&acc1)[1][4] = reinterpret_cast<d4 (&)[1][4]>(acc);
+    splitk_reduce4<1>(acc1, red, wave, lane);
     double *Yb = Xout + (long long)first * ldx;
 #pragma unroll
     for (int t = 0; t < 4; t++)
-        if (t < nt) {
+        if (t == wave && t < nt) {
             const int j = t * 16 + lm;
 #pragma unroll
             for (int rr = 0; rr < 4; rr++) {

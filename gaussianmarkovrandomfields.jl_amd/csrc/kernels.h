@@ -61,30 +61,41 @@ __device__ __forceinline__ void wave_gemm_32x32(gmrfx_d4 (&acc)[2][2], int m0, i
     }
 }
 
-// Split-K reduction for the long-K sweep kernels: the 4 waves of a workgroup hold partial sums of
-// the SAME (16*NA) x 64 output tile (NA row tiles x 4 rhs tiles each; every wave swept a quarter of
-// the K range). After the call wave w owns the total of row tile w in acc[w][*].
-// `red` needs 3*16*64 doubles of LDS. Must be called by all 256 threads.
+// Split-K reduction across the 4 waves of a workgroup, DISTRIBUTED: every wave adds up ONE of the
+// four 16-column tiles of each row tile (12 LDS reads in flight instead of 48 by a single wave,
+// which cost ~100 VGPRs and one wave of occupancy). After the call wave w holds the complete tile
+// acc[a][w] for every a; the partial sums are added in wave order 0..3 (fixed, reproducible).
+// red: 4 * 3 * 4 * 64 doubles (24 KB).
 template <int NA>
 __device__ __forceinline__ void splitk_reduce4(gmrfx_d4 (&acc)[NA][4], double *red, int wave, int lane) {
 #pragma unroll
     for (int a = 0; a < NA; a++) {
         __syncthreads();
-        if (wave != a) {
-            const int slot = wave < a ? wave : wave - 1;
 #pragma unroll
-            for (int t = 0; t < 4; t++)
+        for (int t = 0; t < 4; t++) {
+            if (t != wave) {
+                const int slot = t < wave ? t : t - 1;
 #pragma unroll
-                for (int rr = 0; rr < 4; rr++) red[(slot * 16 + t * 4 + rr) * 64 + lane] = acc[a][t][rr];
+                for (int rr = 0; rr < 4; rr++) red[((wave * 3 + slot) * 4 + rr) * 64 + lane] = acc[a][t][rr];
+            }
         }
         __syncthreads();
-        if (wave == a) {
 #pragma unroll
-            for (int sl = 0; sl < 3; sl++)
+        for (int t = 0; t < 4; t++) {
+            if (t == wave) {
+                gmrfx_d4 part[4];
 #pragma unroll
-                for (int t = 0; t < 4; t++)
+                for (int w = 0; w < 4; w++) {
+                    if (w == wave) part[w] = acc[a][t];
+                    else {
+                        const int slot = t < w ? t : t - 1;
 #pragma unroll
-                    for (int rr = 0; rr < 4; rr++) acc[a][t][rr] += red[(sl * 16 + t * 4 + rr) * 64 + lane];
+                        for (int rr = 0; rr < 4; rr++) part[w][rr] = red[((w * 3 + slot) * 4 + rr) * 64 + lane];
+                    }
+                }
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) acc[a][t][rr] = ((part[0][rr] + part[1][rr]) + part[2][rr]) + part[3][rr];
+            }
         }
     }
 }

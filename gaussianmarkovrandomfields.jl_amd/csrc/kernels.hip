@@ -554,16 +554,15 @@ __global__ __launch_bounds__(256) void k_fwd_update_longk(DevSym S, const int *_
             for (int a = 0; a < NA; a++)
 #pragma unroll
                 for (int t = 0; t < 4; t++)
-                    if (t < nt) acc[a][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][a], bv[u][t], acc[a][t], 0, 0, 0);
+                    acc[a][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][a], bv[u][t], acc[a][t], 0, 0, 0);
     }
     splitk_reduce4<NA>(acc, red, wave, lane);
-    // wave w owns row tile w
+    // wave w owns the 16 right-hand sides 16 w .. 16 w + 15 of every row tile
 #pragma unroll
     for (int a = 0; a < NA; a++) {
-        if (a != wave) continue;
 #pragma unroll
         for (int t = 0; t < 4; t++) {
-            if (t < nt) {
+            if (t == wave && t < nt) {
                 const int j = t * 16 + lm;
 #pragma unroll
                 for (int rr = 0; rr < 4; rr++) {
@@ -623,15 +622,14 @@ __global__ __launch_bounds__(256) void k_bwd_gemm_longk(DevSym S, const int *__r
             for (int a = 0; a < NA; a++)
 #pragma unroll
                 for (int t = 0; t < 4; t++)
-                    if (t < nt) acc[a][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][a], bv[u][t], acc[a][t], 0, 0, 0);
+                    acc[a][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][a], bv[u][t], acc[a][t], 0, 0, 0);
     }
     splitk_reduce4<NA>(acc, red, wave, lane);
 #pragma unroll
     for (int a = 0; a < NA; a++) {
-        if (a != wave) continue;
 #pragma unroll
         for (int t = 0; t < 4; t++) {
-            if (t < nt) {
+            if (t == wave && t < nt) {
                 const int j = t * 16 + lm;
 #pragma unroll
                 for (int rr = 0; rr < 4; rr++) {

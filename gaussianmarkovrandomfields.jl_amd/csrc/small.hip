@@ -401,7 +401,7 @@ __device__ __forceinline__ void fwd_small_front(const DevSym &S, const int s, co
                     const int q = q0 + 4 * u + lk;   // < 64 <= RMAX: always inside fv
 #pragma unroll
                     for (int t = 0; t < 4; t++)
-                        if (t < nt) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], fv[q * LDV + t * 16 + lm], acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], fv[q * LDV + t * 16 + lm], acc[t], 0, 0, 0);
                 }
             }
         }
@@ -447,7 +447,7 @@ __device__ __forceinline__ void fwd_small_front(const DevSym &S, const int s, co
                 if (q0 + 4 * u < c) {
 #pragma unroll
                     for (int t = 0; t < 4; t++)
-                        if (t < nt) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], fv[q * LDV + t * 16 + lm], acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], fv[q * LDV + t * 16 + lm], acc[t], 0, 0, 0);
                 }
             }
         }
@@ -539,7 +539,7 @@ __device__ __forceinline__ void bwd_small_front(const DevSym &S, const int s, co
                 if (q0 + 4 * u < r) {
 #pragma unroll
                     for (int t = 0; t < 4; t++)
-                        if (t < nt) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], fv[q * LDV + t * 16 + lm], acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], fv[q * LDV + t * 16 + lm], acc[t], 0, 0, 0);
                 }
             }
         }
@@ -570,7 +570,7 @@ __device__ __forceinline__ void bwd_small_front(const DevSym &S, const int s, co
                 const int q = q0 + 4 * u + lk;   // < 64 + 16 <= RMAX
 #pragma unroll
                 for (int t = 0; t < 4; t++)
-                    if (t < nt) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], fv[min(q, RMAX - 1) * LDV + t * 16 + lm], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], fv[min(q, RMAX - 1) * LDV + t * 16 + lm], acc[t], 0, 0, 0);
             }
         }
 #pragma unroll
