@@ -301,6 +301,19 @@ __global__ __launch_bounds__(256) void k_gemm_nt(DevSym S, const int *__restrict
         mma(ca, cb);
     }
     // D[m][n]: m (rows of the first operand = C's column) = lk + 4*reg, n = lm = C's row
+    // read-modify-write of C in two passes (all loads, then all stores): one round trip instead of
+    // a chain of 4 TW^2 (the compiler cannot reorder a load of C past the previous store to C)
+    double cv[TW][TW][4];
+#pragma unroll
+    for (int a = 0; a < TW; a++)
+#pragma unroll
+        for (int b = 0; b < TW; b++)
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                const int i = min(i0 + a * 16 + lm, M - 1);
+                const int j = min(j0 + b * 16 + lk + 4 * rr, N - 1);
+                cv[a][b][rr] = C[i + (long long)j * ldc];
+            }
 #pragma unroll
     for (int a = 0; a < TW; a++)
 #pragma unroll
@@ -309,7 +322,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(DevSym S, const int *__restrict
             for (int rr = 0; rr < 4; rr++) {
                 const int i = i0 + a * 16 + lm;
                 const int j = j0 + b * 16 + lk + 4 * rr;
-                if (i < M && j < N && i >= j) C[i + (long long)j * ldc] -= acc[a][b][rr];
+                if (i < M && j < N && i >= j) C[i + (long long)j * ldc] = cv[a][b][rr] - acc[a][b][rr];
             }
 }
 
@@ -605,16 +618,24 @@ __global__ __launch_bounds__(256) void k_bwd_gemm_longk(DevSym S, const int *__r
     constexpr int KU = 4;
     for (int k0 = c + wave * 4 * KU; k0 < r; k0 += 16 * KU) {
         double av[KU][NA], bv[KU][4];
+        long long xr[KU];
+        // row indices of the whole batch first, then all operand loads: two round trips per batch
+        // (interleaved, every X load waits for its own index load)
+#pragma unroll
+        for (int u = 0; u < KU; u++) xr[u] = rows[min(k0 + 4 * u + lk, r - 1)];
 #pragma unroll
         for (int u = 0; u < KU; u++) {
-            const int q = k0 + 4 * u + lk;
-            const int qc = min(q, r - 1);
-            const double mk = q < r ? 1.0 : 0.0;
+            const int qc = min(k0 + 4 * u + lk, r - 1);
 #pragma unroll
-            for (int a = 0; a < NA; a++) av[u][a] = pa[a][qc] * mk;
-            const long long xr = rows[qc];
+            for (int a = 0; a < NA; a++) av[u][a] = pa[a][qc];
 #pragma unroll
-            for (int t = 0; t < 4; t++) bv[u][t] = X[xr * ldx + jc[t]];
+            for (int t = 0; t < 4; t++) bv[u][t] = X[xr[u] * ldx + jc[t]];
+        }
+#pragma unroll
+        for (int u = 0; u < KU; u++) {
+            const double mk = (k0 + 4 * u + lk) < r ? 1.0 : 0.0;
+#pragma unroll
+            for (int a = 0; a < NA; a++) av[u][a] *= mk;
         }
 #pragma unroll
         for (int u = 0; u < KU; u++)
@@ -625,18 +646,25 @@ __global__ __launch_bounds__(256) void k_bwd_gemm_longk(DevSym S, const int *__r
                     acc[a][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][a], bv[u][t], acc[a][t], 0, 0, 0);
     }
     splitk_reduce4<NA>(acc, red, wave, lane);
+    // X -= acc in two passes (all loads, then all stores: one round trip instead of a chain of 8)
 #pragma unroll
-    for (int a = 0; a < NA; a++) {
+    for (int t = 0; t < 4; t++) {
+        if (t == wave && t < nt) {
+            const int j = t * 16 + lm;
+            const int jcl = min(j, nr - 1);
+            double xv[NA][4];
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            if (t == wave && t < nt) {
-                const int j = t * 16 + lm;
+            for (int a = 0; a < NA; a++)
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++)
+                    xv[a][rr] = X[(long long)(first + min(i0 + a * 16 + lk + 4 * rr, c - 1)) * ldx + jcl];
+#pragma unroll
+            for (int a = 0; a < NA; a++)
 #pragma unroll
                 for (int rr = 0; rr < 4; rr++) {
                     const int col = i0 + a * 16 + lk + 4 * rr;
-                    if (col < c && j < nr) X[(long long)(first + col) * ldx + j] -= acc[a][t][rr];
+                    if (col < c && j < nr) X[(long long)(first + col) * ldx + j] = xv[a][rr] - acc[a][t][rr];
                 }
-            }
         }
     }
 }

@@ -525,21 +525,25 @@ __device__ __forceinline__ void bwd_small_front(const DevSym &S, const int s, co
         d4 acc[4];
 #pragma unroll
         for (int t = 0; t < 4; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll 1
-        for (int q0 = c; q0 < r; q0 += 16) {
-            double av[4];
+        // all of this column block's L21 values at once (r - c < RMAX: RMAX / 4 clamped loads in
+        // flight instead of a chain of (r - c) / 16 round trips), masks at use
+        constexpr int NQ = RMAX / 16;
+        double av[NQ][4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int q = q0 + 4 * u + lk;
-                av[u] = pa[min(q, r - 1)] * (q < r ? 1.0 : 0.0);
-            }
+        for (int qb = 0; qb < NQ; qb++)
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int q = min(q0 + 4 * u + lk, RMAX - 1);
-                if (q0 + 4 * u < r) {
+            for (int u = 0; u < 4; u++) av[qb][u] = pa[min(c + qb * 16 + 4 * u + lk, r - 1)];
+#pragma unroll
+        for (int qb = 0; qb < NQ; qb++) {
+            if (c + qb * 16 < r) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int qq = c + qb * 16 + 4 * u + lk;
+                    const int q = min(qq, RMAX - 1);
+                    const double a_ = av[qb][u] * (qq < r ? 1.0 : 0.0);
 #pragma unroll
                     for (int t = 0; t < 4; t++)
-                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], fv[q * LDV + t * 16 + lm], acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, fv[q * LDV + t * 16 + lm], acc[t], 0, 0, 0);
                 }
             }
         }
