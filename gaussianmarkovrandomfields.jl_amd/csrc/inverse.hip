@@ -203,7 +203,7 @@ void launch_inv_stage(hipStream_t st, const DevSym &S, const int *list, int nact
 void launch_xmul(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_c, int trans, const double *L,
                  const double *Xin, double *Xout, int nr, int ldx) {
     if (nfronts <= 0 || max_c <= 0) return;
-    hipLaunchKernelGGL(k_xmul, dim3(cdiv(max_c, 16), nfronts), dim3(256), 0, st, S, list, trans, L, Xin, Xout, nr, ldx);
+    hipLaunchKernelGGL(k_xmul, dim3((unsigned)(cdiv(max_c, 16) | 1), nfronts), dim3(256), 0, st, S, list, trans, L, Xin, Xout, nr, ldx);
 }
 void launch_copy_own(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_c, const double *Xsrc,
                      double *Xdst, int nr, int ldx) {

@@ -743,20 +743,28 @@ __global__ __launch_bounds__(256) void k_gather_diag(const double *__restrict__ 
 // ------------------------------------------------------------------------------------------
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Workgroups are handed to the 8 XCDs round-robin by linear id (x fastest). Rectangular grids whose
+// x extent (or x*y extent) is a multiple of 8 put tile (bi, bj) of EVERY front on the same XCD --
+// with triangular / ragged tile sets that leaves some XCDs idle and others with twice the work
+// (measured: the 4x4-tile level of k_syrk_cb ran 1.9x longer than the 3x3 and 6x6 levels around
+// it). Odd extents make consecutive fronts rotate through all XCDs; the extra workgroups exit at
+// once through the kernels' own range checks.
+static inline unsigned odd(int v) { return (unsigned)(v | 1); }
+
 void launch_assemble(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols,
                      const double *nzval, double *L, double *CB) {
     if (nfronts <= 0) return;
-    hipLaunchKernelGGL(k_assemble, dim3(cdiv(max_cols, ASM_CW), nfronts), dim3(256), 0, st, S, list, nzval, L, CB);
+    hipLaunchKernelGGL(k_assemble, dim3(odd(cdiv(max_cols, ASM_CW)), nfronts), dim3(256), 0, st, S, list, nzval, L, CB);
 }
 void launch_syrk_cb(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_trail, const double *L, double *CB) {
     if (nfronts <= 0 || max_trail <= 0) return;
-    hipLaunchKernelGGL(k_syrk_cb, dim3(cdiv(max_trail, 64), cdiv(max_trail, 64), nfronts), dim3(256), 0, st, S, list, L, CB);
+    hipLaunchKernelGGL(k_syrk_cb, dim3(odd(cdiv(max_trail, 64)), odd(cdiv(max_trail, 64)), nfronts), dim3(256), 0, st, S, list, L, CB);
 }
 void launch_trsm(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int mode, int max_rows_below,
                  double *L, double *Yh, const long long *yoff) {
     if (nactive <= 0 || max_rows_below <= 0) return;
     const bool split = (long long)cdiv(max_rows_below, 64) * nactive <= 128;
-    const dim3 grid(cdiv(max_rows_below, split ? 16 : 64), nactive);
+    const dim3 grid(odd(cdiv(max_rows_below, split ? 16 : 64)), nactive);
     if (mode == 0) {
         if (split) hipLaunchKernelGGL((k_trsm<0, 1>), grid, dim3(256), 0, st, S, list, kb, L, Yh, yoff);
         else hipLaunchKernelGGL((k_trsm<0, 0>), grid, dim3(256), 0, st, S, list, kb, L, Yh, yoff);
@@ -775,24 +783,24 @@ void launch_gemm_nt(hipStream_t st, const DevSym &S, const int *list, int nactiv
     // Levels with a handful of fronts are latency bound: 32x32 workgroup tiles there (four times
     // the workgroups, a quarter of the MFMA chain per wave).
     if ((long long)cdiv(maxM, 64) * cdiv(maxN, 64) * nactive <= 256)
-        hipLaunchKernelGGL(k_gemm_nt<1>, dim3(cdiv(maxM, 32), cdiv(maxN, 32), nactive), dim3(256), 0, st, S, list, k0, K, c0, c1, L);
+        hipLaunchKernelGGL(k_gemm_nt<1>, dim3(odd(cdiv(maxM, 32)), odd(cdiv(maxN, 32)), nactive), dim3(256), 0, st, S, list, k0, K, c0, c1, L);
     else
-        hipLaunchKernelGGL(k_gemm_nt<2>, dim3(cdiv(maxM, 64), cdiv(maxN, 64), nactive), dim3(256), 0, st, S, list, k0, K, c0, c1, L);
+        hipLaunchKernelGGL(k_gemm_nt<2>, dim3(odd(cdiv(maxM, 64)), odd(cdiv(maxN, 64)), nactive), dim3(256), 0, st, S, list, k0, K, c0, c1, L);
 }
 void launch_fwd_assemble(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_rows, double *X,
                          double *W, int nr, int ldx, int own_only) {
     if (nfronts <= 0 || max_rows <= 0) return;
-    hipLaunchKernelGGL(k_fwd_assemble, dim3(cdiv(max_rows, FWD_RB), nfronts), dim3(256), 0, st, S, list, X, W, nr, ldx, own_only);
+    hipLaunchKernelGGL(k_fwd_assemble, dim3(odd(cdiv(max_rows, FWD_RB)), nfronts), dim3(256), 0, st, S, list, X, W, nr, ldx, own_only);
 }
 void launch_fwd_update(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_trail, const double *L,
                        double *X, double *W, int nr, int ldx) {
     if (nfronts <= 0 || max_trail <= 0) return;
-    hipLaunchKernelGGL(k_fwd_update_longk, dim3(cdiv(max_trail, 32), nfronts), dim3(256), 0, st, S, list, L, X, W, nr, ldx);
+    hipLaunchKernelGGL(k_fwd_update_longk, dim3(odd(cdiv(max_trail, 32)), nfronts), dim3(256), 0, st, S, list, L, X, W, nr, ldx);
 }
 void launch_bwd_gemm(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, const double *L,
                      double *X, int nr, int ldx) {
     if (nfronts <= 0 || max_cols <= 0) return;
-    hipLaunchKernelGGL(k_bwd_gemm_longk, dim3(cdiv(max_cols, 32), nfronts), dim3(256), 0, st, S, list, L, X, nr, ldx);
+    hipLaunchKernelGGL(k_bwd_gemm_longk, dim3(odd(cdiv(max_cols, 32)), nfronts), dim3(256), 0, st, S, list, L, X, nr, ldx);
 }
 void launch_permute(hipStream_t st, const int *perm, int n, double *Bc, long long ldb, double *X, int nr, int ldx, int dir) {
     hipLaunchKernelGGL(k_permute, dim3(cdiv(n, 64)), dim3(256), 0, st, perm, n, Bc, ldb, X, nr, ldx, dir);
