@@ -198,7 +198,9 @@ void launch_inv_stage(hipStream_t st, const DevSym &S, const int *list, int nact
     if (nactive <= 0) return;
     const int npair = cdiv(max_c, 2 * B);
     const int ntile = (B / 64) * (B / 64);
-    hipLaunchKernelGGL(k_inv_stage, dim3(ntile, npair, nactive), dim3(256), 0, st, S, list, B, phase, L, T, toff);
+    // odd y extent: most fronts only have pair 0, and with an even extent every (pair 0, front z)
+    // workgroup would land on the same XCD (linear workgroup id mod 8)
+    hipLaunchKernelGGL(k_inv_stage, dim3(ntile, npair | 1, nactive), dim3(256), 0, st, S, list, B, phase, L, T, toff);
 }
 void launch_xmul(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_c, int trans, const double *L,
                  const double *Xin, double *Xout, int nr, int ldx) {

@@ -270,12 +270,12 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 void launch_sel_gather(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_trail,
                        const double *Z, double *ZB) {
     if (nfronts <= 0 || max_trail <= 0) return;
-    hipLaunchKernelGGL(k_sel_gather, dim3(cdiv(max_trail, 16), nfronts), dim3(256), 0, st, S, list, Z, ZB);
+    hipLaunchKernelGGL(k_sel_gather, dim3((unsigned)(cdiv(max_trail, 16) | 1), nfronts), dim3(256), 0, st, S, list, Z, ZB);
 }
 void launch_sel_symm(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int max_rows_below,
                      double *Z, const double *ZB, const double *Yh, const long long *yoff) {
     if (nactive <= 0 || max_rows_below <= 0) return;
-    hipLaunchKernelGGL(k_sel_symm, dim3(cdiv(max_rows_below, 64), nactive), dim3(256), 0, st, S, list, kb, Z, ZB, Yh, yoff);
+    hipLaunchKernelGGL(k_sel_symm, dim3((unsigned)(cdiv(max_rows_below, 64) | 1), nactive), dim3(256), 0, st, S, list, kb, Z, ZB, Yh, yoff);
 }
 void launch_sel_diag(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, const double *L,
                      double *Z, const double *Yh, const long long *yoff) {
@@ -288,7 +288,7 @@ void launch_sel_dense(hipStream_t st, const DevSym &S, const int *list, int nfro
     if (nfronts <= 0) return;
     const int M = phase == 0 ? max_trail : max_c, N = phase == 1 ? max_trail : max_c;
     if (M <= 0 || N <= 0) return;
-    hipLaunchKernelGGL(k_sel_dense, dim3(cdiv(M, 64), cdiv(N, 64), nfronts), dim3(256), 0, st, S, list, phase, L, Z, ZB, Yt, Z21t, woff);
+    hipLaunchKernelGGL(k_sel_dense, dim3((unsigned)(cdiv(M, 64) | 1), (unsigned)(cdiv(N, 64) | 1), nfronts), dim3(256), 0, st, S, list, phase, L, Z, ZB, Yt, Z21t, woff);
 }
 
 }  // namespace gmrfx
