@@ -478,15 +478,18 @@ __global__ __launch_bounds__(256) void k_fwd_assemble(DevSym S, const int *__res
 // trailing rows x 64 right-hand sides, every wave sweeps a quarter of the K range for the WHOLE
 // tile (16 MFMA tiles per k-step from 4 + 4 operand loads; 512-B contiguous panel segments per
 // column), the partial tiles are summed through LDS and each wave writes one row tile.
+template <int NA>   // 16-row tiles per workgroup: 2 normally, 1 for levels with a handful of fronts (twice the
+                    // workgroups, half the MFMA chain of each: one CU only sustains ~0.14 TFLOP/s of FP64 MFMA)
 __global__ __launch_bounds__(256) void k_fwd_update_longk(DevSym S, const int *__restrict__ list,
                                                          const double *__restrict__ L, double *__restrict__ X,
                                                          double *__restrict__ W, int nr, int ldx) {
     __shared__ double red[3 * 16 * 64];
-    __shared__ double Tl[32 * 64];   // children's contributions to this 32-row tile of W_s
+    constexpr int RT = 16 * NA;
+    __shared__ double Tl[RT * 64];   // children's contributions to this tile of W_s
     const int s = list[blockIdx.y];
     const int c = S.sfirst[s + 1] - S.sfirst[s];
     const int r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
-    const int i0 = c + blockIdx.x * 32;
+    const int i0 = c + blockIdx.x * RT;
     if (i0 >= r) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int lm = lane & 15, lk = lane >> 4;
@@ -501,12 +504,12 @@ __global__ __launch_bounds__(256) void k_fwd_update_longk(DevSym S, const int *_
         const int j = threadIdx.x & 63, g = threadIdx.x >> 6;
         const int jcl = min(j, nr - 1);
         const double jm = j < nr ? 1.0 : 0.0;
-        for (int i = g; i < 32; i += 4) Tl[i * 64 + j] = 0.0;
+        for (int i = g; i < RT; i += 4) Tl[i * 64 + j] = 0.0;
         __syncthreads();
         // children two at a time (see k_syrk_cb): records + tile ranges first, then at most 32
         // child rows per tile and child, all loads in flight at once; added in child order
         const long long ch0 = S.childptr[s], ch1 = S.childptr[s + 1];
-        const int T = blockIdx.x;
+        const int T = (blockIdx.x * RT) >> 5;   // 32-row granularity of the tile table
         for (long long cb = ch0; cb < ch1; cb += 2) {
             EdgeRec er[2];
             int a0[2], a1[2];
@@ -532,13 +535,12 @@ __global__ __launch_bounds__(256) void k_fwd_update_longk(DevSym S, const int *_
                     }
 #pragma unroll
                     for (int u = 0; u < 8; u++)
-                        if (a0[q] + g + 4 * u < a1[q]) Tl[(tr[u] - i0) * 64 + j] += wv[u] * jm;
+                        if (a0[q] + g + 4 * u < a1[q] && tr[u] >= i0 && tr[u] < i0 + RT) Tl[(tr[u] - i0) * 64 + j] += wv[u] * jm;
                     __syncthreads();
                 }
             }
         }
     }
-    constexpr int NA = 2;   // row tiles per workgroup (32 rows): 64 accumulator VGPRs, 3 waves/SIMD
     d4 acc[NA][4];
 #pragma unroll
     for (int a = 0; a < NA; a++)
@@ -589,6 +591,7 @@ __global__ __launch_bounds__(256) void k_fwd_update_longk(DevSym S, const int *_
 
 // Backward update of a big front: own columns -= L21' * x_R over ALL trailing rows: a
 // workgroup owns 64 own columns x 64 right-hand sides, its waves split the trailing rows.
+template <int NA>   // see k_fwd_update_longk
 __global__ __launch_bounds__(256) void k_bwd_gemm_longk(DevSym S, const int *__restrict__ list,
                                                        const double *__restrict__ L, double *__restrict__ X, int nr,
                                                        int ldx) {
@@ -596,7 +599,7 @@ __global__ __launch_bounds__(256) void k_bwd_gemm_longk(DevSym S, const int *__r
     const int s = list[blockIdx.y];
     const int c = S.sfirst[s + 1] - S.sfirst[s];
     const int r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
-    const int i0 = blockIdx.x * 32;
+    const int i0 = blockIdx.x * 16 * NA;
     if (i0 >= c || r <= c) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int lm = lane & 15, lk = lane >> 4;
@@ -605,7 +608,6 @@ __global__ __launch_bounds__(256) void k_bwd_gemm_longk(DevSym S, const int *__r
     const double *P = L + S.panelptr[s];
     const int *rows = S.rows + S.rowptr[s];
     const int nt = (nr + 15) >> 4;
-    constexpr int NA = 2;   // row tiles per workgroup (32 rows): 64 accumulator VGPRs, 3 waves/SIMD
     d4 acc[NA][4];
 #pragma unroll
     for (int a = 0; a < NA; a++)
@@ -616,13 +618,18 @@ __global__ __launch_bounds__(256) void k_bwd_gemm_longk(DevSym S, const int *__r
     for (int a = 0; a < NA; a++) pa[a] = P + (long long)min(i0 + a * 16 + lm, c - 1) * ld;
     const int jc[4] = {min(lm, nr - 1), min(16 + lm, nr - 1), min(32 + lm, nr - 1), min(48 + lm, nr - 1)};
     constexpr int KU = 4;
+    // The row indices of batch k+1 are requested together with the operands of batch k: one round
+    // trip per batch instead of two (index -> X row). Long trailing parts (K = r - c up to 2000 at
+    // the top of the tree) make this loop a pure latency chain.
+    long long xr[KU], xn[KU];
+#pragma unroll
+    for (int u = 0; u < KU; u++) xn[u] = rows[min(c + wave * 4 * KU + 4 * u + lk, r - 1)];
     for (int k0 = c + wave * 4 * KU; k0 < r; k0 += 16 * KU) {
         double av[KU][NA], bv[KU][4];
-        long long xr[KU];
-        // row indices of the whole batch first, then all operand loads: two round trips per batch
-        // (interleaved, every X load waits for its own index load)
 #pragma unroll
-        for (int u = 0; u < KU; u++) xr[u] = rows[min(k0 + 4 * u + lk, r - 1)];
+        for (int u = 0; u < KU; u++) xr[u] = xn[u];
+#pragma unroll
+        for (int u = 0; u < KU; u++) xn[u] = rows[min(k0 + 16 * KU + 4 * u + lk, r - 1)];
 #pragma unroll
         for (int u = 0; u < KU; u++) {
             const int qc = min(k0 + 4 * u + lk, r - 1);
@@ -795,12 +802,18 @@ void launch_fwd_assemble(hipStream_t st, const DevSym &S, const int *list, int n
 void launch_fwd_update(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_trail, const double *L,
                        double *X, double *W, int nr, int ldx) {
     if (nfronts <= 0 || max_trail <= 0) return;
-    hipLaunchKernelGGL(k_fwd_update_longk, dim3(odd(cdiv(max_trail, 32)), nfronts), dim3(256), 0, st, S, list, L, X, W, nr, ldx);
+    if ((long long)cdiv(max_trail, 32) * nfronts <= 128)
+        hipLaunchKernelGGL(k_fwd_update_longk<1>, dim3(odd(cdiv(max_trail, 16)), nfronts), dim3(256), 0, st, S, list, L, X, W, nr, ldx);
+    else
+        hipLaunchKernelGGL(k_fwd_update_longk<2>, dim3(odd(cdiv(max_trail, 32)), nfronts), dim3(256), 0, st, S, list, L, X, W, nr, ldx);
 }
 void launch_bwd_gemm(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, const double *L,
                      double *X, int nr, int ldx) {
     if (nfronts <= 0 || max_cols <= 0) return;
-    hipLaunchKernelGGL(k_bwd_gemm_longk, dim3(odd(cdiv(max_cols, 32)), nfronts), dim3(256), 0, st, S, list, L, X, nr, ldx);
+    if ((long long)cdiv(max_cols, 32) * nfronts <= 128)
+        hipLaunchKernelGGL(k_bwd_gemm_longk<1>, dim3(odd(cdiv(max_cols, 16)), nfronts), dim3(256), 0, st, S, list, L, X, nr, ldx);
+    else
+        hipLaunchKernelGGL(k_bwd_gemm_longk<2>, dim3(odd(cdiv(max_cols, 32)), nfronts), dim3(256), 0, st, S, list, L, X, nr, ldx);
 }
 void launch_permute(hipStream_t st, const int *perm, int n, double *Bc, long long ldb, double *X, int nr, int ldx, int dir) {
     hipLaunchKernelGGL(k_permute, dim3(cdiv(n, 64)), dim3(256), 0, st, perm, n, Bc, ldb, X, nr, ldx, dir);
