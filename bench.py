@@ -115,7 +115,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    t_factor, t_solve, t_fwd, t_bwd, t_perm = [], [], [], [], []
+    t_factor, t_solve, t_fwd, t_bwd, t_perm, t_syrk = [], [], [], [], [], []
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -123,6 +123,7 @@ def main():
         s = be.stats()
         t_factor.append(s["ms_factor"]); t_solve.append(s["ms_solve"])
         t_fwd.append(s["ms_solve_fwd"]); t_bwd.append(s["ms_solve_bwd"]); t_perm.append(s["ms_solve_perm"])
+        t_syrk.append(s["ms_syrk"])
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -183,7 +184,6 @@ def main():
         sweep_ms = 0.5 * (mfw + mbw)
         sweep_gbs = bytes_sweep / (sweep_ms * 1e-3) / 1e9
         factor_tf = st["factor_flops"] / (mf * 1e-3) / 1e12
-        dominant_is_factor = mf >= (mfw + mbw)
         # HBM traffic from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
         # runs, gfx950 FETCH_SIZE x2 correction): only valid for the workload they were collected on
         pmc = None
@@ -194,14 +194,30 @@ def main():
                 pmc = pj
         except Exception:
             pmc = None
+        # ---- roofline of the DOMINANT KERNEL: k_syrk_cb (contribution-block SYRK, ~25 % of the step) ----
+        # algorithmic flops: sum over the big fronts of c m (m + 1) (lower triangle of the m x m block,
+        # 2 c flops per entry), one launch per level; time: HIP events around every launch, recorded by
+        # the library on the stream the kernel runs on (gmrfx_stats.ms_syrk), median over the timed steps
+        ms_syrk = med(t_syrk)
+        n_launch = max(int(st["syrk_launches"]), 1)
+        syrk_tf = st["syrk_flops"] / (ms_syrk * 1e-3) / 1e12
+        pk = (pmc or {}).get("per_kernel_GB_per_step", {}).get("k_syrk_cb")
+        roof_kernel = {"bound": "mfma", "achieved": syrk_tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                       "frac": syrk_tf / FP64_MFMA_PEAK_TF,
+                       "traffic": (1e9 * (pk["fetch_x2"] + pk["write"]) / n_launch) if pk else None,
+                       "peak_measured": FP64_MFMA_MEASURED_TF, "frac_of_measured_peak": syrk_tf / FP64_MFMA_MEASURED_TF,
+                       "kernel": "k_syrk_cb", "launches_per_step": n_launch, "avg_launch_ms": ms_syrk / n_launch,
+                       "flops_per_launch": st["syrk_flops"] / n_launch, "ms_per_step": ms_syrk,
+                       "note": "achieved = algorithmic flops of the launches of one step / their summed HIP-event time; "
+                               "traffic = PMC HBM bytes per launch (profiles/r01_pmc_traffic.json)"}
         roof_factor = {"bound": "mfma", "achieved": factor_tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                        "frac": factor_tf / FP64_MFMA_PEAK_TF, "traffic": pmc["factor"]["total_bytes"] if pmc else None,
                        "peak_measured": FP64_MFMA_MEASURED_TF, "frac_of_measured_peak": factor_tf / FP64_MFMA_MEASURED_TF,
-                       "kernel": "numeric factorisation (all fronts)", "ms": mf, "flops": st["factor_flops"]}
+                       "kernel": "numeric factorisation (all ~500 launches)", "ms": mf, "flops": st["factor_flops"]}
         roof_sweep = {"bound": "hbm", "achieved": sweep_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "frac": sweep_gbs / HBM_PEAK_GBS,
                       "traffic": 0.5 * (pmc["sweep_forward"]["total_bytes"] + pmc["sweep_backward"]["total_bytes"]) if pmc else None,
-                      "kernel": "triangular sweep (mean of forward and backward)", "ms": sweep_ms, "bytes": bytes_sweep}
+                      "kernel": "triangular sweep (mean of forward and backward, all launches)", "ms": sweep_ms, "bytes": bytes_sweep}
         out = {
             "metric": "factor+solve(64 RHS) throughput", "value": world * n / (elapsed / args.steps), "unit": "DoF/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
@@ -211,7 +227,7 @@ def main():
                        "n": n, "nnz_Q": int(Q.nnz), "nnz_L": int(st["nnz_l"]), "nnz_L_stored": int(nnzl),
                        "nrhs": args.nrhs, "parallelism": "1 workspace per GPU (replicas)" if world > 1 else "1 GPU",
                        "ordering": "own geometric nested dissection"},
-            "roofline": roof_factor if dominant_is_factor else roof_sweep,
+            "roofline": roof_kernel,
             "roofline_factor": roof_factor, "roofline_sweep": roof_sweep,
             "phases_ms": {"factor": mf, "solve": ms_, "solve_fwd": mfw, "solve_bwd": mbw, "solve_perm": med(t_perm),
                           "symbolic_host": st0["ms_symbolic"], **extras},

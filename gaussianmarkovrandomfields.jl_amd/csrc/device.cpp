@@ -28,6 +28,7 @@ Device::~Device() {
     if (stream) { (void)hipStreamSynchronize(stream); }
     for (void *p : allocs_) (void)hipFree(p);
     for (auto &e : ev_) if (e) (void)hipEventDestroy(e);
+    for (auto &e : ev_syrk_) if (e) (void)hipEventDestroy(e);
     if (ev_fact_) (void)hipEventDestroy(ev_fact_);
     if (ev_inv_) (void)hipEventDestroy(ev_inv_);
     if (stream2) (void)hipStreamDestroy(stream2);
@@ -138,6 +139,7 @@ void Device::upload(const Symbolic &S) {
 
     levels_.clear();
     levels_.resize(S.nlevels);
+    syrk_flops = 0;
     for (i32 l = 0; l < S.nlevels; l++) {
         LevelInfo &L = levels_[l];
         L.first = (int)S.levelptr[l];
@@ -151,6 +153,8 @@ void Device::upload(const Symbolic &S) {
             L.max_rows = std::max(L.max_rows, S.nrows(s));
             L.max_cols = std::max(L.max_cols, S.ncols(s));
             max_trail = std::max(max_trail, S.nrows(s) - S.ncols(s));
+            const double cc = S.ncols(s), mm = S.nrows(s) - S.ncols(s);
+            syrk_flops += cc * mm * (mm + 1);   // lower triangle of the contribution block: 2 c flops per entry
         }
         int nblk = (L.max_cols + NB - 1) / NB;
         L.active.assign(nblk + 1, 0);
@@ -191,6 +195,8 @@ void Device::upload(const Symbolic &S) {
         HC(hipStreamSynchronize(stream));
     }
 
+    ev_syrk_.resize(2 * (size_t)S.nlevels);
+    for (auto &e : ev_syrk_) HC(hipEventCreate(&e));
     first_multiblock_level_ = S.nlevels;
     for (i32 l = 0; l < S.nlevels; l++) if (levels_[l].max_cols > NB) { first_multiblock_level_ = l; break; }
 
@@ -227,6 +233,7 @@ void Device::factor_levels() {
     for (int k = 0, off = 0; k < 3; off += nsub_cls_[k], k++)
         launch_subtree(stream, ds_, 0, d_sub_first_ + off, d_sub_last_ + off, nsub_cls_[k], kClsRows[k], d_nz_, d_L_, d_cb_,
                        d_info_, nullptr, nullptr, 0, 0);
+    int nsy = 0;
     for (auto &L : levels_) {
         for (int k = 0, off = 0; k < 4; off += L.ncls[k], k++)
             launch_factor_small(stream, ds_, d_levellist_ + L.first + off, L.ncls[k], kClsRows[k], d_nz_, d_L_, d_cb_, d_info_);
@@ -248,8 +255,14 @@ void Device::factor_levels() {
                 launch_gemm_nt(stream, ds_, list, L.active[J1], (J1 - OBK) * NB, OBK * NB, J1 * NB, INT_MAX,
                                L.max_rows - J1 * NB, L.max_cols - J1 * NB, d_L_);
         }
-        launch_syrk_cb(stream, ds_, list, nf, level_max_trail(L), d_L_, d_cb_);
+        if (nf > 0 && level_max_trail(L) > 0) {
+            HC(hipEventRecord(ev_syrk_[2 * nsy], stream));
+            launch_syrk_cb(stream, ds_, list, nf, level_max_trail(L), d_L_, d_cb_);
+            HC(hipEventRecord(ev_syrk_[2 * nsy + 1], stream));
+            nsy++;
+        }
     }
+    syrk_launches = nsy;
 }
 
 // The dense inverses are only needed by the sweeps and the selected inversion of the big
@@ -297,6 +310,12 @@ void Device::refactorize(const double *nzval, bool on_device) {
     float ms = 0;
     HC(hipEventElapsedTime(&ms, ev_[0], ev_[1]));
     ms_factor = ms;
+    ms_syrk = 0;
+    for (long long k = 0; k < syrk_launches; k++) {
+        float t = 0;
+        HC(hipEventElapsedTime(&t, ev_syrk_[2 * k], ev_syrk_[2 * k + 1]));
+        ms_syrk += t;
+    }
     factorized = true;
     selinv_valid = false;
 }

@@ -82,6 +82,8 @@ public:
     bool inverse_pending = false;   // dense inverses of the big fronts are computed lazily, on a side stream
     double ms_factor = 0, ms_solve = 0, ms_fwd = 0, ms_bwd = 0, ms_perm = 0, ms_bsolve = 0, ms_logdet = 0, ms_selinv = 0;
     long long last_nrhs = 0;
+    double ms_syrk = 0, syrk_flops = 0;   // dominant kernel (k_syrk_cb): live HIP-event time per refactorisation, flops
+    long long syrk_launches = 0;
     double bytes_total = 0;
     int device = 0;
     hipStream_t stream = nullptr;
@@ -118,6 +120,7 @@ private:
     long long rhs_cap_ = 0, io_cap_ = 0, tmp_cap_ = 0;
     int *d_info_ = nullptr;
     hipEvent_t ev_[8] = {};
+    std::vector<hipEvent_t> ev_syrk_;   // begin/end event of every k_syrk_cb launch
     long long l_size_ = 0, sum_trail_ = 0;
 };
 

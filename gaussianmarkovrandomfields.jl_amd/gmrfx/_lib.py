@@ -29,7 +29,8 @@ class GmrfxStats(C.Structure):
         "n_small_fronts", "n_big_fronts")] + [(k, C.c_double) for k in (
         "factor_flops", "bytes_factor", "bytes_cb_arena", "bytes_device_total", "ms_symbolic", "ms_factor",
         "ms_solve", "ms_solve_fwd", "ms_solve_bwd", "ms_solve_perm", "ms_backward_solve", "ms_logdet",
-        "ms_selinv")] + [("last_nrhs", C.c_int64), ("fail_col", C.c_int64)]
+        "ms_selinv")] + [("last_nrhs", C.c_int64), ("fail_col", C.c_int64), ("ms_syrk", C.c_double),
+                         ("syrk_flops", C.c_double), ("syrk_launches", C.c_int64)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -77,6 +77,11 @@ typedef struct gmrfx_stats {
             ms_logdet, ms_selinv;
     int64_t last_nrhs;
     int64_t fail_col;              /* -1, or first (permuted, 0-based) non-positive pivot   */
+    /* the dominant kernel of the factorisation (contribution-block SYRK, k_syrk_cb): summed HIP-event
+     * time of its launches in the most recent refactorisation, their number, and the flops they do
+     * (sum over big fronts of c m (m + 1), m = r - c: lower triangle only)                  */
+    double  ms_syrk, syrk_flops;
+    int64_t syrk_launches;
 } gmrfx_stats;
 
 /* Message for the most recent failed gmrfx_create on this thread. */
