@@ -11,11 +11,12 @@ k_factor_subtree<48> launch on; the untimed extras after the step -- logdet -- a
 import csv, glob, json, sys, collections
 
 def load(d):
-    f = glob.glob(d + "/*/*counter_collection.csv") or glob.glob(d + "/**/*counter_collection.csv", recursive=True)
-    rows = list(csv.DictReader(open(f[0])))
+    import os
+    f = sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
+    rows = list(csv.DictReader(open(f[-1])))    # newest run in the directory
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     names = [r["Kernel_Name"].split("(")[0].replace("gmrfx::", "").replace("void ", "") for r in rows]
-    start = max(i for i, n in enumerate(names) if n.startswith("k_factor_subtree<48>"))
+    start = max(i for i, n in enumerate(names) if n.startswith("k_factor_subtree<48>") or n.startswith("k_factor_subtree<64>") and not any(m.startswith("k_factor_subtree<48>") for m in names))
     return [(n, float(r["Counter_Value"])) for n, r in zip(names[start:], rows[start:])]
 
 def phase(n):
