@@ -55,19 +55,26 @@ __device__ __forceinline__ void wave_lower_bound2(const int *__restrict__ a, con
 // every target entry has exactly one owner, which applies the children one after the other, so
 // the sum order is fixed (bit-reproducible, no atomics) and no barrier is needed at all; the
 // kernel is a chain of dependent HBM round trips, kept short by the wave-wide searches.
+template <int WIDE>   // 0: one WAVE per column; 1: one WORKGROUP per column (levels with a few tall fronts)
 __global__ __launch_bounds__(256) void k_assemble(DevSym S, const int *__restrict__ list,
                                                   const double *__restrict__ nzval, double *__restrict__ L,
                                                   double *__restrict__ CB) {
     // PANEL part of the front only (front-local columns < c). The contribution-block part is
     // assembled inside k_syrk_cb (children gathered into an LDS tile, CB written exactly once).
+    // WIDE: a column of a top-of-tree front has thousands of rows and the level only has a handful
+    // of fronts -- the whole workgroup shares one column (a quarter of the dependent round trips
+    // per wave); the phases are then separated by barriers (different waves touch the same rows).
+    constexpr int NL = WIDE ? 256 : 64;          // lanes cooperating on one column
     const int s = list[blockIdx.y];
     const int c = S.sfirst[s + 1] - S.sfirst[s];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tc = blockIdx.x * ASM_CW + wave;
+    const int tl = WIDE ? (int)threadIdx.x : lane;
+    const int tc = WIDE ? (int)blockIdx.x : blockIdx.x * ASM_CW + wave;
     if (tc >= c) return;
     const int ld = S.ld[s];
     double *Pc = L + S.panelptr[s] + (long long)tc * ld;
-    for (int i = lane; i < ld; i += 64) Pc[i] = 0.0;
+    for (int i = tl; i < ld; i += NL) Pc[i] = 0.0;
+    if (WIDE) __syncthreads();
     {
         const long long q0 = S.qptr[s];
         const int nq = (int)(S.qptr[s + 1] - q0);
@@ -75,30 +82,32 @@ __global__ __launch_bounds__(256) void k_assemble(DevSym S, const int *__restric
         const int *qs = S.qsrc + q0;
         int lo, hi;
         wave_lower_bound2(qd, nq, tc * ld, (tc + 1) * ld, lane, lo, hi);
-        for (int q = lo + lane; q < hi; q += 64) Pc[qd[q] - tc * ld] = nzval[qs[q]];
+        for (int q = lo + tl; q < hi; q += NL) Pc[qd[q] - tc * ld] = nzval[qs[q]];
     }
+    if (WIDE) __syncthreads();
     for (long long ch = S.childptr[s]; ch < S.childptr[s + 1]; ch++) {
         const EdgeRec er = S.edge[ch];
         const int md = er.md;
         const int *reld = S.rel + er.reloff;
         int j, j1;
         wave_lower_bound2(reld, er.nown, tc, tc + 1, lane, j, j1);   // only rows mapped into own columns
-        if (j1 == j) continue;                    // this child has no row mapped to column tc
+        if (j1 == j) continue;                    // this child has no row mapped to column tc (workgroup-uniform)
         const double *Uc = CB + er.cboff + (long long)j * md;
         // four independent row chunks in flight per lane (rel -> P read-modify-write chain)
-        for (int i0 = j + lane; i0 < md; i0 += 256) {
+        for (int i0 = j + tl; i0 < md; i0 += 4 * NL) {
             int ri[4];
             double u[4], pv[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) ri[q] = reld[min(i0 + 64 * q, md - 1)];
+            for (int q = 0; q < 4; q++) ri[q] = reld[min(i0 + NL * q, md - 1)];
 #pragma unroll
-            for (int q = 0; q < 4; q++) u[q] = Uc[min(i0 + 64 * q, md - 1)];
+            for (int q = 0; q < 4; q++) u[q] = Uc[min(i0 + NL * q, md - 1)];
 #pragma unroll
             for (int q = 0; q < 4; q++) pv[q] = Pc[ri[q]];
 #pragma unroll
             for (int q = 0; q < 4; q++)
-                if (i0 + 64 * q < md) Pc[ri[q]] = pv[q] + u[q];
+                if (i0 + NL * q < md) Pc[ri[q]] = pv[q] + u[q];
         }
+        if (WIDE) __syncthreads();
     }
 }
 
@@ -761,7 +770,10 @@ static inline unsigned odd(int v) { return (unsigned)(v | 1); }
 void launch_assemble(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols,
                      const double *nzval, double *L, double *CB) {
     if (nfronts <= 0) return;
-    hipLaunchKernelGGL(k_assemble, dim3(odd(cdiv(max_cols, ASM_CW)), nfronts), dim3(256), 0, st, S, list, nzval, L, CB);
+    if ((long long)cdiv(max_cols, ASM_CW) * nfronts <= 2200)
+        hipLaunchKernelGGL(k_assemble<1>, dim3(odd(max_cols), nfronts), dim3(256), 0, st, S, list, nzval, L, CB);
+    else
+        hipLaunchKernelGGL(k_assemble<0>, dim3(odd(cdiv(max_cols, ASM_CW)), nfronts), dim3(256), 0, st, S, list, nzval, L, CB);
 }
 void launch_syrk_cb(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_trail, const double *L, double *CB) {
     if (nfronts <= 0 || max_trail <= 0) return;
