@@ -239,7 +239,7 @@ void Device::factor_levels() {
             launch_factor_small(stream, ds_, d_levellist_ + L.first + off, L.ncls[k], kClsRows[k], d_nz_, d_L_, d_cb_, d_info_);
         const int *list = d_levellist_ + L.first + L.nsmall;
         const int nf = L.count - L.nsmall;
-        launch_assemble(stream, ds_, list, nf, L.max_cols, d_nz_, d_L_, d_cb_);
+        launch_assemble(stream, ds_, list, nf, L.max_cols, L.max_rows, d_nz_, d_L_, d_cb_);
         const int nblk = level_nblk(L);
         for (int b = 0; b < nblk; b++) {
             const int kb = b * NB;

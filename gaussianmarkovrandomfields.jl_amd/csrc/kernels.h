@@ -10,7 +10,7 @@ constexpr int NB = 64;       // block-column width of the dense partial factoris
 constexpr int ASM_CW = 4;    // front columns owned by one assembly workgroup
 constexpr int FWD_RB = 32;    // front rows owned by one forward-assembly workgroup
 
-void launch_assemble(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols,
+void launch_assemble(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, int max_rows,
                      const double *nzval, double *L, double *CB);
 void launch_syrk_cb(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_trail, const double *L, double *CB);
 void launch_trsm(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int mode, int max_rows_below,
