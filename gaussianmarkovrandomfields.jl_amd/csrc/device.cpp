@@ -351,13 +351,16 @@ void Device::forward(int nr, int ldx) {
         launch_fwd_assemble(stream, ds_, list, nf, L.max_cols, d_X_, d_W_, nr, ldx, 1);   // own rows only
         // y = L11^-1 b as one triangular product per front (dense inverse, inverse.hip), then the
         // trailing update W -= L21 y with K = all columns of the front
+        // y of the big fronts stays in X2 (no copy back): the update below and the backward sweep read it there
         launch_xmul(stream, ds_, list, nf, L.max_cols, 0, d_L_, d_X_, d_X2_, nr, ldx);
-        launch_copy_own(stream, ds_, list, nf, L.max_cols, d_X2_, d_X_, nr, ldx);
-        launch_fwd_update(stream, ds_, list, nf, level_max_trail(L), d_L_, d_X_, d_W_, nr, ldx);
+        launch_fwd_update(stream, ds_, list, nf, level_max_trail(L), d_L_, d_X2_, d_W_, nr, ldx);
     }
 }
 
-void Device::backward(int nr, int ldx) {
+// y_in_x2: the forward sweep left y of the big fronts in X2 (full solve). The backward sweep then turns it
+// into t = y - L21' x in place there and writes x = L11^-T t straight into X -- no copies. A backward-only
+// solve (F.UP \ z) gets z in X: classic path with one copy per level.
+void Device::backward(int nr, int ldx, bool y_in_x2) {
     wait_inverse();   // (a no-op event wait once the forward sweep has passed it)
     for (int l = (int)levels_.size() - 1; l >= 0; l--) {
         auto &L = levels_[l];
@@ -365,9 +368,14 @@ void Device::backward(int nr, int ldx) {
         const int nf = L.count - L.nsmall;
         for (int k = 0, off = 0; k < 4; off += L.ncls[k], k++)
             launch_bwd_small(stream, ds_, d_levellist_ + L.first + off, L.ncls[k], kClsRows[k], d_L_, d_X_, nr, ldx);
-        if (level_max_trail(L) > 0) launch_bwd_gemm(stream, ds_, list, nf, L.max_cols, d_L_, d_X_, nr, ldx);
-        launch_xmul(stream, ds_, list, nf, L.max_cols, 1, d_L_, d_X_, d_X2_, nr, ldx);
-        launch_copy_own(stream, ds_, list, nf, L.max_cols, d_X2_, d_X_, nr, ldx);
+        if (y_in_x2) {
+            if (level_max_trail(L) > 0) launch_bwd_gemm(stream, ds_, list, nf, L.max_cols, d_L_, d_X_, d_X2_, nr, ldx);
+            launch_xmul(stream, ds_, list, nf, L.max_cols, 1, d_L_, d_X2_, d_X_, nr, ldx);
+        } else {
+            if (level_max_trail(L) > 0) launch_bwd_gemm(stream, ds_, list, nf, L.max_cols, d_L_, d_X_, d_X_, nr, ldx);
+            launch_xmul(stream, ds_, list, nf, L.max_cols, 1, d_L_, d_X_, d_X2_, nr, ldx);
+            launch_copy_own(stream, ds_, list, nf, L.max_cols, d_X2_, d_X_, nr, ldx);
+        }
     }
     for (int k = 0, off = 0; k < 3; off += nsub_cls_[k], k++)
         launch_subtree(stream, ds_, 2, d_sub_first_ + off, d_sub_last_ + off, nsub_cls_[k], kClsRows[k], nullptr, d_L_, nullptr,
@@ -400,7 +408,7 @@ void Device::solve(const double *B, long long ldb, long long nrhs, double *X, lo
         HC(hipEventRecord(ev_[1], stream));
         if (mode == 0) forward(nr, ldx);
         HC(hipEventRecord(ev_[2], stream));
-        backward(nr, ldx);
+        backward(nr, ldx, mode == 0);
         HC(hipEventRecord(ev_[3], stream));
         launch_permute(stream, ds_.perm, (int)n, dXo + j0 * ldout, ldout, d_X_, nr, ldx, 1);
         HC(hipEventRecord(ev_[4], stream));

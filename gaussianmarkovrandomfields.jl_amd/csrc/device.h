@@ -95,7 +95,7 @@ private:
     void ensure_rhs_capacity(long long nrhs);
     void factor_levels();
     void forward(int nr, int ldx);
-    void backward(int nr, int ldx);
+    void backward(int nr, int ldx, bool y_in_x2);
     template <class T> T *dalloc(size_t count);
     std::vector<void *> allocs_;
 

@@ -602,7 +602,7 @@ __global__ __launch_bounds__(256) void k_fwd_update_longk(DevSym S, const int *_
 // workgroup owns 64 own columns x 64 right-hand sides, its waves split the trailing rows.
 template <int NA>   // see k_fwd_update_longk
 __global__ __launch_bounds__(256) void k_bwd_gemm_longk(DevSym S, const int *__restrict__ list,
-                                                       const double *__restrict__ L, double *__restrict__ X, int nr,
+                                                       const double *__restrict__ L, const double *X, double *Xown, int nr,
                                                        int ldx) {
     __shared__ double red[3 * 16 * 64];
     const int s = list[blockIdx.y];
@@ -673,13 +673,13 @@ __global__ __launch_bounds__(256) void k_bwd_gemm_longk(DevSym S, const int *__r
             for (int a = 0; a < NA; a++)
 #pragma unroll
                 for (int rr = 0; rr < 4; rr++)
-                    xv[a][rr] = X[(long long)(first + min(i0 + a * 16 + lk + 4 * rr, c - 1)) * ldx + jcl];
+                    xv[a][rr] = Xown[(long long)(first + min(i0 + a * 16 + lk + 4 * rr, c - 1)) * ldx + jcl];
 #pragma unroll
             for (int a = 0; a < NA; a++)
 #pragma unroll
                 for (int rr = 0; rr < 4; rr++) {
                     const int col = i0 + a * 16 + lk + 4 * rr;
-                    if (col < c && j < nr) X[(long long)(first + col) * ldx + j] = xv[a][rr] - acc[a][t][rr];
+                    if (col < c && j < nr) Xown[(long long)(first + col) * ldx + j] = xv[a][rr] - acc[a][t][rr];
                 }
         }
     }
@@ -876,12 +876,12 @@ void launch_fwd_update(hipStream_t st, const DevSym &S, const int *list, int nfr
         hipLaunchKernelGGL(k_fwd_update_longk<2>, dim3(odd(cdiv(max_trail, 32)), nfronts), dim3(256), 0, st, S, list, L, X, W, nr, ldx);
 }
 void launch_bwd_gemm(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, const double *L,
-                     double *X, int nr, int ldx) {
+                     const double *X, double *Xown, int nr, int ldx) {
     if (nfronts <= 0 || max_cols <= 0) return;
     if ((long long)cdiv(max_cols, 32) * nfronts <= 128)
-        hipLaunchKernelGGL(k_bwd_gemm_longk<1>, dim3(odd(cdiv(max_cols, 16)), nfronts), dim3(256), 0, st, S, list, L, X, nr, ldx);
+        hipLaunchKernelGGL(k_bwd_gemm_longk<1>, dim3(odd(cdiv(max_cols, 16)), nfronts), dim3(256), 0, st, S, list, L, X, Xown, nr, ldx);
     else
-        hipLaunchKernelGGL(k_bwd_gemm_longk<2>, dim3(odd(cdiv(max_cols, 32)), nfronts), dim3(256), 0, st, S, list, L, X, nr, ldx);
+        hipLaunchKernelGGL(k_bwd_gemm_longk<2>, dim3(odd(cdiv(max_cols, 32)), nfronts), dim3(256), 0, st, S, list, L, X, Xown, nr, ldx);
 }
 void launch_permute(hipStream_t st, const int *perm, int n, double *Bc, long long ldb, double *X, int nr, int ldx, int dir) {
     hipLaunchKernelGGL(k_permute, dim3(cdiv(n, 64)), dim3(256), 0, st, perm, n, Bc, ldb, X, nr, ldx, dir);
