@@ -352,6 +352,51 @@ def test_3d_medium_residual():
     assert relerr(ws.selinv_diag(), F.selinv_diag()) < 1e-8
 
 
+def test_midsize_multiblock_fronts_match_oracle():
+    """300 x 300 nodes: the top separators have several hundred columns, so this is the smallest case that
+    runs the two-level blocked panel factorisation (K = 256 updates), the latency variants of TRSM / GEMM /
+    sweep GEMMs, the dense-inverse stages beyond B = 64 and the multi-batch K loops -- checked VALUE BY VALUE
+    against the oracle (the 1M-node test can only check properties)."""
+    m = spde.grid_mesh_2d(300, 300, jitter=0.25, seed=5)
+    Q = sp.csc_matrix(spde.matern_precision(m, 0, 0.2))
+    n = Q.shape[0]
+    ws = gmrfx.GMRFWorkspace(Q, coords=m.points)
+    st = ws.backend.stats()
+    assert st["max_cols"] > 256          # the K = 256 outer update and >= 3 inverse stages are exercised
+    F = orc.OracleFactor(Q, ws.backend.ordering_permutation())
+    Lg, Lo = ws.backend.factor_csc(), F.L()
+    assert abs(Lg - Lo).max() <= 1e-10 * abs(Lo).max()
+    assert abs(ws.logdet() - F.logdet()) <= 1e-11 * abs(F.logdet())
+    rng = np.random.default_rng(11)
+    for nrhs in (1, 70):      # 70 = one full 64-wide chunk + a ragged one
+        B = rng.standard_normal((n, nrhs))
+        X = ws.workspace_solve(B[:, 0] if nrhs == 1 else B)
+        Xo = F.solve(B[:, 0] if nrhs == 1 else B)
+        assert relerr(X, Xo) < 1e-10
+    Z = rng.standard_normal((n, 64))
+    assert relerr(np.column_stack([ws.backward_solve(Z[:, j]) for j in range(2)]), F.backward_solve(Z[:, :2])) < 1e-10
+    assert relerr(ws.selinv_diag(), F.selinv_diag()) < 1e-8
+
+
+def test_disconnected_and_arrow_patterns():
+    """Edge patterns: a block-diagonal Q (forest of elimination trees: several roots) and an arrow matrix
+    (one dense row/column: a front whose row structure is the whole matrix)."""
+    rng = np.random.default_rng(4)
+    blocks = [spde.random_spd_precision(k, 0.2) for k in (1, 7, 40, 130)]
+    Qb = sp.block_diag(blocks, format="csc")
+    n = 300
+    A = sp.diags(rng.uniform(2.0, 3.0, n)).tolil()
+    A[0, :] = 0.01; A[:, 0] = 0.01; A[0, 0] = 5.0
+    for Q in (Qb, sp.csc_matrix(A)):
+        Q = sp.csc_matrix(Q)
+        ws = gmrfx.GMRFWorkspace(Q)
+        F = orc.OracleFactor(Q, ws.backend.ordering_permutation())
+        B = rng.standard_normal((Q.shape[0], 5))
+        assert relerr(ws.workspace_solve(B), np.linalg.solve(Q.toarray(), B)) < 1e-10
+        assert abs(ws.logdet() - np.linalg.slogdet(Q.toarray())[1]) < 1e-9 * max(1.0, abs(F.logdet()))
+        assert relerr(ws.selinv_diag(), np.diag(np.linalg.inv(Q.toarray()))) < 1e-8
+
+
 @pytest.mark.parametrize("name", ["matern64_coords", "cfg1_alpha3_65x65", "matern3d_10", "rand400"])
 def test_subtree_tasks_on_and_off_agree(name, monkeypatch):
     """Whole-subtree workgroup tasks (default) vs pure level scheduling (GMRFX_SUBTREE_MAX=0):
