@@ -241,19 +241,26 @@ void Device::factor_levels() {
         const int nf = L.count - L.nsmall;
         launch_assemble(stream, ds_, list, nf, L.max_cols, L.max_rows, d_nz_, d_L_, d_cb_);
         const int nblk = level_nblk(L);
+        // geometry of the widest front of the level (fronts are sorted by decreasing width): when it is
+        // the only one still active, the panel kernels get it in their arguments (kernels.h, FrontArg)
+        FrontArg f1{0, 0, 0, 0, 0, 0, 0}, f0{0, 0, 0, 0, 0, 0, 0};
+        if (nf > 0) {
+            const i32 s1 = S_->levellist[L.first + L.nsmall];
+            f1 = FrontArg{1, (int)s1, S_->ncols(s1), S_->nrows(s1), (int)S_->ld[s1], (int)S_->sfirst[s1], (long long)S_->panelptr[s1]};
+        }
         for (int b = 0; b < nblk; b++) {
             const int kb = b * NB;
-            launch_potrf64(stream, ds_, list, L.active[b], kb, d_L_, d_info_);
-            launch_trsm(stream, ds_, list, L.active[b], kb, 0, L.max_rows - kb - 1, d_L_, nullptr, nullptr);
+            launch_potrf64(stream, ds_, list, L.active[b], kb, d_L_, d_info_, L.active[b] == 1 ? f1 : f0);
+            launch_trsm(stream, ds_, list, L.active[b], kb, 0, L.max_rows - kb - 1, d_L_, nullptr, nullptr, L.active[b] == 1 ? f1 : f0);
             // two-level blocking: K = 64 updates only inside the current 256-column block, the
             // rest of the panel once per block with K = 256
             const int J1 = (b / OBK + 1) * OBK;   // first 64-block of the next 256-column block
             if (b + 1 < nblk && b + 1 < J1)
                 launch_gemm_nt(stream, ds_, list, L.active[b + 1], kb, NB, kb + NB, J1 * NB, L.max_rows - kb - NB,
-                               std::min(J1 * NB, L.max_cols) - kb - NB, d_L_);
+                               std::min(J1 * NB, L.max_cols) - kb - NB, d_L_, L.active[b + 1] == 1 ? f1 : f0);
             if (b + 1 == J1 && J1 < nblk)
                 launch_gemm_nt(stream, ds_, list, L.active[J1], (J1 - OBK) * NB, OBK * NB, J1 * NB, INT_MAX,
-                               L.max_rows - J1 * NB, L.max_cols - J1 * NB, d_L_);
+                               L.max_rows - J1 * NB, L.max_cols - J1 * NB, d_L_, L.active[J1] == 1 ? f1 : f0);
         }
         if (nf > 0 && level_max_trail(L) > 0) {
             HC(hipEventRecord(ev_syrk_[2 * nsy], stream));
@@ -491,7 +498,7 @@ void Device::selinv_compute() {
         if (snsmall > 0) {
             const int *sl = d_sel_levellist_ + sfirst;
             launch_sel_gather(stream, ds_, sl, snsmall, 128, d_Z_, d_cb_);
-            launch_trsm(stream, ds_, sl, snsmall, 0, 1, 128, d_L_, d_tmp_, d_yoff);
+            launch_trsm(stream, ds_, sl, snsmall, 0, 1, 128, d_L_, d_tmp_, d_yoff, FrontArg{0, 0, 0, 0, 0, 0, 0});
             launch_sel_symm(stream, ds_, sl, snsmall, 0, 128, d_Z_, d_cb_, d_tmp_, d_yoff);
             launch_sel_diag(stream, ds_, sl, snsmall, 0, d_L_, d_Z_, d_tmp_, d_yoff);
         }

@@ -10,13 +10,18 @@ constexpr int NB = 64;       // block-column width of the dense partial factoris
 constexpr int ASM_CW = 4;    // front columns owned by one assembly workgroup
 constexpr int FWD_RB = 32;    // front rows owned by one forward-assembly workgroup
 
+// Geometry of one front. Normally read through list[z] -> sfirst / rowptr / ld / panelptr: two
+// dependent round trips at the start of every kernel. The panel chain at the top of the tree
+// (potrf -> trsm -> gemm, ~120 dependent launches on a single front) gets it in the kernel arguments.
+struct FrontArg { int on, s, c, r, ld, first; long long pp; };
+struct FrontView { int s, c, r, ld, first; long long pp; };
 void launch_assemble(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, int max_rows,
                      const double *nzval, double *L, double *CB);
 void launch_syrk_cb(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_trail, const double *L, double *CB);
 void launch_trsm(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int mode, int max_rows_below,
-                 double *L, double *Yh, const long long *yoff);
+                 double *L, double *Yh, const long long *yoff, const FrontArg &fa);
 void launch_gemm_nt(hipStream_t st, const DevSym &S, const int *list, int nactive, int k0, int K, int c0, int c1,
-                    int maxM, int maxN, double *L);
+                    int maxM, int maxN, double *L, const FrontArg &fa);
 void launch_fwd_assemble(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_rows, double *X,
                          double *W, int nr, int ldx, int own_only);
 void launch_fwd_update(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_trail, const double *L,
@@ -59,6 +64,22 @@ __device__ __forceinline__ void wave_gemm_32x32(gmrfx_d4 (&acc)[2][2], int m0, i
                 for (int b = 0; b < 2; b++)
                     acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][a], bv[u][b], acc[a][b], 0, 0, 0);
     }
+}
+
+__device__ __forceinline__ FrontView front_view(const DevSym &S, const int *__restrict__ list, const int z, const FrontArg &fa) {
+    FrontView v;
+    if (fa.on) {
+        v.s = fa.s; v.c = fa.c; v.r = fa.r; v.ld = fa.ld; v.first = fa.first; v.pp = fa.pp;
+    } else {
+        const int s = list[z];
+        v.s = s;
+        v.first = S.sfirst[s];
+        v.c = S.sfirst[s + 1] - v.first;
+        v.r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
+        v.ld = S.ld[s];
+        v.pp = S.panelptr[s];
+    }
+    return v;
 }
 
 // Split-K reduction across the 4 waves of a workgroup, DISTRIBUTED: every wave adds up ONE of the
@@ -123,7 +144,7 @@ void launch_factor_small(hipStream_t st, const DevSym &S, const int *list, int n
 void launch_subtree(hipStream_t st, const DevSym &S, int phase, const int *sub_first, const int *sub_last, int ntasks,
                     int rmax, const double *nzval, double *L, double *CB, int *info, double *X, double *W, int nr, int ldx);
 void launch_potrf_lds(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, double *L, int *info);
-void launch_potrf64(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, double *L, int *info);   // potrf64.hip
+void launch_potrf64(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, double *L, int *info, const FrontArg &fa);   // potrf64.hip
 void launch_fwd_small(hipStream_t st, const DevSym &S, const int *list, int nfronts, int rmax, const double *L,
                       double *X, double *W, int nr, int ldx);
 void launch_bwd_small(hipStream_t st, const DevSym &S, const int *list, int nfronts, int rmax, const double *L,

@@ -143,21 +143,20 @@ __device__ __forceinline__ void stage_linv(const double *__restrict__ Dg, int ld
 template <int MODE, int SPLIT>
 __global__ __launch_bounds__(256) void k_trsm(DevSym S, const int *__restrict__ list, int kb,
                                               double *__restrict__ L, double *__restrict__ Yh,
-                                              const long long *__restrict__ yoff) {
+                                              const long long *__restrict__ yoff, FrontArg fa) {
     // SPLIT = 0: a workgroup owns 64 rows, each wave 16 of them (all four 16-column tiles);
     // SPLIT = 1 (latency variant for levels with a handful of fronts): a workgroup owns 16 rows
     // and each wave ONE column tile of them -- four times the workgroups, a quarter of the MFMA
     // chain per wave (a single CU sustains only ~0.14 TFLOP/s of FP64 MFMA).
     __shared__ double Ti[NB * NB];
-    const int s = list[blockIdx.y];
-    const int c = S.sfirst[s + 1] - S.sfirst[s];
-    const int r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
+    const FrontView fv = front_view(S, list, blockIdx.y, fa);
+    const int s = fv.s, c = fv.c, r = fv.r;
     if (kb >= c) return;
     const int w = min(NB, c - kb);
     const int row0 = kb + w + blockIdx.x * (SPLIT ? 16 : 64);
     if (row0 >= r) return;
-    const int ld = S.ld[s];
-    double *Pp = L + S.panelptr[s];
+    const int ld = fv.ld;
+    double *Pp = L + fv.pp;
     stage_linv(Pp + kb + (long long)kb * ld, ld, w, Ti, threadIdx.x);
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -230,17 +229,17 @@ __global__ __launch_bounds__(256) void k_trsm(DevSym S, const int *__restrict__ 
 // CB -= L21 L21' (K = all c columns).
 template <int TW>   // MFMA tiles per wave and dimension: wave tile 16*TW squared, workgroup tile twice that
 __global__ __launch_bounds__(256) void k_gemm_nt(DevSym S, const int *__restrict__ list, int k0, int K, int c0, int c1,
-                                                 double *__restrict__ L) {
+                                                 double *__restrict__ L, FrontArg fa) {
     // panel columns [c0, min(c1, c)) of the front, rows c0 .. r-1:  C -= A A'  with A = the K
     // (finished) panel columns k0 .. k0+K-1 of those rows. Two-level blocking: K = 64 updates stay
     // inside the current 256-column block, the rest of the panel is updated once per 256 columns
     // with K = 256 (a quarter of the read-modify-write traffic of a flat right-looking sweep).
-    const int s = list[blockIdx.z];
-    const int c = S.sfirst[s + 1] - S.sfirst[s];
+    const FrontView fv = front_view(S, list, blockIdx.z, fa);
+    const int c = fv.c;
     if (c0 >= c) return;
-    const int r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
-    const int ld = S.ld[s];
-    double *P = L + S.panelptr[s];
+    const int r = fv.r;
+    const int ld = fv.ld;
+    double *P = L + fv.pp;
     const int M = r - c0, N = min(c1, c) - c0, ldc = ld;
     const double *A = P + c0 + (long long)k0 * ld;
     double *C = P + c0 + (long long)c0 * ld;
@@ -836,20 +835,20 @@ void launch_syrk_cb(hipStream_t st, const DevSym &S, const int *list, int nfront
     hipLaunchKernelGGL(k_syrk_cb, dim3(odd(cdiv(max_trail, 64)), odd(cdiv(max_trail, 64)), nfronts), dim3(256), 0, st, S, list, L, CB);
 }
 void launch_trsm(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int mode, int max_rows_below,
-                 double *L, double *Yh, const long long *yoff) {
+                 double *L, double *Yh, const long long *yoff, const FrontArg &fa) {
     if (nactive <= 0 || max_rows_below <= 0) return;
     const bool split = (long long)cdiv(max_rows_below, 64) * nactive <= 128;
     const dim3 grid(odd(cdiv(max_rows_below, split ? 16 : 64)), nactive);
     if (mode == 0) {
-        if (split) hipLaunchKernelGGL((k_trsm<0, 1>), grid, dim3(256), 0, st, S, list, kb, L, Yh, yoff);
-        else hipLaunchKernelGGL((k_trsm<0, 0>), grid, dim3(256), 0, st, S, list, kb, L, Yh, yoff);
+        if (split) hipLaunchKernelGGL((k_trsm<0, 1>), grid, dim3(256), 0, st, S, list, kb, L, Yh, yoff, fa);
+        else hipLaunchKernelGGL((k_trsm<0, 0>), grid, dim3(256), 0, st, S, list, kb, L, Yh, yoff, fa);
     } else {
-        if (split) hipLaunchKernelGGL((k_trsm<1, 1>), grid, dim3(256), 0, st, S, list, kb, L, Yh, yoff);
-        else hipLaunchKernelGGL((k_trsm<1, 0>), grid, dim3(256), 0, st, S, list, kb, L, Yh, yoff);
+        if (split) hipLaunchKernelGGL((k_trsm<1, 1>), grid, dim3(256), 0, st, S, list, kb, L, Yh, yoff, fa);
+        else hipLaunchKernelGGL((k_trsm<1, 0>), grid, dim3(256), 0, st, S, list, kb, L, Yh, yoff, fa);
     }
 }
 void launch_gemm_nt(hipStream_t st, const DevSym &S, const int *list, int nactive, int k0, int K, int c0, int c1,
-                    int maxM, int maxN, double *L) {
+                    int maxM, int maxN, double *L, const FrontArg &fa) {
     if (nactive <= 0 || maxM <= 0 || maxN <= 0) return;
     // 64x64 workgroup tiles, operands straight from L2 at 3-4 waves per SIMD. Measured on MI355X: the
     // sustained v_mfma_f64_16x16x4_f64 rate is 36.3 TFLOP/s (tools/micro/mfma64.hip), this kernel reaches
@@ -858,9 +857,9 @@ void launch_gemm_nt(hipStream_t st, const DevSym &S, const int *list, int nactiv
     // Levels with a handful of fronts are latency bound: 32x32 workgroup tiles there (four times
     // the workgroups, a quarter of the MFMA chain per wave).
     if ((long long)cdiv(maxM, 64) * cdiv(maxN, 64) * nactive <= 256)
-        hipLaunchKernelGGL(k_gemm_nt<1>, dim3(odd(cdiv(maxM, 32)), odd(cdiv(maxN, 32)), nactive), dim3(256), 0, st, S, list, k0, K, c0, c1, L);
+        hipLaunchKernelGGL(k_gemm_nt<1>, dim3(odd(cdiv(maxM, 32)), odd(cdiv(maxN, 32)), nactive), dim3(256), 0, st, S, list, k0, K, c0, c1, L, fa);
     else
-        hipLaunchKernelGGL(k_gemm_nt<2>, dim3(odd(cdiv(maxM, 64)), odd(cdiv(maxN, 64)), nactive), dim3(256), 0, st, S, list, k0, K, c0, c1, L);
+        hipLaunchKernelGGL(k_gemm_nt<2>, dim3(odd(cdiv(maxM, 64)), odd(cdiv(maxN, 64)), nactive), dim3(256), 0, st, S, list, k0, K, c0, c1, L, fa);
 }
 void launch_fwd_assemble(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_rows, double *X,
                          double *W, int nr, int ldx, int own_only) {

@@ -48,14 +48,14 @@ __device__ __forceinline__ double rsqrt_nr(double p) {
 }  // namespace
 
 __global__ __launch_bounds__(256) void k_potrf64(DevSym S, const int *__restrict__ list, int kb,
-                                                 double *__restrict__ L, int *__restrict__ info) {
+                                                 double *__restrict__ L, int *__restrict__ info, FrontArg fa) {
     __shared__ __attribute__((aligned(16))) double Sb[2][4 * 64];   // strip [parity][q * 64 + row]
-    const int s = list[blockIdx.x];
-    const int c = S.sfirst[s + 1] - S.sfirst[s];
+    const FrontView fv = front_view(S, list, blockIdx.x, fa);
+    const int c = fv.c;
     if (kb >= c) return;
     const int w = min(NB, c - kb);
-    const int ld = S.ld[s];
-    double *P = L + S.panelptr[s] + kb + (long long)kb * ld;
+    const int ld = fv.ld;
+    double *P = L + fv.pp + kb + (long long)kb * ld;
     const int tid = threadIdx.x;
     const int ty = tid & 15, tx = tid >> 4;     // lanes walk rows: coalesced panel loads / stores
     const int i0 = 4 * ty, j0 = 4 * tx;
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void k_potrf64(DevSym S, const int *__restrict
 #pragma unroll
                     for (int q = 3; q >= 0; q--)
                         if (!(pv[q] > 0.0) && 4 * p + q < w) bad = q;
-                    if (bad >= 0) atomicMin(info, S.sfirst[s] + kb + 4 * p + bad);
+                    if (bad >= 0) atomicMin(info, fv.first + kb + 4 * p + bad);
                     yy[0][0] = p0 * i00; yy[1][1] = p1 * i11; yy[2][2] = p2 * i22; yy[3][3] = p3 * i33;
                     yy[1][0] = l10; yy[2][0] = l20; yy[3][0] = l30;
                     yy[2][1] = l21; yy[3][1] = l31;
@@ -191,9 +191,10 @@ __global__ __launch_bounds__(256) void k_potrf64(DevSym S, const int *__restrict
     }
 }
 
-void launch_potrf64(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, double *L, int *info) {
+void launch_potrf64(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, double *L, int *info,
+                    const FrontArg &fa) {
     if (nactive <= 0) return;
-    hipLaunchKernelGGL(k_potrf64, dim3(nactive), dim3(256), 0, st, S, list, kb, L, info);
+    hipLaunchKernelGGL(k_potrf64, dim3(nactive), dim3(256), 0, st, S, list, kb, L, info, fa);
 }
 
 }  // namespace gmrfx

@@ -39,7 +39,7 @@ int main(){
   for(int wv : {64, 37}) {
     int sf2[2]={0,wv}; HC(hipMemcpy(dsf,sf2,8,hipMemcpyHostToDevice));
     HC(hipEventRecord(e0,st));
-    for(int r=0;r<reps;r++){ hipMemcpyAsync(dL,dA,n*n*8,hipMemcpyDeviceToDevice,st); hipLaunchKernelGGL(k_potrf64,dim3(1),dim3(256),0,st,S,dlist,0,dL,dinfo); }
+    for(int r=0;r<reps;r++){ hipMemcpyAsync(dL,dA,n*n*8,hipMemcpyDeviceToDevice,st); hipLaunchKernelGGL(k_potrf64,dim3(1),dim3(256),0,st,S,dlist,0,dL,dinfo,FrontArg{0,0,0,0,0,0,0}); }
     HC(hipEventRecord(e1,st)); HC(hipStreamSynchronize(st)); HC(hipEventElapsedTime(&ms,e0,e1));
     printf("k_potrf64 (w=%d) + d2d copy: %.2f us per launch\n", wv, ms*1000/reps);
     { long long c[4][16]={{0}};
