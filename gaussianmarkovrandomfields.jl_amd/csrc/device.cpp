@@ -231,15 +231,15 @@ void Device::factor_levels() {
     HC(hipMemcpyAsync(d_info_, &big, sizeof(int), hipMemcpyHostToDevice, stream));
     // whole small subtrees first (one workgroup each), then the level schedule of everything above
     for (int k = 0, off = 0; k < 3; off += nsub_cls_[k], k++)
-        launch_subtree(stream, ds_, 0, d_sub_first_ + off, d_sub_last_ + off, nsub_cls_[k], kClsRows[k], d_nz_, d_L_, d_cb_,
+        launch_subtree(stream, ds_, 0, d_sub_first_ + off, d_sub_last_ + off, nsub_cls_[k], kClsRows[k], nz_src_, d_L_, d_cb_,
                        d_info_, nullptr, nullptr, 0, 0);
     int nsy = 0;
     for (auto &L : levels_) {
         for (int k = 0, off = 0; k < 4; off += L.ncls[k], k++)
-            launch_factor_small(stream, ds_, d_levellist_ + L.first + off, L.ncls[k], kClsRows[k], d_nz_, d_L_, d_cb_, d_info_);
+            launch_factor_small(stream, ds_, d_levellist_ + L.first + off, L.ncls[k], kClsRows[k], nz_src_, d_L_, d_cb_, d_info_);
         const int *list = d_levellist_ + L.first + L.nsmall;
         const int nf = L.count - L.nsmall;
-        launch_assemble(stream, ds_, list, nf, L.max_cols, L.max_rows, d_nz_, d_L_, d_cb_);
+        launch_assemble(stream, ds_, list, nf, L.max_cols, L.max_rows, nz_src_, d_L_, d_cb_);
         const int nblk = level_nblk(L);
         // geometry of the widest front of the level (fronts are sorted by decreasing width): when it is
         // the only one still active, the panel kernels get it in their arguments (kernels.h, FrontArg)
@@ -302,12 +302,10 @@ void Device::refactorize(const double *nzval, bool on_device) {
     if (!on_device) {
         HC(hipMemcpyAsync(d_nz_, nzval, (size_t)S_->nnz_in * sizeof(double), hipMemcpyHostToDevice, stream));
         src = d_nz_;
-    } else if (nzval != d_nz_) {
-        // keep a private copy so the caller may overwrite its buffer right after the call returns
-        HC(hipMemcpyAsync(d_nz_, nzval, (size_t)S_->nnz_in * sizeof(double), hipMemcpyDeviceToDevice, stream));
-        src = d_nz_;
     }
-    (void)src;
+    // a device-resident nzval is read in place (the Q scatter happens inside the assembly kernels, and
+    // this call only returns once they have finished): no private copy
+    nz_src_ = src;
     HC(hipEventRecord(ev_[0], stream));
     factor_levels();
     HC(hipEventRecord(ev_[1], stream));

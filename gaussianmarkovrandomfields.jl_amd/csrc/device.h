@@ -106,6 +106,7 @@ private:
     int *d_sub_first_ = nullptr, *d_sub_last_ = nullptr, *d_sel_levellist_ = nullptr;
     int nsub_cls_[3] = {0, 0, 0};
     double *d_L_ = nullptr, *d_Z_ = nullptr, *d_cb_ = nullptr, *d_nz_ = nullptr;
+    const double *nz_src_ = nullptr;   // values of the refactorisation in flight (d_nz_ or the caller's device buffer)
     double *d_X_ = nullptr, *d_X2_ = nullptr, *d_W_ = nullptr, *d_io_ = nullptr, *d_tmp_ = nullptr, *d_part_ = nullptr;
     // dense-inverse stages (inverse.hip)
     int *d_invlist_ = nullptr;

@@ -4,7 +4,8 @@ small-grid (latency-bound) launches. usage: prof_summary.py <dir> [steps_incl_wa
 import collections, csv, glob, sys
 import numpy as np
 d = sys.argv[1]; nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-f = glob.glob(f"{d}/**/*kernel_trace.csv", recursive=True)[0]
+import os
+f = sorted(glob.glob(f"{d}/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)[-1]   # newest run in the directory
 rows = list(csv.DictReader(open(f)))
 by = collections.defaultdict(list)
 for r in rows:

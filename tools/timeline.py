@@ -4,7 +4,8 @@ usage: tools/timeline.py <rocprof output dir> [min_us]"""
 import csv, glob, sys
 d = sys.argv[1]
 min_us = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0
-f = glob.glob(d + '/*/*kernel_trace.csv')[0]
+import os
+f = sorted(glob.glob(d + '/*/*kernel_trace.csv'), key=os.path.getmtime)[-1]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 names = [r['Kernel_Name'].split('(')[0].replace('gmrfx::', '').replace('void ', '') for r in rows]
