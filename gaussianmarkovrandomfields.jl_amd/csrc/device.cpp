@@ -128,6 +128,7 @@ void Device::upload(const Symbolic &S) {
     }
     tmp64 = conv<long long>(S.diagoff); up(lp, tmp64); ds_.diagoff = lp; HC(hipStreamSynchronize(stream));
     up(ip, S.perm); ds_.perm = ip;
+    up(ip, S.iperm); d_iperm_ = ip;
     {
         const int *ll; up(ll, S.levellist); d_levellist_ = const_cast<int *>(ll);
         const int *a; up(a, S.sub_first); d_sub_first_ = const_cast<int *>(a);
@@ -409,13 +410,13 @@ void Device::solve(const double *B, long long ldb, long long nrhs, double *X, lo
         const int ldx = nr;
         HC(hipEventRecord(ev_[0], stream));
         // full solve: X = P b ; backward-only (F.UP \ z): z is taken in elimination order as is
-        launch_permute(stream, mode == 0 ? ds_.perm : nullptr, (int)n, const_cast<double *>(dB) + j0 * ldin, ldin, d_X_, nr, ldx, 0);
+        launch_permute(stream, mode == 0 ? d_iperm_ : nullptr, (int)n, const_cast<double *>(dB) + j0 * ldin, ldin, d_X_, nr, ldx, 0);
         HC(hipEventRecord(ev_[1], stream));
         if (mode == 0) forward(nr, ldx);
         HC(hipEventRecord(ev_[2], stream));
         backward(nr, ldx, mode == 0);
         HC(hipEventRecord(ev_[3], stream));
-        launch_permute(stream, ds_.perm, (int)n, dXo + j0 * ldout, ldout, d_X_, nr, ldx, 1);
+        launch_permute(stream, d_iperm_, (int)n, dXo + j0 * ldout, ldout, d_X_, nr, ldx, 1);
         HC(hipEventRecord(ev_[4], stream));
         HC(hipStreamSynchronize(stream));
         float a, b, c, d;

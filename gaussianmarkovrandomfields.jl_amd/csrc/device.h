@@ -102,6 +102,7 @@ private:
     const Symbolic *S_ = nullptr;
     DevSym ds_{};
     std::vector<LevelInfo> levels_;
+    const int *d_iperm_ = nullptr;   // inverse permutation (original row -> position), used by the RHS transposes
     int *d_levellist_ = nullptr;
     int *d_sub_first_ = nullptr, *d_sub_last_ = nullptr, *d_sel_levellist_ = nullptr;
     int nsub_cls_[3] = {0, 0, 0};

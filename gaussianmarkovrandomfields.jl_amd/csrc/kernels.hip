@@ -689,28 +689,34 @@ __global__ __launch_bounds__(256) void k_bwd_gemm_longk(DevSym S, const int *__r
 // ------------------------------------------------------------------------------------------
 // dir 0: X[k, j] = B[perm[k] + j*ldb]   (perm == nullptr: identity)
 // dir 1: B[perm[k] + j*ldb] = X[k, j]
-__global__ __launch_bounds__(256) void k_permute(const int *__restrict__ perm, int n, double *__restrict__ Bc,
+__global__ __launch_bounds__(256) void k_permute(const int *__restrict__ iperm, int n, double *__restrict__ Bc,
                                                  long long ldb, double *__restrict__ X, int nr, int ldx, int dir) {
+    // Caller side: column-major n x nr (a DoF is strided by ldb); solver side: row-major, one DoF =
+    // one contiguous 8 nr-byte row, in elimination order. A workgroup owns 64 consecutive ORIGINAL
+    // rows i: the caller side is then read / written in 512-byte runs per column and the solver side
+    // one whole row (iperm[i]) at a time -- both sides coalesced, the 64 x 64 transpose goes through
+    // LDS. (Walking the elimination order instead and gathering caller rows perm[k] costs 2.7x the
+    // bytes in partially used 64-byte sectors.) iperm == nullptr: identity.
     __shared__ double T[64 * 65];
-    const int k0 = blockIdx.x * 64;
+    __shared__ int rowL[64];
+    const int i0 = blockIdx.x * 64;
     const int tid = threadIdx.x;
     const int a = tid & 63, b = tid >> 6;
+    if (tid < 64) rowL[tid] = (i0 + tid < n) ? (iperm ? iperm[i0 + tid] : i0 + tid) : 0;
     if (dir == 0) {
-        const int k = k0 + a;
-        const long long src = (k < n) ? (perm ? perm[k] : k) : 0;
-        for (int j = b; j < nr; j += 4) T[a * 65 + j] = (k < n) ? Bc[src + (long long)j * ldb] : 0.0;
+        const int i = i0 + a;
+        for (int j = b; j < nr; j += 4) T[a * 65 + j] = (i < n) ? Bc[i + (long long)j * ldb] : 0.0;
         __syncthreads();
         for (int kk = b; kk < 64; kk += 4)
-            if (k0 + kk < n && a < nr) X[(long long)(k0 + kk) * ldx + a] = T[kk * 65 + a];
+            if (i0 + kk < n && a < nr) X[(long long)rowL[kk] * ldx + a] = T[kk * 65 + a];
     } else {
-        for (int kk = b; kk < 64; kk += 4)
-            if (k0 + kk < n && a < nr) T[kk * 65 + a] = X[(long long)(k0 + kk) * ldx + a];
         __syncthreads();
-        const int k = k0 + a;
-        if (k < n) {
-            const long long dst = perm ? perm[k] : k;
-            for (int j = b; j < nr; j += 4) Bc[dst + (long long)j * ldb] = T[a * 65 + j];
-        }
+        for (int kk = b; kk < 64; kk += 4)
+            if (i0 + kk < n && a < nr) T[kk * 65 + a] = X[(long long)rowL[kk] * ldx + a];
+        __syncthreads();
+        const int i = i0 + a;
+        if (i < n)
+            for (int j = b; j < nr; j += 4) Bc[i + (long long)j * ldb] = T[a * 65 + j];
     }
 }
 
