@@ -356,7 +356,7 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
     S.nlevels = 0;
     for (i32 s = 0; s < ns; s++) S.nlevels = std::max(S.nlevels, S.level[s] + 1);
     // small fronts (fused LDS kernels, small.hip): r <= 96 or r <= 128 rows and <= 64 columns
-    S.small_rows = opt.small_front_rows >= 0 ? opt.small_front_rows : 128;
+    S.small_rows = opt.small_front_rows >= 0 ? opt.small_front_rows : 96;    // measured on cfg 2: 96 beats 128 and 64 (tools/sweep notes in DESIGN.md)
     S.is_small.resize(ns);
     static const int kClsRows[4] = {48, 64, 96, 128};
     auto cls = [&](i32 s) -> int {
@@ -369,7 +369,7 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
     // Supernodes are numbered in postorder, so the subtree of s is the id range [s-cnt+1, s].
     S.in_subtree.assign(ns, 0);
     {
-        const int submax = opt.subtree_max >= 0 ? opt.subtree_max : 24;
+        const int submax = opt.subtree_max >= 0 ? opt.subtree_max : 0;   // subtree tasks are off by default: level-batched small fronts measured 3 % faster
         std::vector<i32> cnt(ns, 1), maxr(ns, 0);
         std::vector<uint8_t> ok(ns, 0);
         for (i32 s = 0; s < ns; s++) {

@@ -20,8 +20,8 @@ struct SymOptions {
     double relax_zeros = 0;  // 0 = default
     int coord_dim = 0;
     const double *coords = nullptr;
-    int subtree_max = -1;      // max fronts per subtree task; -1 = default (24), 0 = off
-    int small_front_rows = -1; // fronts with r <= this (and <= 64 columns) use the fused LDS kernels; -1 = default (128), 0 = off
+    int subtree_max = -1;      // max fronts per subtree task; -1 = default (0 = off: bit-identical, measured slower than level batching)
+    int small_front_rows = -1; // fronts with r <= this (and <= 64 columns) use the fused LDS kernels; -1 = default (96), 0 = off
 };
 
 // Symmetric adjacency structure without self loops.

@@ -270,10 +270,11 @@ def test_generic_path_matches_fused_small_front_path(name, monkeypatch):
     assert relerr(ws.workspace_solve(B), F.solve(B)) < 1e-10
     assert relerr(ws.backward_solve(B), F.backward_solve(B)) < 1e-10
     assert relerr(ws.selinv_diag(), F.selinv_diag()) < 1e-8
-    monkeypatch.setenv("GMRFX_SMALL_ROWS", "96")
-    ws96 = gmrfx.GMRFWorkspace(Q, **kw)
-    assert relerr(ws96.workspace_solve(B), F.solve(B)) < 1e-10
-    assert relerr(ws96.selinv_diag(), F.selinv_diag()) < 1e-8
+    for rows in ("64", "128"):      # the other size-class cut-offs (default: 96)
+        monkeypatch.setenv("GMRFX_SMALL_ROWS", rows)
+        wsr = gmrfx.GMRFWorkspace(Q, **kw)
+        assert relerr(wsr.workspace_solve(B), F.solve(B)) < 1e-10
+        assert relerr(wsr.selinv_diag(), F.selinv_diag()) < 1e-8
 
 
 GOLD = sorted(__import__("glob").glob(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "*.npz")))
@@ -399,9 +400,10 @@ def test_disconnected_and_arrow_patterns():
 
 @pytest.mark.parametrize("name", ["matern64_coords", "cfg1_alpha3_65x65", "matern3d_10", "rand400"])
 def test_subtree_tasks_on_and_off_agree(name, monkeypatch):
-    """Whole-subtree workgroup tasks (default) vs pure level scheduling (GMRFX_SUBTREE_MAX=0):
+    """Whole-subtree workgroup tasks (GMRFX_SUBTREE_MAX=24) vs pure level scheduling (the default, = 0):
     same factor bit for bit (same arithmetic per front), same answers."""
     Q, kw = next((sp.csc_matrix(q), k) for n, q, k in CASES if n == name)
+    monkeypatch.setenv("GMRFX_SUBTREE_MAX", "24")
     ws_on = gmrfx.GMRFWorkspace(Q, **kw)
     monkeypatch.setenv("GMRFX_SUBTREE_MAX", "0")
     ws_off = gmrfx.GMRFWorkspace(Q, **kw)
