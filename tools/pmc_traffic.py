@@ -6,8 +6,8 @@
     python3 tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_pmc_traffic.json 1000 64
 
 Counter unit: KB. FETCH_SIZE is doubled (MI355X_MICROARCH.md: gfx950 reports half of the wide
-coalesced reads). Only the dispatches of the LAST bench step are counted (from the last
-k_factor_subtree<48> launch on; the untimed extras after the step -- logdet -- are tiny)."""
+coalesced reads). Only the dispatches of the LAST bench step are counted (from its first
+factorisation kernel on; the untimed extras after the step -- logdet -- are tiny)."""
 import csv, glob, json, sys, collections
 
 def load(d):
@@ -16,8 +16,18 @@ def load(d):
     rows = list(csv.DictReader(open(f[-1])))    # newest run in the directory
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     names = [r["Kernel_Name"].split("(")[0].replace("gmrfx::", "").replace("void ", "") for r in rows]
-    start = max(i for i, n in enumerate(names) if n.startswith("k_factor_subtree<48>") or n.startswith("k_factor_subtree<64>") and not any(m.startswith("k_factor_subtree<48>") for m in names))
+    start = last_step_start(names)
     return [(n, float(r["Counter_Value"])) for n, r in zip(names[start:], rows[start:])]
+
+def last_step_start(names):
+    """index of the first factorisation kernel of the LAST refactorise+solve step"""
+    prev_factor, start = False, 0
+    for i, n in enumerate(names):
+        if not n.startswith("k_"): continue          # runtime copy / fill kernels
+        f = phase(n) == "factor"
+        if f and not prev_factor: start = i
+        prev_factor = f
+    return start
 
 def phase(n):
     if n.startswith(("k_factor", "k_assemble", "k_potrf", "k_trsm", "k_gemm_nt", "k_syrk")): return "factor"

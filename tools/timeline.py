@@ -9,8 +9,13 @@ f = sorted(glob.glob(d + '/*/*kernel_trace.csv'), key=os.path.getmtime)[-1]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 names = [r['Kernel_Name'].split('(')[0].replace('gmrfx::', '').replace('void ', '') for r in rows]
-idx = [i for i, n in enumerate(names) if n.startswith('k_factor_subtree<48>')]
-s = idx[-1]
+FACT = ('k_factor', 'k_assemble', 'k_potrf', 'k_trsm', 'k_gemm_nt', 'k_syrk')
+prev, s = False, 0
+for i, n in enumerate(names):
+    if not n.startswith('k_'): continue
+    f = n.startswith(FACT)
+    if f and not prev: s = i
+    prev = f
 t0 = int(rows[s]['Start_Timestamp']); prev = t0
 for r, n in zip(rows[s:], names[s:]):
     st, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
