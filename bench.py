@@ -49,6 +49,46 @@ def cpu_baseline(nrhs: int, grid: int = 300):
                       f"{t1 - t0:.2f}s + {nrhs} column solves {t2 - t1:.2f}s, 1 thread"}
 
 
+def bench_sharded(args, Q, mesh, dist, rank, world, local_rank):
+    """Strong scaling of ONE refactorisation + logdet over the ranks. Not the headline line."""
+    import numpy as np
+    import torch
+    from gmrfx import shard
+    if dist is None:
+        raise SystemExit("--shard needs N > 1 ranks (torch.distributed.run)")
+    dev = torch.device("cuda", local_rank)
+    n = Q.shape[0]
+    d_nz = torch.from_numpy(np.ascontiguousarray(Q.data)).to(dev)
+    sf = shard.ShardedFactor(Q, dist, device=local_rank, coords=mesh.points)
+
+    def step():
+        sf.refactorize_dev(d_nz.data_ptr())
+        return sf.logdet()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ld = step()
+    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if args.rehearse else dev)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        info = sf.be.shard_info()
+        print(json.dumps({"metric": "sharded refactorize + logdet (one factorisation over all ranks)", "value": n / (float(el.item()) / args.steps),
+                          "unit": "DoF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": 1e3 * float(el.item()) / args.steps, "higher_is_better": True, "scaling": "strong",
+                          "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                          "config": {"workload": f"cfg2 pattern ({args.grid}x{args.grid} mesh), refactorise + logdet, supernodal tree cut into "
+                                                 f"subtrees per rank, {info['n_cb_blocks']} contribution blocks to rank 0, {info['n_top_fronts']} top fronts",
+                                     "exchange": "gloo + host staging (rehearsal)" if args.rehearse else "RCCL point-to-point + all-reduce"},
+                          "check": {"logdet": ld}}))
+    dist.barrier()
+    sf.close()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -61,6 +101,10 @@ def main():
                     help="multi-process rehearsal on a box with ONE GPU: every rank uses cuda:0 and the "
                          "process group runs on gloo (RCCL refuses two ranks on one device)")
     ap.add_argument("--extras", action="store_true", help="also time selinv-diag and 256-sample rand (cfg 3)")
+    ap.add_argument("--shard", action="store_true",
+                    help="extra (N > 1): ONE factorisation sharded over the ranks (subtrees per rank, Schur-complement "
+                         "contribution blocks to rank 0 over the process group, all-reduced logdet; gmrfx/shard.py) "
+                         "instead of independent replicas; prints its own JSON line (strong scaling of refactorise+logdet)")
     ap.add_argument("--pool", type=int, default=0,
                     help="extra: throughput of P independent workspaces driven concurrently on this GPU "
                          "(the reference's WorkspacePool pattern; reported separately, never as `value`)")
@@ -91,6 +135,8 @@ def main():
     mesh = spde.grid_mesh_2d(args.grid, args.grid, jitter=0.25, seed=0)
     Q = spde.matern_precision(mesh, smoothness=0, range_=0.2)   # range = 0.1 * domain width (2.0)
     n = Q.shape[0]
+    if args.shard:
+        return bench_sharded(args, Q, mesh, dist, rank, world, local_rank)
     be = gmrfx.MI355XBackend(Q, coords=mesh.points, device=local_rank, factorize=False)
     st0 = be.stats()
 

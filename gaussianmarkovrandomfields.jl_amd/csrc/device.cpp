@@ -129,6 +129,15 @@ void Device::upload(const Symbolic &S) {
     tmp64 = conv<long long>(S.diagoff); up(lp, tmp64); ds_.diagoff = lp; HC(hipStreamSynchronize(stream));
     up(ip, S.perm); ds_.perm = ip;
     up(ip, S.iperm); d_iperm_ = ip;
+    if (S.shard_world > 1) {
+        std::vector<unsigned char> own(S.n, 0);
+        for (i32 s = 0; s < ns; s++) {
+            const bool mine = S.owner[s] == S.shard_rank || (S.owner[s] == -1 && S.shard_rank == 0);
+            if (mine) for (i32 j = S.sfirst[s]; j < S.sfirst[s + 1]; j++) own[j] = 1;
+        }
+        const unsigned char *op; up(op, own); d_owncol_ = op;
+        HC(hipStreamSynchronize(stream));
+    }
     {
         const int *ll; up(ll, S.levellist); d_levellist_ = const_cast<int *>(ll);
         const int *a; up(a, S.sub_first); d_sub_first_ = const_cast<int *>(a);
@@ -227,15 +236,19 @@ static const int OBK = 4;   // 64-column blocks per outer (256-column) block of 
 static inline int level_max_trail(const LevelInfo &L) { return L.active.back(); }
 static inline int level_nblk(const LevelInfo &L) { return (int)L.active.size() - 2; }
 
-void Device::factor_levels() {
-    const int big = INT_MAX;
-    HC(hipMemcpyAsync(d_info_, &big, sizeof(int), hipMemcpyHostToDevice, stream));
-    // whole small subtrees first (one workgroup each), then the level schedule of everything above
-    for (int k = 0, off = 0; k < 3; off += nsub_cls_[k], k++)
-        launch_subtree(stream, ds_, 0, d_sub_first_ + off, d_sub_last_ + off, nsub_cls_[k], kClsRows[k], nz_src_, d_L_, d_cb_,
-                       d_info_, nullptr, nullptr, 0, 0);
-    int nsy = 0;
-    for (auto &L : levels_) {
+void Device::factor_levels(int lo, int hi) {
+    if (lo == 0) {
+        const int big = INT_MAX;
+        HC(hipMemcpyAsync(d_info_, &big, sizeof(int), hipMemcpyHostToDevice, stream));
+        syrk_launches = 0;
+        // whole small subtrees first (one workgroup each), then the level schedule of everything above
+        for (int k = 0, off = 0; k < 3; off += nsub_cls_[k], k++)
+            launch_subtree(stream, ds_, 0, d_sub_first_ + off, d_sub_last_ + off, nsub_cls_[k], kClsRows[k], nz_src_, d_L_, d_cb_,
+                           d_info_, nullptr, nullptr, 0, 0);
+    }
+    int nsy = (int)syrk_launches;
+    for (int lev = lo; lev < hi; lev++) {
+        auto &L = levels_[lev];
         for (int k = 0, off = 0; k < 4; off += L.ncls[k], k++)
             launch_factor_small(stream, ds_, d_levellist_ + L.first + off, L.ncls[k], kClsRows[k], nz_src_, d_L_, d_cb_, d_info_);
         const int *list = d_levellist_ + L.first + L.nsmall;
@@ -307,8 +320,9 @@ void Device::refactorize(const double *nzval, bool on_device) {
     // a device-resident nzval is read in place (the Q scatter happens inside the assembly kernels, and
     // this call only returns once they have finished): no private copy
     nz_src_ = src;
+    if (sharded()) throw std::invalid_argument("sharded handle: use gmrfx_refactorize_phase (two phases with an exchange in between)");
     HC(hipEventRecord(ev_[0], stream));
-    factor_levels();
+    factor_levels(0, (int)levels_.size());
     HC(hipEventRecord(ev_[1], stream));
     inverse_pending = true;
     HC(hipStreamSynchronize(stream));
@@ -324,6 +338,27 @@ void Device::refactorize(const double *nzval, bool on_device) {
     }
     factorized = true;
     selinv_valid = false;
+}
+
+void Device::refactorize_phase(const double *d_nzval, int phase) {
+    HC(hipSetDevice(device));
+    if (!sharded()) throw std::invalid_argument("gmrfx_refactorize_phase needs a handle created with shard_world > 1");
+    const int split = std::min<int>(S_->shard_level, (int)levels_.size());
+    HC(hipEventRecord(ev_[0], stream));
+    if (phase == 0) {
+        nz_src_ = d_nzval;
+        factorized = false;
+        factor_levels(0, split);
+    } else {
+        factor_levels(split, (int)levels_.size());
+    }
+    HC(hipEventRecord(ev_[1], stream));
+    HC(hipStreamSynchronize(stream));
+    HC(hipGetLastError());
+    float ms = 0;
+    HC(hipEventElapsedTime(&ms, ev_[0], ev_[1]));
+    ms_factor = phase == 0 ? ms : ms_factor + ms;
+    if (phase != 0) { factorized = true; selinv_valid = false; inverse_pending = true; }
 }
 
 long long Device::fail_col() {
@@ -390,6 +425,7 @@ void Device::backward(int nr, int ldx, bool y_in_x2) {
 
 void Device::solve(const double *B, long long ldb, long long nrhs, double *X, long long ldx_out, bool on_device, int mode) {
     HC(hipSetDevice(device));
+    if (sharded()) throw std::invalid_argument("solves on a sharded handle are not implemented yet");
     if (nrhs <= 0) return;
     const long long n = S_->n;
     ensure_rhs_capacity(nrhs);
@@ -442,7 +478,7 @@ double Device::logdet() {
     HC(hipSetDevice(device));
     const int nparts = (int)std::min<long long>(1024, std::max<long long>(1, (S_->n + 255) / 256));
     HC(hipEventRecord(ev_[0], stream));
-    launch_logdet(stream, d_L_, ds_.diagoff, (int)S_->n, d_part_, nparts, d_part_ + 1024);
+    launch_logdet(stream, d_L_, ds_.diagoff, d_owncol_, (int)S_->n, d_part_, nparts, d_part_ + 1024);
     HC(hipEventRecord(ev_[1], stream));
     double out = 0;
     HC(hipMemcpyAsync(&out, d_part_ + 1024, sizeof(double), hipMemcpyDeviceToHost, stream));
@@ -453,6 +489,7 @@ double Device::logdet() {
 
 void Device::selinv_compute() {
     HC(hipSetDevice(device));
+    if (sharded()) throw std::invalid_argument("selected inversion on a sharded handle is not implemented yet");
     if (selinv_valid) return;
     const Symbolic &S = *S_;
     start_inverse_async();

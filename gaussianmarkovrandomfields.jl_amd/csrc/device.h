@@ -69,6 +69,12 @@ public:
     void clone_from(const Device &o, const Symbolic &S);
 
     void refactorize(const double *nzval, bool on_device);
+    // sharded handles: phase 0 = the subtrees this rank owns, phase 1 = the top fronts (rank 0; after the
+    // contribution blocks of the other ranks' subtree roots have been written into cb_arena())
+    void refactorize_phase(const double *d_nzval, int phase);
+    double *cb_arena() { return d_cb_; }
+    double *factor_panels() { return d_L_; }
+    bool sharded() const { return S_ && S_->shard_world > 1; }
     // B: column-major n x nrhs (original ordering); mode 0: full solve, 1: backward only (P' L^-T Z)
     void solve(const double *B, long long ldb, long long nrhs, double *X, long long ldx, bool on_device, int mode);
     double logdet();
@@ -93,7 +99,7 @@ public:
 private:
     void upload(const Symbolic &S);
     void ensure_rhs_capacity(long long nrhs);
-    void factor_levels();
+    void factor_levels(int lo, int hi);
     void forward(int nr, int ldx);
     void backward(int nr, int ldx, bool y_in_x2);
     template <class T> T *dalloc(size_t count);
@@ -102,6 +108,7 @@ private:
     const Symbolic *S_ = nullptr;
     DevSym ds_{};
     std::vector<LevelInfo> levels_;
+    const unsigned char *d_owncol_ = nullptr;   // sharded handles: 1 for the columns of the fronts this rank factors
     const int *d_iperm_ = nullptr;   // inverse permutation (original row -> position), used by the RHS transposes
     int *d_levellist_ = nullptr;
     int *d_sub_first_ = nullptr, *d_sub_last_ = nullptr, *d_sel_levellist_ = nullptr;

@@ -83,6 +83,12 @@ extern "C" int32_t gmrfx_create(int64_t n, const int64_t *colptr, const int64_t 
         if (so.coords && so.coord_dim != 2 && so.coord_dim != 3) throw std::invalid_argument("coord_dim must be 2 or 3");
         if (const char *e = std::getenv("GMRFX_SMALL_ROWS")) so.small_front_rows = std::atoi(e);   // tuning/testing knob
         if (const char *e = std::getenv("GMRFX_SUBTREE_MAX")) so.subtree_max = std::atoi(e);       // 0 disables subtree tasks
+        if (h->opts.shard_world > 1) {
+            if (h->opts.shard_rank < 0 || h->opts.shard_rank >= h->opts.shard_world) throw std::invalid_argument("shard_rank out of range");
+            so.shard_rank = h->opts.shard_rank;
+            so.shard_world = h->opts.shard_world;
+            so.subtree_max = 0;     // subtree tasks are not shard-aware
+        }
         analyze(n, colptr, rowval, index_base, perm, so, h->S);
         h->opts.coords = nullptr;  // caller-owned, not kept
     } catch (const std::invalid_argument &e) {
@@ -144,6 +150,56 @@ static int32_t refactorize_impl(gmrfx_handle *h, const double *nz, int64_t *info
     });
 }
 extern "C" int32_t gmrfx_refactorize(gmrfx_handle *h, const double *nzval, int64_t *info) { return refactorize_impl(h, nzval, info, false); }
+
+// ---- sharded factorisation (include/gmrfx.h) ---------------------------------------------------------
+extern "C" int32_t gmrfx_refactorize_phase(gmrfx_handle *h, const double *d_nzval, int32_t phase) {
+    return guarded(h, [&]() -> int32_t {
+        if (int32_t e = need_device(h, false)) return e;
+        if (phase == 0 && !d_nzval) throw std::invalid_argument("d_nzval is null");
+        if (phase != 0 && phase != 1) throw std::invalid_argument("phase must be 0 or 1");
+        h->D->refactorize_phase(d_nzval, phase);
+        return GMRFX_OK;
+    });
+}
+extern "C" int32_t gmrfx_shard_info(const gmrfx_handle *h, int64_t *n_cb_blocks, int64_t *n_top_fronts, int64_t *shard_level) {
+    if (!h) return GMRFX_ERR_INVALID_ARG;
+    const Symbolic &S = h->S;
+    int64_t ntop = 0;
+    for (i32 s = 0; s < S.nsuper; s++) ntop += S.owner[s] == -1;
+    if (n_cb_blocks) *n_cb_blocks = (int64_t)S.shard_roots.size();
+    if (n_top_fronts) *n_top_fronts = ntop;
+    if (shard_level) *shard_level = S.shard_level;
+    return GMRFX_OK;
+}
+extern "C" int32_t gmrfx_shard_cb_blocks(const gmrfx_handle *h, int64_t *owner, int64_t *offset, int64_t *count) {
+    if (!h || !owner || !offset || !count) return GMRFX_ERR_INVALID_ARG;
+    const Symbolic &S = h->S;
+    for (size_t k = 0; k < S.shard_roots.size(); k++) {
+        const i32 d = S.shard_roots[k];
+        const int64_t m = S.nrows(d) - S.ncols(d);
+        owner[k] = S.owner[d];
+        offset[k] = S.cbptr[d];
+        count[k] = m * m;
+    }
+    return GMRFX_OK;
+}
+extern "C" int32_t gmrfx_shard_owner(const gmrfx_handle *h, int64_t *owner) {
+    if (!h || !owner) return GMRFX_ERR_INVALID_ARG;
+    for (i32 s = 0; s < h->S.nsuper; s++) owner[s] = h->S.owner[s];
+    return GMRFX_OK;
+}
+extern "C" void *gmrfx_device_ptr(gmrfx_handle *h, int32_t which) {
+    if (!h || !h->D) return nullptr;
+    return which == 0 ? (void *)h->D->cb_arena() : (which == 1 ? (void *)h->D->factor_panels() : nullptr);
+}
+extern "C" int32_t gmrfx_logdet_partial(gmrfx_handle *h, double *out) {
+    return guarded(h, [&]() -> int32_t {
+        if (int32_t e = need_device(h, true)) return e;
+        if (!out) throw std::invalid_argument("out is null");
+        *out = h->D->logdet();      // sharded handles sum over their own columns only
+        return GMRFX_OK;
+    });
+}
 extern "C" int32_t gmrfx_refactorize_dev(gmrfx_handle *h, const double *d_nzval, int64_t *info) { return refactorize_impl(h, d_nzval, info, true); }
 
 static int32_t solve_impl(gmrfx_handle *h, const double *B, int64_t ldb, int64_t nrhs, double *X, int64_t ldx, bool dev, int mode) {

@@ -724,13 +724,15 @@ __global__ __launch_bounds__(256) void k_permute(const int *__restrict__ iperm, 
 // log det Q = 2 sum_k log L_kk, fixed-order two-stage reduction (bit-reproducible)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_logdet_partial(const double *__restrict__ L, const long long *__restrict__ diagoff,
-                                                        int n, double *__restrict__ part) {
+                                                        const unsigned char *__restrict__ own, int n, double *__restrict__ part) {
     __shared__ double sh[256];
     const int tid = threadIdx.x;
     const int per = (n + gridDim.x - 1) / gridDim.x;
     const int k0 = blockIdx.x * per, k1 = min(n, k0 + per);
     double acc = 0.0;
-    for (int k = k0 + tid; k < k1; k += 256) acc += log(L[diagoff[k]]);
+    // own (sharded handles): only the columns of the fronts this rank factored; nullptr = all
+    for (int k = k0 + tid; k < k1; k += 256)
+        if (!own || own[k]) acc += log(L[diagoff[k]]);
     sh[tid] = acc;
     __syncthreads();
     for (int st = 128; st > 0; st >>= 1) {
@@ -891,8 +893,9 @@ void launch_bwd_gemm(hipStream_t st, const DevSym &S, const int *list, int nfron
 void launch_permute(hipStream_t st, const int *perm, int n, double *Bc, long long ldb, double *X, int nr, int ldx, int dir) {
     hipLaunchKernelGGL(k_permute, dim3(cdiv(n, 64)), dim3(256), 0, st, perm, n, Bc, ldb, X, nr, ldx, dir);
 }
-void launch_logdet(hipStream_t st, const double *L, const long long *diagoff, int n, double *part, int nparts, double *out) {
-    hipLaunchKernelGGL(k_logdet_partial, dim3(nparts), dim3(256), 0, st, L, diagoff, n, part);
+void launch_logdet(hipStream_t st, const double *L, const long long *diagoff, const unsigned char *own, int n, double *part,
+                   int nparts, double *out) {
+    hipLaunchKernelGGL(k_logdet_partial, dim3(nparts), dim3(256), 0, st, L, diagoff, own, n, part);
     hipLaunchKernelGGL(k_logdet_final, dim3(1), dim3(64), 0, st, part, nparts, out);
 }
 void launch_gather(hipStream_t st, const double *src, const long long *off, long long cnt, double *out) {

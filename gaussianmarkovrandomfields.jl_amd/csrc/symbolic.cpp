@@ -355,6 +355,77 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
     }
     S.nlevels = 0;
     for (i32 s = 0; s < ns; s++) S.nlevels = std::max(S.nlevels, S.level[s] + 1);
+    // ---- sharding over ranks (multi-GPU): split the tree top-down into subtrees, deal them out ----
+    S.shard_rank = opt.shard_rank;
+    S.shard_world = std::max(1, opt.shard_world);
+    S.owner.assign(ns, 0);
+    S.shard_level = S.nlevels;
+    if (S.shard_world > 1) {
+        const int W = S.shard_world;
+        // weight of a front ~ its factorisation flops; of a subtree = sum over its fronts (postorder ids)
+        std::vector<double> wsub(ns, 0.0);
+        for (i32 s = 0; s < ns; s++) {
+            const double c = S.ncols(s), m = S.nrows(s) - S.ncols(s);
+            wsub[s] += c * c * c / 3.0 + c * c * m + c * m * m + 1.0;
+            if (S.sparent[s] != -1) wsub[S.sparent[s]] += wsub[s];
+        }
+        std::vector<i32> T;                     // current subtree roots
+        std::vector<uint8_t> top(ns, 0);
+        for (i32 s = 0; s < ns; s++) if (S.sparent[s] == -1) T.push_back(s);
+        auto makespan = [&](std::vector<i32> &assign_out) {
+            std::vector<i32> ord(T);
+            std::sort(ord.begin(), ord.end(), [&](i32 a, i32 b) { return wsub[a] != wsub[b] ? wsub[a] > wsub[b] : a < b; });
+            std::vector<double> load(W, 0.0);
+            assign_out.assign(ns, -2);
+            for (i32 s : ord) {
+                int r = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+                load[r] += wsub[s];
+                assign_out[s] = r;
+            }
+            return *std::max_element(load.begin(), load.end());
+        };
+        std::vector<i32> asg;
+        for (int it = 0; it < 64; it++) {
+            double tot = 0;
+            for (i32 s : T) tot += wsub[s];
+            const double ms = makespan(asg);
+            if ((int)T.size() >= W && ms <= 1.15 * tot / W) break;
+            // split the heaviest subtree that has children: its root becomes a top front
+            i32 best = -1;
+            for (i32 s : T) if (S.childptr[s + 1] > S.childptr[s] && (best == -1 || wsub[s] > wsub[best])) best = s;
+            if (best == -1) break;
+            top[best] = 1;
+            T.erase(std::find(T.begin(), T.end(), best));
+            for (i64 q = S.childptr[best]; q < S.childptr[best + 1]; q++) T.push_back(S.children[q]);
+        }
+        makespan(asg);
+        // owner: subtree root's rank for everything below it (postorder: parents after children)
+        for (i32 s = ns - 1; s >= 0; s--) {
+            if (top[s]) S.owner[s] = -1;
+            else if (asg[s] >= 0) S.owner[s] = asg[s];
+            else S.owner[s] = S.owner[S.sparent[s]];     // inside a subtree: same as the parent (processed first)
+        }
+        // top fronts go to levels >= shard_level = 1 + highest level of any assigned front
+        i32 lmax = -1;
+        for (i32 s = 0; s < ns; s++) if (S.owner[s] >= 0) lmax = std::max(lmax, S.level[s]);
+        S.shard_level = lmax + 1;
+        for (i32 s = 0; s < ns; s++) {
+            if (S.owner[s] != -1) continue;
+            i32 lv = S.shard_level;
+            for (i64 q = S.childptr[s]; q < S.childptr[s + 1]; q++) {
+                const i32 d = S.children[q];
+                if (S.owner[d] == -1) lv = std::max(lv, S.level[d] + 1);    // children have smaller ids: already final
+                else S.shard_roots.push_back(d);
+            }
+            S.level[s] = lv;
+        }
+        std::sort(S.shard_roots.begin(), S.shard_roots.end());
+        S.nlevels = 0;
+        for (i32 s = 0; s < ns; s++) S.nlevels = std::max(S.nlevels, S.level[s] + 1);
+        S.nlevels = std::max(S.nlevels, S.shard_level);
+    }
+    // does this rank execute front s?  (top fronts: rank 0)
+    auto mine = [&](i32 s) { return S.shard_world == 1 || S.owner[s] == S.shard_rank || (S.owner[s] == -1 && S.shard_rank == 0); };
     // small fronts (fused LDS kernels, small.hip): r <= 96 or r <= 128 rows and <= 64 columns
     S.small_rows = opt.small_front_rows >= 0 ? opt.small_front_rows : 96;    // measured on cfg 2: 96 beats 128 and 64 (tools/sweep notes in DESIGN.md)
     S.is_small.resize(ns);
@@ -398,11 +469,11 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
         }
     }
     S.levelptr.assign(S.nlevels + 1, 0);
-    for (i32 s = 0; s < ns; s++) if (!S.in_subtree[s]) S.levelptr[S.level[s] + 1]++;
+    for (i32 s = 0; s < ns; s++) if (!S.in_subtree[s] && mine(s)) S.levelptr[S.level[s] + 1]++;
     for (i32 l = 0; l < S.nlevels; l++) S.levelptr[l + 1] += S.levelptr[l];
     S.levellist.resize(S.levelptr[S.nlevels]);
     { std::vector<i64> w(S.levelptr.begin(), S.levelptr.end() - 1);
-      for (i32 s = 0; s < ns; s++) if (!S.in_subtree[s]) S.levellist[w[S.level[s]]++] = s; }
+      for (i32 s = 0; s < ns; s++) if (!S.in_subtree[s] && mine(s)) S.levellist[w[S.level[s]]++] = s; }
     S.level_nsmall.assign(S.nlevels, 0);
     S.level_ncls.assign((size_t)S.nlevels * 4, 0);
     for (i32 l = 0; l < S.nlevels; l++) {
@@ -422,11 +493,11 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
     for (i32 s = 0; s < ns; s++) S.n_small += S.in_subtree[s];
     // all-front level lists for the (top-down) selected inversion
     S.sel_levelptr.assign(S.nlevels + 1, 0);
-    for (i32 s = 0; s < ns; s++) S.sel_levelptr[S.level[s] + 1]++;
+    for (i32 s = 0; s < ns; s++) if (mine(s)) S.sel_levelptr[S.level[s] + 1]++;
     for (i32 l = 0; l < S.nlevels; l++) S.sel_levelptr[l + 1] += S.sel_levelptr[l];
-    S.sel_levellist.resize(ns);
+    S.sel_levellist.resize(S.sel_levelptr[S.nlevels]);
     { std::vector<i64> w(S.sel_levelptr.begin(), S.sel_levelptr.end() - 1);
-      for (i32 s = 0; s < ns; s++) S.sel_levellist[w[S.level[s]]++] = s; }
+      for (i32 s = 0; s < ns; s++) if (mine(s)) S.sel_levellist[w[S.level[s]]++] = s; }
     S.sel_level_nsmall.assign(S.nlevels, 0);
     for (i32 l = 0; l < S.nlevels; l++) {
         auto b = S.sel_levellist.begin() + S.sel_levelptr[l], e = S.sel_levellist.begin() + S.sel_levelptr[l + 1];

@@ -22,6 +22,8 @@ struct SymOptions {
     const double *coords = nullptr;
     int subtree_max = -1;      // max fronts per subtree task; -1 = default (0 = off: bit-identical, measured slower than level batching)
     int small_front_rows = -1; // fronts with r <= this (and <= 64 columns) use the fused LDS kernels; -1 = default (96), 0 = off
+    // multi-GPU sharding of ONE factorisation along the supernodal tree (see Symbolic::owner)
+    int shard_rank = 0, shard_world = 1;
 };
 
 // Symmetric adjacency structure without self loops.
@@ -68,6 +70,14 @@ struct Symbolic {
     std::vector<i64> sel_levelptr;
     std::vector<i32> sel_levellist, sel_level_nsmall;
     int small_rows = 0;
+    // Sharding over `shard_world` ranks (every rank runs the same analysis and gets the same answer):
+    // owner[s] = rank that factors front s for the fronts inside an assigned subtree, -1 for the TOP
+    // fronts (the ancestors of the assigned subtree roots), which rank 0 factors after it has received
+    // the contribution blocks of the subtree roots. Top fronts are pushed to levels >= shard_level, all
+    // assigned subtrees live below it, and the level lists of a rank only hold the fronts it executes.
+    std::vector<i32> owner;       // nsuper
+    i32 shard_rank = 0, shard_world = 1, shard_level = 0;   // shard_level = nlevels when world == 1
+    std::vector<i32> shard_roots; // assigned subtree roots whose parent is a top front (their CBs travel to rank 0)
     // Q scatter map, sorted by destination
     std::vector<i64> qsrc;        // index into caller's nzval
     std::vector<i64> qdst;        // offset in factor storage

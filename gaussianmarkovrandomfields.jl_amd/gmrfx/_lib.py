@@ -19,7 +19,7 @@ class GmrfxOpts(C.Structure):
         ("struct_size", C.c_int32), ("uplo", C.c_int32), ("ordering", C.c_int32), ("device", C.c_int32),
         ("symbolic_only", C.c_int32), ("check_posdef", C.c_int32), ("nd_leaf", C.c_int32),
         ("relax_cols", C.c_int32), ("relax_zeros", C.c_double), ("coord_dim", C.c_int32),
-        ("reserved0", C.c_int32), ("coords", C.c_void_p),
+        ("reserved0", C.c_int32), ("coords", C.c_void_p), ("shard_rank", C.c_int32), ("shard_world", C.c_int32),
     ]
 
 
@@ -56,7 +56,8 @@ EXPORTS = [
     "gmrfx_refactorize", "gmrfx_refactorize_dev", "gmrfx_solve", "gmrfx_solve_dev", "gmrfx_backward_solve",
     "gmrfx_backward_solve_dev", "gmrfx_logdet", "gmrfx_selinv_compute", "gmrfx_selinv_diag", "gmrfx_selinv_nnz",
     "gmrfx_selinv_csc", "gmrfx_selinv_extract", "gmrfx_get_perm", "gmrfx_get_stats", "gmrfx_symbolic_sizes",
-    "gmrfx_symbolic_get", "gmrfx_get_factor_values",
+    "gmrfx_symbolic_get", "gmrfx_get_factor_values", "gmrfx_refactorize_phase", "gmrfx_shard_info",
+    "gmrfx_shard_cb_blocks", "gmrfx_shard_owner", "gmrfx_device_ptr", "gmrfx_logdet_partial",
 ]
 
 
@@ -91,8 +92,15 @@ def lib():
         L.gmrfx_symbolic_sizes.argtypes = [vp, vp]
         L.gmrfx_symbolic_get.argtypes = [vp] + [vp] * 10
         L.gmrfx_get_factor_values.argtypes = [vp, vp]
+        L.gmrfx_refactorize_phase.argtypes = [vp, vp, i32]
+        L.gmrfx_shard_info.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
+        L.gmrfx_shard_cb_blocks.argtypes = [vp, vp, vp, vp]
+        L.gmrfx_shard_owner.argtypes = [vp, vp]
+        L.gmrfx_device_ptr.argtypes = [vp, i32]
+        L.gmrfx_device_ptr.restype = C.c_void_p
+        L.gmrfx_logdet_partial.argtypes = [vp, C.POINTER(dbl)]
         for nm in EXPORTS[2:]:
-            if nm != "gmrfx_destroy":
+            if nm not in ("gmrfx_destroy", "gmrfx_device_ptr"):
                 getattr(L, nm).restype = i32
         _lib = L
     return _lib

@@ -51,7 +51,7 @@ class MI355XBackend:
 
     def __init__(self, Q, ordering=None, coords=None, device: int = -1, symbolic_only: bool = False,
                  check_posdef: bool = False, uplo: str = "U", nd_leaf: int = 0, relax_cols: int = 0,
-                 relax_zeros: float = 0.0, factorize: bool = True):
+                 relax_zeros: float = 0.0, factorize: bool = True, shard_rank: int = 0, shard_world: int = 1):
         Q = _as_csc(Q)
         self.n = Q.shape[0]
         self._colptr = np.ascontiguousarray(Q.indptr, dtype=np.int64)
@@ -66,6 +66,9 @@ class MI355XBackend:
         opts.nd_leaf = nd_leaf
         opts.relax_cols = relax_cols
         opts.relax_zeros = relax_zeros
+        opts.shard_rank = shard_rank
+        opts.shard_world = shard_world
+        self.shard_rank, self.shard_world = shard_rank, shard_world
         perm = None
         if isinstance(ordering, str):
             if ordering != "natural":
@@ -89,7 +92,7 @@ class MI355XBackend:
         self._selinv_cache = None
         self._selinv_diag_cache = None
         self.last_info = 0
-        if factorize and not symbolic_only:
+        if factorize and not symbolic_only and shard_world <= 1:
             self.refactorize_values(Q.data)
 
     # -- lifetime ------------------------------------------------------------------------
@@ -254,6 +257,37 @@ class MI355XBackend:
         self._selinv_diag_cache = None
         self.last_info = info.value
         return info.value
+
+    # -- sharded factorisation (include/gmrfx.h "sharded factorisation"; driver: gmrfx/shard.py) -------
+    def refactorize_phase_dev(self, d_nzval_ptr: int, phase: int) -> None:
+        check(lib().gmrfx_refactorize_phase(self._h, d_nzval_ptr, phase), self._h)
+
+    def shard_info(self) -> dict:
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        check(lib().gmrfx_shard_info(self._h, C.byref(a), C.byref(b), C.byref(c)), self._h)
+        return {"n_cb_blocks": a.value, "n_top_fronts": b.value, "shard_level": c.value}
+
+    def shard_cb_blocks(self):
+        """(owner, offset, count) of the contribution blocks that travel to rank 0; offsets in doubles
+        into the contribution-block arena (device_ptr(0))."""
+        k = self.shard_info()["n_cb_blocks"]
+        owner, off, cnt = (np.zeros(k, np.int64) for _ in range(3))
+        if k:
+            check(lib().gmrfx_shard_cb_blocks(self._h, ptr(owner), ptr(off), ptr(cnt)), self._h)
+        return owner, off, cnt
+
+    def shard_owner(self) -> np.ndarray:
+        out = np.zeros(self.stats()["nsuper"], np.int64)
+        check(lib().gmrfx_shard_owner(self._h, ptr(out)), self._h)
+        return out
+
+    def device_ptr(self, which: int) -> int:
+        return int(lib().gmrfx_device_ptr(self._h, which) or 0)
+
+    def logdet_partial(self) -> float:
+        out = C.c_double(0.0)
+        check(lib().gmrfx_logdet_partial(self._h, C.byref(out)), self._h)
+        return out.value
 
     def solve_dev(self, d_B: int, ldb: int, nrhs: int, d_X: int, ldx: int) -> None:
         check(lib().gmrfx_solve_dev(self._h, d_B, ldb, nrhs, d_X, ldx), self._h)

@@ -63,6 +63,11 @@ typedef struct gmrfx_opts {
     int32_t reserved0;
     const double *coords;   /* optional n x coord_dim row-major node coordinates (mesh nodes),
                                enables geometric nested dissection; NULL otherwise */
+    /* Sharding ONE factorisation over shard_world processes (one GPU each): every process creates
+     * its handle with the same pattern / options and its own shard_rank. The supernodal tree is cut
+     * into subtrees dealt to the ranks; the fronts above them (the "top") belong to rank 0. See the
+     * gmrfx_shard_* entry points. shard_world <= 1: unsharded (default). */
+    int32_t shard_rank, shard_world;
 } gmrfx_opts;
 
 typedef struct gmrfx_stats {
@@ -107,6 +112,22 @@ int32_t gmrfx_clone(const gmrfx_handle *h, gmrfx_handle **out);
  * in the elimination order. */
 int32_t gmrfx_refactorize(gmrfx_handle *h, const double *nzval, int64_t *info);
 int32_t gmrfx_refactorize_dev(gmrfx_handle *h, const double *d_nzval, int64_t *info);
+
+/* ---- sharded factorisation (opts.shard_world > 1); SURVEY section 8(e) -------------------------------
+ * A refactorisation is then two phases with one exchange in between, driven by the host language over
+ * its collective library (RCCL through torch.distributed in the Python mirror, gmrfx/shard.py):
+ *   gmrfx_refactorize_phase(h, nzval, 0)   every rank: the subtrees it owns
+ *   [ranks != 0 send the contribution blocks of their subtree roots to rank 0: gmrfx_shard_cb_blocks
+ *    lists them as (owner, offset, count) into the contribution-block arena gmrfx_device_ptr(h, 0)]
+ *   gmrfx_refactorize_phase(h, nzval, 1)   rank 0: the top fronts (no-op elsewhere)
+ * gmrfx_logdet_partial returns this rank's share of log det Q (sum over the ranks = log det Q).
+ * Solves / selected inversion on a sharded handle are not implemented yet (GMRFX_ERR_INVALID_ARG). */
+int32_t gmrfx_refactorize_phase(gmrfx_handle *h, const double *d_nzval, int32_t phase);
+int32_t gmrfx_shard_info(const gmrfx_handle *h, int64_t *n_cb_blocks, int64_t *n_top_fronts, int64_t *shard_level);
+int32_t gmrfx_shard_cb_blocks(const gmrfx_handle *h, int64_t *owner, int64_t *offset, int64_t *count);
+int32_t gmrfx_shard_owner(const gmrfx_handle *h, int64_t *owner /* nsuper; -1 = top */);
+void   *gmrfx_device_ptr(gmrfx_handle *h, int32_t which /* 0: contribution-block arena, 1: factor panels */);
+int32_t gmrfx_logdet_partial(gmrfx_handle *h, double *out);
 
 /* Q X = B. Replaces `F \ b` / `F \ B`: src/workspace/backend.jl:191-209. */
 int32_t gmrfx_solve(gmrfx_handle *h, const double *B, int64_t ldb, int64_t nrhs, double *X, int64_t ldx);

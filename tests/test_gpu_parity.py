@@ -411,3 +411,74 @@ def test_subtree_tasks_on_and_off_agree(name, monkeypatch):
     B = np.random.default_rng(0).standard_normal((Q.shape[0], 64))
     assert np.array_equal(ws_on.workspace_solve(B), ws_off.workspace_solve(B))
     assert np.array_equal(ws_on.selinv_diag(), ws_off.selinv_diag())
+
+
+def _shard_gpu_worker(rank, world, port, q):
+    """One rank of the sharded factorisation (gmrfx/shard.py); all ranks share cuda:0, the process group is
+    gloo (RCCL refuses two ranks on one device): the exchange goes through host staging, everything else is
+    the real HIP path."""
+    try:
+        import os, sys
+        here = os.path.dirname(os.path.abspath(__file__))
+        for p in (os.path.join(os.path.dirname(here), "gaussianmarkovrandomfields.jl_amd"), os.path.join(os.path.dirname(here), "oracle"), here):
+            sys.path.insert(0, p)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import gmrfx as g
+        from gmrfx import spde as sp_, shard
+        m = sp_.grid_mesh_2d(120, 120, jitter=0.25, seed=2)
+        Q = sp_.matern_precision(m, 0, 0.2)
+        dev = torch.device("cuda", 0)
+        d_nz = torch.from_numpy(np.ascontiguousarray(Q.data)).to(dev)
+        sf = shard.ShardedFactor(Q, dist, device=0, coords=m.points)
+        for _ in range(2):                               # twice: the second run reuses every buffer
+            sf.refactorize_dev(d_nz.data_ptr())
+        ld = sf.logdet()
+        owner = sf.be.shard_owner()
+        mine = (owner == rank) | ((owner == -1) & (rank == 0))
+        sy = sf.be.symbolic()
+        vals = sf.be.factor_values()
+        # compare the panels this rank factored with an unsharded handle, bit for bit
+        ref = g.MI355XBackend(Q, coords=m.points, device=0)
+        rv = ref.factor_values()
+        same = True
+        for s in np.nonzero(mine)[0]:
+            a, b = int(sy.panel_ptr[s]), int(sy.panel_ptr[s + 1])
+            c, r, ldp = int(sy.super_first[s + 1] - sy.super_first[s]), int(sy.row_ptr[s + 1] - sy.row_ptr[s]), int(sy.panel_ld[s])
+            Pa = vals[a:a + ldp * c].reshape(c, ldp).T[:r]
+            Pb = rv[a:a + ldp * c].reshape(c, ldp).T[:r]
+            same = same and np.array_equal(np.tril(Pa), np.tril(Pb))
+        q.put((rank, ld, ref.compute_logdet(), bool(same), int(mine.sum()), sf.be.shard_info()))
+        dist.barrier()
+        sf.close(); ref.close()
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put(("error", rank, traceback.format_exc()))
+        raise
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_factorisation_rehearsal_on_one_gpu(world):
+    """ONE factorisation sharded over `world` processes (subtrees per rank, Schur-complement
+    contribution blocks to rank 0, top fronts on rank 0, all-reduced logdet) -- rehearsed with all ranks on
+    this one GPU. Every rank's panels must equal the unsharded factor bit for bit."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_gpu_worker, args=(r, world, 29650 + world, q)) for r in range(world)]
+    [p.start() for p in procs]
+    got = []
+    for _ in range(world):
+        item = q.get(timeout=240)
+        assert item[0] != "error", f"rank {item[1]} failed:\n{item[2]}"
+        got.append(item)
+    [p.join(timeout=120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    for rank, ld, ld_ref, same, nmine, info in got:
+        assert same and nmine > 0
+        assert abs(ld - ld_ref) <= 1e-12 * abs(ld_ref)
+        assert info["n_top_fronts"] >= 1
