@@ -59,10 +59,14 @@ def bench_sharded(args, Q, mesh, dist, rank, world, local_rank):
     dev = torch.device("cuda", local_rank)
     n = Q.shape[0]
     d_nz = torch.from_numpy(np.ascontiguousarray(Q.data)).to(dev)
+    Bh = torch.randn((args.nrhs, n), generator=torch.Generator(device="cpu").manual_seed(1), dtype=torch.float64)
+    d_B = Bh.to(dev)
+    d_X = torch.zeros_like(d_B)
     sf = shard.ShardedFactor(Q, dist, device=local_rank, coords=mesh.points)
 
     def step():
         sf.refactorize_dev(d_nz.data_ptr())
+        sf.solve_dev(d_B.data_ptr(), n, args.nrhs, d_X.data_ptr(), n)     # X lands on rank 0
         return sf.logdet()
 
     for _ in range(args.warmup):
@@ -76,14 +80,16 @@ def bench_sharded(args, Q, mesh, dist, rank, world, local_rank):
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
     if rank == 0:
         info = sf.be.shard_info()
-        print(json.dumps({"metric": "sharded refactorize + logdet (one factorisation over all ranks)", "value": n / (float(el.item()) / args.steps),
+        X = d_X.cpu().numpy().T
+        resid = float(np.linalg.norm(Q @ X - Bh.numpy().T) / np.linalg.norm(Bh.numpy()))
+        print(json.dumps({"metric": "sharded factor+solve(64 RHS)+logdet (ONE factorisation over all ranks)", "value": n / (float(el.item()) / args.steps),
                           "unit": "DoF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": 1e3 * float(el.item()) / args.steps, "higher_is_better": True, "scaling": "strong",
                           "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                          "config": {"workload": f"cfg2 pattern ({args.grid}x{args.grid} mesh), refactorise + logdet, supernodal tree cut into "
+                          "config": {"workload": f"cfg2 pattern ({args.grid}x{args.grid} mesh), refactorise + {args.nrhs}-RHS solve + logdet, supernodal tree cut into "
                                                  f"subtrees per rank, {info['n_cb_blocks']} contribution blocks to rank 0, {info['n_top_fronts']} top fronts",
                                      "exchange": "gloo + host staging (rehearsal)" if args.rehearse else "RCCL point-to-point + all-reduce"},
-                          "check": {"logdet": ld}}))
+                          "check": {"logdet": ld, "rel_residual": resid}}))
     dist.barrier()
     sf.close()
     dist.destroy_process_group()
@@ -104,7 +110,7 @@ def main():
     ap.add_argument("--shard", action="store_true",
                     help="extra (N > 1): ONE factorisation sharded over the ranks (subtrees per rank, Schur-complement "
                          "contribution blocks to rank 0 over the process group, all-reduced logdet; gmrfx/shard.py) "
-                         "instead of independent replicas; prints its own JSON line (strong scaling of refactorise+logdet)")
+                         "instead of independent replicas; prints its own JSON line (strong scaling of refactorise + solve + logdet)")
     ap.add_argument("--pool", type=int, default=0,
                     help="extra: throughput of P independent workspaces driven concurrently on this GPU "
                          "(the reference's WorkspacePool pattern; reported separately, never as `value`)")

@@ -181,7 +181,10 @@ void Device::upload(const Symbolic &S) {
     // fronts with more than one 64-column block, by decreasing width: dense-inverse stages
     {
         std::vector<int> il;
-        for (i32 s = 0; s < ns; s++) if (S.ncols(s) > NB) il.push_back(s);
+        for (i32 s = 0; s < ns; s++) {
+            const bool mine = S.shard_world <= 1 || S.owner[s] == S.shard_rank || (S.owner[s] == -1 && S.shard_rank == 0);
+            if (S.ncols(s) > NB && mine) il.push_back(s);     // sharded handles only hold the panels they factored
+        }
         std::sort(il.begin(), il.end(), [&](int a, int b) { return S.ncols(a) != S.ncols(b) ? S.ncols(a) > S.ncols(b) : a < b; });
         inv_maxc_ = il.empty() ? 0 : S.ncols(il[0]);
         const int *p; up(p, il); d_invlist_ = const_cast<int *>(p);
@@ -378,13 +381,14 @@ void Device::ensure_rhs_capacity(long long nrhs) {
     }
 }
 
-void Device::forward(int nr, int ldx) {
-    for (int k = 0, off = 0; k < 3; off += nsub_cls_[k], k++)
-        launch_subtree(stream, ds_, 1, d_sub_first_ + off, d_sub_last_ + off, nsub_cls_[k], kClsRows[k], nullptr, d_L_, nullptr,
-                       nullptr, d_X_, d_W_, nr, ldx);
-    int lev = 0;
-    for (auto &L : levels_) {
-        if (lev++ == first_multiblock_level_) wait_inverse();
+void Device::forward(int nr, int ldx, int lo, int hi) {
+    if (lo == 0)
+        for (int k = 0, off = 0; k < 3; off += nsub_cls_[k], k++)
+            launch_subtree(stream, ds_, 1, d_sub_first_ + off, d_sub_last_ + off, nsub_cls_[k], kClsRows[k], nullptr, d_L_, nullptr,
+                           nullptr, d_X_, d_W_, nr, ldx);
+    for (int lev = lo; lev < hi; lev++) {
+        auto &L = levels_[lev];
+        if (lev == std::max(lo, first_multiblock_level_)) wait_inverse();
         for (int k = 0, off = 0; k < 4; off += L.ncls[k], k++)
             launch_fwd_small(stream, ds_, d_levellist_ + L.first + off, L.ncls[k], kClsRows[k], d_L_, d_X_, d_W_, nr, ldx);
         const int *list = d_levellist_ + L.first + L.nsmall;
@@ -401,9 +405,9 @@ void Device::forward(int nr, int ldx) {
 // y_in_x2: the forward sweep left y of the big fronts in X2 (full solve). The backward sweep then turns it
 // into t = y - L21' x in place there and writes x = L11^-T t straight into X -- no copies. A backward-only
 // solve (F.UP \ z) gets z in X: classic path with one copy per level.
-void Device::backward(int nr, int ldx, bool y_in_x2) {
+void Device::backward(int nr, int ldx, bool y_in_x2, int hi, int lo) {
     wait_inverse();   // (a no-op event wait once the forward sweep has passed it)
-    for (int l = (int)levels_.size() - 1; l >= 0; l--) {
+    for (int l = hi - 1; l >= lo; l--) {
         auto &L = levels_[l];
         const int *list = d_levellist_ + L.first + L.nsmall;
         const int nf = L.count - L.nsmall;
@@ -418,14 +422,45 @@ void Device::backward(int nr, int ldx, bool y_in_x2) {
             launch_copy_own(stream, ds_, list, nf, L.max_cols, d_X2_, d_X_, nr, ldx);
         }
     }
-    for (int k = 0, off = 0; k < 3; off += nsub_cls_[k], k++)
-        launch_subtree(stream, ds_, 2, d_sub_first_ + off, d_sub_last_ + off, nsub_cls_[k], kClsRows[k], nullptr, d_L_, nullptr,
-                       nullptr, d_X_, nullptr, nr, ldx);
+    if (lo == 0)
+        for (int k = 0, off = 0; k < 3; off += nsub_cls_[k], k++)
+            launch_subtree(stream, ds_, 2, d_sub_first_ + off, d_sub_last_ + off, nsub_cls_[k], kClsRows[k], nullptr, d_L_, nullptr,
+                           nullptr, d_X_, nullptr, nr, ldx);
+}
+
+void Device::solve_phase(const double *d_B, long long ldb, long long nrhs, double *d_Xout, long long ldx_out, int phase) {
+    HC(hipSetDevice(device));
+    if (!sharded()) throw std::invalid_argument("gmrfx_solve_phase needs a handle created with shard_world > 1");
+    if (nrhs <= 0 || nrhs > 64) throw std::invalid_argument("sharded solves take 1..64 right-hand sides per call");
+    const int nr = (int)nrhs, ldx = nr, nl = (int)levels_.size();
+    const int split = std::min<int>(S_->shard_level, nl);
+    const long long n = S_->n;
+    HC(hipEventRecord(ev_[0], stream));
+    if (phase == 0) {
+        ensure_rhs_capacity(nrhs);
+        start_inverse_async();
+        launch_permute(stream, d_iperm_, (int)n, const_cast<double *>(d_B), ldb, d_X_, nr, ldx, 0);
+        forward(nr, ldx, 0, split);
+    } else if (phase == 1) {
+        forward(nr, ldx, split, nl);
+        backward(nr, ldx, true, nl, split);
+    } else if (phase == 2) {
+        backward(nr, ldx, true, split, 0);
+    } else if (phase == 3) {
+        launch_permute(stream, d_iperm_, (int)n, d_Xout, ldx_out, d_X_, nr, ldx, 1);
+    } else throw std::invalid_argument("phase must be 0..3");
+    HC(hipEventRecord(ev_[1], stream));
+    HC(hipStreamSynchronize(stream));
+    HC(hipGetLastError());
+    float ms = 0;
+    HC(hipEventElapsedTime(&ms, ev_[0], ev_[1]));
+    ms_solve = phase == 0 ? ms : ms_solve + ms;
+    last_nrhs = nrhs;
 }
 
 void Device::solve(const double *B, long long ldb, long long nrhs, double *X, long long ldx_out, bool on_device, int mode) {
     HC(hipSetDevice(device));
-    if (sharded()) throw std::invalid_argument("solves on a sharded handle are not implemented yet");
+    if (sharded()) throw std::invalid_argument("sharded handle: use gmrfx_solve_phase (phases with exchanges in between, gmrfx/shard.py)");
     if (nrhs <= 0) return;
     const long long n = S_->n;
     ensure_rhs_capacity(nrhs);
@@ -448,9 +483,9 @@ void Device::solve(const double *B, long long ldb, long long nrhs, double *X, lo
         // full solve: X = P b ; backward-only (F.UP \ z): z is taken in elimination order as is
         launch_permute(stream, mode == 0 ? d_iperm_ : nullptr, (int)n, const_cast<double *>(dB) + j0 * ldin, ldin, d_X_, nr, ldx, 0);
         HC(hipEventRecord(ev_[1], stream));
-        if (mode == 0) forward(nr, ldx);
+        if (mode == 0) forward(nr, ldx, 0, (int)levels_.size());
         HC(hipEventRecord(ev_[2], stream));
-        backward(nr, ldx, mode == 0);
+        backward(nr, ldx, mode == 0, (int)levels_.size(), 0);
         HC(hipEventRecord(ev_[3], stream));
         launch_permute(stream, d_iperm_, (int)n, dXo + j0 * ldout, ldout, d_X_, nr, ldx, 1);
         HC(hipEventRecord(ev_[4], stream));

@@ -72,6 +72,13 @@ public:
     // sharded handles: phase 0 = the subtrees this rank owns, phase 1 = the top fronts (rank 0; after the
     // contribution blocks of the other ranks' subtree roots have been written into cb_arena())
     void refactorize_phase(const double *d_nzval, int phase);
+    // sharded solve (device buffers, nrhs <= 64): 0 = transpose in + forward over the own subtrees, 1 = the top
+    // (forward, then backward; rank 0), 2 = backward over the own subtrees, 3 = transpose out (rank 0, after
+    // the owned rows have been gathered). Between the phases the host moves W / X rows (gmrfx/shard.py).
+    void solve_phase(const double *d_B, long long ldb, long long nrhs, double *d_X, long long ldx, int phase);
+    double *rhs_x() { return d_X_; }
+    double *rhs_w() { return d_W_; }
+    void ensure_rhs(long long nrhs) { ensure_rhs_capacity(nrhs); }
     double *cb_arena() { return d_cb_; }
     double *factor_panels() { return d_L_; }
     bool sharded() const { return S_ && S_->shard_world > 1; }
@@ -100,8 +107,8 @@ private:
     void upload(const Symbolic &S);
     void ensure_rhs_capacity(long long nrhs);
     void factor_levels(int lo, int hi);
-    void forward(int nr, int ldx);
-    void backward(int nr, int ldx, bool y_in_x2);
+    void forward(int nr, int ldx, int lo, int hi);
+    void backward(int nr, int ldx, bool y_in_x2, int hi, int lo);
     template <class T> T *dalloc(size_t count);
     std::vector<void *> allocs_;
 

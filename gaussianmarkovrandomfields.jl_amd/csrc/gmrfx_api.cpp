@@ -190,7 +190,50 @@ extern "C" int32_t gmrfx_shard_owner(const gmrfx_handle *h, int64_t *owner) {
 }
 extern "C" void *gmrfx_device_ptr(gmrfx_handle *h, int32_t which) {
     if (!h || !h->D) return nullptr;
-    return which == 0 ? (void *)h->D->cb_arena() : (which == 1 ? (void *)h->D->factor_panels() : nullptr);
+    try {
+        if (which == 2 || which == 3) h->D->ensure_rhs(64);
+    } catch (...) { return nullptr; }
+    switch (which) {
+        case 0: return h->D->cb_arena();
+        case 1: return h->D->factor_panels();
+        case 2: return h->D->rhs_x();
+        case 3: return h->D->rhs_w();
+        default: return nullptr;
+    }
+}
+extern "C" int32_t gmrfx_solve_phase(gmrfx_handle *h, const double *d_B, int64_t ldb, int64_t nrhs, double *d_X, int64_t ldx, int32_t phase) {
+    return guarded(h, [&]() -> int32_t {
+        if (int32_t e = need_device(h, true)) return e;
+        if (phase == 0 && !d_B) throw std::invalid_argument("d_B is null");
+        if (phase == 0 && ldb < h->S.n) throw std::invalid_argument("ldb < n");
+        if (phase == 3 && (!d_X || ldx < h->S.n)) throw std::invalid_argument("d_X is null or ldx < n");
+        h->D->solve_phase(d_B, ldb, nrhs, d_X, ldx, phase);
+        return GMRFX_OK;
+    });
+}
+// kind 1: update vectors W of the subtree roots (-> rank 0), 2: X rows of the top fronts (rank 0 -> all),
+// 3: X rows of every assigned subtree (-> rank 0). owner / first row / number of rows; a row has nrhs doubles
+// (W rows index gmrfx_device_ptr(h, 3), X rows gmrfx_device_ptr(h, 2); row-major, leading dimension = nrhs).
+extern "C" int32_t gmrfx_shard_rows(const gmrfx_handle *h, int32_t kind, int64_t *nblocks, int64_t *owner, int64_t *row0, int64_t *nrows) {
+    if (!h || !nblocks) return GMRFX_ERR_INVALID_ARG;
+    const Symbolic &S = h->S;
+    std::vector<int64_t> o, a, c;
+    if (kind == 1) {
+        std::vector<int64_t> wptr(S.nsuper + 1, 0);
+        for (i32 s = 0; s < S.nsuper; s++) wptr[s + 1] = wptr[s] + (S.nrows(s) - S.ncols(s));
+        for (i32 d : S.shard_roots) { o.push_back(S.owner[d]); a.push_back(wptr[d]); c.push_back(S.nrows(d) - S.ncols(d)); }
+    } else if (kind == 2) {
+        for (i32 s = 0; s < S.nsuper; s++) if (S.owner[s] == -1) { o.push_back(0); a.push_back(S.sfirst[s]); c.push_back(S.ncols(s)); }
+    } else if (kind == 3) {
+        for (size_t k = 0; k < S.shard_sub_root.size(); k++) {
+            const i32 t = S.shard_sub_root[k];
+            o.push_back(S.owner[t]); a.push_back(S.shard_sub_col0[k]); c.push_back(S.sfirst[t + 1] - S.shard_sub_col0[k]);
+        }
+    } else return GMRFX_ERR_INVALID_ARG;
+    *nblocks = (int64_t)o.size();
+    if (owner && row0 && nrows)
+        for (size_t k = 0; k < o.size(); k++) { owner[k] = o[k]; row0[k] = a[k]; nrows[k] = c[k]; }
+    return GMRFX_OK;
 }
 extern "C" int32_t gmrfx_logdet_partial(gmrfx_handle *h, double *out) {
     return guarded(h, [&]() -> int32_t {

@@ -420,6 +420,17 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
             S.level[s] = lv;
         }
         std::sort(S.shard_roots.begin(), S.shard_roots.end());
+        {   // every assigned subtree (postorder: a subtree is a contiguous id range ending at its root)
+            std::vector<i32> cnt(ns, 1);
+            for (i32 s = 0; s < ns; s++) if (S.sparent[s] != -1) cnt[S.sparent[s]] += cnt[s];
+            for (i32 s = 0; s < ns; s++) {
+                if (S.owner[s] < 0) continue;
+                const i32 p = S.sparent[s];
+                if (p != -1 && S.owner[p] != -1) continue;      // not a subtree root
+                S.shard_sub_root.push_back(s);
+                S.shard_sub_col0.push_back(S.sfirst[s - cnt[s] + 1]);
+            }
+        }
         S.nlevels = 0;
         for (i32 s = 0; s < ns; s++) S.nlevels = std::max(S.nlevels, S.level[s] + 1);
         S.nlevels = std::max(S.nlevels, S.shard_level);

@@ -78,6 +78,7 @@ struct Symbolic {
     std::vector<i32> owner;       // nsuper
     i32 shard_rank = 0, shard_world = 1, shard_level = 0;   // shard_level = nlevels when world == 1
     std::vector<i32> shard_roots; // assigned subtree roots whose parent is a top front (their CBs travel to rank 0)
+    std::vector<i32> shard_sub_root, shard_sub_col0;   // ALL assigned subtrees: root supernode, first column (columns [col0, sfirst[root+1]) are theirs)
     // Q scatter map, sorted by destination
     std::vector<i64> qsrc;        // index into caller's nzval
     std::vector<i64> qdst;        // offset in factor storage

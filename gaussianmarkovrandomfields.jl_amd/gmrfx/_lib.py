@@ -57,7 +57,8 @@ EXPORTS = [
     "gmrfx_backward_solve_dev", "gmrfx_logdet", "gmrfx_selinv_compute", "gmrfx_selinv_diag", "gmrfx_selinv_nnz",
     "gmrfx_selinv_csc", "gmrfx_selinv_extract", "gmrfx_get_perm", "gmrfx_get_stats", "gmrfx_symbolic_sizes",
     "gmrfx_symbolic_get", "gmrfx_get_factor_values", "gmrfx_refactorize_phase", "gmrfx_shard_info",
-    "gmrfx_shard_cb_blocks", "gmrfx_shard_owner", "gmrfx_device_ptr", "gmrfx_logdet_partial",
+    "gmrfx_shard_cb_blocks", "gmrfx_shard_owner", "gmrfx_device_ptr", "gmrfx_logdet_partial", "gmrfx_solve_phase",
+    "gmrfx_shard_rows",
 ]
 
 
@@ -99,6 +100,8 @@ def lib():
         L.gmrfx_device_ptr.argtypes = [vp, i32]
         L.gmrfx_device_ptr.restype = C.c_void_p
         L.gmrfx_logdet_partial.argtypes = [vp, C.POINTER(dbl)]
+        L.gmrfx_solve_phase.argtypes = [vp, vp, i64, i64, vp, i64, i32]
+        L.gmrfx_shard_rows.argtypes = [vp, i32, C.POINTER(i64), vp, vp, vp]
         for nm in EXPORTS[2:]:
             if nm not in ("gmrfx_destroy", "gmrfx_device_ptr"):
                 getattr(L, nm).restype = i32

@@ -281,6 +281,18 @@ class MI355XBackend:
         check(lib().gmrfx_shard_owner(self._h, ptr(out)), self._h)
         return out
 
+    def solve_phase_dev(self, d_B: int, ldb: int, nrhs: int, d_X: int, ldx: int, phase: int) -> None:
+        check(lib().gmrfx_solve_phase(self._h, d_B, ldb, nrhs, d_X, ldx, phase), self._h)
+
+    def shard_rows(self, kind: int):
+        """(owner, first row, rows) of the row blocks of exchange `kind` (1: W up, 2: X top down, 3: X owned up)."""
+        k = C.c_int64(0)
+        check(lib().gmrfx_shard_rows(self._h, kind, C.byref(k), None, None, None), self._h)
+        owner, r0, nr = (np.zeros(k.value, np.int64) for _ in range(3))
+        if k.value:
+            check(lib().gmrfx_shard_rows(self._h, kind, C.byref(k), ptr(owner), ptr(r0), ptr(nr)), self._h)
+        return owner, r0, nr
+
     def device_ptr(self, which: int) -> int:
         return int(lib().gmrfx_device_ptr(self._h, which) or 0)
 

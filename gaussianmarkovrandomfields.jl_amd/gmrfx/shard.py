@@ -34,7 +34,7 @@ class ShardedFactor:
                                 shard_world=self.world, **kw)
         self.owner, self.off, self.cnt = self.be.shard_cb_blocks()
         self.host_staging = dist.get_backend() == "gloo"      # rehearsal: gloo moves host tensors only
-        self._cb = None
+        self._rows = None
 
     def _cb_view(self, off: int, cnt: int):
         base = self.be.device_ptr(0)
@@ -66,6 +66,56 @@ class ShardedFactor:
         self.be.refactorize_phase_dev(d_nzval_ptr, 0)
         self._exchange_cb()
         self.be.refactorize_phase_dev(d_nzval_ptr, 1)
+
+    # ---- sharded solve ---------------------------------------------------------------------------
+    def _rows_view(self, which: int, row0: int, nrows: int, nrhs: int):
+        base = self.be.device_ptr(which)
+        return self.torch.as_tensor(_DevView(base + 8 * int(row0) * nrhs, int(nrows) * nrhs), device=self.dev)
+
+    def _move_rows(self, which: int, blocks, nrhs: int, to_root: bool):
+        """to_root: every owner sends its row blocks to rank 0 (in place, same rows of rank 0's buffer);
+        otherwise rank 0 broadcasts its row blocks to everybody."""
+        t, dist = self.torch, self.dist
+        owner, r0, nr = blocks
+        for k in range(len(owner)):
+            if to_root:
+                src = int(owner[k])
+                if src == 0 or self.rank not in (0, src):
+                    continue
+                v = self._rows_view(which, r0[k], nr[k], nrhs)
+                if self.rank == src:
+                    dist.send(v.cpu() if self.host_staging else v, dst=0, tag=k)
+                elif self.host_staging:
+                    buf = t.empty(v.numel(), dtype=t.float64)
+                    dist.recv(buf, src=src, tag=k)
+                    v.copy_(buf)
+                else:
+                    dist.recv(v, src=src, tag=k)
+            else:
+                v = self._rows_view(which, r0[k], nr[k], nrhs)
+                if self.host_staging:
+                    buf = v.cpu() if self.rank == 0 else t.empty(v.numel(), dtype=t.float64)
+                    dist.broadcast(buf, src=0)
+                    if self.rank != 0:
+                        v.copy_(buf)
+                else:
+                    dist.broadcast(v, src=0)
+        t.cuda.synchronize(self.dev)
+
+    def solve_dev(self, d_B: int, ldb: int, nrhs: int, d_X: int, ldx: int) -> None:
+        """Q X = B with the factor sharded over the ranks; B (full, column-major n x nrhs) on every rank,
+        X (full) is produced on rank 0. 1..64 right-hand sides per call."""
+        be = self.be
+        if self._rows is None:
+            self._rows = {k: be.shard_rows(k) for k in (1, 2, 3)}
+        be.solve_phase_dev(d_B, ldb, nrhs, d_X, ldx, 0)          # transpose in + own forward
+        self._move_rows(3, self._rows[1], nrhs, True)            # W of the subtree roots -> rank 0
+        be.solve_phase_dev(d_B, ldb, nrhs, d_X, ldx, 1)          # the top: forward, backward (rank 0)
+        self._move_rows(2, self._rows[2], nrhs, False)           # x of the top fronts -> everybody
+        be.solve_phase_dev(d_B, ldb, nrhs, d_X, ldx, 2)          # own backward
+        self._move_rows(2, self._rows[3], nrhs, True)            # x of the owned subtrees -> rank 0
+        if self.rank == 0:
+            be.solve_phase_dev(d_B, ldb, nrhs, d_X, ldx, 3)      # transpose out
 
     def logdet(self) -> float:
         """log det Q: all-reduce (sum) of the ranks' partial sums over their own pivots."""

@@ -121,12 +121,19 @@ int32_t gmrfx_refactorize_dev(gmrfx_handle *h, const double *d_nzval, int64_t *i
  *    lists them as (owner, offset, count) into the contribution-block arena gmrfx_device_ptr(h, 0)]
  *   gmrfx_refactorize_phase(h, nzval, 1)   rank 0: the top fronts (no-op elsewhere)
  * gmrfx_logdet_partial returns this rank's share of log det Q (sum over the ranks = log det Q).
- * Solves / selected inversion on a sharded handle are not implemented yet (GMRFX_ERR_INVALID_ARG). */
+ * A solve (device buffers, 1..64 right-hand sides) is four phases: 0 transpose-in + forward sweep over the
+ * own subtrees; [update vectors W of the subtree roots -> rank 0]; 1 the top, forward then backward (rank 0);
+ * [X rows of the top fronts: rank 0 -> all]; 2 backward sweep over the own subtrees; [X rows of the owned
+ * subtrees -> rank 0]; 3 transpose-out on rank 0. gmrfx_shard_rows lists the row blocks of each exchange
+ * (rows of the row-major n x nrhs buffers gmrfx_device_ptr(h, 2) = X and (h, 3) = W).
+ * Selected inversion on a sharded handle is not implemented yet (GMRFX_ERR_INVALID_ARG). */
 int32_t gmrfx_refactorize_phase(gmrfx_handle *h, const double *d_nzval, int32_t phase);
 int32_t gmrfx_shard_info(const gmrfx_handle *h, int64_t *n_cb_blocks, int64_t *n_top_fronts, int64_t *shard_level);
 int32_t gmrfx_shard_cb_blocks(const gmrfx_handle *h, int64_t *owner, int64_t *offset, int64_t *count);
 int32_t gmrfx_shard_owner(const gmrfx_handle *h, int64_t *owner /* nsuper; -1 = top */);
-void   *gmrfx_device_ptr(gmrfx_handle *h, int32_t which /* 0: contribution-block arena, 1: factor panels */);
+void   *gmrfx_device_ptr(gmrfx_handle *h, int32_t which /* 0: contribution-block arena, 1: factor panels, 2: X, 3: W */);
+int32_t gmrfx_solve_phase(gmrfx_handle *h, const double *d_B, int64_t ldb, int64_t nrhs, double *d_X, int64_t ldx, int32_t phase);
+int32_t gmrfx_shard_rows(const gmrfx_handle *h, int32_t kind, int64_t *nblocks, int64_t *owner, int64_t *row0, int64_t *nrows);
 int32_t gmrfx_logdet_partial(gmrfx_handle *h, double *out);
 
 /* Q X = B. Replaces `F \ b` / `F \ B`: src/workspace/backend.jl:191-209. */

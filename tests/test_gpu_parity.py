@@ -437,6 +437,11 @@ def _shard_gpu_worker(rank, world, port, q):
         for _ in range(2):                               # twice: the second run reuses every buffer
             sf.refactorize_dev(d_nz.data_ptr())
         ld = sf.logdet()
+        # sharded solve: B on every rank, X on rank 0; must equal the unsharded solve bit for bit
+        nrhs = 64 if world == 2 else 7
+        Bh = torch.randn((nrhs, Q.shape[0]), generator=torch.Generator().manual_seed(3), dtype=torch.float64)
+        d_B = Bh.to(dev); d_X = torch.zeros_like(d_B)
+        sf.solve_dev(d_B.data_ptr(), Q.shape[0], nrhs, d_X.data_ptr(), Q.shape[0])
         owner = sf.be.shard_owner()
         mine = (owner == rank) | ((owner == -1) & (rank == 0))
         sy = sf.be.symbolic()
@@ -451,6 +456,14 @@ def _shard_gpu_worker(rank, world, port, q):
             Pa = vals[a:a + ldp * c].reshape(c, ldp).T[:r]
             Pb = rv[a:a + ldp * c].reshape(c, ldp).T[:r]
             same = same and np.array_equal(np.tril(Pa), np.tril(Pb))
+        if rank == 0:
+            d_Xr = torch.zeros_like(d_B)
+            ref.solve_dev(d_B.data_ptr(), Q.shape[0], nrhs, d_Xr.data_ptr(), Q.shape[0])
+            torch.cuda.synchronize()
+            same = same and bool(torch.equal(d_X, d_Xr))
+            X = d_X.cpu().numpy().T
+            resid = float(np.linalg.norm(Q @ X - Bh.numpy().T) / np.linalg.norm(Bh.numpy()))
+            same = same and resid < 1e-10
         q.put((rank, ld, ref.compute_logdet(), bool(same), int(mine.sum()), sf.be.shard_info()))
         dist.barrier()
         sf.close(); ref.close()

@@ -84,13 +84,77 @@ def _worker(rank, world, port, q):
     for s in sim.order:                                   # phase 1: the top (rank 0)
         if owner[s] == -1 and mine(s):
             factor_front(s)
+    # ---- sharded solve: own forward, W of the subtree roots -> rank 0, the top on rank 0, x of the top
+    #      fronts -> everybody, own backward, owned x -> rank 0 -----------------------------------------
+    k = 3
+    Bp = np.random.default_rng(5).standard_normal((n, k))          # right-hand sides in elimination order
+    X = Bp.copy()
+    W = {}
+
+    def fwd_front(s):
+        c, r = sim.c[s], sim.r[s]
+        f = np.zeros((r, k)); rows = sim.rows(s)
+        f[:c] = X[rows[:c]]
+        for d in sim.children[s]:
+            f[sim.rel(d)] += W.pop(d)
+        P = sim.panel(sim.L, s)
+        y = np.linalg.solve(np.tril(P[:c]), f[:c])
+        X[rows[:c]] = y
+        W[s] = f[c:] - P[c:] @ y
+
+    def bwd_front(s):
+        c = sim.c[s]; rows = sim.rows(s); P = sim.panel(sim.L, s)
+        X[rows[:c]] = np.linalg.solve(np.tril(P[:c]).T, X[rows[:c]] - P[c:].T @ X[rows[c:]])
+
+    for s in sim.order:
+        if owner[s] >= 0 and mine(s):
+            fwd_front(s)
+    for d in roots:
+        m = int(sim.r[d] - sim.c[d])
+        if owner[d] == 0:
+            continue
+        if rank == owner[d]:
+            dist.send(torch.from_numpy(np.ascontiguousarray(W.pop(d))), dst=0, tag=1000 + int(d))
+        elif rank == 0:
+            buf = torch.empty((m, k), dtype=torch.float64)
+            dist.recv(buf, src=int(owner[d]), tag=1000 + int(d))
+            W[d] = buf.numpy()
+    tops = [s for s in sim.order if owner[s] == -1]
+    if rank == 0:
+        for s in tops:
+            fwd_front(s)
+        for s in tops[::-1]:
+            bwd_front(s)
+    for s in tops:                                        # x of the top fronts' columns: rank 0 -> all
+        rows = sim.rows(s)[:sim.c[s]]
+        buf = torch.from_numpy(np.ascontiguousarray(X[rows]))
+        dist.broadcast(buf, src=0)
+        X[rows] = buf.numpy()
+    for s in sim.order[::-1]:
+        if owner[s] >= 0 and mine(s):
+            bwd_front(s)
+    for s in range(ns):                                   # owned x -> rank 0 (per front here; per subtree on the device)
+        if owner[s] <= 0:
+            continue
+        rows = sim.rows(s)[:sim.c[s]]
+        if rank == owner[s]:
+            dist.send(torch.from_numpy(np.ascontiguousarray(X[rows])), dst=0, tag=2000 + s)
+        elif rank == 0:
+            buf = torch.empty((len(rows), k), dtype=torch.float64)
+            dist.recv(buf, src=int(owner[s]), tag=2000 + s)
+            X[rows] = buf.numpy()
+    solve_err = None
+    if rank == 0:
+        perm = be.ordering_permutation()
+        Qp = Q.toarray()[np.ix_(perm, perm)]
+        solve_err = float(np.abs(Qp @ X - Bp).max() / np.abs(Bp).max())
     part = 2.0 * sum(np.log(np.diag(sim.panel(sim.L, s)[:sim.c[s]])).sum() for s in range(ns) if mine(s))
     t = torch.tensor([part], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     if rank == 0:
         ref = HostSim(gmrfx.MI355XBackend(Q, coords=mesh.points, symbolic_only=True).symbolic(), n, np.asarray(Q.data)).factor().logdet()
         dense = np.linalg.slogdet(Q.toarray())[1]
-        q.put((float(t.item()), ref, dense, info, [int((owner == k).sum()) for k in range(-1, world)]))
+        q.put((float(t.item()), ref, dense, info, [int((owner == kk).sum()) for kk in range(-1, world)], solve_err))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -105,7 +169,8 @@ def test_sharded_factor_plan_and_logdet_gloo(world):
     got = q.get(timeout=300)
     [p.join(timeout=120) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
-    sharded, ref, dense, info, counts = got
+    sharded, ref, dense, info, counts, solve_err = got
+    assert solve_err < 1e-10
     assert abs(sharded - ref) <= 1e-10 * abs(ref)
     assert abs(sharded - dense) <= 1e-9 * abs(dense)
     assert info["n_top_fronts"] >= 1 and all(c > 0 for c in counts[1:])      # every rank owns something
