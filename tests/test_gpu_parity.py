@@ -495,3 +495,12 @@ def test_sharded_factorisation_rehearsal_on_one_gpu(world):
         assert same and nmine > 0
         assert abs(ld - ld_ref) <= 1e-12 * abs(ld_ref)
         assert info["n_top_fronts"] >= 1
+
+
+def test_randomised_pattern_sweep():
+    """36 random patterns (sparse random, ragged 2-D / 3-D meshes, forests, bands, dense multi-block fronts; 1..65
+    right-hand sides) against dense LAPACK identities: tools/fuzz_gpu.py."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_gpu.py"), "36", "7"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

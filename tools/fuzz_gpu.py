@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep on the GPU: many small/medium SPD patterns of different shapes against dense
+LAPACK identities (solve, logdet, selinv diag, backward-solve covariance identity). usage: fuzz_gpu.py [ncases] [seed]"""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gaussianmarkovrandomfields.jl_amd"))
+import numpy as np, scipy.sparse as sp
+import gmrfx
+from gmrfx import spde
+
+ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+
+
+def rand_case(i):
+    kind = i % 6
+    if kind == 0:      # random sparse SPD
+        n = int(rng.integers(1, 900)); dens = float(rng.uniform(0.002, 0.08))
+        return f"rand n={n} d={dens:.3f}", spde.random_spd_precision(n, dens, seed=int(rng.integers(1 << 30))), {}
+    if kind == 1:      # 2-D Matern on a ragged grid with coordinates
+        a, b = int(rng.integers(3, 70)), int(rng.integers(3, 70))
+        m = spde.grid_mesh_2d(a, b, jitter=float(rng.uniform(0, 0.3)), seed=int(rng.integers(1 << 30)))
+        return f"matern2d {a}x{b}", spde.matern_precision(m, int(rng.integers(0, 2)), float(rng.uniform(0.1, 0.6))), {"coords": m.points}
+    if kind == 2:      # 3-D
+        a, b, c = (int(rng.integers(2, 12)) for _ in range(3))
+        m = spde.grid_mesh_3d(a, b, c)
+        return f"matern3d {a}x{b}x{c}", spde.matern_precision(m, 0, float(rng.uniform(0.3, 0.8))), {"coords": m.points}
+    if kind == 3:      # block diagonal (forest) of random blocks
+        blocks = [spde.random_spd_precision(int(rng.integers(1, 200)), 0.1, seed=int(rng.integers(1 << 30))) for _ in range(int(rng.integers(2, 6)))]
+        return "blockdiag", sp.block_diag(blocks, format="csc"), {}
+    if kind == 4:      # banded / chain with natural ordering
+        n = int(rng.integers(2, 1500)); bw = int(rng.integers(1, 12))
+        A = sp.diags([rng.uniform(-0.2, 0.2, n - k) for k in range(1, bw + 1)], list(range(1, bw + 1)), shape=(n, n))
+        A = A + A.T + sp.diags(np.full(n, 2.0 * bw))
+        return f"band n={n} bw={bw}", sp.csc_matrix(A), {"ordering": "natural"} if i % 12 == 4 else {}
+    n = int(rng.integers(65, 400))     # dense-ish: one big front with several 64-blocks
+    G = rng.standard_normal((n, 3 * n))
+    return f"dense n={n}", sp.csc_matrix(G @ G.T / (3 * n) + np.eye(n)), {}
+
+
+worst = 0.0
+t0 = time.time()
+for i in range(ncases):
+    name, Q, kw = rand_case(i)
+    Q = sp.csc_matrix(Q); n = Q.shape[0]
+    ws = gmrfx.GMRFWorkspace(Q, **kw)
+    Qd = Q.toarray()
+    nrhs = int(rng.choice([1, 2, 17, 64, 65]))
+    B = rng.standard_normal((n, nrhs))
+    X = ws.workspace_solve(B[:, 0] if nrhs == 1 else B).reshape(n, -1)
+    Xd = np.linalg.solve(Qd, B)
+    e1 = np.abs(X - Xd).max() / max(np.abs(Xd).max(), 1e-300)
+    e2 = abs(ws.logdet() - np.linalg.slogdet(Qd)[1]) / max(1.0, abs(np.linalg.slogdet(Qd)[1]))
+    Qi = np.linalg.inv(Qd)
+    e3 = np.abs(ws.selinv_diag() - np.diag(Qi)).max() / np.abs(np.diag(Qi)).max()
+    z = rng.standard_normal(n)
+    s = ws.backward_solve(z)                  # s = P' L^-T z  =>  Q s = P' L z ... check via ||L' P s - z|| implicitly: s' Q s = z' z
+    e4 = abs(s @ (Qd @ s) - z @ z) / (z @ z)
+    err = max(e1, e2, e3, e4)
+    worst = max(worst, err)
+    flag = "" if err < 1e-8 else "   <-- FAIL"
+    print(f"{i:3d} {name:28s} n={n:5d} nrhs={nrhs:2d} solve={e1:.1e} logdet={e2:.1e} selinv={e3:.1e} bwd={e4:.1e}{flag}", flush=True)
+    ws.backend.close()
+print(f"worst {worst:.2e} over {ncases} cases in {time.time() - t0:.1f}s")
+sys.exit(0 if worst < 1e-8 else 1)
