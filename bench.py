@@ -28,7 +28,7 @@ FP64_MFMA_PEAK_TF = 78.6   # datasheet FP64 matrix peak (32 FLOP/clk/SIMD x 1024
 FP64_MFMA_MEASURED_TF = 36.3   # sustained v_mfma_f64_16x16x4_f64 on this part (tools/micro/mfma64.hip, 138 cycles/instr)
 
 
-def cpu_baseline(nrhs: int, grid: int = 300):
+def cpu_baseline(nrhs: int, grid: int = 600):
     """Oracle (single-thread C port of the CHOLMOD-path algorithm) on a bounded sample."""
     import numpy as np
     import orc
