@@ -363,15 +363,20 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
     if (S.shard_world > 1) {
         const int W = S.shard_world;
         // weight of a front ~ its factorisation flops; of a subtree = sum over its fronts (postorder ids)
-        std::vector<double> wsub(ns, 0.0);
+        std::vector<double> wsub(ns, 0.0), wown(ns, 0.0);
         for (i32 s = 0; s < ns; s++) {
             const double c = S.ncols(s), m = S.nrows(s) - S.ncols(s);
-            wsub[s] += c * c * c / 3.0 + c * c * m + c * m * m + 1.0;
+            wown[s] = c * c * c / 3.0 + c * c * m + c * m * m + 1.0;
+            wsub[s] += wown[s];
             if (S.sparent[s] != -1) wsub[S.sparent[s]] += wsub[s];
         }
         std::vector<i32> T;                     // current subtree roots
         std::vector<uint8_t> top(ns, 0);
         for (i32 s = 0; s < ns; s++) if (S.sparent[s] == -1) T.push_back(s);
+        // LPT deal of the current subtrees; returns the largest local load. The top runs on rank 0 AFTER all
+        // local work (it needs every subtree root's contribution block), so a plan costs
+        //     max_r local_r + (flops of the top fronts):
+        // splitting the heaviest subtree lowers the first term and raises the second.
         auto makespan = [&](std::vector<i32> &assign_out) {
             std::vector<i32> ord(T);
             std::sort(ord.begin(), ord.end(), [&](i32 a, i32 b) { return wsub[a] != wsub[b] ? wsub[a] > wsub[b] : a < b; });
@@ -385,18 +390,21 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
             return *std::max_element(load.begin(), load.end());
         };
         std::vector<i32> asg;
-        for (int it = 0; it < 64; it++) {
-            double tot = 0;
-            for (i32 s : T) tot += wsub[s];
-            const double ms = makespan(asg);
-            if ((int)T.size() >= W && ms <= 1.15 * tot / W) break;
-            // split the heaviest subtree that has children: its root becomes a top front
+        double wtop = 0;
+        for (int it = 0; it < 256; it++) {
+            const double cost = makespan(asg) + wtop;
             i32 best = -1;
             for (i32 s : T) if (S.childptr[s + 1] > S.childptr[s] && (best == -1 || wsub[s] > wsub[best])) best = s;
             if (best == -1) break;
-            top[best] = 1;
+            // tentatively split `best`
+            std::vector<i32> T0 = T;
             T.erase(std::find(T.begin(), T.end(), best));
             for (i64 q = S.childptr[best]; q < S.childptr[best + 1]; q++) T.push_back(S.children[q]);
+            std::vector<i32> asg2;
+            const double cost2 = makespan(asg2) + wtop + wown[best];
+            if ((int)T0.size() >= W && cost2 >= 0.98 * cost) { T = T0; break; }     // no longer pays
+            top[best] = 1;
+            wtop += wown[best];
         }
         makespan(asg);
         // owner: subtree root's rank for everything below it (postorder: parents after children)
