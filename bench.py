@@ -200,6 +200,25 @@ def main():
         be.backward_solve_dev(d_Z.data_ptr(), n, 256, d_S.data_ptr(), n)
         extras["ms_rand256"] = be.stats()["ms_backward_solve"]
 
+    if args.extras and rank == 0:
+        # Newton iterate: Q_k = Q_prior - diag(h_k), refactorise. Host path = update nzval on the
+        # host and send all of it (what _update_hessian! + the CHOLMOD copy do); device path = send h only.
+        coo = Q.tocoo()                                     # same entry order as Q.data
+        diag_idx = np.flatnonzero(coo.row == coo.col)
+        hvec = -np.random.default_rng(3).uniform(0.1, 1.0, n)
+        be.set_prior(Q.data, diag_idx)
+        tt = {}
+        for name, fn in (("host_values", lambda: be.refactorize_values((lambda z: (z.__setitem__(diag_idx, z[diag_idx] - hvec), z)[1])(Q.data.copy()))),
+                         ("device_update", lambda: be.refactorize_update(hvec))):
+            fn(); torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            tt[name] = 1e3 * (time.perf_counter() - t1) / 3
+        extras["newton_iterate_ms"] = tt
+        be.refactorize_dev(d_nz.data_ptr())      # back to Q itself for the checks below
+
     if args.pool > 1 and rank == 0:
         # P independent handles (own HIP streams), one host thread each; ctypes drops the GIL in the calls
         import threading

@@ -364,6 +364,33 @@ void Device::refactorize_phase(const double *d_nzval, int phase) {
     if (phase != 0) { factorized = true; selinv_valid = false; inverse_pending = true; }
 }
 
+void Device::set_prior(const double *prior_nzval, const long long *map, long long cnt) {
+    HC(hipSetDevice(device));
+    const long long nnz = S_->nnz_in;
+    for (long long k = 0; k < cnt; k++)
+        if (map[k] < 0 || map[k] >= nnz) throw std::invalid_argument("Hessian index map points outside the stored pattern of Q");
+    if (!d_prior_) d_prior_ = dalloc<double>((size_t)nnz);
+    HC(hipMemcpyAsync(d_prior_, prior_nzval, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice, stream));
+    if (cnt > hmap_cnt_ || !d_hmap_) {
+        d_hmap_ = dalloc<long long>((size_t)std::max<long long>(cnt, 1));
+        d_h_ = dalloc<double>((size_t)std::max<long long>(cnt, 1));
+    }
+    hmap_cnt_ = cnt;
+    if (cnt > 0) HC(hipMemcpyAsync(d_hmap_, map, (size_t)cnt * sizeof(long long), hipMemcpyHostToDevice, stream));
+    HC(hipStreamSynchronize(stream));
+}
+void Device::refactorize_update(const double *h, bool on_device) {
+    HC(hipSetDevice(device));
+    if (!d_prior_) throw std::invalid_argument("gmrfx_set_prior has not been called");
+    const double *dh = h;
+    if (!on_device && hmap_cnt_ > 0) {
+        HC(hipMemcpyAsync(d_h_, h, (size_t)hmap_cnt_ * sizeof(double), hipMemcpyHostToDevice, stream));
+        dh = d_h_;
+    }
+    launch_newton_update(stream, d_prior_, d_nz_, S_->nnz_in, d_hmap_, dh, hmap_cnt_);
+    refactorize(d_nz_, true);
+}
+
 long long Device::fail_col() {
     int v = INT_MAX;
     HC(hipMemcpy(&v, d_info_, sizeof(int), hipMemcpyDeviceToHost));

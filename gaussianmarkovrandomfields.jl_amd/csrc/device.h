@@ -69,6 +69,11 @@ public:
     void clone_from(const Device &o, const Symbolic &S);
 
     void refactorize(const double *nzval, bool on_device);
+    // Newton loop with Q resident on the device: set_prior uploads the prior's values (and the
+    // Hessian -> Q index map) once; refactorize_update forms nz = prior, nz[map[k]] -= h[k] on the device from the
+    // cnt Hessian values (host or device) and refactorises -- only h crosses PCIe per iterate.
+    void set_prior(const double *prior_nzval, const long long *map, long long cnt);
+    void refactorize_update(const double *h, bool on_device);
     // sharded handles: phase 0 = the subtrees this rank owns, phase 1 = the top fronts (rank 0; after the
     // contribution blocks of the other ranks' subtree roots have been written into cb_arena())
     void refactorize_phase(const double *d_nzval, int phase);
@@ -121,7 +126,10 @@ private:
     int *d_sub_first_ = nullptr, *d_sub_last_ = nullptr, *d_sel_levellist_ = nullptr;
     int nsub_cls_[3] = {0, 0, 0};
     double *d_L_ = nullptr, *d_Z_ = nullptr, *d_cb_ = nullptr, *d_nz_ = nullptr;
-    const double *nz_src_ = nullptr;   // values of the refactorisation in flight (d_nz_ or the caller's device buffer)
+    const double *nz_src_ = nullptr;
+    double *d_prior_ = nullptr, *d_h_ = nullptr;
+    long long *d_hmap_ = nullptr;
+    long long hmap_cnt_ = 0;   // values of the refactorisation in flight (d_nz_ or the caller's device buffer)
     double *d_X_ = nullptr, *d_X2_ = nullptr, *d_W_ = nullptr, *d_io_ = nullptr, *d_tmp_ = nullptr, *d_part_ = nullptr;
     // dense-inverse stages (inverse.hip)
     int *d_invlist_ = nullptr;

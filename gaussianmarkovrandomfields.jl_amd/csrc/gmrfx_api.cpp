@@ -151,6 +151,33 @@ static int32_t refactorize_impl(gmrfx_handle *h, const double *nz, int64_t *info
 }
 extern "C" int32_t gmrfx_refactorize(gmrfx_handle *h, const double *nzval, int64_t *info) { return refactorize_impl(h, nzval, info, false); }
 
+// ---- Newton loop on the device -----------------------------------------------------------
+extern "C" int32_t gmrfx_set_prior(gmrfx_handle *h, const double *prior_nzval, const int64_t *map, int64_t cnt, int32_t index_base) {
+    return guarded(h, [&]() -> int32_t {
+        if (int32_t e = need_device(h, false)) return e;
+        if (!prior_nzval || (cnt > 0 && !map) || cnt < 0) throw std::invalid_argument("prior_nzval / map is null");
+        std::vector<long long> m((size_t)cnt);
+        for (int64_t k = 0; k < cnt; k++) m[k] = map[k] - index_base;
+        h->D->set_prior(prior_nzval, m.data(), cnt);
+        return GMRFX_OK;
+    });
+}
+static int32_t refactorize_update_impl(gmrfx_handle *h, const double *hv, int64_t *info, bool dev) {
+    return guarded(h, [&]() -> int32_t {
+        if (int32_t e = need_device(h, false)) return e;
+        h->D->refactorize_update(hv, dev);
+        long long fc = h->D->fail_col();
+        if (info) *info = fc < 0 ? 0 : fc + 1;
+        if (fc >= 0 && h->opts.check_posdef) {
+            h->err = "matrix is not positive definite (non-positive pivot at elimination step " + std::to_string(fc + 1) + ")";
+            return GMRFX_ERR_NOT_POSDEF;
+        }
+        return GMRFX_OK;
+    });
+}
+extern "C" int32_t gmrfx_refactorize_update(gmrfx_handle *h, const double *hvals, int64_t *info) { return refactorize_update_impl(h, hvals, info, false); }
+extern "C" int32_t gmrfx_refactorize_update_dev(gmrfx_handle *h, const double *d_hvals, int64_t *info) { return refactorize_update_impl(h, d_hvals, info, true); }
+
 // ---- sharded factorisation (include/gmrfx.h) ---------------------------------------------------------
 extern "C" int32_t gmrfx_refactorize_phase(gmrfx_handle *h, const double *d_nzval, int32_t phase) {
     return guarded(h, [&]() -> int32_t {

@@ -134,6 +134,8 @@ void launch_bwd_gemm(hipStream_t st, const DevSym &S, const int *list, int nfron
                      const double *X, double *Xown, int nr, int ldx);
 // iperm: position of original row i in the elimination order (nullptr: identity)
 void launch_permute(hipStream_t st, const int *iperm, int n, double *Bc, long long ldb, double *X, int nr, int ldx, int dir);
+void launch_newton_update(hipStream_t st, const double *prior, double *nz, long long nnz, const long long *map, const double *h,
+                          long long cnt);
 void launch_logdet(hipStream_t st, const double *L, const long long *diagoff, const unsigned char *own, int n, double *part,
                    int nparts, double *out);
 void launch_gather(hipStream_t st, const double *src, const long long *off, long long cnt, double *out);

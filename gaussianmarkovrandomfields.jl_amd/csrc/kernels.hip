@@ -893,6 +893,21 @@ void launch_bwd_gemm(hipStream_t st, const DevSym &S, const int *list, int nfron
 void launch_permute(hipStream_t st, const int *perm, int n, double *Bc, long long ldb, double *X, int nr, int ldx, int dir) {
     hipLaunchKernelGGL(k_permute, dim3(cdiv(n, 64)), dim3(256), 0, st, perm, n, Bc, ldb, X, nr, ldx, dir);
 }
+// nz[map[k]] = prior[map[k]] - h[k] on top of nz = prior: the Newton-loop update of the reference
+// (_update_hessian!, src/workspace/gaussian_approximation.jl:103-129) with Q kept on the device.
+__global__ __launch_bounds__(256) void k_copy_values(const double *__restrict__ src, double *__restrict__ dst, long long cnt) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < cnt; i += (long long)gridDim.x * 256) dst[i] = src[i];
+}
+__global__ __launch_bounds__(256) void k_subtract_at(double *__restrict__ nz, const long long *__restrict__ map,
+                                                     const double *__restrict__ h, long long cnt) {
+    const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (k < cnt) nz[map[k]] -= h[k];     // the map is injective (one Q entry per Hessian entry)
+}
+void launch_newton_update(hipStream_t st, const double *prior, double *nz, long long nnz, const long long *map, const double *h,
+                          long long cnt) {
+    hipLaunchKernelGGL(k_copy_values, dim3((unsigned)std::min<long long>(4096, (nnz + 255) / 256)), dim3(256), 0, st, prior, nz, nnz);
+    if (cnt > 0) hipLaunchKernelGGL(k_subtract_at, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, nz, map, h, cnt);
+}
 void launch_logdet(hipStream_t st, const double *L, const long long *diagoff, const unsigned char *own, int n, double *part,
                    int nparts, double *out) {
     hipLaunchKernelGGL(k_logdet_partial, dim3(nparts), dim3(256), 0, st, L, diagoff, own, n, part);

@@ -58,7 +58,7 @@ EXPORTS = [
     "gmrfx_selinv_csc", "gmrfx_selinv_extract", "gmrfx_get_perm", "gmrfx_get_stats", "gmrfx_symbolic_sizes",
     "gmrfx_symbolic_get", "gmrfx_get_factor_values", "gmrfx_refactorize_phase", "gmrfx_shard_info",
     "gmrfx_shard_cb_blocks", "gmrfx_shard_owner", "gmrfx_device_ptr", "gmrfx_logdet_partial", "gmrfx_solve_phase",
-    "gmrfx_shard_rows",
+    "gmrfx_shard_rows", "gmrfx_set_prior", "gmrfx_refactorize_update", "gmrfx_refactorize_update_dev",
 ]
 
 
@@ -102,6 +102,9 @@ def lib():
         L.gmrfx_logdet_partial.argtypes = [vp, C.POINTER(dbl)]
         L.gmrfx_solve_phase.argtypes = [vp, vp, i64, i64, vp, i64, i32]
         L.gmrfx_shard_rows.argtypes = [vp, i32, C.POINTER(i64), vp, vp, vp]
+        L.gmrfx_set_prior.argtypes = [vp, vp, vp, i64, i32]
+        L.gmrfx_refactorize_update.argtypes = [vp, vp, C.POINTER(i64)]
+        L.gmrfx_refactorize_update_dev.argtypes = [vp, vp, C.POINTER(i64)]
         for nm in EXPORTS[2:]:
             if nm not in ("gmrfx_destroy", "gmrfx_device_ptr"):
                 getattr(L, nm).restype = i32

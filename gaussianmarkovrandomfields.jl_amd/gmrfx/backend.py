@@ -258,6 +258,29 @@ class MI355XBackend:
         self.last_info = info.value
         return info.value
 
+    # -- Newton loop on the device (src/workspace/gaussian_approximation.jl:63-129) --------
+    def set_prior(self, prior_nzval, hess_map) -> None:
+        """prior_nzval: values of the prior precision in the pattern's CSC order; hess_map: 0-based positions
+        into nzval of the Hessian's entries (`_diag_indices` / `_sparse_hessian_map` of the reference)."""
+        pv = np.ascontiguousarray(prior_nzval, dtype=np.float64)
+        if pv.shape != (self._nnz,):
+            raise ValueError(f"prior precision has {pv.size} stored entries but the workspace pattern has {self._nnz}")
+        hm = np.ascontiguousarray(hess_map, dtype=np.int64)
+        self._hess_cnt = int(hm.size)
+        check(lib().gmrfx_set_prior(self._h, ptr(pv), ptr(hm), hm.size, 0), self._h)
+
+    def refactorize_update(self, hvals) -> int:
+        """Q <- Q_prior - H (entries at hess_map), refactorise; only `hvals` crosses PCIe."""
+        hv = np.ascontiguousarray(hvals, dtype=np.float64)
+        if hv.size != getattr(self, "_hess_cnt", -1):
+            raise ValueError("Hessian values do not match the index map passed to set_prior")
+        info = C.c_int64(0)
+        check(lib().gmrfx_refactorize_update(self._h, ptr(hv), C.byref(info)), self._h)
+        self._selinv_cache = None
+        self._selinv_diag_cache = None
+        self.last_info = info.value
+        return info.value
+
     # -- sharded factorisation (include/gmrfx.h "sharded factorisation"; driver: gmrfx/shard.py) -------
     def refactorize_phase_dev(self, d_nzval_ptr: int, phase: int) -> None:
         check(lib().gmrfx_refactorize_phase(self._h, d_nzval_ptr, phase), self._h)

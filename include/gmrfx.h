@@ -113,6 +113,16 @@ int32_t gmrfx_clone(const gmrfx_handle *h, gmrfx_handle **out);
 int32_t gmrfx_refactorize(gmrfx_handle *h, const double *nzval, int64_t *info);
 int32_t gmrfx_refactorize_dev(gmrfx_handle *h, const double *d_nzval, int64_t *info);
 
+/* ---- Newton loop with Q resident on the device -----------------------------------
+ * Replaces `_update_hessian!` + `ensure_numeric!` of the Gaussian-approximation loop
+ * (src/workspace/gaussian_approximation.jl:103-129: copyto!(ws.Q.nzval, prior_nzval); nzval[map[k]] -= H.nzval[k]).
+ * gmrfx_set_prior uploads the prior's values (same CSC order as the pattern) and the Hessian -> Q index map
+ * (`diag_idx` or `_sparse_hessian_map`, index_base-based positions into nzval) ONCE; every iterate then sends
+ * only the cnt Hessian values and refactorises: Q_k = Q_prior - H_k is formed on the device. */
+int32_t gmrfx_set_prior(gmrfx_handle *h, const double *prior_nzval, const int64_t *map, int64_t cnt, int32_t index_base);
+int32_t gmrfx_refactorize_update(gmrfx_handle *h, const double *hvals, int64_t *info);
+int32_t gmrfx_refactorize_update_dev(gmrfx_handle *h, const double *d_hvals, int64_t *info);
+
 /* ---- sharded factorisation (opts.shard_world > 1); SURVEY section 8(e) -------------------------------
  * A refactorisation is then two phases with one exchange in between, driven by the host language over
  * its collective library (RCCL through torch.distributed in the Python mirror, gmrfx/shard.py):

@@ -504,3 +504,35 @@ def test_randomised_pattern_sweep():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_gpu.py"), "36", "7"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_newton_update_on_device_matches_host_update():
+    """Q_k = Q_prior - H_k formed on the device from the Hessian values only (index map uploaded
+    once) -- same factor, bit for bit, as refactorising from host-side updated values (the reference's
+    _update_hessian!, src/workspace/gaussian_approximation.jl:103-129), for diagonal and sparse Hessians."""
+    m = spde.grid_mesh_2d(48, 48, jitter=0.2, seed=9)
+    Q = sp.csc_matrix(spde.matern_precision(m, 0, 0.3))
+    n = Q.shape[0]
+    rng = np.random.default_rng(12)
+    be = gmrfx.MI355XBackend(Q, coords=m.points)
+    ref = gmrfx.MI355XBackend(Q, coords=m.points)
+    # diagonal Hessian (Diagonal branch): positions of the diagonal entries in nzval
+    diag_idx = np.array([Q.indptr[j] + np.searchsorted(Q.indices[Q.indptr[j]:Q.indptr[j + 1]], j) for j in range(n)])
+    be.set_prior(Q.data, diag_idx)
+    for _ in range(3):
+        h = -rng.uniform(0.1, 2.0, n)                        # H = -diag(.) : Q - H stays SPD
+        be.refactorize_update(h)
+        nz = Q.data.copy(); nz[diag_idx] -= h
+        ref.refactorize_values(nz)
+        assert np.array_equal(be.factor_values(), ref.factor_values())
+        assert be.compute_logdet() == ref.compute_logdet()
+    # sparse Hessian on a sub-pattern of Q (SparseMatrixCSC branch): every 3rd stored entry, symmetric values
+    H = Q.copy(); H.data = -0.05 * np.abs(H.data)
+    keep = np.arange(Q.nnz)[::1]
+    be.set_prior(Q.data, keep)
+    be.refactorize_update(H.data[keep])
+    nz = Q.data.copy(); nz[keep] -= H.data[keep]
+    ref.refactorize_values(nz)
+    assert np.array_equal(be.factor_values(), ref.factor_values())
+    with pytest.raises(ValueError):
+        be.refactorize_update(np.zeros(3))
