@@ -165,6 +165,23 @@ function G.GMRFWorkspace(Q::SparseMatrixCSC{Float64}, ::Type{MI355XBackend}; kwa
     return GMRFWorkspace{Float64, MI355XBackend}(copy(Q), backend, zeros(n), zeros(n), true, false, false, 0.0, 1, 0)
 end
 
+# Newton loop with Q resident on the device (include/gmrfx.h "Newton loop"): the workspace-side
+# `_update_hessian!` (src/workspace/gaussian_approximation.jl:103-129) becomes one upload of the prior values
+# and of the index map (`_diag_indices(ws.Q)` or `_sparse_hessian_map(ws.Q, H)`, 1-based positions into nzval)
+# followed, per iterate, by the Hessian's values only.
+function set_prior!(b::MI355XBackend, prior_nzval::Vector{Float64}, hess_map::Vector{Int})
+    GC.@preserve prior_nzval hess_map check(ccall((:gmrfx_set_prior, LIB), Int32,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Int64}, Int64, Int32), b.h.ptr, prior_nzval, hess_map, length(hess_map), 1), b.h)
+    return nothing
+end
+function refactorize_update!(b::MI355XBackend, hvals::Vector{Float64})
+    info = Ref{Int64}(0)
+    GC.@preserve hvals check(ccall((:gmrfx_refactorize_update, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ref{Int64}),
+        b.h.ptr, hvals, info), b.h)
+    b.selinv = nothing; b.selinv_diag = nothing
+    return nothing
+end
+
 function Base.deepcopy_internal(b::MI355XBackend, ::IdDict)   # deepcopy(cache) in Newton loops
     out = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:gmrfx_clone, LIB), Int32, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}), b.h.ptr, out))
