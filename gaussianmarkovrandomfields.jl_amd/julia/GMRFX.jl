@@ -178,7 +178,7 @@ function refactorize_update!(b::MI355XBackend, hvals::Vector{Float64})
     info = Ref{Int64}(0)
     GC.@preserve hvals check(ccall((:gmrfx_refactorize_update, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ref{Int64}),
         b.h.ptr, hvals, info), b.h)
-    b.selinv = nothing; b.selinv_diag = nothing
+    b.selinv_cache = nothing; b.selinv_diag_cache = nothing
     return nothing
 end
 
