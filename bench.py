@@ -25,7 +25,9 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 FP64_MFMA_PEAK_TF = 78.6   # datasheet FP64 matrix peak (32 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz)
-FP64_MFMA_MEASURED_TF = 36.3   # sustained v_mfma_f64_16x16x4_f64 on this part (tools/micro/mfma64.hip, 138 cycles/instr)
+FP64_MFMA_MEASURED_TF = 75.7   # sustained v_mfma_f64_16x16x4_f64 with >= 2 issuing waves per SIMD (tools/micro/mix64.hip);
+                               # ONE wave per SIMD only issues one per ~138 cycles = 36.3 (tools/micro/mfma64.hip); an LDS-staged
+                               # 128x128-tile DGEMM reaches 54 (tools/micro/dgemm_mfma.hip)
 
 
 def cpu_baseline(nrhs: int, grid: int = 600):
