@@ -126,12 +126,13 @@ __global__ __launch_bounds__(256) void k_inv_stage(DevSym S, const int *__restri
 //   trans = 1: Y[k] = sum_{q >= k} X[q][k] b[q]        (backward)
 // b = rows first..first+c of Xin (row-major, ldx), result goes to the same rows of Xout (it cannot
 // be written in place: other workgroups still need b). One wave = 16 rows x up to 64 RHS.
-__global__ __launch_bounds__(256) void k_xmul(DevSym S, const int *__restrict__ list, int trans,
+template <int NW>   // waves per workgroup splitting K; 8 for launches with about one workgroup per CU (kernels.h)
+__global__ __launch_bounds__(64 * NW) void k_xmul(DevSym S, const int *__restrict__ list, int trans,
                                               const double *__restrict__ L, const double *__restrict__ Xin,
                                               double *__restrict__ Xout, int nr, int ldx) {
     const int s = list[blockIdx.y];
     const int c = S.sfirst[s + 1] - S.sfirst[s];
-    __shared__ double red[3 * 64 * 16];
+    __shared__ double red[NW == 4 ? 3 * 64 * 16 : NW * 16 * 64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int k0 = blockIdx.x * 16;      // one 16-row tile per workgroup, the 4 waves split the K range
     if (k0 >= c) return;
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(256) void k_xmul(DevSym S, const int *__restrict__ 
     const int qlo = trans ? k0 : 0, qhi = trans ? c : min(c, k0 + 16);
     constexpr int KU = 4;
 #pragma unroll 1
-    for (int q0 = qlo + wave * 4 * KU; q0 < qhi; q0 += 16 * KU) {
+    for (int q0 = qlo + wave * 4 * KU; q0 < qhi; q0 += NW * 4 * KU) {
         double av[KU], bv[KU][4];
 #pragma unroll
         for (int u = 0; u < KU; u++) {
@@ -163,8 +164,10 @@ __global__ __launch_bounds__(256) void k_xmul(DevSym S, const int *__restrict__ 
                 acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u][t], acc[t], 0, 0, 0);
     }
     // distributed split-K reduction: wave w ends up with the complete 16 x 16 tile of RHS block w
-    d4 (&acc1)[1][4] = reinterpret_cast<d4 (&)[1][4]>(acc);
-    splitk_reduce4<1>(acc1, red, wave, lane);
+    if (NW == 4) {
+        d4 (&acc1)[1][4] = reinterpret_cast<d4 (&)[1][4]>(acc);
+        splitk_reduce4<1>(acc1, red, wave, lane);
+    } else splitk_reduce_nw<NW>(acc, red, wave, lane);
     double *Yb = Xout + (long long)first * ldx;
 #pragma unroll
     for (int t = 0; t < 4; t++)
@@ -205,7 +208,10 @@ void launch_inv_stage(hipStream_t st, const DevSym &S, const int *list, int nact
 void launch_xmul(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_c, int trans, const double *L,
                  const double *Xin, double *Xout, int nr, int ldx) {
     if (nfronts <= 0 || max_c <= 0) return;
-    hipLaunchKernelGGL(k_xmul, dim3((unsigned)(cdiv(max_c, 16) | 1), nfronts), dim3(256), 0, st, S, list, trans, L, Xin, Xout, nr, ldx);
+    if ((long long)cdiv(max_c, 16) * nfronts <= 256)
+        hipLaunchKernelGGL(k_xmul<8>, dim3((unsigned)(cdiv(max_c, 16) | 1), nfronts), dim3(512), 0, st, S, list, trans, L, Xin, Xout, nr, ldx);
+    else
+        hipLaunchKernelGGL(k_xmul<4>, dim3((unsigned)(cdiv(max_c, 16) | 1), nfronts), dim3(256), 0, st, S, list, trans, L, Xin, Xout, nr, ldx);
 }
 void launch_copy_own(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_c, const double *Xsrc,
                      double *Xdst, int nr, int ldx) {

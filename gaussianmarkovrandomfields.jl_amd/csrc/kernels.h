@@ -82,6 +82,34 @@ __device__ __forceinline__ FrontView front_view(const DevSym &S, const int *__re
     return v;
 }
 
+// Split-K reduction for NW-wave workgroups with ONE 16-row tile (4 RHS tiles of 16 columns): every wave
+// writes its four partial tiles, wave t < 4 then adds tile t over the waves in order 0..NW-1 (fixed,
+// reproducible) and keeps the result in acc[t]. red: NW * 4 * 4 * 64 doubles.
+// NW = 8 is for launches with about one workgroup per CU: a single wave per SIMD can only issue one FP64
+// MFMA per ~138 cycles, two per SIMD reach the full 64-cycle rate (tools/micro/mix64.hip) -- and the K
+// chain per wave halves as well.
+template <int NW>
+__device__ __forceinline__ void splitk_reduce_nw(gmrfx_d4 (&acc)[4], double *red, int wave, int lane) {
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) red[((wave * 4 + t) * 4 + rr) * 64 + lane] = acc[t][rr];
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        if (t == wave) {
+            gmrfx_d4 sum;
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) sum[rr] = red[((0 * 4 + t) * 4 + rr) * 64 + lane];
+#pragma unroll
+            for (int w = 1; w < NW; w++)
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) sum[rr] += red[((w * 4 + t) * 4 + rr) * 64 + lane];
+            acc[t] = sum;
+        }
+    }
+}
+
 // Split-K reduction across the 4 waves of a workgroup, DISTRIBUTED: every wave adds up ONE of the
 // four 16-column tiles of each row tile (12 LDS reads in flight instead of 48 by a single wave,
 // which cost ~100 VGPRs and one wave of occupancy). After the call wave w holds the complete tile

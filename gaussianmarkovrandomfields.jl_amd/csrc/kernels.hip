@@ -599,11 +599,11 @@ __global__ __launch_bounds__(256) void k_fwd_update_longk(DevSym S, const int *_
 
 // Backward update of a big front: own columns -= L21' * x_R over ALL trailing rows: a
 // workgroup owns 64 own columns x 64 right-hand sides, its waves split the trailing rows.
-template <int NA>   // see k_fwd_update_longk
-__global__ __launch_bounds__(256) void k_bwd_gemm_longk(DevSym S, const int *__restrict__ list,
-                                                       const double *__restrict__ L, const double *X, double *Xown, int nr,
-                                                       int ldx) {
-    __shared__ double red[3 * 16 * 64];
+template <int NA, int NW>   // NA: see k_fwd_update_longk; NW: waves per workgroup splitting K (8 only with NA = 1)
+__global__ __launch_bounds__(64 * NW) void k_bwd_gemm_longk(DevSym S, const int *__restrict__ list,
+                                                          const double *__restrict__ L, const double *X, double *Xown, int nr,
+                                                          int ldx) {
+    __shared__ double red[NW == 4 ? 3 * 16 * 64 : NW * 16 * 64];
     const int s = list[blockIdx.y];
     const int c = S.sfirst[s + 1] - S.sfirst[s];
     const int r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
@@ -632,12 +632,12 @@ __global__ __launch_bounds__(256) void k_bwd_gemm_longk(DevSym S, const int *__r
     long long xr[KU], xn[KU];
 #pragma unroll
     for (int u = 0; u < KU; u++) xn[u] = rows[min(c + wave * 4 * KU + 4 * u + lk, r - 1)];
-    for (int k0 = c + wave * 4 * KU; k0 < r; k0 += 16 * KU) {
+    for (int k0 = c + wave * 4 * KU; k0 < r; k0 += NW * 4 * KU) {
         double av[KU][NA], bv[KU][4];
 #pragma unroll
         for (int u = 0; u < KU; u++) xr[u] = xn[u];
 #pragma unroll
-        for (int u = 0; u < KU; u++) xn[u] = rows[min(k0 + 16 * KU + 4 * u + lk, r - 1)];
+        for (int u = 0; u < KU; u++) xn[u] = rows[min(k0 + NW * 4 * KU + 4 * u + lk, r - 1)];
 #pragma unroll
         for (int u = 0; u < KU; u++) {
             const int qc = min(k0 + 4 * u + lk, r - 1);
@@ -660,7 +660,8 @@ __global__ __launch_bounds__(256) void k_bwd_gemm_longk(DevSym S, const int *__r
                 for (int t = 0; t < 4; t++)
                     acc[a][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][a], bv[u][t], acc[a][t], 0, 0, 0);
     }
-    splitk_reduce4<NA>(acc, red, wave, lane);
+    if (NW == 4) splitk_reduce4<NA>(acc, red, wave, lane);
+    else splitk_reduce_nw<NW>(acc[0], red, wave, lane);
     // X -= acc in two passes (all loads, then all stores: one round trip instead of a chain of 8)
 #pragma unroll
     for (int t = 0; t < 4; t++) {
@@ -886,9 +887,9 @@ void launch_bwd_gemm(hipStream_t st, const DevSym &S, const int *list, int nfron
                      const double *X, double *Xown, int nr, int ldx) {
     if (nfronts <= 0 || max_cols <= 0) return;
     if ((long long)cdiv(max_cols, 32) * nfronts <= 128)
-        hipLaunchKernelGGL(k_bwd_gemm_longk<1>, dim3(odd(cdiv(max_cols, 16)), nfronts), dim3(256), 0, st, S, list, L, X, Xown, nr, ldx);
+        hipLaunchKernelGGL((k_bwd_gemm_longk<1, 8>), dim3(odd(cdiv(max_cols, 16)), nfronts), dim3(512), 0, st, S, list, L, X, Xown, nr, ldx);
     else
-        hipLaunchKernelGGL(k_bwd_gemm_longk<2>, dim3(odd(cdiv(max_cols, 32)), nfronts), dim3(256), 0, st, S, list, L, X, Xown, nr, ldx);
+        hipLaunchKernelGGL((k_bwd_gemm_longk<2, 4>), dim3(odd(cdiv(max_cols, 32)), nfronts), dim3(256), 0, st, S, list, L, X, Xown, nr, ldx);
 }
 void launch_permute(hipStream_t st, const int *perm, int n, double *Bc, long long ldb, double *X, int nr, int ldx, int dir) {
     hipLaunchKernelGGL(k_permute, dim3(cdiv(n, 64)), dim3(256), 0, st, perm, n, Bc, ldb, X, nr, ldx, dir);
