@@ -9,7 +9,7 @@
 //
 // Storage: X[k][q] (k > q) lives at P[q + k*ld], i.e. transposed in the strict upper triangle of
 // the c x c diagonal block of the panel, which the factorisation never touches (the 64 x 64
-// diagonal sub-blocks are already filled by k_potrf_lds); diag(X) = 1/diag(L) stays implicit.
+// diagonal sub-blocks are already filled by k_potrf64); diag(X) = 1/diag(L) stays implicit.
 //
 // Construction by recursive doubling, B = 64, 128, 256, ...: for every aligned pair of blocks
 //   [ A  0 ]^-1   [ A^-1           0   ]

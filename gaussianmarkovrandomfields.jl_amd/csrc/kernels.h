@@ -175,7 +175,6 @@ void launch_factor_small(hipStream_t st, const DevSym &S, const int *list, int n
 // phase 0: factor, 1: forward sweep, 2: backward sweep of whole small subtrees (one workgroup per subtree)
 void launch_subtree(hipStream_t st, const DevSym &S, int phase, const int *sub_first, const int *sub_last, int ntasks,
                     int rmax, const double *nzval, double *L, double *CB, int *info, double *X, double *W, int nr, int ldx);
-void launch_potrf_lds(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, double *L, int *info);
 void launch_potrf64(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, double *L, int *info, const FrontArg &fa);   // potrf64.hip
 void launch_fwd_small(hipStream_t st, const DevSym &S, const int *list, int nfronts, int rmax, const double *L,
                       double *X, double *W, int nr, int ldx);

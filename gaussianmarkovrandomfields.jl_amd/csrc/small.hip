@@ -22,15 +22,6 @@ namespace gmrfx {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-// Phase-cycle instrumentation for tools/micro/potrf_prof.hip (compiled out of the library).
-#ifdef GMRFX_CYC
-__device__ long long g_cyc[4][16];
-#define CYC_DECL long long cyc_t = clock64(); const int cyc_w = (threadIdx.x & 63) == 0 ? (int)(threadIdx.x >> 6) : -1
-#define CYC_MARK(k) do { __builtin_amdgcn_sched_barrier(0); long long t_ = clock64(); if (cyc_w >= 0) g_cyc[cyc_w][k] += t_ - cyc_t; cyc_t = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define CYC_DECL
-#define CYC_MARK(k)
-#endif
 
 constexpr int lds_ldf(int R) { return R + 2; }                                   // = 2 (mod 4), odd half: conflict-free tile RMW
 constexpr int lds_ldp(int R) { return (R + 16) % 32 == 16 ? R + 16 : R + 32; }   // = 16 (mod 32): conflict-free operand reads
@@ -51,9 +42,7 @@ __device__ __forceinline__ void lds_partial_cholesky(double *F, double *Pn, doub
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int lm = lane & 15, lk = lane >> 4;
-    CYC_DECL;
     for (int j0 = 0; j0 < c; j0 += 4) {
-        CYC_MARK(0);
         const int nbk = min(4, c - j0);
         // 4x4 diagonal block (identity-padded) -> its Cholesky factor, redundantly per thread
         double dd[4][4];
@@ -82,10 +71,6 @@ __device__ __forceinline__ void lds_partial_cholesky(double *F, double *Pn, doub
         const double l32 = (dd[3][2] - l30 * l20 - l31 * l21) * i22;
         const double p3 = dd[3][3] - l30 * l30 - l31 * l31 - l32 * l32;
         const double i33 = rsqrt_nr(p3);
-#ifdef GMRFX_CYC
-        asm volatile("" ::"v"(i33));
-#endif
-        CYC_MARK(1);
         if (tid == 0) {
             int bad = -1;
             if (!(p3 > 0.0) && nbk > 3) bad = 3;
@@ -138,7 +123,6 @@ __device__ __forceinline__ void lds_partial_cholesky(double *F, double *Pn, doub
                 for (int a = 0; a < 4; a++) if (a >= nbk || b > j0 + a) wv[a] = 0.0;
             }
         }
-        CYC_MARK(2);
         // Pn / Wn were last read by the previous step's tile updates (a barrier ago) and F is not
         // written in this phase: no barrier needed before publishing the panel
         if (tid < RMAX) {
@@ -158,9 +142,7 @@ __device__ __forceinline__ void lds_partial_cholesky(double *F, double *Pn, doub
                 for (int a = 0; a < 4; a++) if (a < nbk && b < j0 + a) Pg[b + (long long)(j0 + a) * ldg] = wv[a];   // X[j0+a][b]
             }
         }
-        CYC_MARK(3);
         __syncthreads();
-        CYC_MARK(4);
         // ---- rank-4 updates on 16x16 tiles ------------------------------------------------------
         const int jn = j0 + nbk;                 // first non-final column
         if (jn < r) {
@@ -187,7 +169,6 @@ __device__ __forceinline__ void lds_partial_cholesky(double *F, double *Pn, doub
                     if (row >= col) F[col * LDF + row] = cc[rr];                // lower part only
                 }
             }
-            CYC_MARK(5);
             // (b) M[i][b] -= sum_q L[i][j0+q] W[q][b] for jn <= i < c, b < jn; stored at F(b, i)
             if (jn < c) {
                 const int tihi = (c - 1) >> 4;                 // column tiles (index i) tlo..tihi
@@ -211,9 +192,7 @@ __device__ __forceinline__ void lds_partial_cholesky(double *F, double *Pn, doub
                 }
             }
         }
-        CYC_MARK(6);
         __syncthreads();
-        CYC_MARK(7);
     }
 
 }
@@ -614,42 +593,6 @@ __global__ __launch_bounds__(256, (RMAX <= 48 ? 4 : (RMAX <= 64 ? 3 : 2))) void 
     }
 }
 
-// 64 x 64 diagonal block of a big front: factor + inverse with the same LDS machinery
-// (16 panel steps of 4 columns instead of 64 single-column steps).
-__global__ __launch_bounds__(256) void k_potrf_lds(DevSym S, const int *__restrict__ list, int kb,
-                                                   double *__restrict__ L, int *__restrict__ info) {
-    constexpr int LDF = lds_ldf(64);
-    __shared__ double F[LDF * 64];
-    __shared__ double Pn[4 * lds_ldp(64)];
-    __shared__ double Wn[4 * LDW];
-    const int s = list[blockIdx.x];
-    const int c = S.sfirst[s + 1] - S.sfirst[s];
-    if (kb >= c) return;
-    const int w = min(NB, c - kb);
-    const int ld = S.ld[s];
-    double *P = L + S.panelptr[s] + kb + (long long)kb * ld;
-    const int tid = threadIdx.x;
-    // 16 unconditional loads per thread (column j = idx / 64, row i = idx % 64), lower part kept
-    double v[16];
-#pragma unroll
-    for (int u = 0; u < 16; u++) {
-        const int idx = tid + 256 * u;
-        const int i = idx & 63, j = idx >> 6;
-        v[u] = P[min(i, w - 1) + (long long)min(j, w - 1) * ld];
-    }
-#pragma unroll
-    for (int u = 0; u < 16; u++) {
-        const int idx = tid + 256 * u;
-        const int i = idx & 63, j = idx >> 6;
-        F[j * LDF + i] = v[u] * ((i < w && j < w && i >= j) ? 1.0 : 0.0);
-    }
-    __syncthreads();
-    lds_partial_cholesky<64>(F, Pn, Wn, w, w, S.sfirst[s] + kb, info, P, ld);
-}
-void launch_potrf_lds(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, double *L, int *info) {
-    if (nactive <= 0) return;
-    hipLaunchKernelGGL(k_potrf_lds, dim3(nactive), dim3(256), 0, st, S, list, kb, L, info);
-}
 
 void launch_factor_small(hipStream_t st, const DevSym &S, const int *list, int nfronts, int rmax,
                          const double *nzval, double *L, double *CB, int *info) {

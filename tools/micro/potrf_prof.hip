@@ -1,10 +1,11 @@
-// micro-benchmark: phase cycles of the 64x64 diagonal-block Cholesky (k_potrf_lds) on one workgroup.
-// build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -DGMRFX_CYC -I../../gaussianmarkovrandomfields.jl_amd/csrc potrf_prof.hip -o potrf_prof
-#include "../../gaussianmarkovrandomfields.jl_amd/csrc/small.hip"
+// micro-benchmark: the 64x64 diagonal-block Cholesky + inverse (k_potrf64) on one workgroup: time per launch,
+// phase cycles (build with -DGMRFX_CYC) and a correctness check of L and X = L^-1.
+// build: hipcc -O3 -std=c++17 --offload-arch=gfx950 [-DGMRFX_CYC] -I../../gaussianmarkovrandomfields.jl_amd/csrc potrf_prof.hip -o potrf_prof
 #include "../../gaussianmarkovrandomfields.jl_amd/csrc/potrf64.hip"
 #include <cstdio>
 #include <vector>
 #include <cmath>
+#include <climits>
 #define HC(x) do{hipError_t e=(x); if(e!=hipSuccess){printf("err %s line %d\n", hipGetErrorString(e), __LINE__); return 1;}}while(0)
 using namespace gmrfx;
 int main(){
@@ -17,54 +18,34 @@ int main(){
   HC(hipMalloc(&dlist,4)); HC(hipMalloc(&dsf,8)); HC(hipMalloc(&dld,4)); HC(hipMalloc(&dinfo,4)); HC(hipMalloc(&dpp,16));
   HC(hipMemcpy(dlist,&list0,4,hipMemcpyHostToDevice)); HC(hipMemcpy(dsf,sf,8,hipMemcpyHostToDevice));
   HC(hipMemcpy(dld,&ldv,4,hipMemcpyHostToDevice)); HC(hipMemcpy(dinfo,&info,4,hipMemcpyHostToDevice)); HC(hipMemcpy(dpp,pp,16,hipMemcpyHostToDevice));
-  DevSym S{}; S.n=n; S.nsuper=1; S.sfirst=dsf; S.ld=dld; S.panelptr=dpp;
+  long long rp[2]={0,n}; long long *drp; HC(hipMalloc(&drp,16)); HC(hipMemcpy(drp,rp,16,hipMemcpyHostToDevice));
+  DevSym S{}; S.n=n; S.nsuper=1; S.sfirst=dsf; S.ld=dld; S.panelptr=dpp; S.rowptr=drp;
   hipStream_t st; HC(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   hipEvent_t e0,e1; HC(hipEventCreate(&e0)); HC(hipEventCreate(&e1));
   const int reps=200; float ms;
-  for(int it=0;it<2;it++){
-#ifdef GMRFX_CYC
-    long long z[64]={0}; HC(hipMemcpyToSymbol(HIP_SYMBOL(g_cyc), z, sizeof(z)));
-#endif
-    HC(hipEventRecord(e0,st));
-    for(int r=0;r<reps;r++){ hipMemcpyAsync(dL,dA,n*n*8,hipMemcpyDeviceToDevice,st); hipLaunchKernelGGL(k_potrf_lds,dim3(1),dim3(256),0,st,S,dlist,0,dL,dinfo); }
-    HC(hipEventRecord(e1,st)); HC(hipStreamSynchronize(st)); HC(hipEventElapsedTime(&ms,e0,e1));
-    long long c[4][16]={{0}};
-#ifdef GMRFX_CYC
-    HC(hipMemcpyFromSymbol(c, HIP_SYMBOL(g_cyc), sizeof(c)));
-#endif
-    printf("potrf64 + d2d copy: %.2f us per launch\n", ms*1000/reps);
-    const char* nm[8]={"loop/head","dd+chain","panel x/w","publish","barrier1","tiles(a)","tiles(b)","barrier2"};
-    for(int w=0;w<4;w++){ printf(" wave %d cycles/step:",w); double tot=0; for(int k=0;k<8;k++){ double v=c[w][k]/(double)reps/16.0; tot+=v; printf(" %s=%.0f",nm[k],v);} printf(" total=%.0f\n",tot); }
-  }
   for(int wv : {64, 37}) {
     int sf2[2]={0,wv}; HC(hipMemcpy(dsf,sf2,8,hipMemcpyHostToDevice));
     HC(hipEventRecord(e0,st));
     for(int r=0;r<reps;r++){ hipMemcpyAsync(dL,dA,n*n*8,hipMemcpyDeviceToDevice,st); hipLaunchKernelGGL(k_potrf64,dim3(1),dim3(256),0,st,S,dlist,0,dL,dinfo,FrontArg{0,0,0,0,0,0,0}); }
     HC(hipEventRecord(e1,st)); HC(hipStreamSynchronize(st)); HC(hipEventElapsedTime(&ms,e0,e1));
     printf("k_potrf64 (w=%d) + d2d copy: %.2f us per launch\n", wv, ms*1000/reps);
-    { long long c[4][16]={{0}};
 #ifdef GMRFX_CYC
+    { long long c[4][16]={{0}};
       HC(hipMemcpyFromSymbol(c, HIP_SYMBOL(g_cyc64), sizeof(c))); long long z[64]={0}; HC(hipMemcpyToSymbol(HIP_SYMBOL(g_cyc64), z, sizeof(z)));
-#endif
       const char* nm[6]={"head","lds-read","chain","Y","update/out","barrier"};
-      for(int w2=0;w2<4;w2++){ printf(" wave %d cycles/step:",w2); double tot=0; for(int k=0;k<6;k++){ double v=c[w2][k]/(double)reps/((wv+3)/4); tot+=v; printf(" %s=%.0f",nm[k],v);} printf(" total=%.0f\n",tot); } }
-
+      for(int w2=0;w2<4;w2++){ printf(" wave %d cycles/step (incl. ~350 per mark):",w2); double tot=0; for(int k=0;k<6;k++){ double v=c[w2][k]/(double)reps/((wv+3)/4); tot+=v; printf(" %s=%.0f",nm[k],v);} printf(" total=%.0f\n",tot); } }
+#endif
     std::vector<double> Lh(n*n); HC(hipMemcpy(Lh.data(),dL,n*n*8,hipMemcpyDeviceToHost));
     double err=0, errx=0, errpad=0;
     for(int j=0;j<wv;j++) for(int i=j;i<wv;i++){ double s=0; for(int k=0;k<=j;k++) s+=Lh[i+k*n]*Lh[j+k*n]; err=fmax(err,fabs(s-A[i+j*n])); }
     // X = L^-1 lower, stored transposed in the strict upper part: X[i][b] at (b, i); diag(X) = 1/diag(L)
     for(int i=0;i<wv;i++) for(int b=0;b<=i;b++){ double s=0; for(int k=b;k<=i;k++){ double x = (k==b)? 1.0/Lh[b+b*n] : Lh[b+k*n]; s+=Lh[i+k*n]*x; } errx=fmax(errx,fabs(s-(i==b?1.0:0.0))); }
     for(int j=0;j<n;j++) for(int i=0;i<n;i++) if(i>=wv||j>=wv) errpad=fmax(errpad,fabs(Lh[i+j*n]-A[i+j*n]));
-    printf("  max |LL'-A| = %.3e, max |L X - I| = %.3e, untouched outside w: %.1e, info=%d\n", err, errx, errpad, 0);
+    printf("  max |LL'-A| = %.3e, max |L X - I| = %.3e, untouched outside w: %.1e\n", err, errx, errpad);
     HC(hipEventRecord(e0,st));
     for(int r=0;r<reps;r++){ hipMemcpyAsync(dL,dA,n*n*8,hipMemcpyDeviceToDevice,st); }
     HC(hipEventRecord(e1,st)); HC(hipStreamSynchronize(st)); HC(hipEventElapsedTime(&ms,e0,e1));
-    printf("d2d copy alone: %.2f us\n", ms*1000/reps);
+    printf("  d2d copy alone: %.2f us\n", ms*1000/reps);
   }
-  { int sf2[2]={0,n}; HC(hipMemcpy(dsf,sf2,8,hipMemcpyHostToDevice)); hipLaunchKernelGGL(k_potrf_lds,dim3(1),dim3(256),0,st,S,dlist,0,dL,dinfo); HC(hipStreamSynchronize(st)); }
-  std::vector<double> Lh(n*n); HC(hipMemcpy(Lh.data(),dL,n*n*8,hipMemcpyDeviceToHost));
-  // check L L' = A (lower)
-  double err=0; for(int j=0;j<n;j++) for(int i=j;i<n;i++){ double s=0; for(int k=0;k<=j;k++) s+=Lh[i+k*n]*Lh[j+k*n]; err=fmax(err,fabs(s-A[i+j*n])); }
-  printf("max |LL'-A| = %.3e\n", err);
   return 0;
 }
