@@ -330,15 +330,16 @@ __device__ __forceinline__ void fwd_small_front(const DevSym &S, const int s, co
     const double jm = j < nr ? 1.0 : 0.0;
     // own rows <- b ; all other rows (trailing and r..RMAX-1) <- 0: masked MFMA k-steps still multiply
     // 0 by whatever is there. Unconditional clamped loads, 8 in flight per thread.
-    for (int i0 = g; i0 < RMAX; i0 += 32) {
-        double v[8];
+    {   // c <= 64 own rows: ONE batch of 16 clamped loads per thread (rows g, g+4, ..); everything else <- 0
+        double v[16];
 #pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = X[(long long)(first + min(i0 + 4 * u, c - 1)) * ldx + jc];
+        for (int u = 0; u < 16; u++) v[u] = X[(long long)(first + min(g + 4 * u, c - 1)) * ldx + jc];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int i = i0 + 4 * u;
+        for (int u = 0; u < 16; u++) {
+            const int i = g + 4 * u;
             if (i < RMAX) fv[i * LDV + j] = (i < c) ? v[u] * jm : 0.0;
         }
+        for (int i = 64 + g; i < RMAX; i += 4) fv[i * LDV + j] = 0.0;
     }
     __syncthreads();
     for (long long ch = S.childptr[s]; ch < S.childptr[s + 1]; ch++) {
@@ -346,16 +347,16 @@ __device__ __forceinline__ void fwd_small_front(const DevSym &S, const int s, co
         const int md = er.md;
         const int *reld = S.rel + er.reloff;
         const double *Wd = W + er.woff * ldx;
-        for (int a0 = g; a0 < md; a0 += 32) {
-            double v[8]; int tr[8];
+        for (int a0 = g; a0 < md; a0 += 64) {      // 16 child rows per thread and pass: one pass for md <= 64
+            double v[16]; int tr[16];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < 16; u++) {
                 const int a = min(a0 + 4 * u, md - 1);
                 tr[u] = reld[a];
-                v[u] = Wd[(long long)a * ldx + jc] * jm;
+                v[u] = Wd[(long long)a * ldx + jc];
             }
 #pragma unroll
-            for (int u = 0; u < 8; u++) if (a0 + 4 * u < md) fv[tr[u] * LDV + j] += v[u];
+            for (int u = 0; u < 16; u++) if (a0 + 4 * u < md) fv[tr[u] * LDV + j] += v[u] * jm;
         }
         __syncthreads();
     }
