@@ -28,7 +28,7 @@ def rand_case(i):
         blocks = [spde.random_spd_precision(int(rng.integers(1, 200)), 0.1, seed=int(rng.integers(1 << 30))) for _ in range(int(rng.integers(2, 6)))]
         return "blockdiag", sp.block_diag(blocks, format="csc"), {}
     if kind == 4:      # banded / chain with natural ordering
-        n = int(rng.integers(2, 1500)); bw = int(rng.integers(1, 12))
+        n = int(rng.integers(2, 1500)); bw = min(int(rng.integers(1, 12)), n - 1)
         A = sp.diags([rng.uniform(-0.2, 0.2, n - k) for k in range(1, bw + 1)], list(range(1, bw + 1)), shape=(n, n))
         A = A + A.T + sp.diags(np.full(n, 2.0 * bw))
         return f"band n={n} bw={bw}", sp.csc_matrix(A), {"ordering": "natural"} if i % 12 == 4 else {}
