@@ -74,6 +74,7 @@ void Device::upload(const Symbolic &S) {
     tmp64 = conv<long long>(S.panelptr); up(lp, tmp64); ds_.panelptr = lp; HC(hipStreamSynchronize(stream));
     up(ip, S.ld); ds_.ld = ip;
     tmp64 = conv<long long>(S.cbptr); up(lp, tmp64); ds_.cbptr = lp; HC(hipStreamSynchronize(stream));
+    tmp64 = conv<long long>(S.zbptr); up(lp, tmp64); d_zbptr_ = lp; HC(hipStreamSynchronize(stream));
     tmp64 = conv<long long>(S.childptr); up(lp, tmp64); ds_.childptr = lp; HC(hipStreamSynchronize(stream));
     up(ip, S.children); ds_.children = ip;
     up(ip, S.sparent); ds_.sparent = ip;
@@ -554,6 +555,8 @@ void Device::selinv_compute() {
     if (sharded()) throw std::invalid_argument("selected inversion on a sharded handle is not implemented yet");
     if (selinv_valid) return;
     const Symbolic &S = *S_;
+    DevSym dsz = ds_;            // the selected inversion has its own slot layout in the contribution-block arena
+    dsz.cbptr = d_zbptr_;
     start_inverse_async();
     wait_inverse();
     if (!d_Z_) d_Z_ = dalloc<double>((size_t)l_size_);
@@ -588,17 +591,17 @@ void Device::selinv_compute() {
         const int nf = scount - snsmall;
         // big fronts: whole-front step through the dense inverse (selinv.hip, k_sel_dense).
         // Yt lives at d_tmp_ + yoff[s], Z21t right behind it (offset (r-c)*c): pass both bases.
-        launch_sel_gather(stream, ds_, list, nf, level_max_trail(L), d_Z_, d_cb_);
+        launch_sel_gather(stream, dsz, list, nf, level_max_trail(L), d_Z_, d_cb_);
         for (int phase = 0; phase < 3; phase++)
-            launch_sel_dense(stream, ds_, list, nf, phase, L.max_cols, level_max_trail(L), d_L_, d_Z_, d_cb_, d_tmp_,
+            launch_sel_dense(stream, dsz, list, nf, phase, L.max_cols, level_max_trail(L), d_L_, d_Z_, d_cb_, d_tmp_,
                              d_tmp_, d_yoff);
         // small fronts of the level (<= 128 rows, <= 64 columns: one block step)
         if (snsmall > 0) {
             const int *sl = d_sel_levellist_ + sfirst;
-            launch_sel_gather(stream, ds_, sl, snsmall, 128, d_Z_, d_cb_);
-            launch_trsm(stream, ds_, sl, snsmall, 0, 1, 128, d_L_, d_tmp_, d_yoff, FrontArg{0, 0, 0, 0, 0, 0, 0});
-            launch_sel_symm(stream, ds_, sl, snsmall, 0, 128, d_Z_, d_cb_, d_tmp_, d_yoff);
-            launch_sel_diag(stream, ds_, sl, snsmall, 0, d_L_, d_Z_, d_tmp_, d_yoff);
+            launch_sel_gather(stream, dsz, sl, snsmall, 128, d_Z_, d_cb_);
+            launch_trsm(stream, dsz, sl, snsmall, 0, 1, 128, d_L_, d_tmp_, d_yoff, FrontArg{0, 0, 0, 0, 0, 0, 0});
+            launch_sel_symm(stream, dsz, sl, snsmall, 0, 128, d_Z_, d_cb_, d_tmp_, d_yoff);
+            launch_sel_diag(stream, dsz, sl, snsmall, 0, d_L_, d_Z_, d_tmp_, d_yoff);
         }
     }
     HC(hipEventRecord(ev_[1], stream));

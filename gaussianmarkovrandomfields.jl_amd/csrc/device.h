@@ -121,6 +121,7 @@ private:
     DevSym ds_{};
     std::vector<LevelInfo> levels_;
     const unsigned char *d_owncol_ = nullptr;   // sharded handles: 1 for the columns of the fronts this rank factors
+    const long long *d_zbptr_ = nullptr;   // arena offsets of the trailing inverse blocks (Symbolic::zbptr)
     const int *d_iperm_ = nullptr;   // inverse permutation (original row -> position), used by the RHS transposes
     int *d_levellist_ = nullptr;
     int *d_sub_first_ = nullptr, *d_sub_last_ = nullptr, *d_sel_levellist_ = nullptr;

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <map>
 #include <numeric>
 #include <stdexcept>
 
@@ -524,6 +525,84 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
         i32 k = 0;
         for (auto it = b; it != e; ++it) if (cls(*it) < 4) k++;
         S.sel_level_nsmall[l] = k;
+    }
+
+    // ---- contribution-block arena with lifetime reuse ------------------------------------------
+    // The level schedule fixes when a block is written and when it is last read: CB_s lives from level(s) to
+    // level(parent(s)) in the factorisation; in the (top-down) selected inversion the trailing inverse block
+    // of s lives from level(s) down to the lowest level of its children. Slots are handed out first-fit level
+    // by level (the blocks a level reads are only released after the level's own blocks have their slots, so
+    // nothing a level writes aliases anything it reads). Offsets are computed over ALL fronts, so every rank of
+    // a sharded factorisation sees the same layout. Subtree tasks run fronts out of level order: linear layout.
+    S.zbptr = S.cbptr;
+    if (!(opt.subtree_max > 0)) {
+        struct Arena {      // best fit, coalescing free list (offset-ordered map + size-ordered index)
+            std::map<i64, i64> by_off;
+            std::multimap<i64, i64> by_size;
+            i64 top = 0;
+            void drop(std::map<i64, i64>::iterator it) {
+                auto r = by_size.equal_range(it->second);
+                for (auto k = r.first; k != r.second; ++k) if (k->second == it->first) { by_size.erase(k); break; }
+                by_off.erase(it);
+            }
+            void put(i64 off, i64 sz) { by_off[off] = sz; by_size.emplace(sz, off); }
+            i64 alloc(i64 sz) {
+                auto k = by_size.lower_bound(sz);
+                if (k != by_size.end()) {
+                    const i64 off = k->second, rest = k->first - sz;
+                    drop(by_off.find(off));
+                    if (rest > 0) put(off + sz, rest);
+                    return off;
+                }
+                const i64 off = top;
+                top += sz;
+                return off;
+            }
+            void release(i64 off, i64 sz) {
+                auto nx = by_off.lower_bound(off);
+                if (nx != by_off.end() && off + sz == nx->first) { sz += nx->second; drop(nx); }
+                auto pv = by_off.lower_bound(off);
+                if (pv != by_off.begin()) {
+                    --pv;
+                    if (pv->first + pv->second == off) { off = pv->first; sz += pv->second; drop(pv); }
+                }
+                if (off + sz == top) top = off;      // give the tail back
+                else put(off, sz);
+            }
+        };
+        auto bsz = [&](i32 s) { const i64 m = S.nrows(s) - S.ncols(s); return ((m * m) + 15) & ~i64(15); };
+        std::vector<std::vector<i32>> bylevel(S.nlevels);
+        for (i32 s = 0; s < ns; s++) bylevel[S.level[s]].push_back(s);
+        i64 peak = 0;
+        {   // factorisation: bottom-up
+            Arena A;
+            for (i32 l = 0; l < S.nlevels; l++) {
+                for (i32 s : bylevel[l]) if (bsz(s) > 0) S.cbptr[s] = A.alloc(bsz(s));
+                peak = std::max(peak, A.top);
+                for (i32 s : bylevel[l])
+                    for (i64 q = S.childptr[s]; q < S.childptr[s + 1]; q++) {
+                        const i32 d = S.children[q];
+                        if (bsz(d) > 0) A.release(S.cbptr[d], bsz(d));
+                    }
+            }
+        }
+        {   // selected inversion: top-down
+            Arena A;
+            std::vector<i32> minchild(ns, -1);
+            for (i32 s = 0; s < ns; s++) {
+                i32 mc = S.level[s];                                   // no children: released after its own level
+                for (i64 q = S.childptr[s]; q < S.childptr[s + 1]; q++) mc = std::min(mc, S.level[S.children[q]]);
+                minchild[s] = mc;
+            }
+            std::vector<std::vector<i32>> dies(S.nlevels);
+            for (i32 s = 0; s < ns; s++) dies[minchild[s]].push_back(s);
+            for (i32 l = S.nlevels - 1; l >= 0; l--) {
+                for (i32 s : bylevel[l]) if (bsz(s) > 0) S.zbptr[s] = A.alloc(bsz(s));
+                peak = std::max(peak, A.top);
+                for (i32 s : dies[l]) if (bsz(s) > 0) A.release(S.zbptr[s], bsz(s));
+            }
+        }
+        S.cb_arena = std::max<i64>(peak, 16);
     }
 
     // ---- Q scatter map -------------------------------------------------------------------

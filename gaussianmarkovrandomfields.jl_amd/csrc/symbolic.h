@@ -47,7 +47,10 @@ struct Symbolic {
     std::vector<i32> rel;         // sum_rows; for k >= c_s: index of rows[k] in the parent's row list
     std::vector<i64> panelptr;    // nsuper+1, offsets in doubles into the factor storage
     std::vector<i32> ld;          // nsuper, leading dimension of the panel (>= r_s)
-    std::vector<i64> cbptr;       // nsuper, offset in doubles of the (r-c)x(r-c) contribution block
+    std::vector<i64> cbptr;       // nsuper, offset in doubles of the (r-c)x(r-c) contribution block (arena slots are REUSED:
+                                  // a block lives from its front's level to its parent's level)
+    std::vector<i64> zbptr;       // nsuper, the same arena as the selected inversion uses it (trailing inverse blocks:
+                                  // a block lives from its front's level DOWN to its lowest child's level)
     i64 cb_arena = 0;             // doubles
     // supernodal tree
     std::vector<i64> childptr;    // nsuper+1
