@@ -321,6 +321,7 @@ void Device::refactorize(const double *nzval, bool on_device) {
         HC(hipMemcpyAsync(d_nz_, nzval, (size_t)S_->nnz_in * sizeof(double), hipMemcpyHostToDevice, stream));
         src = d_nz_;
     }
+    nz_held_ = (src == d_nz_);
     // a device-resident nzval is read in place (the Q scatter happens inside the assembly kernels, and
     // this call only returns once they have finished): no private copy
     nz_src_ = src;
@@ -548,6 +549,37 @@ double Device::logdet() {
     HC(hipStreamSynchronize(stream));
     float ms; HC(hipEventElapsedTime(&ms, ev_[0], ev_[1])); ms_logdet = ms;
     return out;
+}
+
+void Device::quadform(const double *d_nz, const double *d_X, long long ldx, long long nvec, const double *d_mu, double *out_host) {
+    HC(hipSetDevice(device));
+    const Symbolic &S = *S_;
+    if (nvec <= 0) return;
+    if (nvec > 65535) throw std::invalid_argument("quadform: at most 65535 vectors per call");
+    if (ldx < S.n) throw std::invalid_argument("quadform: ldx < n");
+    if (!d_nz) {
+        if (!nz_held_) throw std::invalid_argument("quadform: the handle does not hold Q's values (last refactorisation read a caller device buffer): pass them");
+        d_nz = d_nz_;
+    }
+    if (!d_in_colptr_) {
+        d_in_colptr_ = dalloc<long long>(S.in_colptr.size());
+        d_in_row_ = dalloc<int>(std::max<size_t>(S.in_row.size(), 1));
+        HC(hipMemcpyAsync(d_in_colptr_, S.in_colptr.data(), S.in_colptr.size() * sizeof(long long), hipMemcpyHostToDevice, stream));
+        HC(hipMemcpyAsync(d_in_row_, S.in_row.data(), S.in_row.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+    }
+    const int nblk = quadform_blocks((int)S.n);
+    if (nvec > qf_cap_) {
+        // old buffers stay in allocs_ until the handle dies; growth is geometric
+        qf_cap_ = std::max<long long>(nvec, 2 * qf_cap_);
+        d_qf_part_ = dalloc<double>((size_t)qf_cap_ * nblk);
+        d_qf_out_ = dalloc<double>((size_t)qf_cap_);
+    }
+    HC(hipEventRecord(ev_[0], stream));
+    launch_quadform(stream, (int)S.n, d_in_colptr_, d_in_row_, d_nz, S.in_use, d_X, ldx, (int)nvec, d_mu, d_qf_part_, d_qf_out_);
+    HC(hipEventRecord(ev_[1], stream));
+    HC(hipMemcpyAsync(out_host, d_qf_out_, (size_t)nvec * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HC(hipStreamSynchronize(stream));
+    float ms; HC(hipEventElapsedTime(&ms, ev_[0], ev_[1])); ms_quadform = ms;
 }
 
 void Device::selinv_compute() {

@@ -90,6 +90,10 @@ public:
     // B: column-major n x nrhs (original ordering); mode 0: full solve, 1: backward only (P' L^-T Z)
     void solve(const double *B, long long ldb, long long nrhs, double *X, long long ldx, bool on_device, int mode);
     double logdet();
+    // q[v] = (x_v - mu)' Q (x_v - mu), v < nvec, on the device: x_v = d_X + v * ldx, d_mu nullable (zero mean).
+    // d_nz = Q's values in the pattern's CSC order (device); nullptr = the values of the last refactorisation
+    // when the handle holds them itself (host-pointer refactorize / refactorize_update).
+    void quadform(const double *d_nz, const double *d_X, long long ldx, long long nvec, const double *d_mu, double *out_host);
     void selinv_compute();
     void selinv_diag(double *out_host);
     void gather_z(const long long *offsets_host, long long cnt, double *out_host);  // offsets into panel storage, -1 -> 0.0
@@ -100,6 +104,7 @@ public:
     bool inverse_pending = false;   // dense inverses of the big fronts are computed lazily, on a side stream
     double ms_factor = 0, ms_solve = 0, ms_fwd = 0, ms_bwd = 0, ms_perm = 0, ms_bsolve = 0, ms_logdet = 0, ms_selinv = 0;
     long long last_nrhs = 0;
+    double ms_quadform = 0;
     double ms_syrk = 0, syrk_flops = 0;   // dominant kernel (k_syrk_cb): live HIP-event time per refactorisation, flops
     long long syrk_launches = 0;
     double bytes_total = 0;
@@ -144,6 +149,12 @@ private:
     int first_multiblock_level_ = 0;
     long long rhs_cap_ = 0, io_cap_ = 0, tmp_cap_ = 0;
     int *d_info_ = nullptr;
+    // caller's CSC pattern, uploaded on the first quadform call
+    long long *d_in_colptr_ = nullptr;
+    int *d_in_row_ = nullptr;
+    double *d_qf_part_ = nullptr, *d_qf_out_ = nullptr;
+    long long qf_cap_ = 0;
+    bool nz_held_ = false;    // d_nz_ holds the values of the factorisation
     hipEvent_t ev_[8] = {};
     std::vector<hipEvent_t> ev_syrk_;   // begin/end event of every k_syrk_cb launch
     long long l_size_ = 0, sum_trail_ = 0;

@@ -414,6 +414,42 @@ extern "C" int32_t gmrfx_get_perm(const gmrfx_handle *h, int32_t base, int64_t *
     return GMRFX_OK;
 }
 
+static int32_t quadform_impl(gmrfx_handle *h, const double *nz, const double *X, int64_t ldx, int64_t nvec,
+                             const double *mu, double *out, bool dev) {
+    return guarded(h, [&]() -> int32_t {
+        if (int32_t e = need_device(h, false)) return e;
+        if (nvec < 0 || (nvec > 0 && (!X || !out))) { h->err = "quadform: null X/out or negative nvec"; return GMRFX_ERR_INVALID_ARG; }
+        if (nvec == 0) return GMRFX_OK;
+        if (ldx < h->S.n) { h->err = "quadform: ldx < n"; return GMRFX_ERR_INVALID_ARG; }
+        if (dev) { h->D->quadform(nz, X, ldx, nvec, mu, out); return GMRFX_OK; }
+        // host operands: stage them through plain device buffers (freed on return)
+        const i64 n = h->S.n;
+        struct Buf { void *p = nullptr; ~Buf() { if (p) (void)hipFree(p); } } bx, bm, bn;
+        hip_check(hipSetDevice(h->D->device), "hipSetDevice");
+        hip_check(hipMalloc(&bx.p, (size_t)std::max<i64>(n * nvec, 1) * sizeof(double)), "hipMalloc");
+        hip_check(hipMemcpy2D(bx.p, (size_t)n * sizeof(double), X, (size_t)ldx * sizeof(double), (size_t)n * sizeof(double),
+                              (size_t)nvec, hipMemcpyHostToDevice), "hipMemcpy2D");
+        if (mu) {
+            hip_check(hipMalloc(&bm.p, (size_t)std::max<i64>(n, 1) * sizeof(double)), "hipMalloc");
+            hip_check(hipMemcpy(bm.p, mu, (size_t)n * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy");
+        }
+        if (nz) {
+            hip_check(hipMalloc(&bn.p, (size_t)std::max<i64>(h->S.nnz_in, 1) * sizeof(double)), "hipMalloc");
+            hip_check(hipMemcpy(bn.p, nz, (size_t)h->S.nnz_in * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy");
+        }
+        h->D->quadform((const double *)bn.p, (const double *)bx.p, n, nvec, (const double *)bm.p, out);
+        return GMRFX_OK;
+    });
+}
+extern "C" int32_t gmrfx_quadform(gmrfx_handle *h, const double *nzval, const double *X, int64_t ldx, int64_t nvec,
+                                  const double *mu, double *out) {
+    return quadform_impl(h, nzval, X, ldx, nvec, mu, out, false);
+}
+extern "C" int32_t gmrfx_quadform_dev(gmrfx_handle *h, const double *d_nzval, const double *d_X, int64_t ldx, int64_t nvec,
+                                      const double *d_mu, double *out) {
+    return quadform_impl(h, d_nzval, d_X, ldx, nvec, d_mu, out, true);
+}
+
 extern "C" int32_t gmrfx_get_stats(const gmrfx_handle *h, gmrfx_stats *out, int32_t struct_size) {
     if (!h || !out || struct_size <= 0) return GMRFX_ERR_INVALID_ARG;
     gmrfx_stats st;
@@ -434,6 +470,7 @@ extern "C" int32_t gmrfx_get_stats(const gmrfx_handle *h, gmrfx_stats *out, int3
         st.ms_solve_perm = D.ms_perm; st.ms_backward_solve = D.ms_bsolve; st.ms_logdet = D.ms_logdet; st.ms_selinv = D.ms_selinv;
         st.last_nrhs = D.last_nrhs;
         st.ms_syrk = D.ms_syrk; st.syrk_flops = D.syrk_flops; st.syrk_launches = D.syrk_launches;
+        st.ms_quadform = D.ms_quadform;
         if (D.factorized) st.fail_col = const_cast<Device &>(D).fail_col();
     }
     std::memcpy(out, &st, std::min<size_t>((size_t)struct_size, sizeof(st)));

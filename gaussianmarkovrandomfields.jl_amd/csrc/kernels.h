@@ -164,6 +164,9 @@ void launch_bwd_gemm(hipStream_t st, const DevSym &S, const int *list, int nfron
 void launch_permute(hipStream_t st, const int *iperm, int n, double *Bc, long long ldb, double *X, int nr, int ldx, int dir);
 void launch_newton_update(hipStream_t st, const double *prior, double *nz, long long nnz, const long long *map, const double *h,
                           long long cnt);
+int quadform_blocks(int n);
+void launch_quadform(hipStream_t st, int n, const long long *colptr, const int *row, const double *val, int use_lower,
+                     const double *X, long long ldx, int nvec, const double *mu, double *part, double *out);
 void launch_logdet(hipStream_t st, const double *L, const long long *diagoff, const unsigned char *own, int n, double *part,
                    int nparts, double *out);
 void launch_gather(hipStream_t st, const double *src, const long long *off, long long cnt, double *out);

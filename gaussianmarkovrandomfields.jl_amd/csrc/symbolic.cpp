@@ -615,6 +615,11 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
             if (i < j) has_up = true; else if (i > j) has_lo = true;
         }
     int use = (has_up && has_lo) ? (opt.uplo == 0 ? 0 : 1) : (has_up ? 0 : 1);  // 0 upper, 1 lower
+    S.in_use = use;
+    S.in_colptr.resize(n + 1);
+    for (i64 j = 0; j <= n; j++) S.in_colptr[j] = colptr[j] - base;
+    S.in_row.resize(S.in_colptr[n]);
+    for (i64 p = 0; p < S.in_colptr[n]; p++) S.in_row[p] = (i32)(rowval[p] - base);
     // count per destination supernode
     S.qptr.assign(ns + 1, 0);
     for (i64 j = 0; j < n; j++)

@@ -82,6 +82,11 @@ struct Symbolic {
     i32 shard_rank = 0, shard_world = 1, shard_level = 0;   // shard_level = nlevels when world == 1
     std::vector<i32> shard_roots; // assigned subtree roots whose parent is a top front (their CBs travel to rank 0)
     std::vector<i32> shard_sub_root, shard_sub_col0;   // ALL assigned subtrees: root supernode, first column (columns [col0, sfirst[root+1]) are theirs)
+    // the caller's pattern (0-based) and which stored triangle defines Q: kept for the quadratic form
+    // x'Qx (sqmahal / logpdf), which runs on the caller's CSC values, not on the factor
+    std::vector<i64> in_colptr;   // n+1
+    std::vector<i32> in_row;      // nnz_in
+    int in_use = 0;               // 0: entries with row <= col define Q, 1: row >= col
     // Q scatter map, sorted by destination
     std::vector<i64> qsrc;        // index into caller's nzval
     std::vector<i64> qdst;        // offset in factor storage

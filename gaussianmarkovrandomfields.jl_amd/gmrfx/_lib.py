@@ -30,7 +30,8 @@ class GmrfxStats(C.Structure):
         "factor_flops", "bytes_factor", "bytes_cb_arena", "bytes_device_total", "ms_symbolic", "ms_factor",
         "ms_solve", "ms_solve_fwd", "ms_solve_bwd", "ms_solve_perm", "ms_backward_solve", "ms_logdet",
         "ms_selinv")] + [("last_nrhs", C.c_int64), ("fail_col", C.c_int64), ("ms_syrk", C.c_double),
-                         ("syrk_flops", C.c_double), ("syrk_launches", C.c_int64)]
+                         ("syrk_flops", C.c_double), ("syrk_launches", C.c_int64),
+                         ("ms_quadform", C.c_double)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -59,6 +60,7 @@ EXPORTS = [
     "gmrfx_symbolic_get", "gmrfx_get_factor_values", "gmrfx_refactorize_phase", "gmrfx_shard_info",
     "gmrfx_shard_cb_blocks", "gmrfx_shard_owner", "gmrfx_device_ptr", "gmrfx_logdet_partial", "gmrfx_solve_phase",
     "gmrfx_shard_rows", "gmrfx_set_prior", "gmrfx_refactorize_update", "gmrfx_refactorize_update_dev",
+    "gmrfx_quadform", "gmrfx_quadform_dev",
 ]
 
 
@@ -105,6 +107,8 @@ def lib():
         L.gmrfx_set_prior.argtypes = [vp, vp, vp, i64, i32]
         L.gmrfx_refactorize_update.argtypes = [vp, vp, C.POINTER(i64)]
         L.gmrfx_refactorize_update_dev.argtypes = [vp, vp, C.POINTER(i64)]
+        L.gmrfx_quadform.argtypes = [vp, vp, vp, i64, i64, vp, vp]
+        L.gmrfx_quadform_dev.argtypes = [vp, vp, vp, i64, i64, vp, vp]
         for nm in EXPORTS[2:]:
             if nm not in ("gmrfx_destroy", "gmrfx_device_ptr"):
                 getattr(L, nm).restype = i32

@@ -153,6 +153,30 @@ class MI355XBackend:
         check(lib().gmrfx_logdet(self._h, C.byref(out)), self._h)
         return out.value
 
+    def sqmahal(self, x, mean=None, nzval=None):
+        """(x - mean)' Q (x - mean) on the device: `dot(r, d.precision * r)` of logpdf (workspace_gmrf.jl:288-292)
+        and sqmahal (gmrf.jl:94-97). x: n vector or n x k matrix (one value per column). nzval: Q's values in the
+        pattern's order; None = the values of the last refactorisation."""
+        X = np.asarray(x, dtype=np.float64)
+        if X.shape[0] != self.n:
+            raise ValueError("dimension mismatch")
+        vec = X.ndim == 1
+        Xf = np.asfortranarray(X.reshape(self.n, -1))
+        mu = None if mean is None else np.ascontiguousarray(mean, dtype=np.float64)
+        if mu is not None and mu.shape != (self.n,):
+            raise ValueError("dimension mismatch")
+        nz = None if nzval is None else np.ascontiguousarray(nzval, dtype=np.float64)
+        if nz is not None and nz.shape != (self._nnz,):
+            raise ValueError("nzval length does not match the pattern")
+        out = np.empty(Xf.shape[1])
+        check(lib().gmrfx_quadform(self._h, ptr(nz), ptr(Xf), self.n, Xf.shape[1], ptr(mu), ptr(out)), self._h)
+        return float(out[0]) if vec else out
+
+    def logpdf(self, z, mean=None) -> float:
+        """logpdf(d::WorkspaceGMRF, z) without constraints (workspace_gmrf.jl:288-292):
+        -0.5 r'Qr + 0.5 logdet(Q) - 0.5 n log(2 pi), on the values of the last refactorisation."""
+        return -0.5 * self.sqmahal(z, mean) + 0.5 * self.compute_logdet() - 0.5 * self.n * np.log(2.0 * np.pi)
+
     def compute_selinv(self) -> None:
         """Lazy like the CHOLMOD backend (backend.jl:215-221): the getters trigger the work."""
         return None
@@ -329,6 +353,12 @@ class MI355XBackend:
 
     def backward_solve_dev(self, d_Z: int, ldz: int, nrhs: int, d_X: int, ldx: int) -> None:
         check(lib().gmrfx_backward_solve_dev(self._h, d_Z, ldz, nrhs, d_X, ldx), self._h)
+
+    def quadform_dev(self, d_nzval: int, d_X: int, ldx: int, nvec: int, d_mu: int = 0) -> np.ndarray:
+        """Device-pointer form of sqmahal; d_nzval / d_mu may be 0 (see gmrfx_quadform_dev)."""
+        out = np.empty(nvec)
+        check(lib().gmrfx_quadform_dev(self._h, d_nzval or None, d_X, ldx, nvec, d_mu or None, ptr(out)), self._h)
+        return out
 
     def selinv_compute_dev(self) -> None:
         check(lib().gmrfx_selinv_compute(self._h), self._h)

@@ -98,6 +98,16 @@ class GMRFWorkspace:
         self.ensure_numeric()
         return self.backend.backend_backward_solve(x)
 
+    def sqmahal(self, x, mean=None):
+        """(x - mean)' Q (x - mean) on the device (gmrf.jl:94-97); x: vector or n x k matrix."""
+        self.ensure_numeric()
+        return self.backend.sqmahal(x, mean)
+
+    def logpdf(self, z, mean=None) -> float:
+        """logpdf(d::WorkspaceGMRF, z) without constraints (workspace_gmrf.jl:288-292)."""
+        n = self.dimension()
+        return -0.5 * self.sqmahal(z, mean) + 0.5 * self.logdet() - 0.5 * n * np.log(2.0 * np.pi)
+
 
 class WorkspacePool:
     """N independent workspaces handed out through a queue (workspace_pool.jl:42-119). Distinct

@@ -182,6 +182,19 @@ function refactorize_update!(b::MI355XBackend, hvals::Vector{Float64})
     return nothing
 end
 
+# dot(r, Q * r), r = x - mean, on the device with the values of the last refactorize! (the quadratic form of
+# logpdf(::WorkspaceGMRF, z), src/workspace/workspace_gmrf.jl:288-292, and sqmahal, src/gmrf.jl:94-97).
+# X: n vector or n x k matrix (one value per column).
+function sqmahal(b::MI355XBackend, X::StridedVecOrMat{Float64}; mean::Union{Nothing, Vector{Float64}} = nothing)
+    nvec = size(X, 2)
+    out = Vector{Float64}(undef, nvec)
+    mu = mean === nothing ? Ptr{Float64}(C_NULL) : pointer(mean)
+    GC.@preserve X mean out check(ccall((:gmrfx_quadform, LIB), Int32,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Ptr{Float64}),
+        b.h.ptr, C_NULL, X, X isa AbstractVector ? length(X) : stride(X, 2), nvec, mu, out), b.h)
+    return X isa AbstractVector ? out[1] : out
+end
+
 function Base.deepcopy_internal(b::MI355XBackend, ::IdDict)   # deepcopy(cache) in Newton loops
     out = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:gmrfx_clone, LIB), Int32, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}), b.h.ptr, out))

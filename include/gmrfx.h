@@ -87,6 +87,7 @@ typedef struct gmrfx_stats {
      * (sum over big fronts of c m (m + 1), m = r - c: lower triangle only)                  */
     double  ms_syrk, syrk_flops;
     int64_t syrk_launches;
+    double  ms_quadform;           /* most recent gmrfx_quadform(_dev): kernels only             */
 } gmrfx_stats;
 
 /* Message for the most recent failed gmrfx_create on this thread. */
@@ -158,6 +159,19 @@ int32_t gmrfx_backward_solve_dev(gmrfx_handle *h, const double *d_Z, int64_t ldz
 /* +log det Q = 2 sum log L_jj. Replaces `logdet(F)`: src/workspace/backend.jl:211-213
  * (seam A negates: src/solvers/logdet.jl:27-31). */
 int32_t gmrfx_logdet(gmrfx_handle *h, double *out);
+
+/* out[v] = (x_v - mu)' Q (x_v - mu) for the nvec columns of the column-major n x nvec X (mu: n values or NULL for a
+ * zero mean), on Q's CSC values `nzval` (same order as the pattern given to gmrfx_create; NULL = the values of the
+ * last refactorisation when the handle holds them, i.e. after gmrfx_refactorize or gmrfx_refactorize_update).
+ * Replaces `dot(r, d.precision * r)` in logpdf(::WorkspaceGMRF, z), src/workspace/workspace_gmrf.jl:288-292, and
+ * sqmahal, src/gmrf.jl:94-97; with gmrfx_refactorize_dev + gmrfx_logdet the hyper-parameter loop of
+ * docs/src/literate-tutorials/workspace_factorization_reuse.jl:94-102 keeps Q and z in HBM. Only the stored triangle
+ * that defines Q (gmrfx_opts.uplo) is read. Does not need a factorisation. The _dev form takes device pointers for
+ * nzval, X and mu; out is a host array of nvec doubles in both. nvec <= 65535. */
+int32_t gmrfx_quadform(gmrfx_handle *h, const double *nzval, const double *X, int64_t ldx, int64_t nvec,
+                       const double *mu, double *out);
+int32_t gmrfx_quadform_dev(gmrfx_handle *h, const double *d_nzval, const double *d_X, int64_t ldx, int64_t nvec,
+                           const double *d_mu, double *out);
 
 /* Takahashi selected inverse; computed lazily once per refactorisation and cached on the
  * device. Replaces SelectedInversion.selinv / selinv_diag: src/workspace/backend.jl:215-257,

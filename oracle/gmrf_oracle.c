@@ -256,6 +256,26 @@ double orc_logdet(const orc_factor *F) {
     return 2.0 * s;
 }
 
+/* (x - mu)' Symmetric(Q, uplo) (x - mu): `dot(r, d.precision * r)` of logpdf(::WorkspaceGMRF, z),
+ * /root/reference/src/workspace/workspace_gmrf.jl:288-292, and sqmahal, /root/reference/src/gmrf.jl:94-97.
+ * Plain restatement: y = Symmetric(Q) r column by column (only the `uplo` triangle is read, mirrored), then r'y.
+ * mu may be NULL. */
+double orc_sqmahal(i64 n, const i64 *Ap, const i64 *Ai, const double *Ax, int uplo, const double *x, const double *mu) {
+    double *r = (double *)xmalloc((size_t)(n > 0 ? n : 1) * sizeof(double));
+    double *y = (double *)calloc((size_t)(n > 0 ? n : 1), sizeof(double));
+    for (i64 j = 0; j < n; j++) r[j] = x[j] - (mu ? mu[j] : 0.0);
+    for (i64 j = 0; j < n; j++)
+        for (i64 p = Ap[j]; p < Ap[j + 1]; p++) {
+            i64 i = Ai[p];
+            if (i == j) y[i] += Ax[p] * r[j];
+            else if ((uplo == 'U' && i < j) || (uplo == 'L' && i > j)) { y[i] += Ax[p] * r[j]; y[j] += Ax[p] * r[i]; }
+        }
+    double s = 0.0;
+    for (i64 j = 0; j < n; j++) s += r[j] * y[j];
+    free(r); free(y);
+    return s;
+}
+
 /* Takahashi recursion on pattern(L), last column first. */
 static void ensure_selinv(orc_factor *F) {
     if (F->Zx) return;

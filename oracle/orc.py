@@ -42,8 +42,27 @@ def lib():
         L.orc_logdet.argtypes = [C.c_void_p]
         L.orc_selinv_diag.argtypes = [C.c_void_p, f64p]
         L.orc_selinv_csc.argtypes = [C.c_void_p, i64p, i64p, f64p]
+        L.orc_sqmahal.restype = C.c_double
+        L.orc_sqmahal.argtypes = [C.c_int64, i64p, i64p, f64p, C.c_int, f64p, C.c_void_p]
         _LIB = L
     return _LIB
+
+
+def sqmahal(Q, x, mean=None, uplo: str = "U") -> float:
+    """(x - mean)' Symmetric(Q, uplo) (x - mean): gmrf.jl:94-97 / workspace_gmrf.jl:288-292."""
+    Q = sp.csc_matrix(Q)
+    Ap = np.ascontiguousarray(Q.indptr, dtype=np.int64)
+    Ai = np.ascontiguousarray(Q.indices, dtype=np.int64)
+    Ax = np.ascontiguousarray(Q.data, dtype=np.float64)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    mu = None if mean is None else np.ascontiguousarray(mean, dtype=np.float64)
+    return lib().orc_sqmahal(Q.shape[0], Ap, Ai, Ax, ord(uplo), x, None if mu is None else mu.ctypes.data_as(C.c_void_p))
+
+
+def logpdf(F: "OracleFactor", Q, z, mean=None, uplo: str = "U") -> float:
+    """logpdf(d::WorkspaceGMRF, z), unconstrained: workspace_gmrf.jl:288-292 (logdetcov = -logdet Q)."""
+    n = Q.shape[0]
+    return -0.5 * sqmahal(Q, z, mean, uplo) + 0.5 * F.logdet() - 0.5 * n * np.log(2.0 * np.pi)
 
 
 class OracleFactor:

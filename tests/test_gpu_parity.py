@@ -72,6 +72,62 @@ def test_solve_matches_oracle(case, nrhs):
         assert relerr(X.reshape(n, -1), np.linalg.solve(Q.toarray(), B[:, :X.reshape(n, -1).shape[1]])) < 1e-9
 
 
+def test_sqmahal_and_logpdf_match_oracle(case):
+    # dot(r, Q r) and logpdf of workspace_gmrf.jl:288-292, Q's values and z resident on the device
+    _, Q, ws, F = case
+    n = Q.shape[0]
+    rng = np.random.default_rng(11)
+    z = rng.standard_normal(n); mu = rng.standard_normal(n)
+    for mean in (None, mu):
+        q = ws.sqmahal(z, mean)
+        qo = orc.sqmahal(Q, z, mean)
+        assert abs(q - qo) <= 1e-12 * max(1.0, abs(qo))
+        r = z - (0 if mean is None else mean)
+        assert abs(q - r @ (Q @ r)) <= 1e-11 * max(1.0, abs(qo))
+        lp, lpo = ws.logpdf(z, mean), orc.logpdf(F, Q, z, mean)
+        assert abs(lp - lpo) <= 1e-10 * max(1.0, abs(lpo))
+    # a batch of vectors gives the same numbers as one call per vector (fixed summation order)
+    Z = rng.standard_normal((n, 5))
+    qb = ws.sqmahal(Z, mu)
+    assert qb.shape == (5,)
+    for k in range(5):
+        assert qb[k] == ws.sqmahal(Z[:, k].copy(), mu)
+
+
+def test_sqmahal_reads_only_the_defining_triangle():
+    # Symmetric(Q) semantics (gmrf_workspace.jl:176): with both triangles stored the upper one defines Q
+    # (or the lower with uplo="L"); garbage in the other triangle must not matter. One stored triangle is
+    # used as it is. Explicit values override the handle's.
+    Q = sp.csc_matrix(spde.matern_precision(spde.grid_mesh_2d(20, 20, jitter=0.25), 0, 0.3))
+    n = Q.shape[0]
+    rng = np.random.default_rng(5)
+    z = rng.standard_normal((n, 3))
+    want = np.einsum("ik,ik->k", z, Q @ z)
+    U, Lo = sp.triu(Q).tocsc(), sp.tril(Q).tocsc()
+    G = (U + 7.0 * sp.tril(Q, -1)).tocsc()          # lower triangle is garbage
+    be = gmrfx.MI355XBackend(G)
+    assert np.abs(be.sqmahal(z) - want).max() <= 1e-11 * np.abs(want).max()
+    G2 = (Lo + 7.0 * sp.triu(Q, 1)).tocsc()
+    be2 = gmrfx.MI355XBackend(G2, uplo="L")
+    assert np.abs(be2.sqmahal(z) - want).max() <= 1e-11 * np.abs(want).max()
+    for T in (U, Lo):
+        bt = gmrfx.MI355XBackend(T)
+        assert np.abs(bt.sqmahal(z) - want).max() <= 1e-11 * np.abs(want).max()
+        assert abs(bt.sqmahal(z[:, 0].copy(), nzval=2.0 * T.data) - 2.0 * want[0]) <= 1e-11 * abs(want[0])
+    # device-pointer form; a handle refactorised from a caller's device buffer does not hold the values
+    import torch
+    d_nz = torch.from_numpy(np.ascontiguousarray(Q.data)).cuda()
+    d_z = torch.from_numpy(np.ascontiguousarray(z.T)).cuda()     # row k = vector k
+    bq = gmrfx.MI355XBackend(Q, factorize=False)
+    bq.refactorize_dev(d_nz.data_ptr())
+    got = bq.quadform_dev(d_nz.data_ptr(), d_z.data_ptr(), n, 3)
+    assert np.abs(got - want).max() <= 1e-11 * np.abs(want).max()
+    with pytest.raises(ValueError):
+        bq.quadform_dev(0, d_z.data_ptr(), n, 3)
+    with pytest.raises(ValueError):
+        bq.sqmahal(np.zeros(n + 1))
+
+
 def test_logdet(case):
     _, Q, ws, F = case
     assert abs(ws.logdet() - F.logdet()) <= 1e-10 * max(1.0, abs(F.logdet()))

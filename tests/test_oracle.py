@@ -95,3 +95,19 @@ def test_matern_generator_matches_reference_formulas():
     # 3-D nu=1 (alpha = 5/2) is not expressible, as in the reference (Integer(alpha) throws)
     import math
     assert spde.smoothness_to_nu(0, 3) == 0.5 and math.isclose(spde.range_to_kappa(2.0, 1.0), math.sqrt(8) / 2)
+
+
+def test_oracle_sqmahal_and_logpdf_dense_identity():
+    # dot(r, Q r) and the unconstrained logpdf of workspace_gmrf.jl:288-292 against the dense formulas
+    Q = sp.csc_matrix(spde.random_spd_precision(60, 0.1))
+    n = Q.shape[0]
+    rng = np.random.default_rng(0)
+    z, mu = rng.standard_normal(n), rng.standard_normal(n)
+    r = z - mu
+    assert abs(orc.sqmahal(Q, z, mu) - r @ Q.toarray() @ r) < 1e-10
+    assert abs(orc.sqmahal(sp.tril(Q).tocsc(), z, mu, uplo="L") - r @ Q.toarray() @ r) < 1e-10
+    assert abs(orc.sqmahal(sp.triu(Q).tocsc(), z, None) - z @ Q.toarray() @ z) < 1e-10
+    F = orc.OracleFactor(Q)
+    from scipy.stats import multivariate_normal
+    want = multivariate_normal(mean=mu, cov=np.linalg.inv(Q.toarray())).logpdf(z)
+    assert abs(orc.logpdf(F, Q, z, mu) - want) < 1e-8 * max(1.0, abs(want))
