@@ -113,6 +113,9 @@ def main():
                     help="extra (N > 1): ONE factorisation sharded over the ranks (subtrees per rank, Schur-complement "
                          "contribution blocks to rank 0 over the process group, all-reduced logdet; gmrfx/shard.py) "
                          "instead of independent replicas; prints its own JSON line (strong scaling of refactorise + solve + logdet)")
+    ap.add_argument("--no-logpdf", action="store_true",
+                    help="skip the (untimed) logpdf loop after the timed steps: keeps kernel traces / PMC passes to whole "
+                         "refactorise+solve steps (tools/prof_summary.py, tools/pmc_traffic.py)")
     ap.add_argument("--pool", type=int, default=0,
                     help="extra: throughput of P independent workspaces driven concurrently on this GPU "
                          "(the reference's WorkspacePool pattern; reported separately, never as `value`)")
@@ -224,8 +227,8 @@ def main():
     # hyper-parameter loop (docs/.../workspace_factorization_reuse.jl:94-102): new values -> numeric
     # factorisation -> logpdf(z) = -r'Qr/2 + logdet(Q)/2 - n log(2 pi)/2, Q's values and z resident in HBM.
     # Untimed by `value`; wall clock of 5 evaluations including the two scalar read-backs each.
-    logpdf_ms = None
-    if rank == 0:
+    logpdf_ms = ms_quadform = logpdf_relerr = None
+    if rank == 0 and not args.no_logpdf:
         d_z = d_B[0]
         def logpdf_eval():
             be.refactorize_dev(d_nz.data_ptr())
@@ -326,7 +329,7 @@ def main():
             "roofline_factor": roof_factor, "roofline_sweep": roof_sweep,
             "phases_ms": {"factor": mf, "solve": ms_, "solve_fwd": mfw, "solve_bwd": mbw, "solve_perm": med(t_perm),
                           "symbolic_host": st0["ms_symbolic"], **extras},
-            "logpdf_per_s": 1e3 / logpdf_ms, "logpdf_ms": logpdf_ms, "ms_quadform": ms_quadform,
+            "logpdf_per_s": (1e3 / logpdf_ms) if logpdf_ms else None, "logpdf_ms": logpdf_ms, "ms_quadform": ms_quadform,
             "logpdf_relerr_vs_host": logpdf_relerr,
             "check": {"rel_residual": resid, "logdet": logdet, "fail_col": st["fail_col"]},
             "supernodes": int(st["nsuper"]), "levels": int(st["nlevels"]),
