@@ -206,6 +206,20 @@ def main():
         extras["ms_rand256"] = be.stats()["ms_backward_solve"]
 
     if args.extras and rank == 0:
+        # predictor marginal variances: diag(A Sigma A') for a P1 evaluation matrix with one random
+        # point per node (3 weights per row), contracted on the device from the selected-inverse panels; wall clock
+        # including the host-side pair planning and the transfers
+        import scipy.sparse as sp
+        rg = np.random.default_rng(4)
+        cells = mesh.cells[rg.integers(0, len(mesh.cells), size=n)]
+        A = sp.csr_matrix((rg.dirichlet(np.ones(3), size=n).ravel(), (np.repeat(np.arange(n), 3), cells.ravel())), shape=(n, n))
+        t1 = time.perf_counter()
+        vdiag = be.row_diag_ASigmaAt(A)
+        extras["row_diag_ASigmaAt_wall_ms"] = 1e3 * (time.perf_counter() - t1)
+        extras["row_diag_rows"] = int(n)
+        extras["row_diag_min_max"] = [float(vdiag.min()), float(vdiag.max())]
+
+    if args.extras and rank == 0:
         # Newton iterate: Q_k = Q_prior - diag(h_k), refactorise. Host path = update nzval on the
         # host and send all of it (what _update_hessian! + the CHOLMOD copy do); device path = send h only.
         coo = Q.tocoo()                                     # same entry order as Q.data

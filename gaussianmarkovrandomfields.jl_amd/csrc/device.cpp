@@ -668,6 +668,25 @@ void Device::gather_z(const long long *offsets_host, long long cnt, double *out_
     (void)hipFree(d_out);
 }
 
+void Device::weighted_z_sums(const long long *segptr_host, long long nseg, const long long *off_host, const double *w_host,
+                             double *out_host) {
+    HC(hipSetDevice(device));
+    if (nseg <= 0) return;
+    if (nseg > 0x7fffffffLL) throw std::invalid_argument("too many segments");
+    const long long cnt = segptr_host[nseg];
+    struct Buf { void *p = nullptr; ~Buf() { if (p) (void)hipFree(p); } } bseg, boff, bw, bout;
+    HC(hipMalloc(&bseg.p, (size_t)(nseg + 1) * sizeof(long long)));
+    HC(hipMalloc(&boff.p, (size_t)std::max<long long>(cnt, 1) * sizeof(long long)));
+    HC(hipMalloc(&bw.p, (size_t)std::max<long long>(cnt, 1) * sizeof(double)));
+    HC(hipMalloc(&bout.p, (size_t)nseg * sizeof(double)));
+    HC(hipMemcpyAsync(bseg.p, segptr_host, (size_t)(nseg + 1) * sizeof(long long), hipMemcpyHostToDevice, stream));
+    HC(hipMemcpyAsync(boff.p, off_host, (size_t)cnt * sizeof(long long), hipMemcpyHostToDevice, stream));
+    HC(hipMemcpyAsync(bw.p, w_host, (size_t)cnt * sizeof(double), hipMemcpyHostToDevice, stream));
+    launch_seg_wsum(stream, d_Z_, (const long long *)bseg.p, nseg, (const long long *)boff.p, (const double *)bw.p, (double *)bout.p);
+    HC(hipMemcpyAsync(out_host, bout.p, (size_t)nseg * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HC(hipStreamSynchronize(stream));
+}
+
 void Device::copy_factor(double *out_host) {
     HC(hipSetDevice(device));
     HC(hipMemcpy(out_host, d_L_, (size_t)l_size_ * sizeof(double), hipMemcpyDeviceToHost));

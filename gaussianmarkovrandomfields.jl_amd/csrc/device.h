@@ -97,6 +97,8 @@ public:
     void selinv_compute();
     void selinv_diag(double *out_host);
     void gather_z(const long long *offsets_host, long long cnt, double *out_host);  // offsets into panel storage, -1 -> 0.0
+    // out[g] = sum_{t in segment g} w[t] * Z[off[t]] (off = -1 -> 0), all arrays on the host; Z = selected inverse panels
+    void weighted_z_sums(const long long *segptr_host, long long nseg, const long long *off_host, const double *w_host, double *out_host);
     void copy_factor(double *out_host);
     long long fail_col();
 

@@ -7,6 +7,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "device.h"
@@ -380,6 +381,32 @@ extern "C" int32_t gmrfx_selinv_csc(gmrfx_handle *h, int32_t base, int64_t *colp
     });
 }
 
+// Host-side planning loops (offset lookups into the supernodal structure) over [0, n): split over a few threads
+// when long; fn(lo, hi) must only write its own range. Exceptions inside fn are collected and rethrown.
+template <class F> static void parallel_ranges(i64 n, F &&fn) {
+    const unsigned hw = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    if (n < 200000 || hw == 1) { fn((i64)0, n); return; }
+    std::vector<std::thread> th;
+    std::vector<std::exception_ptr> err(hw);
+    for (unsigned t = 0; t < hw; t++)
+        th.emplace_back([&, t] {
+            try { fn(n * t / hw, n * (t + 1) / hw); } catch (...) { err[t] = std::current_exception(); }
+        });
+    for (auto &x : th) x.join();
+    for (auto &e : err) if (e) std::rethrow_exception(e);
+}
+
+// offset of Sigma(i, j) (original indices) in the selected-inverse panels, -1 outside the factor pattern
+static inline long long z_offset(const Symbolic &S, i64 i, i64 j) {
+    i32 a = S.iperm[i], b = S.iperm[j];
+    if (a < b) std::swap(a, b);
+    const i32 s = S.col2super[b];
+    const i32 *rows = S.rows.data() + S.rowptr[s];
+    const i32 r = S.nrows(s);
+    const i32 *it = std::lower_bound(rows, rows + r, a);
+    return (it != rows + r && *it == a) ? (long long)(S.panelptr[s] + (i64)(b - S.sfirst[s]) * S.ld[s] + (it - rows)) : -1;
+}
+
 extern "C" int32_t gmrfx_selinv_extract(gmrfx_handle *h, int64_t ncol, const int64_t *colptr, const int64_t *rowval,
                                         int32_t base, double *out) {
     return guarded(h, [&]() -> int32_t {
@@ -391,19 +418,88 @@ extern "C" int32_t gmrfx_selinv_extract(gmrfx_handle *h, int64_t ncol, const int
         h->D->selinv_compute();
         const i64 nz = colptr[ncol] - base;
         std::vector<long long> off((size_t)nz);
-        for (i64 j = 0; j < ncol; j++)
-            for (i64 p = colptr[j] - base; p < colptr[j + 1] - base; p++) {
-                i64 i = rowval[p] - base;
-                if (i < 0 || i >= S.n) throw std::invalid_argument("rowval out of range");
-                i32 a = S.iperm[i], b = S.iperm[j];
-                if (a < b) std::swap(a, b);
-                const i32 s = S.col2super[b];
-                const i32 *rows = S.rows.data() + S.rowptr[s];
-                const i32 r = S.nrows(s);
-                const i32 *it = std::lower_bound(rows, rows + r, a);
-                off[p] = (it != rows + r && *it == a) ? (long long)(S.panelptr[s] + (i64)(b - S.sfirst[s]) * S.ld[s] + (it - rows)) : -1;
-            }
+        parallel_ranges(ncol, [&](i64 lo, i64 hi) {
+            for (i64 j = lo; j < hi; j++)
+                for (i64 p = colptr[j] - base; p < colptr[j + 1] - base; p++) {
+                    i64 i = rowval[p] - base;
+                    if (i < 0 || i >= S.n) throw std::invalid_argument("rowval out of range");
+                    off[p] = z_offset(S, i, j);
+                }
+        });
         h->D->gather_z(off.data(), nz, out);
+        return GMRFX_OK;
+    });
+}
+
+extern "C" int32_t gmrfx_selinv_dot(gmrfx_handle *h, int64_t ncol, const int64_t *colptr, const int64_t *rowval,
+                                    const double *nzval, int32_t base, double *out) {
+    return guarded(h, [&]() -> int32_t {
+        if (int32_t e = need_device(h, true)) return e;
+        const Symbolic &S = h->S;
+        if (ncol != S.n) throw std::invalid_argument("B must have n columns");
+        if (!colptr || !rowval || !nzval || !out) throw std::invalid_argument("null argument");
+        if (base != 0 && base != 1) throw std::invalid_argument("index_base must be 0 or 1");
+        h->D->selinv_compute();
+        const i64 nz = colptr[ncol] - base;
+        std::vector<long long> off((size_t)nz);
+        parallel_ranges(ncol, [&](i64 lo, i64 hi) {
+            for (i64 j = lo; j < hi; j++)
+                for (i64 p = colptr[j] - base; p < colptr[j + 1] - base; p++) {
+                    i64 i = rowval[p] - base;
+                    if (i < 0 || i >= S.n) throw std::invalid_argument("rowval out of range");
+                    off[p] = z_offset(S, i, j);
+                }
+        });
+        // fixed chunks of 4096 entries are summed on the device, the chunk sums on the host in order
+        const i64 CH = 4096, nseg = (nz + CH - 1) / CH;
+        std::vector<long long> seg((size_t)nseg + 1);
+        for (i64 g = 0; g <= nseg; g++) seg[g] = std::min(g * CH, nz);
+        std::vector<double> part((size_t)nseg);
+        h->D->weighted_z_sums(seg.data(), nseg, off.data(), nzval + 0, part.data());
+        double acc = 0.0;
+        for (double v : part) acc += v;
+        *out = acc;
+        return GMRFX_OK;
+    });
+}
+
+extern "C" int32_t gmrfx_selinv_row_diag(gmrfx_handle *h, int64_t m, const int64_t *rowptr, const int64_t *colind,
+                                         const double *values, int32_t base, double *out) {
+    return guarded(h, [&]() -> int32_t {
+        if (int32_t e = need_device(h, true)) return e;
+        const Symbolic &S = h->S;
+        if (m < 0 || !rowptr || (m > 0 && !out)) throw std::invalid_argument("null argument");
+        if (base != 0 && base != 1) throw std::invalid_argument("index_base must be 0 or 1");
+        if (m == 0) return GMRFX_OK;
+        const i64 nz = rowptr[m] - base;
+        if (nz > 0 && (!colind || !values)) throw std::invalid_argument("null argument");
+        h->D->selinv_compute();
+        // per row i: the pairs (p, q <= p) of its entries; Sigma is symmetric, so off-diagonal pairs count twice
+        std::vector<long long> seg((size_t)m + 1);
+        seg[0] = 0;
+        for (i64 i = 0; i < m; i++) {
+            const i64 k = rowptr[i + 1] - rowptr[i];
+            if (k < 0) throw std::invalid_argument("rowptr not monotone");
+            seg[i + 1] = seg[i] + k * (k + 1) / 2;
+        }
+        std::vector<long long> off((size_t)seg[m]);
+        std::vector<double> w((size_t)seg[m]);
+        parallel_ranges(m, [&](i64 lo, i64 hi) {
+            for (i64 i = lo; i < hi; i++) {
+                long long t = seg[i];
+                for (i64 p = rowptr[i] - base; p < rowptr[i + 1] - base; p++) {
+                    const i64 jp = colind[p] - base;
+                    if (jp < 0 || jp >= S.n) throw std::invalid_argument("colind out of range");
+                    for (i64 q = rowptr[i] - base; q <= p; q++) {
+                        const i64 jq = colind[q] - base;
+                        off[t] = z_offset(S, jp, jq);
+                        w[t] = (q == p ? 1.0 : 2.0) * values[p] * values[q];
+                        t++;
+                    }
+                }
+            }
+        });
+        h->D->weighted_z_sums(seg.data(), m, off.data(), w.data(), out);
         return GMRFX_OK;
     });
 }

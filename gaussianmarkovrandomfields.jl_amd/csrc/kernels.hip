@@ -756,6 +756,22 @@ __global__ __launch_bounds__(256) void k_gather(const double *__restrict__ src, 
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i < cnt) { const long long o = off[i]; out[i] = (o >= 0) ? src[o] : 0.0; }
 }
+// out[g] = sum over t in [segptr[g], segptr[g+1]) of w[t] * src[off[t]] (off < 0 -> 0): one wave per segment, lanes
+// stride the segment, butterfly sum in a fixed order (reproducible). Consumers of the selected inverse that only
+// need contractions (diag(A Sigma A'), tr(Sigma B)) never move Sigma's values to the host.
+__global__ __launch_bounds__(64) void k_seg_wsum(const double *__restrict__ src, const long long *__restrict__ segptr,
+                                                 const long long *__restrict__ off, const double *__restrict__ w,
+                                                 double *__restrict__ out) {
+    const long long t0 = segptr[blockIdx.x], t1 = segptr[blockIdx.x + 1];
+    double acc = 0.0;
+    for (long long t = t0 + threadIdx.x; t < t1; t += 64) {
+        const long long o = off[t];
+        acc += w[t] * src[o >= 0 ? o : 0] * (o >= 0 ? 1.0 : 0.0);
+    }
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) acc += __shfl_xor(acc, sh, 64);
+    if (threadIdx.x == 0) out[blockIdx.x] = acc;
+}
 __global__ __launch_bounds__(256) void k_gather_diag(const double *__restrict__ src, const long long *__restrict__ diagoff,
                                                      const int *__restrict__ perm, int n, double *__restrict__ out) {
     const int k = blockIdx.x * 256 + threadIdx.x;
@@ -917,6 +933,11 @@ void launch_logdet(hipStream_t st, const double *L, const long long *diagoff, co
 void launch_gather(hipStream_t st, const double *src, const long long *off, long long cnt, double *out) {
     if (cnt <= 0) return;
     hipLaunchKernelGGL(k_gather, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, src, off, cnt, out);
+}
+void launch_seg_wsum(hipStream_t st, const double *src, const long long *segptr, long long nseg, const long long *off,
+                     const double *w, double *out) {
+    if (nseg <= 0) return;
+    hipLaunchKernelGGL(k_seg_wsum, dim3((unsigned)nseg), dim3(64), 0, st, src, segptr, off, w, out);
 }
 void launch_gather_diag(hipStream_t st, const double *src, const long long *diagoff, const int *perm, int n, double *out) {
     hipLaunchKernelGGL(k_gather_diag, dim3(cdiv(n, 256)), dim3(256), 0, st, src, diagoff, perm, n, out);

@@ -228,6 +228,33 @@ class MI355XBackend:
         B = _as_csc(B)
         return float(np.dot(self.selinv_extract_at(B).data, B.data))
 
+    def selinv_dot_device(self, B) -> float:
+        """tr(Q^-1 B) for a Float64 B, contracted on the device (gmrfx_selinv_dot)."""
+        B = _as_csc(B)
+        if B.shape != (self.n, self.n):
+            raise ValueError("dimension mismatch")
+        colptr = np.ascontiguousarray(B.indptr, dtype=np.int64)
+        rowval = np.ascontiguousarray(B.indices, dtype=np.int64)
+        vals = np.ascontiguousarray(B.data, dtype=np.float64)
+        out = C.c_double(0.0)
+        check(lib().gmrfx_selinv_dot(self._h, self.n, ptr(colptr), ptr(rowval), ptr(vals), 0, C.byref(out)), self._h)
+        return out.value
+
+    def row_diag_ASigmaAt(self, A) -> np.ndarray:
+        """diag(A Sigma A') for a sparse design matrix A (m x n): the predictor marginal variances of
+        linear_predictor_marginals.jl:125-165, contracted on the device from the selected-inverse panels
+        (Sigma = 0 outside the factor pattern, as there)."""
+        A = sp.csr_matrix(A)
+        if A.shape[1] != self.n:
+            raise ValueError("dimension mismatch")
+        A.sum_duplicates()
+        rowptr = np.ascontiguousarray(A.indptr, dtype=np.int64)
+        colind = np.ascontiguousarray(A.indices, dtype=np.int64)
+        vals = np.ascontiguousarray(A.data, dtype=np.float64)
+        out = np.empty(A.shape[0])
+        check(lib().gmrfx_selinv_row_diag(self._h, A.shape[0], ptr(rowptr), ptr(colind), ptr(vals), 0, ptr(out)), self._h)
+        return out
+
     # -- extras --------------------------------------------------------------------------------
     def ordering_permutation(self) -> np.ndarray:
         """Elimination order actually used (0-based): pass it to CHOLMOD to factor the same PQP'."""

@@ -94,6 +94,11 @@ class GMRFWorkspace:
         self.ensure_selinv()
         return self.backend.selinv_extract_at(B)
 
+    def row_diag_ASigmaAt(self, A) -> np.ndarray:
+        """diag(A Sigma A') of a sparse design matrix (linear_predictor_marginals.jl:125-165), on the device."""
+        self.ensure_selinv()
+        return self.backend.row_diag_ASigmaAt(A)
+
     def backward_solve(self, x):
         self.ensure_numeric()
         return self.backend.backend_backward_solve(x)

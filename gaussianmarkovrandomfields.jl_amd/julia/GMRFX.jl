@@ -140,6 +140,29 @@ end
 # values of Sigma are gathered on the GPU; the contraction stays in Julia so B may carry Duals
 selinv_dot(b::MI355XBackend, B::SparseMatrixCSC) = dot(nonzeros(selinv_extract_at(b, B)), nonzeros(B))
 
+# Float64 B: contracted on the device. Anything else (ForwardDiff.Dual values): gather Sigma on B's pattern and
+# contract in Julia, as the generic fallback does.
+function selinv_dot(b::MI355XBackend, B::SparseMatrixCSC{Float64, Int})
+    out = Ref{Float64}(0.0)
+    cp, rv, nz = B.colptr, B.rowval, B.nzval
+    GC.@preserve cp rv nz check(ccall((:gmrfx_selinv_dot, LIB), Int32,
+        (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Int32, Ref{Float64}),
+        b.h.ptr, size(B, 2), cp, rv, nz, 1, out), b.h)
+    return out[]
+end
+selinv_dot(b::MI355XBackend, B::AbstractMatrix) = dot(selinv_extract_at(b, sparse(B)), B)
+
+# diag(A * Sigma * A') for a sparse design matrix (rows of A = columns of At): src/linear_predictor_marginals.jl:125-165
+function row_diag_AΣAt(b::MI355XBackend, A::SparseMatrixCSC{Float64, Int})
+    At = sparse(transpose(A))
+    out = Vector{Float64}(undef, size(A, 1))
+    cp, rv, nz = At.colptr, At.rowval, At.nzval
+    GC.@preserve cp rv nz out check(ccall((:gmrfx_selinv_row_diag, LIB), Int32,
+        (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Int32, Ptr{Float64}),
+        b.h.ptr, size(A, 1), cp, rv, nz, 1, out), b.h)
+    return out
+end
+
 function backend_backward_solve(b::MI355XBackend, x::AbstractVector)
     Z = Vector{Float64}(x); X = similar(Z)          # copies views (backend.jl:282-283)
     GC.@preserve Z X check(ccall((:gmrfx_backward_solve, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64),

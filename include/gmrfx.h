@@ -186,6 +186,18 @@ int32_t gmrfx_selinv_csc(gmrfx_handle *h, int32_t index_base, int64_t *colptr, i
  * SelectedInversion.selinv_extract(Z, B): src/workspace/backend.jl:275-279. */
 int32_t gmrfx_selinv_extract(gmrfx_handle *h, int64_t ncol, const int64_t *colptr, const int64_t *rowval,
                              int32_t index_base, double *out_nzval);
+/* Contractions with the selected inverse, reduced on the device (only the results cross PCIe).
+ * gmrfx_selinv_dot: *out = sum over the stored entries of B (n columns, CSC) of Sigma_ij * B_ij = tr(Q^-1 B) for a
+ * symmetric B whose pattern lies inside the factor pattern (entries outside it contribute 0). Replaces
+ * selinv_dot(b, B) for Float64 B: src/workspace/backend.jl:258-267 (Dual-valued B: use gmrfx_selinv_extract and
+ * contract in Julia).
+ * gmrfx_selinv_row_diag: out[i] = sum_{p,q in row i} A_ip A_iq Sigma[j_p, j_q] = (A Sigma A')_ii for the m rows of a
+ * sparse design matrix given by rows (CSR arrays = the CSC arrays of A'). Replaces _row_diag_AΣAt(A, Σ) /
+ * selinv_extract_at(ws, A' * A): src/linear_predictor_marginals.jl:125-165. */
+int32_t gmrfx_selinv_dot(gmrfx_handle *h, int64_t ncol, const int64_t *colptr, const int64_t *rowval,
+                         const double *nzval, int32_t index_base, double *out);
+int32_t gmrfx_selinv_row_diag(gmrfx_handle *h, int64_t m, const int64_t *rowptr, const int64_t *colind,
+                              const double *values, int32_t index_base, double *out);
 
 /* Elimination order actually used (index_base-based), so CHOLMOD can be run on the identical
  * P Q P' (`CHOLMODBackend(Q; ordering = perm)`, src/workspace/backend.jl:147-149). */

@@ -136,3 +136,28 @@ class OracleFactor:
         Zp = np.empty(self.n + 1, np.int64); Zi = np.empty(nz, np.int64); Zv = np.empty(nz)
         lib().orc_selinv_csc(self._h, Zp, Zi, Zv)
         return sp.csc_matrix((Zv, Zi, Zp), shape=(self.n, self.n))
+
+
+def row_diag_ASigmaAt(F: "OracleFactor", A) -> np.ndarray:
+    """v[i] = sum_{p,q} A[i,p] A[i,q] Sigma[p,q] with Sigma the selected inverse (0 outside the factor pattern):
+    the loop of _row_diag_AΣAt, /root/reference/src/linear_predictor_marginals.jl:145-159, restated."""
+    A = sp.csr_matrix(A)
+    Sig = F.selinv().tocsr()
+    Sig.sort_indices()
+    out = np.zeros(A.shape[0])
+    for i in range(A.shape[0]):
+        lo, hi = A.indptr[i], A.indptr[i + 1]
+        s = 0.0
+        for p in range(lo, hi):
+            for q in range(lo, hi):
+                s += A.data[p] * A.data[q] * Sig[A.indices[p], A.indices[q]]
+        out[i] = s
+    return out
+
+
+def selinv_dot(F: "OracleFactor", B) -> float:
+    """dot(selinv(Q), B) = tr(Q^-1 B): /root/reference/src/workspace/backend.jl:258-267 (Sigma = 0 outside
+    the factor pattern)."""
+    B = sp.csc_matrix(B)
+    Sig = F.selinv().tocsc()
+    return float(Sig.multiply(B).sum())

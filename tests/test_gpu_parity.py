@@ -72,6 +72,61 @@ def test_solve_matches_oracle(case, nrhs):
         assert relerr(X.reshape(n, -1), np.linalg.solve(Q.toarray(), B[:, :X.reshape(n, -1).shape[1]])) < 1e-9
 
 
+def test_selinv_contractions_on_device_match_oracle(case):
+    # diag(A Sigma A') (linear_predictor_marginals.jl:125-165) and tr(Sigma B) (backend.jl:258-267) reduced on the
+    # device from the selected-inverse panels: only m values / one scalar come back
+    _, Q, ws, F = case
+    n = Q.shape[0]
+    rng = np.random.default_rng(17)
+    # rows with two entries (j, k) that are neighbours in Q: every pair lies in pattern(Q), hence in the factor
+    # pattern of BOTH implementations (the GPU's supernodes store a superset of the oracle's pattern(L))
+    C = sp.triu(Q, 0).tocoo()
+    pick = rng.choice(len(C.row), size=min(len(C.row), 300), replace=False)
+    rows = np.repeat(np.arange(len(pick)), 2)
+    cols = np.stack([C.row[pick], C.col[pick]], axis=1).ravel()
+    A = sp.csr_matrix((rng.standard_normal(2 * len(pick)), (rows, cols)), shape=(len(pick), n))   # j == k rows: summed
+    A = sp.vstack([A, sp.csr_matrix((1, n))]).tocsr()          # an empty row too
+    v = ws.row_diag_ASigmaAt(A)
+    vo = orc.row_diag_ASigmaAt(F, A)
+    assert v.shape == (len(pick) + 1,) and v[-1] == 0.0
+    assert np.abs(v - vo).max() <= 1e-8 * max(np.abs(vo).max(), 1e-300)
+    # arbitrary columns: pairs outside the stored pattern count as 0 -- the same numbers as contracting the
+    # extracted sparse Sigma on the host (what the reference does with selinv_extract_at(ws, A'A))
+    k = min(3, n)
+    m = 60
+    rows = np.repeat(np.arange(m), k)
+    cols = np.concatenate([rng.choice(n, size=k, replace=False) for _ in range(m)])
+    A2 = sp.csr_matrix((rng.standard_normal(m * k), (rows, cols)), shape=(m, n))
+    S_loc = ws.selinv_extract_at(sp.csc_matrix(abs(A2).T @ abs(A2))).toarray()
+    want = np.einsum("ij,jk,ik->i", A2.toarray(), S_loc, A2.toarray())
+    assert np.abs(ws.row_diag_ASigmaAt(A2) - want).max() <= 1e-10 * max(np.abs(want).max(), 1e-300)
+    # B = Q itself: tr(Q^-1 Q) = n, the reference's own identity for selinv_dot (test_gmrf_workspace.jl)
+    ws.ensure_selinv()
+    d = ws.backend.selinv_dot_device(Q)
+    assert abs(d - n) <= 1e-8 * n
+    assert abs(d - orc.selinv_dot(F, Q)) <= 1e-8 * n
+    assert abs(d - ws.selinv_dot(Q)) <= 1e-10 * n
+
+
+def test_predictor_variances_of_fem_evaluation_matrix():
+    # A = P1 evaluation at random points of the mesh (3 barycentric weights per row): the nodes of one triangle
+    # are mutual neighbours in Q, so pattern(A'A) lies in pattern(L + L') and diag(A Sigma A') is exact
+    mesh = spde.grid_mesh_2d(18, 18, jitter=0.25)
+    Q = sp.csc_matrix(spde.matern_precision(mesh, 0, 0.4))
+    n = Q.shape[0]
+    rng = np.random.default_rng(2)
+    cells = mesh.cells[rng.integers(0, len(mesh.cells), size=250)]
+    wts = rng.dirichlet(np.ones(3), size=len(cells))
+    A = sp.csr_matrix((wts.ravel(), (np.repeat(np.arange(len(cells)), 3), cells.ravel())), shape=(len(cells), n))
+    ws = gmrfx.GMRFWorkspace(Q, coords=mesh.points)
+    v = ws.row_diag_ASigmaAt(A)
+    Sigma = np.linalg.inv(Q.toarray())
+    want = np.einsum("ij,jk,ik->i", A.toarray(), Sigma, A.toarray())
+    assert np.abs(v - want).max() <= 1e-9 * np.abs(want).max()
+    with pytest.raises(ValueError):
+        ws.backend.row_diag_ASigmaAt(sp.csr_matrix((2, n + 1)))
+
+
 def test_sqmahal_and_logpdf_match_oracle(case):
     # dot(r, Q r) and logpdf of workspace_gmrf.jl:288-292, Q's values and z resident on the device
     _, Q, ws, F = case

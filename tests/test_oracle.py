@@ -111,3 +111,19 @@ def test_oracle_sqmahal_and_logpdf_dense_identity():
     from scipy.stats import multivariate_normal
     want = multivariate_normal(mean=mu, cov=np.linalg.inv(Q.toarray())).logpdf(z)
     assert abs(orc.logpdf(F, Q, z, mu) - want) < 1e-8 * max(1.0, abs(want))
+
+
+def test_oracle_selinv_contractions_dense_identity():
+    # chain-like pattern with full fill inside the band: Sigma on the factor pattern is exact, so the restated
+    # _row_diag_AΣAt / selinv_dot agree with dense algebra whenever the pairs stay inside the pattern
+    Q = sp.csc_matrix(spde.matern_precision(spde.grid_mesh_2d(9, 9), 0, 0.4))
+    n = Q.shape[0]
+    F = orc.OracleFactor(Q)
+    Sigma = np.linalg.inv(Q.toarray())
+    assert abs(orc.selinv_dot(F, Q) - n) < 1e-9 * n
+    A = sp.csr_matrix(abs(Q[:40]))          # rows of Q: pairs within a row are within distance 2 hops x 2 -> check via oracle pattern
+    Sig = F.selinv().toarray()
+    want = np.einsum("ij,jk,ik->i", A.toarray(), Sig, A.toarray())      # Sigma = 0 outside the pattern, as the reference documents
+    assert np.abs(orc.row_diag_ASigmaAt(F, A) - want).max() < 1e-10 * np.abs(want).max()
+    pat = (F.selinv() != 0).toarray()
+    assert np.abs((Sig - Sigma)[pat]).max() < 1e-9
