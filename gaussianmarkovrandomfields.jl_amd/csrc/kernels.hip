@@ -742,12 +742,19 @@ __global__ __launch_bounds__(256) void k_logdet_partial(const double *__restrict
     }
     if (tid == 0) part[blockIdx.x] = sh[0];
 }
-__global__ void k_logdet_final(const double *__restrict__ part, int nparts, double *__restrict__ out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double acc = 0.0;
-        for (int i = 0; i < nparts; i++) acc += part[i];
-        out[0] = 2.0 * acc;
+__global__ __launch_bounds__(256) void k_logdet_final(const double *__restrict__ part, int nparts, double *__restrict__ out) {
+    // fixed tree over the (at most 1024) block sums: reproducible, and 4 us instead of 50 for one serial thread
+    __shared__ double sh[256];
+    const int tid = threadIdx.x;
+    double acc = 0.0;
+    for (int i = tid; i < nparts; i += 256) acc += part[i];
+    sh[tid] = acc;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st) sh[tid] += sh[tid + st];
+        __syncthreads();
     }
+    if (tid == 0) out[0] = 2.0 * sh[0];
 }
 
 // Gather values at precomputed offsets (-1 -> 0.0): selected-inverse extraction.
@@ -928,7 +935,7 @@ void launch_newton_update(hipStream_t st, const double *prior, double *nz, long 
 void launch_logdet(hipStream_t st, const double *L, const long long *diagoff, const unsigned char *own, int n, double *part,
                    int nparts, double *out) {
     hipLaunchKernelGGL(k_logdet_partial, dim3(nparts), dim3(256), 0, st, L, diagoff, own, n, part);
-    hipLaunchKernelGGL(k_logdet_final, dim3(1), dim3(64), 0, st, part, nparts, out);
+    hipLaunchKernelGGL(k_logdet_final, dim3(1), dim3(256), 0, st, part, nparts, out);
 }
 void launch_gather(hipStream_t st, const double *src, const long long *off, long long cnt, double *out) {
     if (cnt <= 0) return;
