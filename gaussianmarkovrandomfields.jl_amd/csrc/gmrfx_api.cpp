@@ -546,6 +546,72 @@ extern "C" int32_t gmrfx_quadform_dev(gmrfx_handle *h, const double *d_nzval, co
     return quadform_impl(h, d_nzval, d_X, ldx, nvec, d_mu, out, true);
 }
 
+namespace gmrfx {
+struct KlTask { long long rows_off; long long cols_off; int nrows, ncols; };
+long long kl_cholesky_run(int device, long long n, const double *theta, long long ldt, bool theta_on_device,
+                          const std::vector<KlTask> &tasks, const std::vector<int> &rows, const std::vector<int> &cols,
+                          const long long *Lcolptr, long long nnzL, double reg, double *nzval_out);
+}
+
+extern "C" int32_t gmrfx_kl_cholesky(int64_t n, const double *theta, int64_t ldt, int32_t theta_on_device,
+                                     const int64_t *L_colptr, int64_t ntasks, const int64_t *task_rowptr,
+                                     const int64_t *task_rows, const int64_t *task_colptr, const int64_t *task_cols,
+                                     int32_t base, double reg, int32_t device, double *nzval, int64_t *info) {
+    if (info) *info = 0;
+    try {
+        if (n <= 0 || !theta || ldt < n || !L_colptr || !nzval) throw std::invalid_argument("kl_cholesky: null argument / ldt < n");
+        if (ntasks < 0 || (ntasks > 0 && (!task_rowptr || !task_rows || !task_colptr || !task_cols)))
+            throw std::invalid_argument("kl_cholesky: null task arrays");
+        if (base != 0 && base != 1) throw std::invalid_argument("index_base must be 0 or 1");
+        if (n > 0x7fffffffLL || ntasks > 0x7fffffffLL) throw std::invalid_argument("kl_cholesky: too large");
+        std::vector<long long> colptr((size_t)n + 1);
+        for (i64 j = 0; j <= n; j++) colptr[j] = L_colptr[j] - base;
+        for (i64 j = 0; j < n; j++) if (colptr[j + 1] < colptr[j]) throw std::invalid_argument("L_colptr not monotone");
+        const i64 nnzL = colptr[n];
+        std::vector<KlTask> tasks((size_t)ntasks);
+        const i64 nr = ntasks ? task_rowptr[ntasks] - base : 0, nc = ntasks ? task_colptr[ntasks] - base : 0;
+        std::vector<int> rows((size_t)nr), cols((size_t)nc);
+        for (i64 k = 0; k < nr; k++) {
+            const i64 v = task_rows[k] - base;
+            if (v < 0 || v >= n) throw std::invalid_argument("task_rows out of range");
+            rows[k] = (int)v;
+        }
+        for (i64 k = 0; k < nc; k++) {
+            const i64 v = task_cols[k] - base;
+            if (v < 0 || v >= n) throw std::invalid_argument("task_cols out of range");
+            cols[k] = (int)v;
+        }
+        for (i64 t = 0; t < ntasks; t++) {
+            KlTask &tk = tasks[t];
+            tk.rows_off = task_rowptr[t] - base; tk.cols_off = task_colptr[t] - base;
+            const i64 a = task_rowptr[t + 1] - task_rowptr[t], b = task_colptr[t + 1] - task_colptr[t];
+            if (a <= 0 || b < 0) throw std::invalid_argument("kl_cholesky: empty task");
+            tk.nrows = (int)a; tk.ncols = (int)b;
+            for (i64 q = 0; q < b; q++) {
+                const int col = cols[tk.cols_off + q];
+                const i64 nk = colptr[col + 1] - colptr[col];
+                if (nk < 1 || nk > a) throw std::invalid_argument("kl_cholesky: a column has more entries than its task has rows");
+            }
+        }
+        const long long bad = kl_cholesky_run(device, n, theta, ldt, theta_on_device != 0, tasks, rows, cols, colptr.data(), nnzL, reg, nzval);
+        if (bad >= 0) {
+            if (info) *info = bad + 1;
+            g_create_err = "kl_cholesky: local covariance block of task " + std::to_string(bad) + " is not positive definite";
+            return GMRFX_ERR_NOT_POSDEF;
+        }
+        return GMRFX_OK;
+    } catch (const std::invalid_argument &e) {
+        g_create_err = e.what();
+        return GMRFX_ERR_INVALID_ARG;
+    } catch (const std::bad_alloc &) {
+        g_create_err = "out of host memory";
+        return GMRFX_ERR_ALLOC;
+    } catch (const std::exception &e) {
+        g_create_err = e.what();
+        return std::string(e.what()).find("no HIP device") != std::string::npos ? GMRFX_ERR_NO_DEVICE : GMRFX_ERR_HIP;
+    }
+}
+
 extern "C" int32_t gmrfx_get_stats(const gmrfx_handle *h, gmrfx_stats *out, int32_t struct_size) {
     if (!h || !out || struct_size <= 0) return GMRFX_ERR_INVALID_ARG;
     gmrfx_stats st;

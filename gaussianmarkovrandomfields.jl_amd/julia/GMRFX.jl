@@ -218,6 +218,27 @@ function sqmahal(b::MI355XBackend, X::StridedVecOrMat{Float64}; mean::Union{Noth
     return X isa AbstractVector ? out[1] : out
 end
 
+# KL (Vecchia) sparse approximate Cholesky on the GPU (src/kl_cholesky/kl_cholesky.jl:32-55): same contract as the
+# reference method, for a dense Float64 covariance. One task per column: its row indices in descending order.
+function G.sparse_approximate_cholesky!(Θ::Matrix{Float64}, L::SparseMatrixCSC{Float64, Int}; device::Integer = -1)
+    n = size(L, 2)
+    rows = similar(L.rowval)
+    for k in 1:n
+        r = nzrange(L, k)
+        rows[r] .= @view L.rowval[reverse(r)]
+    end
+    cols = collect(1:n); colptr_t = collect(1:(n + 1)); info = Ref{Int64}(0)
+    GC.@preserve Θ L rows cols colptr_t begin
+        code = ccall((:gmrfx_kl_cholesky, LIB), Int32,
+            (Int64, Ptr{Float64}, Int64, Int32, Ptr{Int64}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64},
+             Int32, Float64, Int32, Ptr{Float64}, Ref{Int64}),
+            n, Θ, stride(Θ, 2), 0, L.colptr, n, L.colptr, rows, colptr_t, cols, 1, 1.0e-6, device, L.nzval, info)
+    end
+    code == 5 && throw(PosDefException(Int(info[])))
+    check(code)
+    return
+end
+
 function Base.deepcopy_internal(b::MI355XBackend, ::IdDict)   # deepcopy(cache) in Newton loops
     out = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:gmrfx_clone, LIB), Int32, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}), b.h.ptr, out))

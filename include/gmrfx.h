@@ -219,6 +219,23 @@ int32_t gmrfx_symbolic_get(const gmrfx_handle *h, int64_t *super_first, int64_t 
  * with the oracle's L (unique for a given permutation). */
 int32_t gmrfx_get_factor_values(gmrfx_handle *h, double *out);
 
+/* KL-optimal sparse approximate Cholesky factor, L L' ~ Theta^-1: a batch of small dense problems, one
+ * workgroup each. A task = local rows R (task_rows[task_rowptr[t] .. task_rowptr[t+1]), in the caller's local order)
+ * + the columns of L it fills (task_cols[task_colptr[t] ..)): M = Theta[R, R] + reg I = U'U, and for every member
+ * column k with N_k = nnz(L[:, k]) <= |R|: U x = e_{N_k}, nzval[column k] = x[N_k : -1 : 1].
+ *   - sparse_approximate_cholesky!(Theta, L), src/kl_cholesky/kl_cholesky.jl:32-55: one task per column, R = the
+ *     column's row indices in DESCENDING order, reg = 1e-6;
+ *   - sparse_approximate_cholesky(Theta, sc::SupernodeClustering), :74-113: one task per supernode, R = its rows
+ *     (descending), member columns = sc.column_indices[s], reg = 1e-8.
+ * Theta: dense n x n column-major (leading dimension ldt), host or device memory (theta_on_device); L_colptr: the n+1
+ * column pointers of the pattern of L; nzval: host array of nnz(L) doubles, written in L's storage order. A local block
+ * that is not positive definite gives GMRFX_ERR_NOT_POSDEF and *info = 1 + task index (the reference throws
+ * PosDefException from cholesky!). No handle: errors are reported through gmrfx_last_create_error(). GPU only. */
+int32_t gmrfx_kl_cholesky(int64_t n, const double *theta, int64_t ldt, int32_t theta_on_device,
+                          const int64_t *L_colptr, int64_t ntasks, const int64_t *task_rowptr, const int64_t *task_rows,
+                          const int64_t *task_colptr, const int64_t *task_cols, int32_t index_base, double reg,
+                          int32_t device, double *nzval, int64_t *info);
+
 #ifdef __cplusplus
 }
 #endif

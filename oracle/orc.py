@@ -161,3 +161,52 @@ def selinv_dot(F: "OracleFactor", B) -> float:
     B = sp.csc_matrix(B)
     Sig = F.selinv().tocsc()
     return float(Sig.multiply(B).sum())
+
+
+# ---- KL (Vecchia) sparse approximate Cholesky: /root/reference/src/kl_cholesky/kl_cholesky.jl ----------------------
+
+def kl_cholesky_inplace(Theta, L, reg: float = 1e-6) -> sp.csc_matrix:
+    """sparse_approximate_cholesky!(Theta, L), kl_cholesky.jl:32-55, restated loop by loop: per column k the row
+    indices in reverse order, M = Theta[S, S] + reg I = U'U (cholesky!), U x = e_last (ldiv!), L[S, k] = x."""
+    import scipy.linalg as sl
+    Theta = np.asarray(Theta, dtype=np.float64)
+    L = sp.csc_matrix(L, dtype=np.float64).copy()
+    L.sort_indices()
+    for k in range(L.shape[1]):
+        idx = np.arange(L.indptr[k], L.indptr[k + 1])[::-1]
+        S = L.indices[idx]
+        M = Theta[np.ix_(S, S)] + reg * np.eye(len(S))
+        U = sl.cholesky(M, lower=False)
+        x = np.zeros(len(S)); x[-1] = 1.0
+        x = sl.solve_triangular(U, x, lower=False)
+        L.data[idx] = x
+    return L
+
+
+def kl_cholesky_supernodal(Theta, column_indices, row_indices, reg: float = 1e-8) -> sp.csc_matrix:
+    """sparse_approximate_cholesky(Theta, sc), kl_cholesky.jl:74-113 (+ the pattern of :57-72), restated: per
+    supernode one Cholesky of Theta[R, R] + reg I (R as given: descending), per member column k the right-hand
+    side e_{N_k}, N_k = nnz(L[:, k]), and L.nzval[column k] = x[N_k:-1:1]."""
+    import scipy.linalg as sl
+    Theta = np.asarray(Theta, dtype=np.float64)
+    n = Theta.shape[0]
+    Is, Js = [], []
+    for cols, rows in zip(column_indices, row_indices):
+        for j in cols:
+            for i in rows:
+                if j <= i:
+                    Is.append(i); Js.append(j)
+    L = sp.csc_matrix((np.ones(len(Is)), (Is, Js)), shape=(n, n))
+    L.sum_duplicates(); L.sort_indices()
+    for cols, rows in zip(column_indices, row_indices):
+        R = np.asarray(rows)
+        M = Theta[np.ix_(R, R)] + reg * np.eye(len(R))
+        U = sl.cholesky(M, lower=False)
+        X = np.zeros((len(R), len(cols)))
+        for q, k in enumerate(cols):
+            X[L.indptr[k + 1] - L.indptr[k] - 1, q] = 1.0
+        X = sl.solve_triangular(U, X, lower=False)
+        for q, k in enumerate(cols):
+            nk = L.indptr[k + 1] - L.indptr[k]
+            L.data[L.indptr[k]:L.indptr[k + 1]] = X[:nk, q][::-1]
+    return L

@@ -647,3 +647,77 @@ def test_newton_update_on_device_matches_host_update():
     assert np.array_equal(be.factor_values(), ref.factor_values())
     with pytest.raises(ValueError):
         be.refactorize_update(np.zeros(3))
+
+
+# ---- KL (Vecchia) sparse approximate Cholesky: kl_cholesky.jl:32-55 and :74-113 -------------------
+
+def _kl_problem(n, rho_len, seed):
+    rng = np.random.default_rng(seed)
+    X = rng.random((n, 2))
+    d = np.linalg.norm(X[:, None, :] - X[None, :, :], axis=-1)
+    K = (1 + np.sqrt(3) * d / 0.3) * np.exp(-np.sqrt(3) * d / 0.3)          # Matern 3/2, as in the reference's test
+    from gmrfx import klchol
+    return X, K, klchol.radius_pattern(X, rho_len)
+
+
+@pytest.mark.parametrize("n,rho_len", [(4, 2.0), (60, 0.25), (300, 0.12), (300, 0.3), (500, 0.5), (400, 2.0)])
+def test_kl_cholesky_columns_match_oracle(n, rho_len):
+    # local systems of up to 32 / 64 / 128 rows (LDS classes) and beyond (global-scratch class; (400, 2.0) is the
+    # complete pattern: 400-row systems and L L' = (K + 1e-6 I)^-1 exactly)
+    from gmrfx import klchol
+    X, K, P = _kl_problem(n, rho_len, seed=n)
+    L = klchol.sparse_approximate_cholesky_inplace(K, P)
+    Lo = orc.kl_cholesky_inplace(K, P)
+    assert (L.indices == Lo.indices).all() and (L.indptr == Lo.indptr).all()
+    assert abs(L - Lo).max() <= 1e-8 * abs(Lo).max()
+    assert abs(sp.triu(L, 1)).sum() == 0 and (L.diagonal() > 0).all()
+    if rho_len >= 2.0:
+        Qk = (L @ L.T).toarray()
+        want = np.linalg.inv(K + 1e-6 * np.eye(n))
+        assert np.abs(Qk - want).max() <= 1e-6 * np.abs(want).max()
+
+
+def test_kl_cholesky_reference_known_answers():
+    # test/kl_cholesky/test_sparse_cholesky.jl:14-25: diagonal Theta, full lower pattern
+    from gmrfx import klchol
+    Theta = np.diag([1.0, 2.0, 3.0, 4.0])
+    L = klchol.sparse_approximate_cholesky_inplace(Theta, sp.csc_matrix(np.tril(np.ones((4, 4)))))
+    assert abs(sp.triu(L, 1)).sum() == 0
+    assert np.abs((L @ L.T).toarray() - np.linalg.inv(Theta)).max() < 1e-4
+    # a block that is not positive definite is reported, not silently factored (the reference throws PosDefException)
+    bad = np.array([[1.0, 2.0], [2.0, 1.0]])
+    with pytest.raises(gmrfx.PosDefException):
+        klchol.sparse_approximate_cholesky_inplace(bad, sp.csc_matrix(np.tril(np.ones((2, 2)))))
+    with pytest.raises(ValueError):
+        klchol._run(np.eye(3), [0, 1, 2, 3], [0, 1], [5], [0, 1], [0], 1e-6, -1)
+
+
+def test_kl_cholesky_supernodal_matches_oracle():
+    from gmrfx import klchol
+    X, K, P = _kl_problem(240, 0.2, seed=7)
+    n = len(X)
+    # supernodes in the spirit of form_supernodes (supernodes.jl:58-90): walk the columns, open a supernode at the
+    # first unassigned column j, adopt the unassigned rows of its pattern that lie close to it; the supernode's
+    # rows = the union of the members' patterns, descending
+    assigned = np.zeros(n, bool)
+    col_idx, row_idx = [], []
+    for j in range(n):
+        if assigned[j]:
+            continue
+        pj = P.indices[P.indptr[j]:P.indptr[j + 1]]
+        members = [i for i in pj if not assigned[i] and np.linalg.norm(X[i] - X[j]) < 0.08]
+        assigned[members] = True
+        rows = set()
+        for k in members:
+            rows.update(P.indices[P.indptr[k]:P.indptr[k + 1]].tolist())
+        rows.update(members)
+        col_idx.append(sorted(members)); row_idx.append(sorted(rows, reverse=True))
+    assert max(map(len, col_idx)) > 1
+    L = klchol.sparse_approximate_cholesky_supernodal(K, col_idx, row_idx)
+    Lo = orc.kl_cholesky_supernodal(K, col_idx, row_idx)
+    assert (L.indices == Lo.indices).all() and (L.indptr == Lo.indptr).all()
+    assert abs(L - Lo).max() <= 1e-8 * abs(Lo).max()
+    # and the resulting precision is a usable GMRF: it enters the hot path and its logdet matches the dense one
+    Qk = sp.csc_matrix(L @ L.T)
+    ws = gmrfx.GMRFWorkspace(Qk)
+    assert abs(ws.logdet() - np.linalg.slogdet(Qk.toarray())[1]) <= 1e-9 * abs(ws.logdet())

@@ -127,3 +127,34 @@ def test_oracle_selinv_contractions_dense_identity():
     assert np.abs(orc.row_diag_ASigmaAt(F, A) - want).max() < 1e-10 * np.abs(want).max()
     pat = (F.selinv() != 0).toarray()
     assert np.abs((Sig - Sigma)[pat]).max() < 1e-9
+
+
+def test_oracle_kl_cholesky_reference_identities():
+    # the known answers of the reference's own tests (test/kl_cholesky/test_sparse_cholesky.jl:14-40): diagonal
+    # Theta with the full lower pattern gives L L' = inv(Theta) (atol 1e-4 because of the 1e-6 I), L lower
+    # triangular with a positive diagonal; and, for ANY SPD Theta, the full pattern makes L L' exactly
+    # (Theta + 1e-6 I)^-1 -- the KL-optimal factor of a complete pattern is the exact inverse factor
+    Theta = np.diag([1.0, 2.0, 3.0, 4.0])
+    full = sp.csc_matrix(np.tril(np.ones((4, 4))))
+    L = orc.kl_cholesky_inplace(Theta, full)
+    assert abs(sp.triu(L, 1)).sum() == 0
+    assert np.abs((L @ L.T).toarray() - np.linalg.inv(Theta)).max() < 1e-4
+    rng = np.random.default_rng(42)
+    A = rng.random((6, 6)); Theta = (A + A.T) / 2 + 6 * np.eye(6)
+    L = orc.kl_cholesky_inplace(Theta, sp.csc_matrix(np.tril(np.ones((6, 6)))))
+    assert (L.diagonal() > 0).all()
+    assert np.abs((L @ L.T).toarray() - np.linalg.inv(Theta + 1e-6 * np.eye(6))).max() < 1e-12
+    # one supernode holding every column = the same complete pattern (regularisation 1e-8 there)
+    Ls = orc.kl_cholesky_supernodal(Theta, [list(range(6))], [list(range(5, -1, -1))])
+    assert np.abs((Ls @ Ls.T).toarray() - np.linalg.inv(Theta + 1e-8 * np.eye(6))).max() < 1e-12
+    # supernodes whose members have exactly the supernode's pattern agree with the column-wise routine
+    # (test_sparse_cholesky.jl:82-108 compares the two variants through their approximation error)
+    X = np.stack(np.meshgrid(np.arange(0, 1.01, 0.3), np.arange(0, 1.01, 0.3)), -1).reshape(-1, 2)
+    K = np.exp(-((X[:, None, :] - X[None, :, :]) ** 2).sum(-1) / 0.4)
+    n = len(X)
+    cols = [[k] for k in range(n)]
+    rows = [sorted([i for i in range(k, n) if np.linalg.norm(X[i] - X[k]) < 0.7], reverse=True) for k in range(n)]
+    pat = sp.csc_matrix((np.ones(sum(map(len, rows))), (np.concatenate(rows), np.repeat(np.arange(n), list(map(len, rows))))), shape=(n, n))
+    La = orc.kl_cholesky_inplace(K, pat, reg=1e-8)
+    Lb = orc.kl_cholesky_supernodal(K, cols, rows, reg=1e-8)
+    assert abs(La - Lb).max() < 1e-12 * abs(La).max()
