@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 
@@ -45,8 +46,16 @@ void Device::init(const Symbolic &S, int dev) {
     if (dev >= count) throw std::runtime_error("HIP device ordinal out of range");
     device = dev;
     HC(hipSetDevice(device));
-    HC(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    HC(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+    {
+        // the main stream carries the dependent chain of the factorisation / sweeps: highest priority; the side
+        // stream (dense inverses) only fills idle capacity: lowest
+        int lo = 0, hi = 0;
+        HC(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        const char *e = std::getenv("GMRFX_STREAM_PRIO");
+        const bool prio = !e || std::atoi(e) != 0;
+        HC(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, prio ? hi : 0));
+        HC(hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, prio ? lo : 0));
+    }
     HC(hipEventCreateWithFlags(&ev_fact_, hipEventDisableTiming));
     HC(hipEventCreateWithFlags(&ev_inv_, hipEventDisableTiming));
     for (auto &ev : ev_) HC(hipEventCreate(&ev));
