@@ -3,3 +3,4 @@ libgmrfx.so to GaussianMarkovRandomFields.jl's solver seams. See INTEGRATION.md.
 from .backend import MI355XBackend, SymbolicInfo  # noqa: F401
 from .workspace import GMRFWorkspace, WorkspacePool  # noqa: F401
 from ._lib import GmrfxError, NoDeviceError, PosDefException  # noqa: F401
+from .kron import KroneckerWorkspace  # noqa: F401

@@ -721,3 +721,24 @@ def test_kl_cholesky_supernodal_matches_oracle():
     Qk = sp.csc_matrix(L @ L.T)
     ws = gmrfx.GMRFWorkspace(Qk)
     assert abs(ws.logdet() - np.linalg.slogdet(Qk.toarray())[1]) <= 1e-9 * abs(ws.logdet())
+
+
+def test_kronecker_workspace_matches_dense_kron():
+    # Q = kron(Q_t, Q_s) (SeparableModel, separable.jl:143-156: rightmost factor fastest), answered from the two
+    # factor-scale workspaces; logdet by the factor rule of precision_logdet (separable.jl:122-141)
+    Qt = sp.csc_matrix(spde.ar1_precision(6, 0.9))
+    Qs = sp.csc_matrix(spde.matern_precision(spde.grid_mesh_2d(7, 7, jitter=0.2), 0, 0.5))
+    kw = gmrfx.KroneckerWorkspace(Qt, Qs)
+    Q = sp.kron(Qt, Qs).toarray()
+    n = Q.shape[0]
+    assert kw.dimension() == n
+    assert abs(kw.logdet() - np.linalg.slogdet(Q)[1]) <= 1e-10 * abs(kw.logdet())
+    rng = np.random.default_rng(0)
+    b = rng.standard_normal(n)
+    assert relerr(kw.solve(b), np.linalg.solve(Q, b)) < 1e-10
+    Sigma = np.linalg.inv(Q)
+    assert relerr(kw.selinv_diag(), np.diag(Sigma)) < 1e-9
+    A = np.stack([kw.backward_solve(e) for e in np.eye(n)], axis=1)      # the sampling map z -> x
+    assert relerr(A @ A.T, Sigma) < 1e-9
+    with pytest.raises(ValueError):
+        kw.solve(np.zeros(n + 1))
