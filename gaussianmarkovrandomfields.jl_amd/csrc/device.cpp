@@ -26,6 +26,7 @@ template <class T> T *Device::dalloc(size_t count) {
 }
 
 Device::~Device() {
+    for (size_t k = 0; k < rd_plans_.size(); k++) rowdiag_plan_free((long long)k);
     if (stream) { (void)hipStreamSynchronize(stream); }
     for (void *p : allocs_) (void)hipFree(p);
     for (auto &e : ev_) if (e) (void)hipEventDestroy(e);
@@ -694,6 +695,48 @@ void Device::weighted_z_sums(const long long *segptr_host, long long nseg, const
     launch_seg_wsum(stream, d_Z_, (const long long *)bseg.p, nseg, (const long long *)boff.p, (const double *)bw.p, (double *)bout.p);
     HC(hipMemcpyAsync(out_host, bout.p, (size_t)nseg * sizeof(double), hipMemcpyDeviceToHost, stream));
     HC(hipStreamSynchronize(stream));
+}
+
+long long Device::rowdiag_plan_create(const long long *segptr_host, long long nseg, const long long *off_host, const int *p_host,
+                                      const int *q_host, long long nvals) {
+    HC(hipSetDevice(device));
+    if (nseg > 0x7fffffffLL) throw std::invalid_argument("too many rows");
+    RowDiagPlan P;
+    P.nseg = nseg; P.cnt = nseg > 0 ? segptr_host[nseg] : 0; P.nvals = nvals;
+    auto grab = [&](void **p, size_t bytes) { HC(hipMalloc(p, std::max<size_t>(bytes, 8))); };
+    grab((void **)&P.seg, (size_t)(nseg + 1) * sizeof(long long));
+    grab((void **)&P.off, (size_t)P.cnt * sizeof(long long));
+    grab((void **)&P.p, (size_t)P.cnt * sizeof(int));
+    grab((void **)&P.q, (size_t)P.cnt * sizeof(int));
+    grab((void **)&P.vals, (size_t)nvals * sizeof(double));
+    grab((void **)&P.out, (size_t)nseg * sizeof(double));
+    HC(hipMemcpyAsync(P.seg, segptr_host, (size_t)(nseg + 1) * sizeof(long long), hipMemcpyHostToDevice, stream));
+    HC(hipMemcpyAsync(P.off, off_host, (size_t)P.cnt * sizeof(long long), hipMemcpyHostToDevice, stream));
+    HC(hipMemcpyAsync(P.p, p_host, (size_t)P.cnt * sizeof(int), hipMemcpyHostToDevice, stream));
+    HC(hipMemcpyAsync(P.q, q_host, (size_t)P.cnt * sizeof(int), hipMemcpyHostToDevice, stream));
+    HC(hipStreamSynchronize(stream));
+    for (size_t k = 0; k < rd_plans_.size(); k++)
+        if (!rd_plans_[k].seg) { rd_plans_[k] = P; return (long long)k; }
+    rd_plans_.push_back(P);
+    return (long long)rd_plans_.size() - 1;
+}
+
+void Device::rowdiag_plan_apply(long long id, const double *values_host, double *out_host) {
+    HC(hipSetDevice(device));
+    if (id < 0 || id >= (long long)rd_plans_.size() || !rd_plans_[id].seg) throw std::invalid_argument("unknown row-diag plan");
+    const RowDiagPlan &P = rd_plans_[id];
+    if (P.nseg <= 0) return;
+    HC(hipMemcpyAsync(P.vals, values_host, (size_t)P.nvals * sizeof(double), hipMemcpyHostToDevice, stream));
+    launch_seg_wsum_pairs(stream, d_Z_, P.seg, P.nseg, P.off, P.p, P.q, P.vals, P.out);
+    HC(hipMemcpyAsync(out_host, P.out, (size_t)P.nseg * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HC(hipStreamSynchronize(stream));
+}
+
+void Device::rowdiag_plan_free(long long id) {
+    if (id < 0 || id >= (long long)rd_plans_.size() || !rd_plans_[id].seg) return;
+    RowDiagPlan &P = rd_plans_[id];
+    (void)hipFree(P.seg); (void)hipFree(P.off); (void)hipFree(P.p); (void)hipFree(P.q); (void)hipFree(P.vals); (void)hipFree(P.out);
+    P = RowDiagPlan{};
 }
 
 void Device::copy_factor(double *out_host) {

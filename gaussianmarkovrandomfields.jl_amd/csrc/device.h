@@ -99,6 +99,12 @@ public:
     void gather_z(const long long *offsets_host, long long cnt, double *out_host);  // offsets into panel storage, -1 -> 0.0
     // out[g] = sum_{t in segment g} w[t] * Z[off[t]] (off = -1 -> 0), all arrays on the host; Z = selected inverse panels
     void weighted_z_sums(const long long *segptr_host, long long nseg, const long long *off_host, const double *w_host, double *out_host);
+    // diag(A Sigma A') with the pair plan of a design matrix kept on the device: only A's values go in and the m
+    // results come out per call (the plan depends on the pattern of A and on the symbolic structure only)
+    long long rowdiag_plan_create(const long long *segptr_host, long long nseg, const long long *off_host, const int *p_host,
+                                  const int *q_host, long long nvals);
+    void rowdiag_plan_apply(long long id, const double *values_host, double *out_host);
+    void rowdiag_plan_free(long long id);
     void copy_factor(double *out_host);
     long long fail_col();
 
@@ -151,6 +157,8 @@ private:
     int first_multiblock_level_ = 0;
     long long rhs_cap_ = 0, io_cap_ = 0, tmp_cap_ = 0;
     int *d_info_ = nullptr;
+    struct RowDiagPlan { long long nseg = 0, cnt = 0, nvals = 0; long long *seg = nullptr, *off = nullptr; int *p = nullptr, *q = nullptr; double *vals = nullptr, *out = nullptr; };
+    std::vector<RowDiagPlan> rd_plans_;
     // caller's CSC pattern, uploaded on the first quadform call
     long long *d_in_colptr_ = nullptr;
     int *d_in_row_ = nullptr;

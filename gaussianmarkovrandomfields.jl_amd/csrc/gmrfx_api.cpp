@@ -463,43 +463,82 @@ extern "C" int32_t gmrfx_selinv_dot(gmrfx_handle *h, int64_t ncol, const int64_t
     });
 }
 
+// pairs (p, q <= p) of the entries of every row of a sparse design matrix + the offsets of Sigma[j_p, j_q]
+static void plan_row_pairs(const Symbolic &S, int64_t m, const int64_t *rowptr, const int64_t *colind, int32_t base,
+                           std::vector<long long> &seg, std::vector<long long> &off, std::vector<int> &pi, std::vector<int> &qi) {
+    seg.assign((size_t)m + 1, 0);
+    for (i64 i = 0; i < m; i++) {
+        const i64 k = rowptr[i + 1] - rowptr[i];
+        if (k < 0) throw std::invalid_argument("rowptr not monotone");
+        seg[i + 1] = seg[i] + k * (k + 1) / 2;
+    }
+    const i64 nz = rowptr[m] - base;
+    if (nz > 0x7fffffffLL) throw std::invalid_argument("design matrix too large");
+    off.resize((size_t)seg[m]); pi.resize((size_t)seg[m]); qi.resize((size_t)seg[m]);
+    parallel_ranges(m, [&](i64 lo, i64 hi) {
+        for (i64 i = lo; i < hi; i++) {
+            long long t = seg[i];
+            for (i64 p = rowptr[i] - base; p < rowptr[i + 1] - base; p++) {
+                const i64 jp = colind[p] - base;
+                if (jp < 0 || jp >= S.n) throw std::invalid_argument("colind out of range");
+                for (i64 q = rowptr[i] - base; q <= p; q++) {
+                    off[t] = z_offset(S, jp, colind[q] - base);
+                    pi[t] = (int)p; qi[t] = (int)q;
+                    t++;
+                }
+            }
+        }
+    });
+}
+
 extern "C" int32_t gmrfx_selinv_row_diag(gmrfx_handle *h, int64_t m, const int64_t *rowptr, const int64_t *colind,
                                          const double *values, int32_t base, double *out) {
     return guarded(h, [&]() -> int32_t {
         if (int32_t e = need_device(h, true)) return e;
-        const Symbolic &S = h->S;
         if (m < 0 || !rowptr || (m > 0 && !out)) throw std::invalid_argument("null argument");
         if (base != 0 && base != 1) throw std::invalid_argument("index_base must be 0 or 1");
         if (m == 0) return GMRFX_OK;
-        const i64 nz = rowptr[m] - base;
-        if (nz > 0 && (!colind || !values)) throw std::invalid_argument("null argument");
+        if (rowptr[m] - base > 0 && (!colind || !values)) throw std::invalid_argument("null argument");
         h->D->selinv_compute();
-        // per row i: the pairs (p, q <= p) of its entries; Sigma is symmetric, so off-diagonal pairs count twice
-        std::vector<long long> seg((size_t)m + 1);
-        seg[0] = 0;
-        for (i64 i = 0; i < m; i++) {
-            const i64 k = rowptr[i + 1] - rowptr[i];
-            if (k < 0) throw std::invalid_argument("rowptr not monotone");
-            seg[i + 1] = seg[i] + k * (k + 1) / 2;
-        }
-        std::vector<long long> off((size_t)seg[m]);
-        std::vector<double> w((size_t)seg[m]);
-        parallel_ranges(m, [&](i64 lo, i64 hi) {
-            for (i64 i = lo; i < hi; i++) {
-                long long t = seg[i];
-                for (i64 p = rowptr[i] - base; p < rowptr[i + 1] - base; p++) {
-                    const i64 jp = colind[p] - base;
-                    if (jp < 0 || jp >= S.n) throw std::invalid_argument("colind out of range");
-                    for (i64 q = rowptr[i] - base; q <= p; q++) {
-                        const i64 jq = colind[q] - base;
-                        off[t] = z_offset(S, jp, jq);
-                        w[t] = (q == p ? 1.0 : 2.0) * values[p] * values[q];
-                        t++;
-                    }
-                }
-            }
-        });
+        std::vector<long long> seg, off;
+        std::vector<int> pi, qi;
+        plan_row_pairs(h->S, m, rowptr, colind, base, seg, off, pi, qi);
+        std::vector<double> w(off.size());
+        for (size_t t = 0; t < w.size(); t++) w[t] = (pi[t] == qi[t] ? 1.0 : 2.0) * values[pi[t]] * values[qi[t]];
         h->D->weighted_z_sums(seg.data(), m, off.data(), w.data(), out);
+        return GMRFX_OK;
+    });
+}
+
+extern "C" int32_t gmrfx_selinv_row_diag_plan(gmrfx_handle *h, int64_t m, const int64_t *rowptr, const int64_t *colind,
+                                              int32_t base, int64_t *plan) {
+    return guarded(h, [&]() -> int32_t {
+        if (int32_t e = need_device(h, false)) return e;
+        if (m < 0 || !rowptr || !plan) throw std::invalid_argument("null argument");
+        if (base != 0 && base != 1) throw std::invalid_argument("index_base must be 0 or 1");
+        if (m > 0 && rowptr[m] - base > 0 && !colind) throw std::invalid_argument("null argument");
+        std::vector<long long> seg, off;
+        std::vector<int> pi, qi;
+        plan_row_pairs(h->S, m, rowptr, colind, base, seg, off, pi, qi);
+        *plan = h->D->rowdiag_plan_create(seg.data(), m, off.data(), pi.data(), qi.data(), m > 0 ? rowptr[m] - base : 0);
+        return GMRFX_OK;
+    });
+}
+
+extern "C" int32_t gmrfx_selinv_row_diag_apply(gmrfx_handle *h, int64_t plan, const double *values, double *out) {
+    return guarded(h, [&]() -> int32_t {
+        if (int32_t e = need_device(h, true)) return e;
+        if (!values || !out) throw std::invalid_argument("null argument");
+        h->D->selinv_compute();
+        h->D->rowdiag_plan_apply(plan, values, out);
+        return GMRFX_OK;
+    });
+}
+
+extern "C" int32_t gmrfx_selinv_row_diag_free(gmrfx_handle *h, int64_t plan) {
+    return guarded(h, [&]() -> int32_t {
+        if (int32_t e = need_device(h, false)) return e;
+        h->D->rowdiag_plan_free(plan);
         return GMRFX_OK;
     });
 }

@@ -169,6 +169,8 @@ void launch_quadform(hipStream_t st, int n, const long long *colptr, const int *
                      const double *X, long long ldx, int nvec, const double *mu, double *part, double *out);
 void launch_seg_wsum(hipStream_t st, const double *src, const long long *segptr, long long nseg, const long long *off,
                      const double *w, double *out);
+void launch_seg_wsum_pairs(hipStream_t st, const double *src, const long long *segptr, long long nseg, const long long *off,
+                           const int *pi, const int *qi, const double *vals, double *out);
 void launch_logdet(hipStream_t st, const double *L, const long long *diagoff, const unsigned char *own, int n, double *part,
                    int nparts, double *out);
 void launch_gather(hipStream_t st, const double *src, const long long *off, long long cnt, double *out);

@@ -779,6 +779,23 @@ __global__ __launch_bounds__(64) void k_seg_wsum(const double *__restrict__ src,
     for (int sh = 32; sh > 0; sh >>= 1) acc += __shfl_xor(acc, sh, 64);
     if (threadIdx.x == 0) out[blockIdx.x] = acc;
 }
+// The same with the weights formed on the fly from the values of a sparse design matrix: entry t is the pair
+// (p, q) of entries of one row, weight = A_p A_q (twice for p != q: Sigma is symmetric and only q <= p is listed).
+__global__ __launch_bounds__(64) void k_seg_wsum_pairs(const double *__restrict__ src, const long long *__restrict__ segptr,
+                                                       const long long *__restrict__ off, const int *__restrict__ pi,
+                                                       const int *__restrict__ qi, const double *__restrict__ vals,
+                                                       double *__restrict__ out) {
+    const long long t0 = segptr[blockIdx.x], t1 = segptr[blockIdx.x + 1];
+    double acc = 0.0;
+    for (long long t = t0 + threadIdx.x; t < t1; t += 64) {
+        const long long o = off[t];
+        const int p = pi[t], q = qi[t];
+        acc += (p == q ? 1.0 : 2.0) * vals[p] * vals[q] * src[o >= 0 ? o : 0] * (o >= 0 ? 1.0 : 0.0);
+    }
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) acc += __shfl_xor(acc, sh, 64);
+    if (threadIdx.x == 0) out[blockIdx.x] = acc;
+}
 __global__ __launch_bounds__(256) void k_gather_diag(const double *__restrict__ src, const long long *__restrict__ diagoff,
                                                      const int *__restrict__ perm, int n, double *__restrict__ out) {
     const int k = blockIdx.x * 256 + threadIdx.x;
@@ -945,6 +962,11 @@ void launch_seg_wsum(hipStream_t st, const double *src, const long long *segptr,
                      const double *w, double *out) {
     if (nseg <= 0) return;
     hipLaunchKernelGGL(k_seg_wsum, dim3((unsigned)nseg), dim3(64), 0, st, src, segptr, off, w, out);
+}
+void launch_seg_wsum_pairs(hipStream_t st, const double *src, const long long *segptr, long long nseg, const long long *off,
+                           const int *pi, const int *qi, const double *vals, double *out) {
+    if (nseg <= 0) return;
+    hipLaunchKernelGGL(k_seg_wsum_pairs, dim3((unsigned)nseg), dim3(64), 0, st, src, segptr, off, pi, qi, vals, out);
 }
 void launch_gather_diag(hipStream_t st, const double *src, const long long *diagoff, const int *perm, int n, double *out) {
     hipLaunchKernelGGL(k_gather_diag, dim3(cdiv(n, 256)), dim3(256), 0, st, src, diagoff, perm, n, out);

@@ -61,6 +61,7 @@ EXPORTS = [
     "gmrfx_shard_cb_blocks", "gmrfx_shard_owner", "gmrfx_device_ptr", "gmrfx_logdet_partial", "gmrfx_solve_phase",
     "gmrfx_shard_rows", "gmrfx_set_prior", "gmrfx_refactorize_update", "gmrfx_refactorize_update_dev",
     "gmrfx_quadform", "gmrfx_quadform_dev", "gmrfx_selinv_dot", "gmrfx_selinv_row_diag", "gmrfx_kl_cholesky",
+    "gmrfx_selinv_row_diag_plan", "gmrfx_selinv_row_diag_apply", "gmrfx_selinv_row_diag_free",
 ]
 
 
@@ -112,6 +113,9 @@ def lib():
         L.gmrfx_selinv_dot.argtypes = [vp, i64, vp, vp, vp, i32, C.POINTER(dbl)]
         L.gmrfx_selinv_row_diag.argtypes = [vp, i64, vp, vp, vp, i32, vp]
         L.gmrfx_kl_cholesky.argtypes = [i64, vp, i64, i32, vp, i64, vp, vp, vp, vp, i32, dbl, i32, vp, C.POINTER(i64)]
+        L.gmrfx_selinv_row_diag_plan.argtypes = [vp, i64, vp, vp, i32, C.POINTER(i64)]
+        L.gmrfx_selinv_row_diag_apply.argtypes = [vp, i64, vp, vp]
+        L.gmrfx_selinv_row_diag_free.argtypes = [vp, i64]
         for nm in EXPORTS[2:]:
             if nm not in ("gmrfx_destroy", "gmrfx_device_ptr"):
                 getattr(L, nm).restype = i32

@@ -110,7 +110,7 @@ class MI355XBackend:
     def clone(self) -> "MI355XBackend":
         """deepcopy(cache) semantics (arithmetic/condition/gaussian_approximation.jl:103-109)."""
         other = object.__new__(MI355XBackend)
-        other.__dict__.update({k: v for k, v in self.__dict__.items() if k not in ("_h",)})
+        other.__dict__.update({k: v for k, v in self.__dict__.items() if k not in ("_h", "_rd_plans")})   # plans live in the handle
         h = C.c_void_p()
         check(lib().gmrfx_clone(self._h, C.byref(h)))
         other._h = h
@@ -243,7 +243,31 @@ class MI355XBackend:
     def row_diag_ASigmaAt(self, A) -> np.ndarray:
         """diag(A Sigma A') for a sparse design matrix A (m x n): the predictor marginal variances of
         linear_predictor_marginals.jl:125-165, contracted on the device from the selected-inverse panels
-        (Sigma = 0 outside the factor pattern, as there)."""
+        (Sigma = 0 outside the factor pattern, as there). The pair plan of A's pattern is kept on the device and
+        reused while the pattern stays the same (the hyper-parameter loop changes Q, not A)."""
+        A = sp.csr_matrix(A)
+        if A.shape[1] != self.n:
+            raise ValueError("dimension mismatch")
+        A.sum_duplicates()
+        rowptr = np.ascontiguousarray(A.indptr, dtype=np.int64)
+        colind = np.ascontiguousarray(A.indices, dtype=np.int64)
+        vals = np.ascontiguousarray(A.data, dtype=np.float64)
+        import zlib
+        key = (A.shape[0], len(colind), zlib.crc32(rowptr.tobytes()), zlib.crc32(colind.tobytes()))
+        plans = self.__dict__.setdefault("_rd_plans", {})
+        if key not in plans:
+            if len(plans) >= 4:                                   # a handful of design matrices at most
+                old_key = next(iter(plans))
+                check(lib().gmrfx_selinv_row_diag_free(self._h, plans.pop(old_key)), self._h)
+            pid = C.c_int64(-1)
+            check(lib().gmrfx_selinv_row_diag_plan(self._h, A.shape[0], ptr(rowptr), ptr(colind), 0, C.byref(pid)), self._h)
+            plans[key] = pid.value
+        out = np.empty(A.shape[0])
+        check(lib().gmrfx_selinv_row_diag_apply(self._h, plans[key], ptr(vals), ptr(out)), self._h)
+        return out
+
+    def row_diag_ASigmaAt_once(self, A) -> np.ndarray:
+        """One-shot form (gmrfx_selinv_row_diag): plans, contracts and forgets."""
         A = sp.csr_matrix(A)
         if A.shape[1] != self.n:
             raise ValueError("dimension mismatch")

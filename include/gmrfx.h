@@ -198,6 +198,13 @@ int32_t gmrfx_selinv_dot(gmrfx_handle *h, int64_t ncol, const int64_t *colptr, c
                          const double *nzval, int32_t index_base, double *out);
 int32_t gmrfx_selinv_row_diag(gmrfx_handle *h, int64_t m, const int64_t *rowptr, const int64_t *colind,
                               const double *values, int32_t index_base, double *out);
+/* The same in two steps for a design matrix whose PATTERN stays fixed while Q changes (the hyper-parameter loop):
+ * _plan looks the pairs up once and keeps them on the device (valid for the lifetime of the handle, across
+ * refactorisations), _apply sends A's values (same order as colind) and returns the m variances, _free drops the plan. */
+int32_t gmrfx_selinv_row_diag_plan(gmrfx_handle *h, int64_t m, const int64_t *rowptr, const int64_t *colind,
+                                   int32_t index_base, int64_t *plan);
+int32_t gmrfx_selinv_row_diag_apply(gmrfx_handle *h, int64_t plan, const double *values, double *out);
+int32_t gmrfx_selinv_row_diag_free(gmrfx_handle *h, int64_t plan);
 
 /* Elimination order actually used (index_base-based), so CHOLMOD can be run on the identical
  * P Q P' (`CHOLMODBackend(Q; ordering = perm)`, src/workspace/backend.jl:147-149). */

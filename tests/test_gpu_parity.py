@@ -125,6 +125,19 @@ def test_predictor_variances_of_fem_evaluation_matrix():
     assert np.abs(v - want).max() <= 1e-9 * np.abs(want).max()
     with pytest.raises(ValueError):
         ws.backend.row_diag_ASigmaAt(sp.csr_matrix((2, n + 1)))
+    # the pair plan stays on the device: new values of A and a new Q reuse it (one plan, same numbers as one-shot)
+    assert len(ws.backend._rd_plans) == 1
+    A2 = A.copy(); A2.data *= 1.5
+    Q2 = sp.csc_matrix(spde.matern_precision(mesh, 0, 0.7))
+    ws.update_precision(Q2)
+    v2 = ws.row_diag_ASigmaAt(A2)
+    assert len(ws.backend._rd_plans) == 1
+    assert (v2 == ws.backend.row_diag_ASigmaAt_once(A2)).all()
+    want2 = np.einsum("ij,jk,ik->i", A2.toarray(), np.linalg.inv(Q2.toarray()), A2.toarray())
+    assert np.abs(v2 - want2).max() <= 1e-9 * np.abs(want2).max()
+    # a clone has its own handle and builds its own plan
+    wc = ws.backend.clone()
+    assert np.abs(wc.row_diag_ASigmaAt(A2) - v2).max() <= 1e-12 * np.abs(v2).max()
 
 
 def test_sqmahal_and_logpdf_match_oracle(case):
