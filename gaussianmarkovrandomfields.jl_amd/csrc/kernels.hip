@@ -157,21 +157,23 @@ __global__ __launch_bounds__(256) void k_trsm(DevSym S, const int *__restrict__ 
     if (row0 >= r) return;
     const int ld = fv.ld;
     double *Pp = L + fv.pp;
-    stage_linv(Pp + kb + (long long)kb * ld, ld, w, Ti, threadIdx.x);
-    __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int lm = lane & 15, lk = lane >> 4;
     const int i0 = SPLIT ? row0 : row0 + wave * 16;
-    if (i0 >= r) return;
     const int i = i0 + lm;
     const double *A = Pp + (long long)kb * ld;
     const double *pa = A + min(i, r - 1);
+    // this wave's rows of the block column are requested BEFORE the inverse block is staged: the two global
+    // round trips of this latency-bound kernel overlap instead of following each other
     double bv[16];
 #pragma unroll
     for (int u = 0; u < 16; u++) {
         const int q = 4 * u + lk;
         bv[u] = pa[(long long)min(q, w - 1) * ld];   // B[kk=q][n=i]; Ti is zero for q >= w, rows >= r never stored
     }
+    stage_linv(Pp + kb + (long long)kb * ld, ld, w, Ti, threadIdx.x);
+    __syncthreads();
+    if (i0 >= r) return;
     double *out = MODE == 0 ? Pp + (long long)kb * ld : Yh + yoff[s];
     const int ldo = MODE == 0 ? ld : r;
     // Linv is lower triangular: MODE 0 (A Linv') needs q <= k, MODE 1 (L Linv) needs q >= k
