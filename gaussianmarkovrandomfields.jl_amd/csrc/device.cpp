@@ -30,6 +30,10 @@ Device::~Device() {
     if (stream) { (void)hipStreamSynchronize(stream); }
     for (void *p : allocs_) (void)hipFree(p);
     for (auto &e : ev_) if (e) (void)hipEventDestroy(e);
+    for (auto &l : ev_lane_) for (auto &e : l) if (e) (void)hipEventDestroy(e);
+    if (ev_ready_) (void)hipEventDestroy(ev_ready_);
+    if (ev_done1_) (void)hipEventDestroy(ev_done1_);
+    if (stream3) (void)hipStreamDestroy(stream3);
     for (auto &e : ev_syrk_) if (e) (void)hipEventDestroy(e);
     if (ev_fact_) (void)hipEventDestroy(ev_fact_);
     if (ev_inv_) (void)hipEventDestroy(ev_inv_);
@@ -56,10 +60,14 @@ void Device::init(const Symbolic &S, int dev) {
         const bool prio = !e || std::atoi(e) != 0;
         HC(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, prio ? hi : 0));
         HC(hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, prio ? lo : 0));
+        HC(hipStreamCreateWithPriority(&stream3, hipStreamNonBlocking, prio ? hi : 0));
     }
     HC(hipEventCreateWithFlags(&ev_fact_, hipEventDisableTiming));
     HC(hipEventCreateWithFlags(&ev_inv_, hipEventDisableTiming));
     for (auto &ev : ev_) HC(hipEventCreate(&ev));
+    for (auto &l : ev_lane_) for (auto &ev : l) HC(hipEventCreate(&ev));
+    HC(hipEventCreateWithFlags(&ev_ready_, hipEventDisableTiming));
+    HC(hipEventCreateWithFlags(&ev_done1_, hipEventDisableTiming));
     upload(S);
 }
 
@@ -418,6 +426,11 @@ void Device::ensure_rhs_capacity(long long nrhs) {
         d_W_ = dalloc<double>((size_t)std::max<long long>(sum_trail_, 1) * 64);
         rhs_cap_ = 64;
     }
+    if (nrhs > 64 && !d_Xb_ && !sharded()) {
+        d_Xb_ = dalloc<double>((size_t)S_->n * 64);
+        d_X2b_ = dalloc<double>((size_t)S_->n * 64);
+        d_Wb_ = dalloc<double>((size_t)std::max<long long>(sum_trail_, 1) * 64);
+    }
 }
 
 void Device::forward(int nr, int ldx, int lo, int hi) {
@@ -515,27 +528,67 @@ void Device::solve(const double *B, long long ldb, long long nrhs, double *X, lo
         dB = d_io_; dXo = d_io_; ldin = n; ldout = n;
     }
     double t_perm = 0, t_fwd = 0, t_bwd = 0;
-    for (long long j0 = 0; j0 < nrhs; j0 += 64) {
+    // 64-column passes, alternating between the two lanes when there is more than one pass. forward() / backward()
+    // enqueue on the members `stream`, d_X_, d_X2_, d_W_: a lane is selected by swapping them in for the duration
+    // of the (asynchronous) enqueue.
+    const bool two = nrhs > 64 && d_Xb_ != nullptr;
+    struct LaneState { hipStream_t st; double *X, *X2, *W; };
+    LaneState lanes[2] = {{stream, d_X_, d_X2_, d_W_}, {stream3, d_Xb_, d_X2b_, d_Wb_}};
+    if (two) {
+        // lane 1 starts after everything already enqueued on the main stream (factorisation, upload of B)
+        HC(hipEventRecord(ev_ready_, stream));
+        HC(hipStreamWaitEvent(stream3, ev_ready_, 0));
+    }
+    bool busy[2] = {false, false};
+    auto collect = [&](int ln) {
+        if (!busy[ln]) return;
+        HC(hipEventSynchronize(ev_lane_[ln][4]));
+        float a, b, c, d;
+        HC(hipEventElapsedTime(&a, ev_lane_[ln][0], ev_lane_[ln][1]));
+        HC(hipEventElapsedTime(&b, ev_lane_[ln][1], ev_lane_[ln][2]));
+        HC(hipEventElapsedTime(&c, ev_lane_[ln][2], ev_lane_[ln][3]));
+        HC(hipEventElapsedTime(&d, ev_lane_[ln][3], ev_lane_[ln][4]));
+        t_perm += a + d; t_fwd += b; t_bwd += c;
+        busy[ln] = false;
+    };
+    const hipStream_t main_stream = stream;
+    double *const X0 = d_X_, *const X20 = d_X2_, *const W0 = d_W_;
+    struct Restore {     // the members come back even if a HIP call throws while a lane is swapped in
+        Device &D; hipStream_t st; double *X, *X2, *W;
+        ~Restore() { D.stream = st; D.d_X_ = X; D.d_X2_ = X2; D.d_W_ = W; }
+    } restore{*this, main_stream, X0, X20, W0};
+    HC(hipEventRecord(ev_[0], stream));
+    int pass = 0;
+    for (long long j0 = 0; j0 < nrhs; j0 += 64, pass++) {
         const int nr = (int)std::min<long long>(64, nrhs - j0);
         const int ldx = nr;
-        HC(hipEventRecord(ev_[0], stream));
+        const int ln = two ? (pass & 1) : 0;
+        collect(ln);                         // the lane's previous pass has finished: its buffers are free
+        stream = lanes[ln].st; d_X_ = lanes[ln].X; d_X2_ = lanes[ln].X2; d_W_ = lanes[ln].W;
+        hipEvent_t *ev = ev_lane_[ln];
+        HC(hipEventRecord(ev[0], stream));
         // full solve: X = P b ; backward-only (F.UP \ z): z is taken in elimination order as is
         launch_permute(stream, mode == 0 ? d_iperm_ : nullptr, (int)n, const_cast<double *>(dB) + j0 * ldin, ldin, d_X_, nr, ldx, 0);
-        HC(hipEventRecord(ev_[1], stream));
+        HC(hipEventRecord(ev[1], stream));
         if (mode == 0) forward(nr, ldx, 0, (int)levels_.size());
-        HC(hipEventRecord(ev_[2], stream));
+        HC(hipEventRecord(ev[2], stream));
         backward(nr, ldx, mode == 0, (int)levels_.size(), 0);
-        HC(hipEventRecord(ev_[3], stream));
+        HC(hipEventRecord(ev[3], stream));
         launch_permute(stream, d_iperm_, (int)n, dXo + j0 * ldout, ldout, d_X_, nr, ldx, 1);
-        HC(hipEventRecord(ev_[4], stream));
-        HC(hipStreamSynchronize(stream));
-        float a, b, c, d;
-        HC(hipEventElapsedTime(&a, ev_[0], ev_[1]));
-        HC(hipEventElapsedTime(&b, ev_[1], ev_[2]));
-        HC(hipEventElapsedTime(&c, ev_[2], ev_[3]));
-        HC(hipEventElapsedTime(&d, ev_[3], ev_[4]));
-        t_perm += a + d; t_fwd += b; t_bwd += c;
+        HC(hipEventRecord(ev[4], stream));
+        busy[ln] = true;
+        stream = main_stream; d_X_ = X0; d_X2_ = X20; d_W_ = W0;
     }
+    if (two) {
+        HC(hipEventRecord(ev_done1_, stream3));
+        HC(hipStreamWaitEvent(stream, ev_done1_, 0));
+    }
+    HC(hipEventRecord(ev_[1], stream));
+    collect(0);
+    collect(1);
+    HC(hipStreamSynchronize(stream));
+    float wall = 0;
+    HC(hipEventElapsedTime(&wall, ev_[0], ev_[1]));
     HC(hipGetLastError());
     if (!on_device) {
         const long long need = n * nrhs;
@@ -543,8 +596,10 @@ void Device::solve(const double *B, long long ldb, long long nrhs, double *X, lo
         else HC(hipMemcpy2DAsync(X, ldx_out * sizeof(double), d_io_, n * sizeof(double), n * sizeof(double), nrhs, hipMemcpyDeviceToHost, stream));
         HC(hipStreamSynchronize(stream));
     }
+    // per-phase times are sums over the passes; with two lanes the passes overlap, so the totals are the
+    // elapsed time on the device from the first launch to the last completion
     ms_perm = t_perm; ms_fwd = t_fwd; ms_bwd = t_bwd;
-    if (mode == 0) ms_solve = t_perm + t_fwd + t_bwd; else ms_bsolve = t_perm + t_bwd;
+    if (mode == 0) ms_solve = two ? wall : t_perm + t_fwd + t_bwd; else ms_bsolve = two ? wall : t_perm + t_bwd;
     last_nrhs = nrhs;
 }
 
