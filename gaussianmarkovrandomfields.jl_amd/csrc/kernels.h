@@ -31,12 +31,19 @@ typedef double gmrfx_d4 __attribute__((ext_vector_type(4)));
 // X[k][q] of the dense inverse X = L11^-1 of a big front (0 above the diagonal): strict lower part
 // stored transposed in the strict upper triangle of the panel's diagonal block, diag = 1/L's.
 // Unconditional clamped load + arithmetic mask (see inverse.hip).
+// 1 / v by v_rcp_f64 + one Newton step (error <= 1 ulp for the normal, positive pivots it is used on): 3
+// instructions where the IEEE division sequence takes ~15 -- and the accessors below sit in GEMM inner loops,
+// evaluated for EVERY operand element (the diagonal select is computed unconditionally).
+__device__ __forceinline__ double fast_rcp(double v) {
+    const double y = __builtin_amdgcn_rcp(v);
+    return __builtin_fma(__builtin_fma(-v, y, 1.0), y, y);
+}
 __device__ __forceinline__ double xinv_elem(const double *__restrict__ P, int ld, int c, int k, int q) {
     const int kk = min(max(k, 0), c - 1), qq = min(max(q, 0), c - 1);
     const double v = P[min(kk, qq) + (long long)max(kk, qq) * ld];
     const bool in = k >= 0 && q >= 0 && k < c && q < c;
     double x = v * ((in && q < k) ? 1.0 : 0.0);
-    if (in && k == q) x = 1.0 / v;
+    if (in && k == q) x = fast_rcp(v);
     return x;
 }
 // 32x32 (2x2 MFMA tiles) wave-level product  acc[a][b] += sum_{q in [qlo,qhi)} fa(m0+16a+lm, q) * fb(q, n0+16b+lm)

@@ -131,7 +131,7 @@ __device__ __forceinline__ void stage_linv(const double *__restrict__ Dg, int ld
         const int q = idx % NB, k = idx / NB;
         const double mk = (k < w && q < k) ? 1.0 : 0.0;
         double x = v[u] * mk;
-        if (q == k && k < w) x = 1.0 / v[u];
+        if (q == k && k < w) x = fast_rcp(v[u]);
         Ti[k * NB + q] = x;
     }
 }

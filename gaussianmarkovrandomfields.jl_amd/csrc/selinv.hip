@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void k_sel_diag(DevSym S, const int *__restric
         double v = 0.0;
         if (i < w && j < w) {
             if (j < i) v = Dg[j + (long long)i * ld];
-            else if (j == i) v = 1.0 / Dg[i + (long long)i * ld];
+            else if (j == i) v = fast_rcp(Dg[i + (long long)i * ld]);
         }
         T[idx] = v;
     }

@@ -310,7 +310,7 @@ __device__ __forceinline__ double linv_elem(const double *__restrict__ P, int ld
     const double v = P[min(kk, qq) + (long long)max(kk, qq) * ld];
     const bool on = (k < c && q < c) && (lower ? (q < k) : (q > k));
     double x = v * (on ? 1.0 : 0.0);
-    if (k == q && k < c) x = 1.0 / v;
+    if (k == q && k < c) x = fast_rcp(v);
     return x;
 }
 
