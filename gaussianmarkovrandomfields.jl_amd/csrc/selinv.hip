@@ -213,7 +213,16 @@ __global__ __launch_bounds__(256) void k_sel_dense(DevSym S, const int *__restri
         // m = i (row of L21), n = k
         auto fa = [&](int i, int q) { return P[(c + min(i, m - 1)) + (long long)min(max(q, 0), c - 1) * ld]; };
         auto fb = [&](int q, int k) { return xinv_elem(P, ld, c, q, k); };
-        wave_gemm_32x32(acc, m0, n0, n0, c, fa, fb, lm, lk);
+        // q < n0 + 32 touches the diagonal of X for this tile's columns: masked accessors; beyond it every
+        // X[q][k] (k < q) is a plain element P[k + q ld]: pointer form (rows / columns clamped at the edges only)
+        const int qs = min((n0 + 32 + 3) & ~3, c), qe = c & ~3;
+        wave_gemm_32x32(acc, m0, n0, n0, qs, fa, fb, lm, lk);
+        if (qe > qs) {
+            const double *const pa[2] = {P + c + min(m0 + lm, m - 1), P + c + min(m0 + 16 + lm, m - 1)};
+            const double *const pb[2] = {P + min(n0 + lm, c - 1), P + min(n0 + 16 + lm, c - 1)};
+            wave_gemm_32x32_strided(acc, pa, ld, pb, ld, qs, qe, lk);
+        }
+        if (c > max(qe, qs)) wave_gemm_32x32(acc, m0, n0, max(qe, qs), c, fa, fb, lm, lk);
 #pragma unroll
         for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -230,7 +239,21 @@ __global__ __launch_bounds__(256) void k_sel_dense(DevSym S, const int *__restri
             const int qq = min(max(q, 0), m - 1), ii = min(i, m - 1);
             return ZBs[max(ii, qq) + (long long)min(ii, qq) * m];
         };
-        wave_gemm_32x32(acc, m0, n0, 0, m, fa, fb, lm, lk);
+        // Z22 is symmetric with only its lower triangle stored: q below the tile's rows i reads ZB[i + q m]
+        // (contiguous along the lanes), q above them ZB[q + i m] (contiguous along q); the 32 q's on the tile's
+        // own diagonal block go through the accessor
+        const int ql = min(n0 & ~3, m), qh = min((n0 + 32 + 3) & ~3, m), qe = m & ~3;
+        const double *const pa[2] = {Y + min(m0 + lm, c - 1), Y + min(m0 + 16 + lm, c - 1)};
+        if (ql > 0) {
+            const double *const pb[2] = {ZBs + min(n0 + lm, m - 1), ZBs + min(n0 + 16 + lm, m - 1)};
+            wave_gemm_32x32_strided(acc, pa, c, pb, m, 0, ql, lk);
+        }
+        wave_gemm_32x32(acc, m0, n0, ql, qh, fa, fb, lm, lk);
+        if (qe > qh) {
+            const double *const pb[2] = {ZBs + (long long)min(n0 + lm, m - 1) * m, ZBs + (long long)min(n0 + 16 + lm, m - 1) * m};
+            wave_gemm_32x32_strided(acc, pa, c, pb, 1, qh, qe, lk);
+        }
+        if (m > max(qe, qh)) wave_gemm_32x32(acc, m0, n0, max(qe, qh), m, fa, fb, lm, lk);
 #pragma unroll
         for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -247,11 +270,35 @@ __global__ __launch_bounds__(256) void k_sel_dense(DevSym S, const int *__restri
         // m = b, n = a (a >= b)
         auto fa1 = [&](int b, int k) { return xinv_elem(P, ld, c, k, b); };
         auto fb1 = [&](int k, int a) { return xinv_elem(P, ld, c, k, a); };
-        wave_gemm_32x32(acc, m0, n0, n0, c, fa1, fb1, lm, lk);
+        // a >= b tiles only (n0 >= m0): k < n0 + 32 touches the diagonal of X for the tile's a's; beyond it both
+        // X[k][b] and X[k][a] are plain elements of the upper triangle
+        const int ks = min((n0 + 32 + 3) & ~3, c), ke = c & ~3;
+        wave_gemm_32x32(acc, m0, n0, n0, ks, fa1, fb1, lm, lk);
+        if (ke > ks) {
+            const double *const pa[2] = {P + min(m0 + lm, c - 1), P + min(m0 + 16 + lm, c - 1)};
+            const double *const pb[2] = {P + min(n0 + lm, c - 1), P + min(n0 + 16 + lm, c - 1)};
+            wave_gemm_32x32_strided(acc, pa, ld, pb, ld, ks, ke, lk);
+        }
+        if (c > max(ke, ks)) wave_gemm_32x32(acc, m0, n0, max(ke, ks), c, fa1, fb1, lm, lk);
         if (m > 0) {
             auto fa2 = [&](int b, int q) { return -Zt[min(b, c - 1) + (long long)min(max(q, 0), m - 1) * c]; };
             auto fb2 = [&](int q, int a) { return Y[min(a, c - 1) + (long long)min(max(q, 0), m - 1) * c]; };
-            wave_gemm_32x32(acc, m0, n0, 0, m, fa2, fb2, lm, lk);
+            // no masks at all in this product: pointer form over the whole q range (its sign is applied at the
+            // end: the partial sums of the two products are kept apart in two accumulators)
+            d4 acc2[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++) acc2[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+            const int me = m & ~3;
+            const double *const pa[2] = {Zt + min(m0 + lm, c - 1), Zt + min(m0 + 16 + lm, c - 1)};
+            const double *const pb[2] = {Y + min(n0 + lm, c - 1), Y + min(n0 + 16 + lm, c - 1)};
+            wave_gemm_32x32_strided(acc2, pa, c, pb, c, 0, me, lk);
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++) acc[a][b] -= acc2[a][b];
+            if (m > me) wave_gemm_32x32(acc, m0, n0, me, m, fa2, fb2, lm, lk);
         }
 #pragma unroll
         for (int a = 0; a < 2; a++)

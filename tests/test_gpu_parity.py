@@ -574,21 +574,29 @@ def _shard_gpu_worker(rank, world, port, q):
         ref = g.MI355XBackend(Q, coords=m.points, device=0)
         rv = ref.factor_values()
         same = True
+        why = []
         for s in np.nonzero(mine)[0]:
             a, b = int(sy.panel_ptr[s]), int(sy.panel_ptr[s + 1])
             c, r, ldp = int(sy.super_first[s + 1] - sy.super_first[s]), int(sy.row_ptr[s + 1] - sy.row_ptr[s]), int(sy.panel_ld[s])
             Pa = vals[a:a + ldp * c].reshape(c, ldp).T[:r]
             Pb = rv[a:a + ldp * c].reshape(c, ldp).T[:r]
-            same = same and np.array_equal(np.tril(Pa), np.tril(Pb))
+            if not np.array_equal(np.tril(Pa), np.tril(Pb)):
+                same = False
+                why.append(f"panel {s} (c={c}, r={r}) differs by {np.abs(np.tril(Pa) - np.tril(Pb)).max():.3e}")
         if rank == 0:
             d_Xr = torch.zeros_like(d_B)
             ref.solve_dev(d_B.data_ptr(), Q.shape[0], nrhs, d_Xr.data_ptr(), Q.shape[0])
             torch.cuda.synchronize()
-            same = same and bool(torch.equal(d_X, d_Xr))
+            if not bool(torch.equal(d_X, d_Xr)):
+                same = False
+                why.append(f"sharded solve differs from the unsharded one by {float((d_X - d_Xr).abs().max()):.3e}")
             X = d_X.cpu().numpy().T
             resid = float(np.linalg.norm(Q @ X - Bh.numpy().T) / np.linalg.norm(Bh.numpy()))
-            same = same and resid < 1e-10
-        q.put((rank, ld, ref.compute_logdet(), bool(same), int(mine.sum()), sf.be.shard_info()))
+            if not resid < 1e-10:
+                same = False
+                why.append(f"residual {resid:.3e}")
+        info = dict(sf.be.shard_info()); info["why"] = why[:5]
+        q.put((rank, ld, ref.compute_logdet(), bool(same), int(mine.sum()), info))
         dist.barrier()
         sf.close(); ref.close()
         dist.destroy_process_group()
@@ -616,7 +624,7 @@ def test_sharded_factorisation_rehearsal_on_one_gpu(world):
     [p.join(timeout=120) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     for rank, ld, ld_ref, same, nmine, info in got:
-        assert same and nmine > 0
+        assert same and nmine > 0, f"rank {rank}: {info.get('why')}"
         assert abs(ld - ld_ref) <= 1e-12 * abs(ld_ref)
         assert info["n_top_fronts"] >= 1
 
