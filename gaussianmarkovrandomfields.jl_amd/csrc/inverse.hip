@@ -54,7 +54,16 @@ __global__ __launch_bounds__(256) void k_inv_stage(DevSym S, const int *__restri
         // D[m][n]: m = i (rows of Bm), n = j.  A_mfma[m=i][q] = Bm[i][q] = P[(o+B+i) + (o+q)*ld]
         //                                      B_mfma[q][n=j] = Ainv[q][j] (q >= j) = X[o+q][o+j]
         const double *Ablk = P + o + (long long)o * ld;   // origin of block A inside the panel
-        for (int q0 = (j0 & ~15); q0 < B; q0 += 4 * KU) {
+        // q >= j0 + 32 is below the diagonal of Ainv for every column j of this wave tile: plain elements
+        // Ablk[j + q ld], pointer form; only the first k-steps need the masked accessor
+        const int qs = min(j0 + 32, B);
+        if (B > qs) {
+            const double *const pa[2] = {P + (o + B + min(i0 + lm, nC - 1)) + (long long)o * ld,
+                                         P + (o + B + min(i0 + 16 + lm, nC - 1)) + (long long)o * ld};
+            const double *const pb[2] = {Ablk + j0 + lm, Ablk + j0 + 16 + lm};
+            wave_gemm_32x32_strided(acc, pa, ld, pb, ld, qs, B, lk);
+        }
+        for (int q0 = (j0 & ~15); q0 < qs; q0 += 4 * KU) {
             double av[KU][2], bv[KU][2];
 #pragma unroll
             for (int u = 0; u < KU; u++) {
@@ -90,7 +99,14 @@ __global__ __launch_bounds__(256) void k_inv_stage(DevSym S, const int *__restri
         //                                      B_mfma[q][n=j] = T[q][j] = T'[j + q*B]
         const double *Cblk = P + (o + B) + (long long)(o + B) * ld;
         const int qhi = min(nC, i0 + 32);
-        for (int q0 = 0; q0 < qhi; q0 += 4 * KU) {
+        // q < i0 is left of the diagonal of Cinv for every row i of this wave tile: plain elements Cblk[q + i ld]
+        const int qb = min(i0, nC) & ~15;
+        if (qb > 0) {
+            const double *const pa[2] = {Cblk + (long long)min(i0 + lm, nC - 1) * ld, Cblk + (long long)min(i0 + 16 + lm, nC - 1) * ld};
+            const double *const pb[2] = {Tp + j0 + lm, Tp + j0 + 16 + lm};
+            wave_gemm_32x32_strided(acc, pa, 1, pb, B, 0, qb, lk);
+        }
+        for (int q0 = qb; q0 < qhi; q0 += 4 * KU) {
             double av[KU][2], bv[KU][2];
 #pragma unroll
             for (int u = 0; u < KU; u++) {
