@@ -106,11 +106,13 @@ __global__ __launch_bounds__(256) void k_sel_symm(DevSym S, const int *__restric
     }
 }
 
-// Z[blk,blk] = D^-T D^-1 - Yh' Z[below,blk]; one workgroup per front.
+// Z[blk,blk] = D^-T D^-1 - Yh' Z[below,blk]; one workgroup per front, wave t owns the 16 rows a = 16 t ..
+// Both products run on the MFMA with the SAME accumulator layout (m = b, n = a: a on the lanes, so the final
+// stores walk down a column of Z), G = Yh' Znew straight from HBM with batched clamped loads, D^-T D^-1 from
+// the transposed inverse staged in LDS; no second LDS tile, no scalar dot products.
 __global__ __launch_bounds__(256) void k_sel_diag(DevSym S, const int *__restrict__ list, int kb,
                                                   const double *__restrict__ L, double *__restrict__ Z,
                                                   const double *__restrict__ Yh, const long long *__restrict__ yoff) {
-    __shared__ double D[NB * NB];   // G = Yh' Znew
     __shared__ double T[NB * NB];   // T[j + i*NB] = (D^-1)[i][j]  (transposed inverse)
     const int s = list[blockIdx.x];
     const int c = S.sfirst[s + 1] - S.sfirst[s];
@@ -134,41 +136,51 @@ __global__ __launch_bounds__(256) void k_sel_diag(DevSym S, const int *__restric
         }
         T[idx] = v;
     }
-    // G = Yh' * Znew (K = rows below), kept in registers; wave t owns tile-row t (16 x 64)
+    __syncthreads();
     const int wave = tid >> 6, lane = tid & 63;
     const int lm = lane & 15, lk = lane >> 4;
     const int a0 = wave * 16;
-    d4 acc[4];
+    if (a0 >= w) return;
+    d4 g[4], x[4];
 #pragma unroll
-    for (int t = 0; t < 4; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
-    if (a0 < w) {
-        for (int q0 = o; q0 < r; q0 += 4) {
-            const int q = q0 + lk;
-            const int ka = a0 + lm;
-            const double ya = (q < r && ka < w) ? Y[q + (long long)ka * r] : 0.0;
+    for (int t = 0; t < 4; t++) { g[t] = (d4){0.0, 0.0, 0.0, 0.0}; x[t] = (d4){0.0, 0.0, 0.0, 0.0}; }
+    // G[a][b] = sum_{q below} Yh[q][a] Znew[q][b]; rows q clamped, the Yh operand carries the mask
+    const int ka = min(a0 + lm, w - 1);
+    const double am = (a0 + lm < w) ? 1.0 : 0.0;
+    const double *py = Y + (long long)ka * r;
+    const double *pz[4];
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const int kbcol = t * 16 + lm;
-                const double zb = (q < r && kbcol < w) ? Zp[q + (long long)(kb + kbcol) * ld] : 0.0;
-                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ya, zb, acc[t], 0, 0, 0);
-            }
+    for (int t = 0; t < 4; t++) pz[t] = Zp + (long long)(kb + min(t * 16 + lm, w - 1)) * ld;
+    for (int q0 = o; q0 < r; q0 += 16) {
+        double ya[4], zb[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int q = q0 + 4 * u + lk;
+            const int qc = min(q, r - 1);
+            ya[u] = py[qc] * (q < r ? am : 0.0);
+#pragma unroll
+            for (int t = 0; t < 4; t++) zb[u][t] = pz[t][qc];
         }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) g[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(zb[u][t], ya[u], g[t], 0, 0, 0);
     }
-    __syncthreads();
-    // store G in LDS. D[m][n] of the MFMA -> G[a0 + lk + 4*rr][t*16 + lm]
+    // X[a][b] = sum_k Dinv[k][a] Dinv[k][b] (zero for k < a): k-steps from a0 on
+    for (int k0 = a0; k0 < NB; k0 += 4) {
+        const double ta = T[(a0 + lm) + (k0 + lk) * NB];
+#pragma unroll
+        for (int t = 0; t < 4; t++) x[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(T[(t * 16 + lm) + (k0 + lk) * NB], ta, x[t], 0, 0, 0);
+    }
+    // D[m = b][n = a]: b = 16 t + lk + 4 rr, a = a0 + lm
+    const int a = a0 + lm;
 #pragma unroll
     for (int t = 0; t < 4; t++)
 #pragma unroll
-        for (int rr = 0; rr < 4; rr++) D[(a0 + lk + 4 * rr) + (t * 16 + lm) * NB] = acc[t][rr];
-    __syncthreads();
-    // Z[a,b] = sum_{k >= a} Dinv[k,a] Dinv[k,b] - G[a,b], a >= b
-    for (int idx = tid; idx < w * w; idx += 256) {
-        const int a = idx % w, b = idx / w;
-        if (a < b) continue;
-        double v = 0.0;
-        for (int k = a; k < w; k++) v += T[a + k * NB] * T[b + k * NB];
-        Zp[(kb + a) + (long long)(kb + b) * ld] = v - D[a + b * NB];
-    }
+        for (int rr = 0; rr < 4; rr++) {
+            const int bcol = t * 16 + lk + 4 * rr;
+            if (a < w && bcol < w && a >= bcol) Zp[(kb + a) + (long long)(kb + bcol) * ld] = x[t][rr] - g[t][rr];
+        }
 }
 
 // ------------------------------------------------------------------------------------------
