@@ -39,13 +39,24 @@ __global__ __launch_bounds__(256) void k_sel_gather(DevSym S, const int *__restr
     const double *Zp = Z + S.panelptr[p];
     const double *ZBp = ZB + S.cbptr[p];
     double *out = ZB + S.cbptr[s];
-    for (int j = j0; j < j1; j++) {
-        const int b = rel[j];
-        for (int i = j + threadIdx.x; i < m; i += 256) {
-            const int a = rel[i];
-            const double v = (b < cp) ? Zp[a + (long long)b * ldp] : ZBp[(a - cp) + (long long)(b - cp) * mp];
-            out[i + (long long)j * m] = v;
-        }
+    // the 16 source columns of this tile (uniform per workgroup), then every thread walks the rows with the 16
+    // loads of its row in flight at once (rows above the diagonal of the tile are clamped onto it and not stored)
+    const double *src[16];
+    int bb[16];
+#pragma unroll
+    for (int jj = 0; jj < 16; jj++) {
+        const int b = rel[min(j0 + jj, m - 1)];
+        bb[jj] = b;
+        src[jj] = (b < cp) ? Zp + (long long)b * ldp : ZBp + (long long)(b - cp) * mp - cp;
+    }
+    for (int i = j0 + threadIdx.x; i < m; i += 256) {
+        const int a = rel[i];
+        double v[16];
+#pragma unroll
+        for (int jj = 0; jj < 16; jj++) v[jj] = src[jj][max(a, bb[jj])];
+#pragma unroll
+        for (int jj = 0; jj < 16; jj++)
+            if (j0 + jj < j1 && i >= j0 + jj) out[i + (long long)(j0 + jj) * m] = v[jj];
     }
 }
 
