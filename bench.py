@@ -83,6 +83,7 @@ def bench_sharded(args, Q, mesh, dist, rank, world, local_rank):
     Bh = torch.randn((args.nrhs, n), generator=torch.Generator(device="cpu").manual_seed(1), dtype=torch.float64)
     d_B = Bh.to(dev)
     d_X = torch.zeros_like(d_B)
+    torch.cuda.synchronize()     # torch's fill runs on torch's stream; the library's streams do not wait for it
     sf = shard.ShardedFactor(Q, dist, device=local_rank, coords=mesh.points)
 
     def step():

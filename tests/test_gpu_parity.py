@@ -565,6 +565,7 @@ def _shard_gpu_worker(rank, world, port, q):
         nrhs = 64 if world == 2 else 7
         Bh = torch.randn((nrhs, Q.shape[0]), generator=torch.Generator().manual_seed(3), dtype=torch.float64)
         d_B = Bh.to(dev); d_X = torch.zeros_like(d_B)
+        torch.cuda.synchronize()      # torch's fill kernel runs on torch's stream, the library on its own ones
         sf.solve_dev(d_B.data_ptr(), Q.shape[0], nrhs, d_X.data_ptr(), Q.shape[0])
         owner = sf.be.shard_owner()
         mine = (owner == rank) | ((owner == -1) & (rank == 0))
@@ -585,6 +586,7 @@ def _shard_gpu_worker(rank, world, port, q):
                 why.append(f"panel {s} (c={c}, r={r}) differs by {np.abs(np.tril(Pa) - np.tril(Pb)).max():.3e}")
         if rank == 0:
             d_Xr = torch.zeros_like(d_B)
+            torch.cuda.synchronize()
             ref.solve_dev(d_B.data_ptr(), Q.shape[0], nrhs, d_Xr.data_ptr(), Q.shape[0])
             torch.cuda.synchronize()
             if not bool(torch.equal(d_X, d_Xr)):

@@ -13,6 +13,7 @@ n = Q.shape[0]
 be = gmrfx.MI355XBackend(Q, coords=mesh.points)
 for nr in (1, 2, 4, 8, 16, 32, 64, 128, 256):
     B = torch.randn((nr, n), dtype=torch.float64, device="cuda"); X = torch.empty_like(B)
+    torch.cuda.synchronize()
     for rep in range(3):
         be.solve_dev(B.data_ptr(), n, nr, X.data_ptr(), n)
     s = be.stats()
