@@ -5,7 +5,9 @@ import os
 import re
 
 import numpy as np
+import pytest
 
+import gmrfx
 from gmrfx import _lib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -58,3 +60,18 @@ def test_bad_arguments_are_reported_not_crashed():
     rc = _lib.lib().gmrfx_create(2, _lib.ptr(colptr), _lib.ptr(rowval), 0, None, None, C.byref(h))
     assert rc == _lib.ERR_INVALID_ARG and h.value is None
     assert b"range" in _lib.lib().gmrfx_last_create_error()
+
+
+def test_kl_cholesky_validates_and_fails_loudly_without_a_gpu():
+    # no CPU fallback anywhere: argument errors are reported before the device is touched, and on a box without
+    # a GPU the numeric entry point returns a HIP error instead of computing on the host
+    import scipy.sparse as sp
+    from gmrfx import klchol
+    with pytest.raises(ValueError):
+        klchol._run(np.eye(3), [0, 1, 2, 3], [0, 1], [5], [0, 1], [0], 1e-6, -1)          # row index out of range
+    with pytest.raises(ValueError):
+        klchol._run(np.eye(3), [0, 2, 3, 4], [0, 1], [0], [0, 1], [0], 1e-6, -1)          # column longer than its task
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(gmrfx.GmrfxError):
+            klchol.sparse_approximate_cholesky_inplace(np.eye(3), sp.csc_matrix(np.tril(np.ones((3, 3)))))
