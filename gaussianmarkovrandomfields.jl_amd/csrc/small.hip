@@ -423,12 +423,12 @@ __device__ __forceinline__ void fwd_small_front(const DevSym &S, const int s, co
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
+                // unconditional: av[u] is zero beyond column c and fv is finite everywhere (no runtime-conditional
+                // MFMA inside the unrolled loop: see the rules in DESIGN.md)
                 const int q = min(q0 + 4 * u + lk, RMAX - 1);
-                if (q0 + 4 * u < c) {
 #pragma unroll
-                    for (int t = 0; t < 4; t++)
-                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], fv[q * LDV + t * 16 + lm], acc[t], 0, 0, 0);
-                }
+                for (int t = 0; t < 4; t++)
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], fv[q * LDV + t * 16 + lm], acc[t], 0, 0, 0);
             }
         }
 #pragma unroll
