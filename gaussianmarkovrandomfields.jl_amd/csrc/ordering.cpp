@@ -11,7 +11,11 @@
 // every separator vertex touches both sides. Leaves (<= nd_leaf vertices) are ordered by a
 // halo-aware minimum-degree on bit masks.
 #include <algorithm>
+#include <atomic>
 #include <bitset>
+#include <cstdlib>
+#include <exception>
+#include <thread>
 #include <cmath>
 #include <numeric>
 #include <stdexcept>
@@ -64,15 +68,18 @@ struct ND {
     int leaf;
     std::vector<i32> label;   // region id of each vertex; -1 once ordered/separator
     std::vector<i32> &perm;
-    i32 next_id = 1;
-    std::vector<i32> dist, queue;  // BFS scratch
+    std::atomic<i32> next_id{1};   // region ids only have to be distinct: the result does not depend on their values
+    std::vector<i32> dist;         // per-vertex BFS scratch (disjoint vertex sets per task)
+    // BFS visit order: one per thread (the two halves of a dissection run as separate tasks near the top)
+    static std::vector<i32> &tls_queue() { static thread_local std::vector<i32> q; return q; }
+#define queue tls_queue()
 
     ND(const Graph &g, const SymOptions &o, std::vector<i32> &p)
         : G(g), xy(o.coords), dim(o.coords ? o.coord_dim : 0), leaf(o.nd_leaf > 0 ? o.nd_leaf : 64),
           label(g.n, 0), perm(p) {
         if (leaf > 64) leaf = 64;
         dist.assign(g.n, -1);
-        queue.reserve(1024);
+        lidx.assign(g.n, -1);
     }
 
     // ---- leaf ordering: minimum degree with a fixed halo --------------------------------
@@ -124,7 +131,6 @@ struct ND {
     // Partitions v into [A' | B' | S]. Returns sizes.
     std::vector<i32> lidx;   // scratch: local index of a boundary vertex (size n, -1 = none)
     void split(i32 *v, i64 cnt, i32 idA, i32 idB, i64 &nA, i64 &nB, i64 &nS) {
-        if (lidx.empty()) lidx.assign(G.n, -1);
         std::vector<i32> Lv, Rv;   // boundary vertices of A (left) and B (right)
         for (i64 k = 0; k < cnt; k++) {
             i32 u = v[k]; i32 other = label[u] == idA ? idB : idA;
@@ -309,7 +315,7 @@ struct ND {
         clear_bfs();
     }
 
-    void run(i32 *v, i64 cnt, i64 pos) {
+    void run(i32 *v, i64 cnt, i64 pos, int depth = 0) {
         if (cnt <= leaf) { order_leaf(v, cnt, pos); return; }
         i32 id = label[v[0]];
         i32 idA = next_id++, idB = next_id++;
@@ -324,9 +330,22 @@ struct ND {
             return;
         }
         for (i64 k = 0; k < nS; k++) { perm[pos + nA + nB + k] = v[nA + nB + k]; label[v[nA + nB + k]] = -1; }
-        run(v, nA, pos);
-        run(v + nA, nB, pos + nA);
+        // The two halves touch disjoint vertices (their only common neighbours are separator vertices, whose
+        // labels are final): near the top of the tree they run as two tasks. The ordering does not depend on
+        // which thread runs what -- every rank of a sharded factorisation must get the same permutation.
+        if (depth < par_depth && std::min(nA, nB) > 20000) {
+            std::exception_ptr err;
+            std::thread t([&] { try { run(v, nA, pos, depth + 1); } catch (...) { err = std::current_exception(); } });
+            try { run(v + nA, nB, pos + nA, depth + 1); } catch (...) { t.join(); throw; }
+            t.join();
+            if (err) std::rethrow_exception(err);
+        } else {
+            run(v, nA, pos, depth + 1);
+            run(v + nA, nB, pos + nA, depth + 1);
+        }
     }
+    int par_depth = 3;   // up to 8 concurrent tasks
+#undef queue
 };
 
 }  // namespace
@@ -337,6 +356,8 @@ void nested_dissection(const Graph &G, const SymOptions &opt, std::vector<i32> &
     std::vector<i32> verts(n);
     std::iota(verts.begin(), verts.end(), 0);
     ND nd(G, opt, perm);
+    if (const char *e = std::getenv("GMRFX_ND_THREADS")) nd.par_depth = std::atoi(e) <= 1 ? 0 : (std::atoi(e) <= 2 ? 1 : (std::atoi(e) <= 4 ? 2 : 3));   // 1 = serial (testing knob)
+    else if (std::thread::hardware_concurrency() <= 1) nd.par_depth = 0;
     nd.run(verts.data(), n, 0);
 }
 

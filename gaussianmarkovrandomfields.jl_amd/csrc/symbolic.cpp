@@ -10,6 +10,7 @@
 #include <map>
 #include <numeric>
 #include <stdexcept>
+#include <thread>
 
 namespace gmrfx {
 namespace {
@@ -648,25 +649,44 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
                 S.qsrc[q] = p;
                 ra[q] = a; rb[q] = b;
             }
-        std::vector<i32> pos(n, -1);
-        for (i32 s = 0; s < ns; s++) {
-            i64 r0 = S.rowptr[s], r1 = S.rowptr[s + 1];
-            for (i64 k = r0; k < r1; k++) pos[S.rows[k]] = (i32)(k - r0);
-            for (i64 q = S.qptr[s]; q < S.qptr[s + 1]; q++) {
-                i32 pr = pos[ra[q]];
-                if (pr < 0) throw std::runtime_error("internal: Q entry outside supernode structure");
-                S.qdst[q] = S.panelptr[s] + (i64)(rb[q] - S.sfirst[s]) * S.ld[s] + pr;
+        // destinations and the per-supernode sort are independent across supernodes: ranges of supernodes with
+        // about equal numbers of entries go to a few threads (own scratch each; destinations are unique, so the
+        // sorted result does not depend on the split)
+        auto work = [&](i32 s0, i32 s1) {
+            std::vector<i32> pos(n, -1);
+            std::vector<std::pair<i64, i64>> tmp;
+            for (i32 s = s0; s < s1; s++) {
+                i64 r0 = S.rowptr[s], r1 = S.rowptr[s + 1];
+                for (i64 k = r0; k < r1; k++) pos[S.rows[k]] = (i32)(k - r0);
+                for (i64 q = S.qptr[s]; q < S.qptr[s + 1]; q++) {
+                    i32 pr = pos[ra[q]];
+                    if (pr < 0) throw std::runtime_error("internal: Q entry outside supernode structure");
+                    S.qdst[q] = S.panelptr[s] + (i64)(rb[q] - S.sfirst[s]) * S.ld[s] + pr;
+                }
+                for (i64 k = r0; k < r1; k++) pos[S.rows[k]] = -1;
+                // sort the supernode's list by destination (column-major inside the panel)
+                i64 a = S.qptr[s], b = S.qptr[s + 1];
+                tmp.resize(b - a);
+                for (i64 q = a; q < b; q++) tmp[q - a] = {S.qdst[q], S.qsrc[q]};
+                std::sort(tmp.begin(), tmp.end());
+                for (i64 q = a; q < b; q++) { S.qdst[q] = tmp[q - a].first; S.qsrc[q] = tmp[q - a].second; }
             }
-            for (i64 k = r0; k < r1; k++) pos[S.rows[k]] = -1;
-        }
-        // sort each supernode's list by destination (column-major inside the panel)
-        std::vector<std::pair<i64, i64>> tmp;
-        for (i32 s = 0; s < ns; s++) {
-            i64 a = S.qptr[s], b = S.qptr[s + 1];
-            tmp.resize(b - a);
-            for (i64 q = a; q < b; q++) tmp[q - a] = {S.qdst[q], S.qsrc[q]};
-            std::sort(tmp.begin(), tmp.end());
-            for (i64 q = a; q < b; q++) { S.qdst[q] = tmp[q - a].first; S.qsrc[q] = tmp[q - a].second; }
+        };
+        const unsigned hw = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+        if (nq < 2000000 || hw == 1) work(0, ns);
+        else {
+            std::vector<i32> cut(hw + 1, ns);
+            cut[0] = 0;
+            for (unsigned t = 1, s = 0; t < hw; t++) {
+                while ((i32)s < ns && S.qptr[s] < nq * (i64)t / hw) s++;
+                cut[t] = (i32)s;
+            }
+            std::vector<std::thread> th;
+            std::vector<std::exception_ptr> err(hw);
+            for (unsigned t = 0; t < hw; t++)
+                th.emplace_back([&, t] { try { work(cut[t], cut[t + 1]); } catch (...) { err[t] = std::current_exception(); } });
+            for (auto &x : th) x.join();
+            for (auto &e : err) if (e) std::rethrow_exception(e);
         }
     }
 
