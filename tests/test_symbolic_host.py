@@ -118,3 +118,23 @@ def test_numeric_calls_fail_loudly_without_device():
         b.compute_logdet()
     with pytest.raises(gmrfx.NoDeviceError):
         b.get_selinv_diag()
+
+
+@pytest.mark.parametrize("with_coords", [True, False])
+def test_threaded_symbolic_analysis_equals_serial(with_coords, monkeypatch):
+    # near the top of the dissection tree the two halves run as separate host tasks, and the scatter map is built
+    # per supernode range on several threads: ordering, supernodes and maps must not depend on that (every rank of
+    # a sharded factorisation runs the analysis for itself and has to arrive at the same structure)
+    g = 460 if with_coords else 230        # 460 x 460: more than 2e6 scatter entries, the threaded map build as well
+    mesh = spde.grid_mesh_2d(g, g, jitter=0.25, seed=4)
+    Q = sp.csc_matrix(spde.matern_precision(mesh, 0, 0.2))
+    kw = {"coords": mesh.points} if with_coords else {}
+    got = []
+    for threads in ("1", "8"):
+        monkeypatch.setenv("GMRFX_ND_THREADS", threads)
+        be = gmrfx.MI355XBackend(Q, symbolic_only=True, **kw)
+        sy = be.symbolic()
+        got.append((be.ordering_permutation(), np.asarray(sy.super_first), np.asarray(sy.row_ptr), np.asarray(sy.rows),
+                    np.asarray(sy.q_src), np.asarray(sy.q_dst)))
+    for a, b in zip(*got):
+        assert np.array_equal(a, b)
