@@ -61,6 +61,11 @@ void Device::init(const Symbolic &S, int dev) {
         HC(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, prio ? hi : 0));
         HC(hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, prio ? lo : 0));
         HC(hipStreamCreateWithPriority(&stream3, hipStreamNonBlocking, prio ? hi : 0));
+        if (const char *c = std::getenv("GMRFX_INV_CAP")) {      // testing knob: power of two >= 64
+            int v = std::atoi(c), p2 = NB;
+            while (p2 < v) p2 *= 2;
+            inv_cap_ = p2;
+        }
     }
     HC(hipEventCreateWithFlags(&ev_fact_, hipEventDisableTiming));
     HC(hipEventCreateWithFlags(&ev_inv_, hipEventDisableTiming));
@@ -316,15 +321,17 @@ void Device::start_inverse_async() {
     if (!inverse_pending) return;
     HC(hipEventRecord(ev_fact_, stream));
     HC(hipStreamWaitEvent(stream2, ev_fact_, 0));
-    invert_diag_blocks(stream2);
+    invert_diag_blocks(stream2, NB, inv_cap_);
     HC(hipEventRecord(ev_inv_, stream2));
     inverse_pending = false;
+    inverse_full_ = inv_maxc_ <= inv_cap_;
 }
 void Device::wait_inverse() { HC(hipStreamWaitEvent(stream, ev_inv_, 0)); }
 
-void Device::invert_diag_blocks(hipStream_t stream) {
+void Device::invert_diag_blocks(hipStream_t stream, int b_from, int b_to) {
     int stage = 0;
-    for (int B = NB; B < inv_maxc_; B *= 2, stage++) {
+    for (int B = NB; B < std::min(inv_maxc_, b_to); B *= 2, stage++) {
+        if (B < b_from) continue;
         const int na = inv_nact_[stage];
         if (na <= 0) break;
         launch_inv_stage(stream, ds_, d_invlist_, na, B, inv_maxc_, 1, d_L_, d_invT_, d_inv_toff_[stage]);
@@ -449,7 +456,13 @@ void Device::forward(int nr, int ldx, int lo, int hi) {
         // y = L11^-1 b as one triangular product per front (dense inverse, inverse.hip), then the
         // trailing update W -= L21 y with K = all columns of the front
         // y of the big fronts stays in X2 (no copy back): the update below and the backward sweep read it there
-        launch_xmul(stream, ds_, list, nf, L.max_cols, 0, d_L_, d_X_, d_X2_, nr, ldx);
+        // fronts wider than inv_cap_: block by block (y_j = X_jj b_j, then the own rows below -= L[.., block j] y_j)
+        const int nbk = std::max(1, (L.max_cols + inv_cap_ - 1) / inv_cap_);
+        for (int j = 0; j < nbk; j++) {
+            const int na = nbk == 1 ? nf : L.active[std::min<size_t>((size_t)j * inv_cap_ / NB, L.active.size() - 2)];
+            launch_xmul(stream, ds_, list, na, L.max_cols, 0, d_L_, d_X_, d_X2_, nr, ldx, j, inv_cap_);
+            if (j + 1 < nbk) launch_fwd_own_update(stream, ds_, list, L.active[(size_t)(j + 1) * inv_cap_ / NB], L.max_cols, d_L_, d_X2_, d_X_, nr, ldx, j, inv_cap_);
+        }
         launch_fwd_update(stream, ds_, list, nf, level_max_trail(L), d_L_, d_X2_, d_W_, nr, ldx);
     }
 }
@@ -465,13 +478,24 @@ void Device::backward(int nr, int ldx, bool y_in_x2, int hi, int lo) {
         const int nf = L.count - L.nsmall;
         for (int k = 0, off = 0; k < 4; off += L.ncls[k], k++)
             launch_bwd_small(stream, ds_, d_levellist_ + L.first + off, L.ncls[k], kClsRows[k], d_L_, d_X_, nr, ldx);
+        const int nbk = std::max(1, (L.max_cols + inv_cap_ - 1) / inv_cap_);
         if (y_in_x2) {
             if (level_max_trail(L) > 0) launch_bwd_gemm(stream, ds_, list, nf, L.max_cols, d_L_, d_X_, d_X2_, nr, ldx);
-            launch_xmul(stream, ds_, list, nf, L.max_cols, 1, d_L_, d_X2_, d_X_, nr, ldx);
+            // fronts wider than inv_cap_: from the last block up, t_j -= L[own rows below, block j]' x, x_j = X_jj' t_j
+            for (int j = nbk - 1; j >= 0; j--) {
+                const int na = nbk == 1 ? nf : L.active[std::min<size_t>((size_t)j * inv_cap_ / NB, L.active.size() - 2)];
+                if (j + 1 < nbk) launch_bwd_gemm(stream, ds_, list, L.active[(size_t)(j + 1) * inv_cap_ / NB], L.max_cols, d_L_, d_X_, d_X2_, nr, ldx, j, inv_cap_);
+                launch_xmul(stream, ds_, list, na, L.max_cols, 1, d_L_, d_X2_, d_X_, nr, ldx, j, inv_cap_);
+            }
         } else {
             if (level_max_trail(L) > 0) launch_bwd_gemm(stream, ds_, list, nf, L.max_cols, d_L_, d_X_, d_X_, nr, ldx);
-            launch_xmul(stream, ds_, list, nf, L.max_cols, 1, d_L_, d_X_, d_X2_, nr, ldx);
-            launch_copy_own(stream, ds_, list, nf, L.max_cols, d_X2_, d_X_, nr, ldx);
+            for (int j = nbk - 1; j >= 0; j--) {
+                const int na = nbk == 1 ? nf : L.active[std::min<size_t>((size_t)j * inv_cap_ / NB, L.active.size() - 2)];
+                if (j + 1 < nbk) launch_bwd_gemm(stream, ds_, list, L.active[(size_t)(j + 1) * inv_cap_ / NB], L.max_cols, d_L_, d_X_, d_X_, nr, ldx, j, inv_cap_);
+                launch_xmul(stream, ds_, list, na, L.max_cols, 1, d_L_, d_X_, d_X2_, nr, ldx, j, inv_cap_);
+                // x_j has to be back in X before the block above reads it
+                launch_copy_own(stream, ds_, list, na, L.max_cols, d_X2_, d_X_, nr, ldx, j, inv_cap_);
+            }
         }
     }
     if (lo == 0)
@@ -656,6 +680,10 @@ void Device::selinv_compute() {
     dsz.cbptr = d_zbptr_;
     start_inverse_async();
     wait_inverse();
+    if (!inverse_full_) {      // the sweeps only need inv_cap_-column inverses; the Takahashi step needs all of L11^-1
+        invert_diag_blocks(stream, inv_cap_, 1 << 30);
+        inverse_full_ = true;
+    }
     if (!d_Z_) d_Z_ = dalloc<double>((size_t)l_size_);
     // workspaces: small fronts: Yh = r x 64 per front; big fronts: Yt and Z21t = (r-c) x c each
     long long *d_yoff = nullptr;

@@ -152,7 +152,12 @@ private:
     std::vector<long long *> d_inv_toff_;   // per stage: offsets of the T buffers
     double *d_invT_ = nullptr;
     int inv_maxc_ = 0;
-    void invert_diag_blocks(hipStream_t st);
+    // Recursive doubling of the diagonal-block inverses stops at inv_cap_ columns (a full inverse of a c-column
+    // front costs O(c^3): most of a 3-D solve); wider fronts substitute block by block in the sweeps. The selected
+    // inversion needs the full inverses and runs the remaining stages on demand (B from inv_cap_ up).
+    int inv_cap_ = 4096;
+    bool inverse_full_ = false;
+    void invert_diag_blocks(hipStream_t st, int b_from, int b_to);
     void start_inverse_async();
     void wait_inverse();
     int first_multiblock_level_ = 0;

@@ -17,6 +17,8 @@
 // all pairs of all fronts of a stage run in the same two launches (FP64 MFMA, 64x64 tiles).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace gmrfx {
@@ -145,16 +147,21 @@ __global__ __launch_bounds__(256) void k_inv_stage(DevSym S, const int *__restri
 template <int NW>   // waves per workgroup splitting K; 8 for launches with about one workgroup per CU (kernels.h)
 __global__ __launch_bounds__(64 * NW) void k_xmul(DevSym S, const int *__restrict__ list, int trans,
                                               const double *__restrict__ L, const double *__restrict__ Xin,
-                                              double *__restrict__ Xout, int nr, int ldx) {
+                                              double *__restrict__ Xout, int nr, int ldx, int blk, int cap) {
+    // Fronts wider than `cap` columns only have the inverses of their cap x cap diagonal blocks (the recursive
+    // doubling stops there: a full inverse costs O(c^3)); the sweeps then substitute block by block and this
+    // kernel is called once per block `blk`: the block is treated as a front of its own.
     const int s = list[blockIdx.y];
-    const int c = S.sfirst[s + 1] - S.sfirst[s];
+    const int cfull = S.sfirst[s + 1] - S.sfirst[s];
+    const int col0 = blk * cap;
+    const int c = min(cap, cfull - col0);
     __shared__ double red[NW == 4 ? 3 * 64 * 16 : NW * 16 * 64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int k0 = blockIdx.x * 16;      // one 16-row tile per workgroup, the 4 waves split the K range
     if (k0 >= c) return;
     const int ld = S.ld[s];
-    const int first = S.sfirst[s];
-    const double *P = L + S.panelptr[s];
+    const int first = S.sfirst[s] + col0;
+    const double *P = L + S.panelptr[s] + col0 + (long long)col0 * ld;
     const double *Bb = Xin + (long long)first * ldx;
     const int lm = lane & 15, lk = lane >> 4;
     const int nt = (nr + 15) >> 4;
@@ -200,10 +207,14 @@ __global__ __launch_bounds__(64 * NW) void k_xmul(DevSym S, const int *__restric
 // Xdst[own rows of the listed fronts] = Xsrc[same rows]
 __global__ __launch_bounds__(256) void k_copy_own(DevSym S, const int *__restrict__ list,
                                                   const double *__restrict__ Xsrc, double *__restrict__ Xdst, int nr,
-                                                  int ldx) {
+                                                  int ldx, int blk, int cap) {
+    // own rows of block blk (the whole front when cap covers it)
     const int s = list[blockIdx.y];
-    const int c = S.sfirst[s + 1] - S.sfirst[s];
-    const long long base = (long long)S.sfirst[s] * ldx;
+    const int cfull = S.sfirst[s + 1] - S.sfirst[s];
+    const int col0 = blk * cap;
+    const int c = min(cap, cfull - col0);
+    if (c <= 0) return;
+    const long long base = (long long)(S.sfirst[s] + col0) * ldx;
     const long long cnt = (long long)c * ldx;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < cnt; i += (long long)gridDim.x * 256) {
         if ((int)(i % ldx) < nr) Xdst[base + i] = Xsrc[base + i];
@@ -222,18 +233,21 @@ void launch_inv_stage(hipStream_t st, const DevSym &S, const int *list, int nact
     hipLaunchKernelGGL(k_inv_stage, dim3(ntile, npair | 1, nactive), dim3(256), 0, st, S, list, B, phase, L, T, toff);
 }
 void launch_xmul(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_c, int trans, const double *L,
-                 const double *Xin, double *Xout, int nr, int ldx) {
+                 const double *Xin, double *Xout, int nr, int ldx, int blk, int cap) {
     if (nfronts <= 0 || max_c <= 0) return;
+    max_c = std::min(max_c - blk * cap, cap);      // width of block `blk` of the widest front
+    if (max_c <= 0) return;
     if ((long long)cdiv(max_c, 16) * nfronts <= 256)
-        hipLaunchKernelGGL(k_xmul<8>, dim3((unsigned)(cdiv(max_c, 16) | 1), nfronts), dim3(512), 0, st, S, list, trans, L, Xin, Xout, nr, ldx);
+        hipLaunchKernelGGL(k_xmul<8>, dim3((unsigned)(cdiv(max_c, 16) | 1), nfronts), dim3(512), 0, st, S, list, trans, L, Xin, Xout, nr, ldx, blk, cap);
     else
-        hipLaunchKernelGGL(k_xmul<4>, dim3((unsigned)(cdiv(max_c, 16) | 1), nfronts), dim3(256), 0, st, S, list, trans, L, Xin, Xout, nr, ldx);
+        hipLaunchKernelGGL(k_xmul<4>, dim3((unsigned)(cdiv(max_c, 16) | 1), nfronts), dim3(256), 0, st, S, list, trans, L, Xin, Xout, nr, ldx, blk, cap);
 }
 void launch_copy_own(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_c, const double *Xsrc,
-                     double *Xdst, int nr, int ldx) {
+                     double *Xdst, int nr, int ldx, int blk, int cap) {
+    max_c = std::min(max_c - blk * cap, cap);
     if (nfronts <= 0 || max_c <= 0) return;
     const int nb = std::max(1, std::min(64, cdiv(max_c * ldx, 256)));
-    hipLaunchKernelGGL(k_copy_own, dim3(nb, nfronts), dim3(256), 0, st, S, list, Xsrc, Xdst, nr, ldx);
+    hipLaunchKernelGGL(k_copy_own, dim3(nb, nfronts), dim3(256), 0, st, S, list, Xsrc, Xdst, nr, ldx, blk, cap);
 }
 
 }  // namespace gmrfx

@@ -201,12 +201,15 @@ __device__ __forceinline__ void splitk_reduce4(gmrfx_d4 (&acc)[NA][4], double *r
 void launch_inv_stage(hipStream_t st, const DevSym &S, const int *list, int nactive, int B, int max_c, int phase,
                       double *L, double *T, const long long *toff);
 void launch_xmul(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_c, int trans, const double *L,
-                 const double *Xin, double *Xout, int nr, int ldx);
+                 const double *Xin, double *Xout, int nr, int ldx, int blk = 0, int cap = 1 << 30);
 void launch_copy_own(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_c, const double *Xsrc,
-                     double *Xdst, int nr, int ldx);
+                     double *Xdst, int nr, int ldx, int blk = 0, int cap = 1 << 30);
 // X: rows of the ancestors (already final x, read only); Xown: the fronts' own rows, updated in place
 void launch_bwd_gemm(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, const double *L,
-                     const double *X, double *Xown, int nr, int ldx);
+                     const double *X, double *Xown, int nr, int ldx, int blk = -1, int cap = 1 << 30);
+// blocked substitution inside fronts wider than `cap` columns (forward): own rows below block blk -= L[.., block] y_blk
+void launch_fwd_own_update(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, const double *L,
+                           const double *Y, double *X, int nr, int ldx, int blk, int cap);
 // iperm: position of original row i in the elimination order (nullptr: identity)
 void launch_permute(hipStream_t st, const int *iperm, int n, double *Bc, long long ldb, double *X, int nr, int ldx, int dir);
 void launch_newton_update(hipStream_t st, const double *prior, double *nz, long long nnz, const long long *map, const double *h,

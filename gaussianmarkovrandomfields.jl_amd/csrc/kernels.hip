@@ -13,6 +13,8 @@
 // B[lane>>4][lane&15] (cdna_hip_programming.md section 3).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include <climits>
 
 #include "kernels.h"
@@ -599,17 +601,94 @@ __global__ __launch_bounds__(256) void k_fwd_update_longk(DevSym S, const int *_
     }
 }
 
+// Blocked forward substitution inside a front wider than `cap` columns: after y_blk = X_blk b_blk, the own rows
+// below the block get  b[i] -= sum_{q in block} L[i][q] y[q].  A workgroup owns 32 rows x 64 right-hand sides,
+// its four waves split the K range (the block's columns); the partial tiles are summed through LDS.
+__global__ __launch_bounds__(256) void k_fwd_own_update(DevSym S, const int *__restrict__ list,
+                                                        const double *__restrict__ L, const double *__restrict__ Y,
+                                                        double *__restrict__ X, int nr, int ldx, int blk, int cap) {
+    __shared__ double red[3 * 16 * 64];
+    const int s = list[blockIdx.y];
+    const int c = S.sfirst[s + 1] - S.sfirst[s];
+    const int q0 = blk * cap, q1 = min(c, (blk + 1) * cap);     // K range: the block's columns
+    const int i0 = q1 + blockIdx.x * 32;                        // own rows below the block
+    if (i0 >= c) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lm = lane & 15, lk = lane >> 4;
+    const int ld = S.ld[s];
+    const int first = S.sfirst[s];
+    const double *P = L + S.panelptr[s];
+    const double *Yb = Y + (long long)first * ldx;
+    double *Xb = X + (long long)first * ldx;
+    const int nt = (nr + 15) >> 4;
+    d4 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc[a][t] = (d4){0.0, 0.0, 0.0, 0.0};
+    const double *pa[2] = {P + min(i0 + lm, c - 1), P + min(i0 + 16 + lm, c - 1)};
+    const int jc[4] = {min(lm, nr - 1), min(16 + lm, nr - 1), min(32 + lm, nr - 1), min(48 + lm, nr - 1)};
+    constexpr int KU = 4;
+    for (int k0 = q0 + wave * 4 * KU; k0 < q1; k0 += 16 * KU) {
+        double av[KU][2], bv[KU][4];
+#pragma unroll
+        for (int u = 0; u < KU; u++) {
+            const int kk = k0 + 4 * u + lk;
+            const int kc = min(kk, q1 - 1);
+            const double mk = kk < q1 ? 1.0 : 0.0;
+#pragma unroll
+            for (int a = 0; a < 2; a++) av[u][a] = pa[a][(long long)kc * ld] * mk;
+#pragma unroll
+            for (int t = 0; t < 4; t++) bv[u][t] = Yb[(long long)kc * ldx + jc[t]];
+        }
+#pragma unroll
+        for (int u = 0; u < KU; u++)
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    acc[a][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][a], bv[u][t], acc[a][t], 0, 0, 0);
+    }
+    splitk_reduce4<2>(acc, red, wave, lane);
+    // wave w owns the 16 right-hand sides 16 w .. of both row tiles: X -= acc (loads first, then stores)
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        if (t == wave && t < nt) {
+            const int j = t * 16 + lm, jcl = min(j, nr - 1);
+            double xv[2][4];
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) xv[a][rr] = Xb[(long long)min(i0 + a * 16 + lk + 4 * rr, c - 1) * ldx + jcl];
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) {
+                    const int i = i0 + a * 16 + lk + 4 * rr;
+                    if (i < c && j < nr) Xb[(long long)i * ldx + j] = xv[a][rr] - acc[a][t][rr];
+                }
+        }
+    }
+}
+
 // Backward update of a big front: own columns -= L21' * x_R over ALL trailing rows: a
 // workgroup owns 64 own columns x 64 right-hand sides, its waves split the trailing rows.
 template <int NA, int NW>   // NA: see k_fwd_update_longk; NW: waves per workgroup splitting K (8 only with NA = 1)
 __global__ __launch_bounds__(64 * NW) void k_bwd_gemm_longk(DevSym S, const int *__restrict__ list,
                                                           const double *__restrict__ L, const double *X, double *Xown, int nr,
-                                                          int ldx) {
+                                                          int ldx, int blk, int cap) {
+    // blk < 0: all own columns, K = the trailing rows [c, r). blk >= 0 (blocked substitution inside a front wider
+    // than `cap` columns): own columns of block blk only, K = the OWN rows below the block, [(blk + 1) cap, c)
+    // -- the same product with other bounds (rows[] lists the own columns first, so x of own rows is found the
+    // same way as x of trailing rows).
     __shared__ double red[NW == 4 ? 3 * 16 * 64 : NW * 16 * 64];
     const int s = list[blockIdx.y];
-    const int c = S.sfirst[s + 1] - S.sfirst[s];
-    const int r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
-    const int i0 = blockIdx.x * 16 * NA;
+    const int cfull = S.sfirst[s + 1] - S.sfirst[s];
+    const int rfull = (int)(S.rowptr[s + 1] - S.rowptr[s]);
+    const int col0 = blk < 0 ? 0 : blk * cap;
+    const int c = blk < 0 ? cfull : min(cfull, (blk + 1) * cap);      // own columns [col0, c); K starts at row c
+    const int r = blk < 0 ? rfull : cfull;                             // K ends at row r
+    const int i0 = col0 + blockIdx.x * 16 * NA;
     if (i0 >= c || r <= c) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int lm = lane & 15, lk = lane >> 4;
@@ -926,12 +1005,20 @@ void launch_fwd_update(hipStream_t st, const DevSym &S, const int *list, int nfr
         hipLaunchKernelGGL(k_fwd_update_longk<2>, dim3(odd(cdiv(max_trail, 32)), nfronts), dim3(256), 0, st, S, list, L, X, W, nr, ldx);
 }
 void launch_bwd_gemm(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, const double *L,
-                     const double *X, double *Xown, int nr, int ldx) {
+                     const double *X, double *Xown, int nr, int ldx, int blk, int cap) {
     if (nfronts <= 0 || max_cols <= 0) return;
+    if (blk >= 0) max_cols = std::min(max_cols - blk * cap, cap);
+    if (max_cols <= 0) return;
     if ((long long)cdiv(max_cols, 32) * nfronts <= 128)
-        hipLaunchKernelGGL((k_bwd_gemm_longk<1, 8>), dim3(odd(cdiv(max_cols, 16)), nfronts), dim3(512), 0, st, S, list, L, X, Xown, nr, ldx);
+        hipLaunchKernelGGL((k_bwd_gemm_longk<1, 8>), dim3(odd(cdiv(max_cols, 16)), nfronts), dim3(512), 0, st, S, list, L, X, Xown, nr, ldx, blk, cap);
     else
-        hipLaunchKernelGGL((k_bwd_gemm_longk<2, 4>), dim3(odd(cdiv(max_cols, 32)), nfronts), dim3(256), 0, st, S, list, L, X, Xown, nr, ldx);
+        hipLaunchKernelGGL((k_bwd_gemm_longk<2, 4>), dim3(odd(cdiv(max_cols, 32)), nfronts), dim3(256), 0, st, S, list, L, X, Xown, nr, ldx, blk, cap);
+}
+void launch_fwd_own_update(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, const double *L,
+                           const double *Y, double *X, int nr, int ldx, int blk, int cap) {
+    const int rows_below = max_cols - (blk + 1) * cap;      // own rows below the block in the widest front
+    if (nfronts <= 0 || rows_below <= 0) return;
+    hipLaunchKernelGGL(k_fwd_own_update, dim3(odd(cdiv(rows_below, 32)), nfronts), dim3(256), 0, st, S, list, L, Y, X, nr, ldx, blk, cap);
 }
 void launch_permute(hipStream_t st, const int *perm, int n, double *Bc, long long ldb, double *X, int nr, int ldx, int dir) {
     hipLaunchKernelGGL(k_permute, dim3(cdiv(n, 64)), dim3(256), 0, st, perm, n, Bc, ldb, X, nr, ldx, dir);

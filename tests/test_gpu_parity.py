@@ -765,3 +765,32 @@ def test_kronecker_workspace_matches_dense_kron():
     assert relerr(A @ A.T, Sigma) < 1e-9
     with pytest.raises(ValueError):
         kw.solve(np.zeros(n + 1))
+
+
+@pytest.mark.parametrize("cap", ["64", "128", "256"])
+def test_blocked_substitution_in_wide_fronts(cap, monkeypatch):
+    """Fronts wider than the inverse cap (4096 columns by default; GMRFX_INV_CAP lowers it here) only hold the
+    inverses of their cap-column diagonal blocks: the sweeps substitute block by block inside them, the selected
+    inversion completes the inverses on demand. Same answers as with full inverses."""
+    monkeypatch.setenv("GMRFX_INV_CAP", cap)
+    rng = np.random.default_rng(int(cap))
+    m3 = spde.grid_mesh_3d(13, 12, 11)
+    cases = [sp.csc_matrix(np.cov(rng.standard_normal((330, 900))) + np.eye(330)),            # one dense 330-column front
+             sp.csc_matrix(spde.matern_precision(spde.grid_mesh_2d(70, 66, jitter=0.2), 0, 0.3)),
+             sp.csc_matrix(spde.matern_precision(m3, 0, 0.5))]
+    kws = [{}, {}, {"coords": m3.points}]
+    for k, (Q, kw) in enumerate(zip(cases, kws)):
+        ws = gmrfx.GMRFWorkspace(Q, **kw)
+        if k == 0:
+            assert ws.backend.stats()["max_cols"] > int(cap)      # the dense case is blocked at every cap tried here
+        F = orc.OracleFactor(Q, ws.backend.ordering_permutation())
+        n = Q.shape[0]
+        for nrhs in (1, 64, 70):
+            B = rng.standard_normal((n, nrhs))
+            assert relerr(ws.workspace_solve(B), F.solve(B)) < 1e-10
+            assert relerr(ws.backward_solve(B), F.backward_solve(B)) < 1e-10
+        assert relerr(ws.selinv_diag(), F.selinv_diag()) < 1e-8
+        B = rng.standard_normal((n, 5))                   # a solve after the inverses have been completed
+        assert relerr(ws.workspace_solve(B), F.solve(B)) < 1e-10
+        ws.update_precision(sp.csc_matrix(1.5 * Q))       # refactorise: back to capped inverses
+        assert relerr(ws.workspace_solve(B), F.solve(B) / 1.5) < 1e-10
