@@ -155,7 +155,7 @@ private:
     // Recursive doubling of the diagonal-block inverses stops at inv_cap_ columns (a full inverse of a c-column
     // front costs O(c^3): most of a 3-D solve); wider fronts substitute block by block in the sweeps. The selected
     // inversion needs the full inverses and runs the remaining stages on demand (B from inv_cap_ up).
-    int inv_cap_ = 4096;
+    int inv_cap_ = 2048;     // measured: cfg 2 flat between 1024 and 4096 (6.18 vs 6.26 ms), 3-D 100^3 solve 44 vs 54 ms
     bool inverse_full_ = false;
     void invert_diag_blocks(hipStream_t st, int b_from, int b_to);
     void start_inverse_async();

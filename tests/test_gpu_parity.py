@@ -769,7 +769,7 @@ def test_kronecker_workspace_matches_dense_kron():
 
 @pytest.mark.parametrize("cap", ["64", "128", "256"])
 def test_blocked_substitution_in_wide_fronts(cap, monkeypatch):
-    """Fronts wider than the inverse cap (4096 columns by default; GMRFX_INV_CAP lowers it here) only hold the
+    """Fronts wider than the inverse cap (2048 columns by default; GMRFX_INV_CAP lowers it here) only hold the
     inverses of their cap-column diagonal blocks: the sweeps substitute block by block inside them, the selected
     inversion completes the inverses on demand. Same answers as with full inverses."""
     monkeypatch.setenv("GMRFX_INV_CAP", cap)
