@@ -17,9 +17,6 @@ struct FrontArg { int on, s, c, r, ld, first; long long pp; };
 struct FrontView { int s, c, r, ld, first; long long pp; };
 void launch_assemble(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, int max_rows,
                      const double *nzval, double *L, double *CB);
-void launch_nt128_panel(hipStream_t st, const DevSym &S, const int *list, int nactive, int k0, int K, int c0, int c1,
-                        int maxM, int maxN, double *L, const FrontArg &fa);
-void launch_nt128_cb(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_trail, double *L, double *CB);
 void launch_syrk_cb(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_trail, const double *L, double *CB);
 void launch_trsm(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int mode, int max_rows_below,
                  double *L, double *Yh, const long long *yoff, const FrontArg &fa);

@@ -13,8 +13,6 @@
 // B[lane>>4][lane&15] (cdna_hip_programming.md section 3).
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
-
 #include <algorithm>
 
 #include <climits>
@@ -344,7 +342,6 @@ __global__ __launch_bounds__(256) void k_gemm_nt(DevSym S, const int *__restrict
 // One workgroup per 64x64 lower tile: the children's entries that fall into the tile are gathered
 // into an LDS tile (fixed child order, no atomics), the product runs on the FP64 MFMA, the
 // epilogue stores LDS tile minus accumulators. No zero-fill, no read-modify-write of CB in HBM.
-template <int GATHER_ONLY>   // 1: only the extend-add of the children is written; the product follows in k_nt128 (gemm128.hip)
 __global__ __launch_bounds__(256) void k_syrk_cb(DevSym S, const int *__restrict__ list, const double *__restrict__ L,
                                                  double *__restrict__ CB) {
     __shared__ double Tl[64 * 65];
@@ -417,7 +414,7 @@ __global__ __launch_bounds__(256) void k_syrk_cb(DevSym S, const int *__restrict
     auto fa = [&](int j, int q) { return A[min(j, m - 1) + (long long)min(max(q, 0), c - 1) * ld]; };
     auto fb = [&](int q, int i) { return A[min(i, m - 1) + (long long)min(max(q, 0), c - 1) * ld]; };
     // D[m_ = j][n = i] = sum_q L21[j][q] L21[i][q]: rows i on the lanes (contiguous in column-major CB)
-    if (!GATHER_ONLY) wave_gemm_32x32(acc, j0, i0, 0, c, fa, fb, lm, lk);
+    wave_gemm_32x32(acc, j0, i0, 0, c, fa, fb, lm, lk);
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -963,25 +960,9 @@ void launch_assemble(hipStream_t st, const DevSym &S, const int *list, int nfron
     else
         hipLaunchKernelGGL(k_assemble<0>, dim3(odd(cdiv(max_cols, ASM_CW)), nfronts), dim3(256), 0, st, S, list, nzval, L, CB);
 }
-// launches with at least this many 128 x 128 tiles (and fronts of at least 2048 rows) take the LDS-staged
-// kernel of gemm128.hip: 8 tiles per CU by default, i.e. the huge fronts of 3-D problems only
-static int nt128_min_tiles() {
-    const char *e = std::getenv("GMRFX_NT128_MIN");     // read per call: a testing knob, two launches per level
-    return e ? std::atoi(e) : 2048;
-}
-static int nt128_min_rows() {
-    const char *e = std::getenv("GMRFX_NT128_ROWS");
-    return e ? std::atoi(e) : 2048;
-}
 void launch_syrk_cb(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_trail, const double *L, double *CB) {
     if (nfronts <= 0 || max_trail <= 0) return;
-    const long long t128 = cdiv(max_trail, 128);
-    if (!std::getenv("GMRFX_NT128_NOCB") && max_trail >= nt128_min_rows() && t128 * (t128 + 1) / 2 * nfronts >= nt128_min_tiles()) {
-        hipLaunchKernelGGL(k_syrk_cb<1>, dim3(odd(cdiv(max_trail, 64)), odd(cdiv(max_trail, 64)), nfronts), dim3(256), 0, st, S, list, L, CB);
-        launch_nt128_cb(st, S, list, nfronts, max_trail, const_cast<double *>(L), CB);
-        return;
-    }
-    hipLaunchKernelGGL(k_syrk_cb<0>, dim3(odd(cdiv(max_trail, 64)), odd(cdiv(max_trail, 64)), nfronts), dim3(256), 0, st, S, list, L, CB);
+    hipLaunchKernelGGL(k_syrk_cb, dim3(odd(cdiv(max_trail, 64)), odd(cdiv(max_trail, 64)), nfronts), dim3(256), 0, st, S, list, L, CB);
 }
 void launch_trsm(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int mode, int max_rows_below,
                  double *L, double *Yh, const long long *yoff, const FrontArg &fa) {
@@ -999,10 +980,6 @@ void launch_trsm(hipStream_t st, const DevSym &S, const int *list, int nactive, 
 void launch_gemm_nt(hipStream_t st, const DevSym &S, const int *list, int nactive, int k0, int K, int c0, int c1,
                     int maxM, int maxN, double *L, const FrontArg &fa) {
     if (nactive <= 0 || maxM <= 0 || maxN <= 0) return;
-    if (!std::getenv("GMRFX_NT128_NOPANEL") && maxM >= nt128_min_rows() && (long long)cdiv(maxM, 128) * cdiv(maxN, 128) * nactive >= 2LL * nt128_min_tiles()) {
-        launch_nt128_panel(st, S, list, nactive, k0, K, c0, c1, maxM, maxN, L, fa);     // huge fronts: gemm128.hip
-        return;
-    }
     // 64x64 workgroup tiles, operands straight from L2 at 3-4 waves per SIMD. Measured on MI355X: the
     // sustained v_mfma_f64_16x16x4_f64 rate is 36.3 TFLOP/s (tools/micro/mfma64.hip), this kernel reaches
     // ~27 TFLOP/s on the top-of-tree SYRKs; 128x128 tiles (register- or LDS-staged) were tried and lost

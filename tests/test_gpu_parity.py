@@ -794,24 +794,3 @@ def test_blocked_substitution_in_wide_fronts(cap, monkeypatch):
         assert relerr(ws.workspace_solve(B), F.solve(B)) < 1e-10
         ws.update_precision(sp.csc_matrix(1.5 * Q))       # refactorise: back to capped inverses
         assert relerr(ws.workspace_solve(B), F.solve(B) / 1.5) < 1e-10
-
-
-def test_lds_staged_128_tiles_match_oracle(monkeypatch):
-    """The 128 x 128 LDS-staged update kernel (gemm128.hip) only runs for launches with thousands of such tiles
-    (huge 3-D fronts); GMRFX_NT128_MIN / GMRFX_NT128_ROWS = 1 route every big-front panel update and contribution
-    block through it here: ragged sizes, several fronts per level, K not a multiple of 16."""
-    monkeypatch.setenv("GMRFX_NT128_MIN", "1")
-    monkeypatch.setenv("GMRFX_NT128_ROWS", "1")
-    rng = np.random.default_rng(128)
-    m3 = spde.grid_mesh_3d(14, 13, 12)
-    cases = [(sp.csc_matrix(np.cov(rng.standard_normal((523, 1400))) + np.eye(523)), {}),          # one dense front, 523 = 4*128 + 11
-             (sp.csc_matrix(spde.matern_precision(spde.grid_mesh_2d(90, 77, jitter=0.2), 0, 0.3)), {}),
-             (sp.csc_matrix(spde.matern_precision(m3, 0, 0.5)), {"coords": m3.points})]
-    for Q, kw in cases:
-        ws = gmrfx.GMRFWorkspace(Q, **kw)
-        F = orc.OracleFactor(Q, ws.backend.ordering_permutation())
-        Lg, Lo = ws.backend.factor_csc(), F.L()
-        assert abs(Lg - Lo).max() <= 1e-10 * abs(Lo).max()
-        assert abs(ws.logdet() - F.logdet()) <= 1e-10 * abs(F.logdet())
-        B = rng.standard_normal((Q.shape[0], 9))
-        assert relerr(ws.workspace_solve(B), F.solve(B)) < 1e-10
