@@ -7,6 +7,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -388,10 +389,10 @@ template <class F> static void parallel_ranges(i64 n, F &&fn) {
     if (n < 200000 || hw == 1) { fn((i64)0, n); return; }
     std::vector<std::thread> th;
     std::vector<std::exception_ptr> err(hw);
-    for (unsigned t = 0; t < hw; t++)
-        th.emplace_back([&, t] {
-            try { fn(n * t / hw, n * (t + 1) / hw); } catch (...) { err[t] = std::current_exception(); }
-        });
+    for (unsigned t = 0; t < hw; t++) {
+        auto job = [&, t] { try { fn(n * t / hw, n * (t + 1) / hw); } catch (...) { err[t] = std::current_exception(); } };
+        try { th.emplace_back(job); } catch (const std::system_error &) { job(); }     // no thread to be had: inline
+    }
     for (auto &x : th) x.join();
     for (auto &e : err) if (e) std::rethrow_exception(e);
 }

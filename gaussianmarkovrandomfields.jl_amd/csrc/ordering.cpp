@@ -15,6 +15,7 @@
 #include <bitset>
 #include <cstdlib>
 #include <exception>
+#include <system_error>
 #include <thread>
 #include <cmath>
 #include <numeric>
@@ -335,9 +336,14 @@ struct ND {
         // which thread runs what -- every rank of a sharded factorisation must get the same permutation.
         if (depth < par_depth && std::min(nA, nB) > 20000) {
             std::exception_ptr err;
-            std::thread t([&] { try { run(v, nA, pos, depth + 1); } catch (...) { err = std::current_exception(); } });
-            try { run(v + nA, nB, pos + nA, depth + 1); } catch (...) { t.join(); throw; }
-            t.join();
+            std::thread t;
+            try {
+                t = std::thread([&] { try { run(v, nA, pos, depth + 1); } catch (...) { err = std::current_exception(); } });
+            } catch (const std::system_error &) {      // no thread to be had (process limits): same work, serially
+                run(v, nA, pos, depth + 1);
+            }
+            try { run(v + nA, nB, pos + nA, depth + 1); } catch (...) { if (t.joinable()) t.join(); throw; }
+            if (t.joinable()) t.join();
             if (err) std::rethrow_exception(err);
         } else {
             run(v, nA, pos, depth + 1);

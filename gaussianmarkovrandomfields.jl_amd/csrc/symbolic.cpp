@@ -10,6 +10,7 @@
 #include <map>
 #include <numeric>
 #include <stdexcept>
+#include <system_error>
 #include <thread>
 
 namespace gmrfx {
@@ -683,8 +684,13 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
             }
             std::vector<std::thread> th;
             std::vector<std::exception_ptr> err(hw);
-            for (unsigned t = 0; t < hw; t++)
-                th.emplace_back([&, t] { try { work(cut[t], cut[t + 1]); } catch (...) { err[t] = std::current_exception(); } });
+            for (unsigned t = 0; t < hw; t++) {
+                try {
+                    th.emplace_back([&, t] { try { work(cut[t], cut[t + 1]); } catch (...) { err[t] = std::current_exception(); } });
+                } catch (const std::system_error &) {      // no thread to be had: this range on the calling thread
+                    try { work(cut[t], cut[t + 1]); } catch (...) { err[t] = std::current_exception(); }
+                }
+            }
             for (auto &x : th) x.join();
             for (auto &e : err) if (e) std::rethrow_exception(e);
         }
