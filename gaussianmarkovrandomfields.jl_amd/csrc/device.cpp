@@ -20,15 +20,29 @@ void hip_check(hipError_t e, const char *what) {
 template <class T> T *Device::dalloc(size_t count) {
     void *p = nullptr;
     HC(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
-    allocs_.push_back(p);
+    allocs_.push_back({p, std::max<size_t>(count, 1) * sizeof(T)});
     bytes_total += (double)(std::max<size_t>(count, 1) * sizeof(T));
     return (T *)p;
+}
+
+template <class T> T *Device::dregrow(T *old, size_t count) {
+    if (old) {
+        HC(hipDeviceSynchronize());       // nothing in flight may still read the old buffer
+        for (size_t k = 0; k < allocs_.size(); k++)
+            if (allocs_[k].first == (void *)old) {
+                bytes_total -= (double)allocs_[k].second;
+                allocs_.erase(allocs_.begin() + (long)k);
+                break;
+            }
+        (void)hipFree(old);
+    }
+    return dalloc<T>(count);
 }
 
 Device::~Device() {
     for (size_t k = 0; k < rd_plans_.size(); k++) rowdiag_plan_free((long long)k);
     if (stream) { (void)hipStreamSynchronize(stream); }
-    for (void *p : allocs_) (void)hipFree(p);
+    for (auto &p : allocs_) (void)hipFree(p.first);
     for (auto &e : ev_) if (e) (void)hipEventDestroy(e);
     for (auto &l : ev_lane_) for (auto &e : l) if (e) (void)hipEventDestroy(e);
     if (ev_ready_) (void)hipEventDestroy(ev_ready_);
@@ -103,16 +117,17 @@ void Device::upload(const Symbolic &S) {
     up(ip, S.sparent); ds_.sparent = ip;
     tmp64 = conv<long long>(S.qptr); up(lp, tmp64); ds_.qptr = lp; HC(hipStreamSynchronize(stream));
     {
-        std::vector<int> qs(S.qsrc.size()), qd(S.qdst.size());
+        std::vector<int> qs(S.qsrc.size()), qd(S.qdst.size()), qc(S.qdst.size());
         for (i32 s = 0; s < ns; s++)
             for (i64 q = S.qptr[s]; q < S.qptr[s + 1]; q++) {
                 qs[q] = (int)S.qsrc[q];
-                i64 rel = S.qdst[q] - S.panelptr[s];
-                if (rel >= INT_MAX) throw std::runtime_error("panel too large for 32-bit scatter offsets");
-                qd[q] = (int)rel;
+                const i64 rel = S.qdst[q] - S.panelptr[s];      // column-major offset inside the panel (may exceed 2^31)
+                qc[q] = (int)(rel / S.ld[s]);
+                qd[q] = (int)(rel % S.ld[s]);
             }
         up(ip, qs); ds_.qsrc = ip;
         up(ip, qd); ds_.qdst = ip;
+        up(ip, qc); ds_.qcol = ip;
         HC(hipStreamSynchronize(stream));
     }
     {
@@ -377,6 +392,7 @@ void Device::refactorize_phase(const double *d_nzval, int phase) {
     HC(hipEventRecord(ev_[0], stream));
     if (phase == 0) {
         nz_src_ = d_nzval;
+        nz_held_ = false;       // the values live in the caller's device buffer
         factorized = false;
         factor_levels(0, split);
     } else {
@@ -398,9 +414,10 @@ void Device::set_prior(const double *prior_nzval, const long long *map, long lon
         if (map[k] < 0 || map[k] >= nnz) throw std::invalid_argument("Hessian index map points outside the stored pattern of Q");
     if (!d_prior_) d_prior_ = dalloc<double>((size_t)nnz);
     HC(hipMemcpyAsync(d_prior_, prior_nzval, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice, stream));
-    if (cnt > hmap_cnt_ || !d_hmap_) {
-        d_hmap_ = dalloc<long long>((size_t)std::max<long long>(cnt, 1));
-        d_h_ = dalloc<double>((size_t)std::max<long long>(cnt, 1));
+    if (cnt > hmap_cap_ || !d_hmap_) {
+        d_hmap_ = dregrow(d_hmap_, (size_t)std::max<long long>(cnt, 1));
+        d_h_ = dregrow(d_h_, (size_t)std::max<long long>(cnt, 1));
+        hmap_cap_ = cnt;
     }
     hmap_cnt_ = cnt;
     if (cnt > 0) HC(hipMemcpyAsync(d_hmap_, map, (size_t)cnt * sizeof(long long), hipMemcpyHostToDevice, stream));
@@ -546,7 +563,7 @@ void Device::solve(const double *B, long long ldb, long long nrhs, double *X, lo
     long long ldin = ldb, ldout = ldx_out;
     if (!on_device) {
         const long long need = n * nrhs;
-        if (need > io_cap_) { d_io_ = dalloc<double>((size_t)need); io_cap_ = need; }
+        if (need > io_cap_) { io_cap_ = std::max(need, 2 * io_cap_); d_io_ = dregrow(d_io_, (size_t)io_cap_); }
         if (ldb == n) HC(hipMemcpyAsync(d_io_, B, (size_t)need * sizeof(double), hipMemcpyHostToDevice, stream));
         else HC(hipMemcpy2DAsync(d_io_, n * sizeof(double), B, ldb * sizeof(double), n * sizeof(double), nrhs, hipMemcpyHostToDevice, stream));
         dB = d_io_; dXo = d_io_; ldin = n; ldout = n;
@@ -658,10 +675,9 @@ void Device::quadform(const double *d_nz, const double *d_X, long long ldx, long
     }
     const int nblk = quadform_blocks((int)S.n);
     if (nvec > qf_cap_) {
-        // old buffers stay in allocs_ until the handle dies; growth is geometric
-        qf_cap_ = std::max<long long>(nvec, 2 * qf_cap_);
-        d_qf_part_ = dalloc<double>((size_t)qf_cap_ * nblk);
-        d_qf_out_ = dalloc<double>((size_t)qf_cap_);
+        qf_cap_ = std::max<long long>(nvec, 2 * qf_cap_);     // geometric growth, the old buffers are freed
+        d_qf_part_ = dregrow(d_qf_part_, (size_t)qf_cap_ * nblk);
+        d_qf_out_ = dregrow(d_qf_out_, (size_t)qf_cap_);
     }
     HC(hipEventRecord(ev_[0], stream));
     launch_quadform(stream, (int)S.n, d_in_colptr_, d_in_row_, d_nz, S.in_use, d_X, ldx, (int)nvec, d_mu, d_qf_part_, d_qf_out_);
@@ -700,7 +716,7 @@ void Device::selinv_compute() {
             }
             mx = std::max(mx, off);
         }
-        if (mx > tmp_cap_) { d_tmp_ = dalloc<double>((size_t)mx); tmp_cap_ = mx; }
+        if (mx > tmp_cap_) { d_tmp_ = dregrow(d_tmp_, (size_t)mx); tmp_cap_ = mx; }
         HC(hipMalloc((void **)&d_yoff, std::max<size_t>(yoff.size(), 1) * sizeof(long long)));
         HC(hipMemcpyAsync(d_yoff, yoff.data(), yoff.size() * sizeof(long long), hipMemcpyHostToDevice, stream));
         HC(hipStreamSynchronize(stream));
@@ -740,7 +756,7 @@ void Device::selinv_compute() {
 void Device::selinv_diag(double *out_host) {
     HC(hipSetDevice(device));
     const long long n = S_->n;
-    if (n > io_cap_) { d_io_ = dalloc<double>((size_t)n); io_cap_ = n; }
+    if (n > io_cap_) { d_io_ = dregrow(d_io_, (size_t)n); io_cap_ = n; }
     launch_gather_diag(stream, d_Z_, ds_.diagoff, ds_.perm, (int)n, d_io_);
     HC(hipMemcpyAsync(out_host, d_io_, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, stream));
     HC(hipStreamSynchronize(stream));

@@ -36,7 +36,9 @@ struct DevSym {
     const int *sparent;
     const long long *qptr;      // nsuper+1
     const int *qsrc;            // index into caller nzval
-    const int *qdst;            // offset inside the destination panel
+    const int *qdst;            // destination ROW inside the panel column qcol (entries sorted by column, then row)
+    const int *qcol;            // front-local destination column (row / column kept apart: a panel may hold more
+                                // than 2^31 entries -- the 47 000-column root of a 126^3-node 3-D mesh)
     const long long *wptr;      // nsuper+1: prefix sum of trailing rows (r-c)
     const long long *diagoff;   // n
     const int *perm;            // n
@@ -129,7 +131,9 @@ private:
     void forward(int nr, int ldx, int lo, int hi);
     void backward(int nr, int ldx, bool y_in_x2, int hi, int lo);
     template <class T> T *dalloc(size_t count);
-    std::vector<void *> allocs_;
+    // growable buffer: frees the previous allocation (after the streams have drained) and takes it off the books
+    template <class T> T *dregrow(T *old, size_t count);
+    std::vector<std::pair<void *, size_t>> allocs_;
 
     const Symbolic *S_ = nullptr;
     DevSym ds_{};
@@ -144,7 +148,7 @@ private:
     const double *nz_src_ = nullptr;
     double *d_prior_ = nullptr, *d_h_ = nullptr;
     long long *d_hmap_ = nullptr;
-    long long hmap_cnt_ = 0;   // values of the refactorisation in flight (d_nz_ or the caller's device buffer)
+    long long hmap_cnt_ = 0, hmap_cap_ = 0;   // values of the refactorisation in flight (d_nz_ or the caller's device buffer)
     double *d_X_ = nullptr, *d_X2_ = nullptr, *d_W_ = nullptr, *d_io_ = nullptr, *d_tmp_ = nullptr, *d_part_ = nullptr;
     // dense-inverse stages (inverse.hip)
     int *d_invlist_ = nullptr;

@@ -388,6 +388,7 @@ template <class F> static void parallel_ranges(i64 n, F &&fn) {
     const unsigned hw = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
     if (n < 200000 || hw == 1) { fn((i64)0, n); return; }
     std::vector<std::thread> th;
+    th.reserve(hw);      // no reallocation (and so no bad_alloc with joinable threads alive) inside the loop
     std::vector<std::exception_ptr> err(hw);
     for (unsigned t = 0; t < hw; t++) {
         auto job = [&, t] { try { fn(n * t / hw, n * (t + 1) / hw); } catch (...) { err[t] = std::current_exception(); } };
@@ -395,6 +396,14 @@ template <class F> static void parallel_ranges(i64 n, F &&fn) {
     }
     for (auto &x : th) x.join();
     for (auto &e : err) if (e) std::rethrow_exception(e);
+}
+
+// A caller-supplied compressed pattern (ptr has ncol + 1 entries): ptr[0] == base, monotone. Everything that
+// sizes a buffer from ptr[ncol] and then walks ptr[j] .. ptr[j + 1] checks this first (INVALID_ARG, not a heap overrun).
+static void check_compressed_ptr(const int64_t *ptr, int64_t ncol, int32_t base, const char *what) {
+    if (ptr[0] != base) throw std::invalid_argument(std::string(what) + "[0] != index_base");
+    for (int64_t j = 0; j < ncol; j++)
+        if (ptr[j + 1] < ptr[j]) throw std::invalid_argument(std::string(what) + " not monotone");
 }
 
 // offset of Sigma(i, j) (original indices) in the selected-inverse panels, -1 outside the factor pattern
@@ -416,6 +425,7 @@ extern "C" int32_t gmrfx_selinv_extract(gmrfx_handle *h, int64_t ncol, const int
         if (ncol != S.n) throw std::invalid_argument("pattern must have n columns");
         if (!colptr || !rowval || !out) throw std::invalid_argument("null argument");
         if (base != 0 && base != 1) throw std::invalid_argument("index_base must be 0 or 1");
+        check_compressed_ptr(colptr, ncol, base, "colptr");
         h->D->selinv_compute();
         const i64 nz = colptr[ncol] - base;
         std::vector<long long> off((size_t)nz);
@@ -440,6 +450,7 @@ extern "C" int32_t gmrfx_selinv_dot(gmrfx_handle *h, int64_t ncol, const int64_t
         if (ncol != S.n) throw std::invalid_argument("B must have n columns");
         if (!colptr || !rowval || !nzval || !out) throw std::invalid_argument("null argument");
         if (base != 0 && base != 1) throw std::invalid_argument("index_base must be 0 or 1");
+        check_compressed_ptr(colptr, ncol, base, "colptr");
         h->D->selinv_compute();
         const i64 nz = colptr[ncol] - base;
         std::vector<long long> off((size_t)nz);
@@ -467,6 +478,7 @@ extern "C" int32_t gmrfx_selinv_dot(gmrfx_handle *h, int64_t ncol, const int64_t
 // pairs (p, q <= p) of the entries of every row of a sparse design matrix + the offsets of Sigma[j_p, j_q]
 static void plan_row_pairs(const Symbolic &S, int64_t m, const int64_t *rowptr, const int64_t *colind, int32_t base,
                            std::vector<long long> &seg, std::vector<long long> &off, std::vector<int> &pi, std::vector<int> &qi) {
+    check_compressed_ptr(rowptr, m, base, "rowptr");
     seg.assign((size_t)m + 1, 0);
     for (i64 i = 0; i < m; i++) {
         const i64 k = rowptr[i + 1] - rowptr[i];
@@ -483,7 +495,9 @@ static void plan_row_pairs(const Symbolic &S, int64_t m, const int64_t *rowptr, 
                 const i64 jp = colind[p] - base;
                 if (jp < 0 || jp >= S.n) throw std::invalid_argument("colind out of range");
                 for (i64 q = rowptr[i] - base; q <= p; q++) {
-                    off[t] = z_offset(S, jp, colind[q] - base);
+                    const i64 jq = colind[q] - base;
+                    if (jq < 0 || jq >= S.n) throw std::invalid_argument("colind out of range");
+                    off[t] = z_offset(S, jp, jq);
                     pi[t] = (int)p; qi[t] = (int)q;
                     t++;
                 }

@@ -83,8 +83,8 @@ __global__ __launch_bounds__(256) void k_assemble(DevSym S, const int *__restric
         const int *qd = S.qdst + q0;
         const int *qs = S.qsrc + q0;
         int lo, hi;
-        wave_lower_bound2(qd, nq, tc * ld, (tc + 1) * ld, lane, lo, hi);
-        for (int q = lo + tl; q < hi; q += NL) Pc[qd[q] - tc * ld] = nzval[qs[q]];
+        wave_lower_bound2(S.qcol + q0, nq, tc, tc + 1, lane, lo, hi);
+        for (int q = lo + tl; q < hi; q += NL) Pc[qd[q]] = nzval[qs[q]];
     }
     if (WIDE) __syncthreads();
     for (long long ch = S.childptr[s]; ch < S.childptr[s + 1]; ch++) {
@@ -912,8 +912,8 @@ __global__ __launch_bounds__(256) void k_assemble_lds(DevSym S, const int *__res
         const int *qd = S.qdst + q0;
         const int *qs = S.qsrc + q0;
         int lo, hi;
-        wave_lower_bound2(qd, nq, tc * ld, (tc + 1) * ld, lane, lo, hi);
-        for (int q = lo + lane; q < hi; q += 64) Cw[qd[q] - tc * ld] = nzval[qs[q]];
+        wave_lower_bound2(S.qcol + q0, nq, tc, tc + 1, lane, lo, hi);
+        for (int q = lo + lane; q < hi; q += 64) Cw[qd[q]] = nzval[qs[q]];
     }
     for (long long ch = S.childptr[s]; ch < S.childptr[s + 1]; ch++) {
         const EdgeRec er = S.edge[ch];

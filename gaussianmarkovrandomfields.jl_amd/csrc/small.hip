@@ -217,8 +217,7 @@ __device__ __forceinline__ void factor_small_front(const DevSym &S, const int s,
         const long long q0 = S.qptr[s];
         const int nq = (int)(S.qptr[s + 1] - q0);
         for (int q = tid; q < nq; q += 256) {
-            const int rel = S.qdst[q0 + q];
-            const int col = rel / ld, row = rel - col * ld;
+            const int col = S.qcol[q0 + q], row = S.qdst[q0 + q];
             F[col * LDF + row] = nzval[S.qsrc[q0 + q]];
         }
     }

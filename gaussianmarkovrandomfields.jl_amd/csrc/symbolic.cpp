@@ -683,6 +683,7 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
                 cut[t] = (i32)s;
             }
             std::vector<std::thread> th;
+            th.reserve(hw);     // no reallocation inside the loop: nothing can throw with joinable threads alive
             std::vector<std::exception_ptr> err(hw);
             for (unsigned t = 0; t < hw; t++) {
                 try {

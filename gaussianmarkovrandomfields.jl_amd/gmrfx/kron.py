@@ -1,5 +1,5 @@
 """Separable (Kronecker) precision Q = kron(Q_1, Q_2) -- SURVEY 8 f3, prior-level operations only: everything is
-answered from the two factor-scale workspaces, the n_1 n_2 x n_1 n_2 product is never formed.
+answered from the two factor-scale backends, the n_1 n_2 x n_1 n_2 product is never formed.
 
 Reference: SeparableModel, src/latent_models/separable.jl:122-172 -- `precision_matrix` folds `kron` over the
 components (the RIGHTMOST component varies fastest: x[i1 * n2 + i2]), `precision_logdet` uses
@@ -10,14 +10,14 @@ from __future__ import annotations
 
 import numpy as np
 
-from .workspace import GMRFWorkspace
+from .backend import MI355XBackend
 
 
 class KroneckerWorkspace:
     def __init__(self, Q1, Q2, kw1=None, kw2=None):
-        self.ws1 = GMRFWorkspace(Q1, **(kw1 or {}))
-        self.ws2 = GMRFWorkspace(Q2, **(kw2 or {}))
-        self.n1, self.n2 = self.ws1.dimension(), self.ws2.dimension()
+        self.ws1 = MI355XBackend(Q1, **(kw1 or {}))
+        self.ws2 = MI355XBackend(Q2, **(kw2 or {}))
+        self.n1, self.n2 = self.ws1.n, self.ws2.n
 
     def dimension(self) -> int:
         return self.n1 * self.n2
@@ -34,20 +34,20 @@ class KroneckerWorkspace:
 
     def logdet(self) -> float:
         """precision_logdet (separable.jl:122-141): sum_i (N / n_i) logdet(Q_i)."""
-        return self.n2 * self.ws1.logdet() + self.n1 * self.ws2.logdet()
+        return self.n2 * self.ws1.compute_logdet() + self.n1 * self.ws2.compute_logdet()
 
     def solve(self, b):
         """(Q_1 (x) Q_2)^-1 b = vec(Q_2^-1 B Q_1^-1)."""
-        W = self.ws2.workspace_solve(self._mat(b)).reshape(self.n2, self.n1)
-        Y = self.ws1.workspace_solve(np.asfortranarray(W.T)).reshape(self.n1, self.n2)
+        W = self.ws2.backend_solve(self._mat(b)).reshape(self.n2, self.n1)
+        Y = self.ws1.backend_solve(np.asfortranarray(W.T)).reshape(self.n1, self.n2)
         return self._vec(Y.T)
 
     def backward_solve(self, z):
         """A sample of N(0, Q^-1) from z ~ N(0, I): (A_1 (x) A_2) z with A_i = P_i' L_i^-T (backend.jl:281-284)."""
-        W = self.ws2.backward_solve(self._mat(z)).reshape(self.n2, self.n1)
-        Y = self.ws1.backward_solve(np.asfortranarray(W.T)).reshape(self.n1, self.n2)
+        W = self.ws2.backend_backward_solve(self._mat(z)).reshape(self.n2, self.n1)
+        Y = self.ws1.backend_backward_solve(np.asfortranarray(W.T)).reshape(self.n1, self.n2)
         return self._vec(Y.T)
 
     def selinv_diag(self):
         """diag(Q^-1) = kron(diag(Q_1^-1), diag(Q_2^-1))."""
-        return np.kron(self.ws1.selinv_diag(), self.ws2.selinv_diag())
+        return np.kron(self.ws1.get_selinv_diag(), self.ws2.get_selinv_diag())

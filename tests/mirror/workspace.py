@@ -1,4 +1,4 @@
-"""GMRFWorkspace / WorkspacePool -- mirror of src/workspace/gmrf_workspace.jl:31-302 and
+"""TEST INFRASTRUCTURE (not part of the product package): GMRFWorkspace / WorkspacePool -- mirror of src/workspace/gmrf_workspace.jl:31-302 and
 src/workspace/workspace_pool.jl:42-119 on top of MI355XBackend: owns a Q buffer with a fixed
 pattern, lazy validity flags, the logdet cache; every numeric result comes from the backend."""
 from __future__ import annotations
@@ -9,7 +9,7 @@ from contextlib import contextmanager
 import numpy as np
 import scipy.sparse as sp
 
-from .backend import MI355XBackend, _as_csc
+from gmrfx.backend import MI355XBackend, _as_csc
 
 
 class GMRFWorkspace:

@@ -11,6 +11,7 @@ import scipy.sparse as sp
 import gmrfx
 import orc
 from gmrfx import spde
+from mirror import GMRFWorkspace, WorkspacePool
 
 pytestmark = pytest.mark.gpu
 
@@ -39,7 +40,7 @@ CASES = list(_cases())
 def case(request):
     name, Q, kw = request.param
     Q = sp.csc_matrix(Q)
-    ws = gmrfx.GMRFWorkspace(Q, **kw)
+    ws = GMRFWorkspace(Q, **kw)
     F = orc.OracleFactor(Q, ws.backend.ordering_permutation())
     return name, Q, ws, F
 
@@ -118,7 +119,7 @@ def test_predictor_variances_of_fem_evaluation_matrix():
     cells = mesh.cells[rng.integers(0, len(mesh.cells), size=250)]
     wts = rng.dirichlet(np.ones(3), size=len(cells))
     A = sp.csr_matrix((wts.ravel(), (np.repeat(np.arange(len(cells)), 3), cells.ravel())), shape=(len(cells), n))
-    ws = gmrfx.GMRFWorkspace(Q, coords=mesh.points)
+    ws = GMRFWorkspace(Q, coords=mesh.points)
     v = ws.row_diag_ASigmaAt(A)
     Sigma = np.linalg.inv(Q.toarray())
     want = np.einsum("ij,jk,ik->i", A.toarray(), Sigma, A.toarray())
@@ -277,7 +278,7 @@ def test_getters_are_cached_and_invalidate(case):
 
 def test_pattern_mismatch_and_length_errors():
     Q = spde.random_spd_precision(20)
-    ws = gmrfx.GMRFWorkspace(Q)
+    ws = GMRFWorkspace(Q)
     Qbad = Q.copy().tolil(); Qbad[0, 19] = 0.0; Qbad[19, 0] = 0.0
     Qbad = sp.csc_matrix(Qbad); Qbad.eliminate_zeros()
     if Qbad.nnz != Q.nnz:
@@ -317,7 +318,7 @@ def test_explicit_permutation_and_orderings_agree():
     ld = np.linalg.slogdet(Q.toarray())[1]
     dg = np.diag(np.linalg.inv(Q.toarray()))
     for kw in ({}, {"ordering": rng.permutation(n)}, {"ordering": "natural"}, {"coords": m.points}):
-        ws = gmrfx.GMRFWorkspace(Q, **kw)
+        ws = GMRFWorkspace(Q, **kw)
         assert relerr(ws.workspace_solve(b), ref) < 1e-10
         assert abs(ws.logdet() - ld) < 1e-10 * abs(ld)
         assert relerr(ws.selinv_diag(), dg) < 1e-8
@@ -337,7 +338,7 @@ def test_clone_is_independent():
 def test_sampling_moments():
     """cov(backward_solve(z)) = Q^-1 in ORIGINAL ordering (test_gmrf_workspace.jl:85-100)."""
     Q = spde.random_spd_precision(20)
-    ws = gmrfx.GMRFWorkspace(Q)
+    ws = GMRFWorkspace(Q)
     rng = np.random.default_rng(123)
     Zs = rng.standard_normal((20, 50000))
     S = ws.backward_solve(Zs)
@@ -350,7 +351,7 @@ def test_pool_threads():
     import threading
     m = spde.grid_mesh_2d(20, 20, jitter=0.2)
     Q = spde.matern_precision(m, 0, 0.3)
-    pool = gmrfx.WorkspacePool(Q, size=3, coords=m.points)
+    pool = WorkspacePool(Q, size=3, coords=m.points)
     ref = np.linalg.slogdet(Q.toarray())[1]
     out = {}
 
@@ -369,7 +370,7 @@ def test_residual_property_256():
     """Size-independent property at a size the dense check cannot reach: ||QX-B||/||B||."""
     m = spde.grid_mesh_2d(256, 256, jitter=0.25)
     Q = spde.matern_precision(m, 0, 0.2)
-    ws = gmrfx.GMRFWorkspace(Q, coords=m.points)
+    ws = GMRFWorkspace(Q, coords=m.points)
     B = np.random.default_rng(1).standard_normal((Q.shape[0], 64))
     X = ws.workspace_solve(B)
     assert np.linalg.norm(Q @ X - B) / np.linalg.norm(B) < 1e-10
@@ -386,7 +387,7 @@ def test_generic_path_matches_fused_small_front_path(name, monkeypatch):
     (GMRFX_SMALL_ROWS=0) must both agree with the oracle."""
     Q, kw = next((sp.csc_matrix(q), k) for n, q, k in CASES if n == name)
     monkeypatch.setenv("GMRFX_SMALL_ROWS", "0")
-    ws = gmrfx.GMRFWorkspace(Q, **kw)
+    ws = GMRFWorkspace(Q, **kw)
     assert ws.backend.stats()["n_small_fronts"] == 0
     F = orc.OracleFactor(Q, ws.backend.ordering_permutation())
     assert abs(ws.backend.factor_csc() - F.L()).max() <= 1e-10 * abs(F.L()).max()
@@ -396,7 +397,7 @@ def test_generic_path_matches_fused_small_front_path(name, monkeypatch):
     assert relerr(ws.selinv_diag(), F.selinv_diag()) < 1e-8
     for rows in ("64", "128"):      # the other size-class cut-offs (default: 96)
         monkeypatch.setenv("GMRFX_SMALL_ROWS", rows)
-        wsr = gmrfx.GMRFWorkspace(Q, **kw)
+        wsr = GMRFWorkspace(Q, **kw)
         assert relerr(wsr.workspace_solve(B), F.solve(B)) < 1e-10
         assert relerr(wsr.selinv_diag(), F.selinv_diag()) < 1e-8
 
@@ -410,7 +411,7 @@ def test_hip_path_matches_golden_fixtures(path):
     g = np.load(path)
     n = int(g["n"])
     Q = sp.csc_matrix((g["nzval"], g["rowval"], g["colptr"]), shape=(n, n))
-    ws = gmrfx.GMRFWorkspace(Q, ordering=g["perm"])
+    ws = GMRFWorkspace(Q, ordering=g["perm"])
     # the user's order is kept up to an etree postorder: same fill, exact integer check
     assert ws.backend.stats()["nnz_l"] == int(g["L_colcount"].sum())
     assert relerr(ws.workspace_solve(g["B"]), g["X"]) < 1e-10
@@ -465,18 +466,6 @@ def test_full_size_properties_cfg2():
         assert abs(be.backend_solve(e)[k] - d[k]) < 1e-7 * d[k]
 
 
-def test_3d_medium_residual():
-    m3 = spde.grid_mesh_3d(28, 28, 28)
-    Q = spde.matern_precision(m3, 0, 0.5)
-    ws = gmrfx.GMRFWorkspace(Q, coords=m3.points)
-    B = np.random.default_rng(2).standard_normal((Q.shape[0], 8))
-    X = ws.workspace_solve(B)
-    assert np.linalg.norm(Q @ X - B) / np.linalg.norm(B) < 1e-10
-    F = orc.OracleFactor(Q, ws.backend.ordering_permutation())
-    assert abs(ws.logdet() - F.logdet()) < 1e-10 * abs(F.logdet())
-    assert relerr(ws.selinv_diag(), F.selinv_diag()) < 1e-8
-
-
 def test_midsize_multiblock_fronts_match_oracle():
     """300 x 300 nodes: the top separators have several hundred columns, so this is the smallest case that
     runs the two-level blocked panel factorisation (K = 256 updates), the latency variants of TRSM / GEMM /
@@ -485,7 +474,7 @@ def test_midsize_multiblock_fronts_match_oracle():
     m = spde.grid_mesh_2d(300, 300, jitter=0.25, seed=5)
     Q = sp.csc_matrix(spde.matern_precision(m, 0, 0.2))
     n = Q.shape[0]
-    ws = gmrfx.GMRFWorkspace(Q, coords=m.points)
+    ws = GMRFWorkspace(Q, coords=m.points)
     st = ws.backend.stats()
     assert st["max_cols"] > 256          # the K = 256 outer update and >= 3 inverse stages are exercised
     F = orc.OracleFactor(Q, ws.backend.ordering_permutation())
@@ -514,7 +503,7 @@ def test_disconnected_and_arrow_patterns():
     A[0, :] = 0.01; A[:, 0] = 0.01; A[0, 0] = 5.0
     for Q in (Qb, sp.csc_matrix(A)):
         Q = sp.csc_matrix(Q)
-        ws = gmrfx.GMRFWorkspace(Q)
+        ws = GMRFWorkspace(Q)
         F = orc.OracleFactor(Q, ws.backend.ordering_permutation())
         B = rng.standard_normal((Q.shape[0], 5))
         assert relerr(ws.workspace_solve(B), np.linalg.solve(Q.toarray(), B)) < 1e-10
@@ -528,9 +517,9 @@ def test_subtree_tasks_on_and_off_agree(name, monkeypatch):
     same factor bit for bit (same arithmetic per front), same answers."""
     Q, kw = next((sp.csc_matrix(q), k) for n, q, k in CASES if n == name)
     monkeypatch.setenv("GMRFX_SUBTREE_MAX", "24")
-    ws_on = gmrfx.GMRFWorkspace(Q, **kw)
+    ws_on = GMRFWorkspace(Q, **kw)
     monkeypatch.setenv("GMRFX_SUBTREE_MAX", "0")
-    ws_off = gmrfx.GMRFWorkspace(Q, **kw)
+    ws_off = GMRFWorkspace(Q, **kw)
     assert np.array_equal(ws_on.backend.factor_values(), ws_off.backend.factor_values())
     B = np.random.default_rng(0).standard_normal((Q.shape[0], 64))
     assert np.array_equal(ws_on.workspace_solve(B), ws_off.workspace_solve(B))
@@ -642,14 +631,26 @@ def test_randomised_pattern_sweep():
 
 def test_newton_update_on_device_matches_host_update():
     """Q_k = Q_prior - H_k formed on the device from the Hessian values only (index map uploaded
-    once) -- same factor, bit for bit, as refactorising from host-side updated values (the reference's
-    _update_hessian!, src/workspace/gaussian_approximation.jl:103-129), for diagonal and sparse Hessians."""
+    once). Checked against the ORACLE factor of Q_prior - H_k (value by value, logdet, one solve) and, bit for bit,
+    against refactorising from host-side updated values (the reference's _update_hessian!,
+    src/workspace/gaussian_approximation.jl:103-129), for diagonal and sparse Hessians."""
     m = spde.grid_mesh_2d(48, 48, jitter=0.2, seed=9)
     Q = sp.csc_matrix(spde.matern_precision(m, 0, 0.3))
     n = Q.shape[0]
     rng = np.random.default_rng(12)
     be = gmrfx.MI355XBackend(Q, coords=m.points)
     ref = gmrfx.MI355XBackend(Q, coords=m.points)
+    perm = be.ordering_permutation()
+    b = rng.standard_normal(n)
+
+    def against_oracle(nz):
+        Qk = sp.csc_matrix((nz, Q.indices, Q.indptr), shape=Q.shape)
+        F = orc.OracleFactor(Qk, perm)
+        Lg, Lo = be.factor_csc(), F.L()
+        assert abs(Lg - Lo).max() <= 1e-10 * abs(Lo).max()
+        assert abs(be.compute_logdet() - F.logdet()) <= 1e-11 * abs(F.logdet())
+        assert relerr(be.backend_solve(b), F.solve(b)) < 1e-10
+
     # diagonal Hessian (Diagonal branch): positions of the diagonal entries in nzval
     diag_idx = np.array([Q.indptr[j] + np.searchsorted(Q.indices[Q.indptr[j]:Q.indptr[j + 1]], j) for j in range(n)])
     be.set_prior(Q.data, diag_idx)
@@ -657,15 +658,22 @@ def test_newton_update_on_device_matches_host_update():
         h = -rng.uniform(0.1, 2.0, n)                        # H = -diag(.) : Q - H stays SPD
         be.refactorize_update(h)
         nz = Q.data.copy(); nz[diag_idx] -= h
+        against_oracle(nz)
         ref.refactorize_values(nz)
         assert np.array_equal(be.factor_values(), ref.factor_values())
         assert be.compute_logdet() == ref.compute_logdet()
-    # sparse Hessian on a sub-pattern of Q (SparseMatrixCSC branch): every 3rd stored entry, symmetric values
+    # sparse Hessian on a SUB-pattern of Q (SparseMatrixCSC branch): the diagonal plus every third off-diagonal pair
+    # (i, j) / (j, i) -- a symmetric selection -- with symmetric negative-definite values
+    coo = Q.tocoo()
+    lo, hi = np.minimum(coo.row, coo.col), np.maximum(coo.row, coo.col)
+    keep = np.flatnonzero((lo == hi) | ((lo * 7919 + hi) % 3 == 0))
+    assert 0 < keep.size < Q.nnz
     H = Q.copy(); H.data = -0.05 * np.abs(H.data)
-    keep = np.arange(Q.nnz)[::1]
+    H.data[diag_idx] = -(0.2 + np.abs(Q).sum(axis=0).A1 * 0.05)      # diagonally dominant: -H is SPD
     be.set_prior(Q.data, keep)
     be.refactorize_update(H.data[keep])
     nz = Q.data.copy(); nz[keep] -= H.data[keep]
+    against_oracle(nz)
     ref.refactorize_values(nz)
     assert np.array_equal(be.factor_values(), ref.factor_values())
     with pytest.raises(ValueError):
@@ -742,7 +750,7 @@ def test_kl_cholesky_supernodal_matches_oracle():
     assert abs(L - Lo).max() <= 1e-8 * abs(Lo).max()
     # and the resulting precision is a usable GMRF: it enters the hot path and its logdet matches the dense one
     Qk = sp.csc_matrix(L @ L.T)
-    ws = gmrfx.GMRFWorkspace(Qk)
+    ws = GMRFWorkspace(Qk)
     assert abs(ws.logdet() - np.linalg.slogdet(Qk.toarray())[1]) <= 1e-9 * abs(ws.logdet())
 
 
@@ -780,7 +788,7 @@ def test_blocked_substitution_in_wide_fronts(cap, monkeypatch):
              sp.csc_matrix(spde.matern_precision(m3, 0, 0.5))]
     kws = [{}, {}, {"coords": m3.points}]
     for k, (Q, kw) in enumerate(zip(cases, kws)):
-        ws = gmrfx.GMRFWorkspace(Q, **kw)
+        ws = GMRFWorkspace(Q, **kw)
         if k == 0:
             assert ws.backend.stats()["max_cols"] > int(cap)      # the dense case is blocked at every cap tried here
         F = orc.OracleFactor(Q, ws.backend.ordering_permutation())

@@ -4,8 +4,10 @@ LAPACK identities (solve, logdet, selinv diag, backward-solve covariance identit
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gaussianmarkovrandomfields.jl_amd"))
 import numpy as np, scipy.sparse as sp
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import gmrfx
 from gmrfx import spde
+from mirror import GMRFWorkspace
 
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
@@ -42,7 +44,7 @@ t0 = time.time()
 for i in range(ncases):
     name, Q, kw = rand_case(i)
     Q = sp.csc_matrix(Q); n = Q.shape[0]
-    ws = gmrfx.GMRFWorkspace(Q, **kw)
+    ws = GMRFWorkspace(Q, **kw)
     Qd = Q.toarray()
     nrhs = int(rng.choice([1, 2, 17, 64, 65]))
     B = rng.standard_normal((n, nrhs))
