@@ -44,9 +44,10 @@ def _as_csc(Q) -> sp.csc_matrix:
 class MI355XBackend:
     """`MI355XBackend(Symmetric(Q); ordering=nothing, coords=nothing)`.
 
-    ordering: None (own nested dissection), "natural", or an explicit permutation vector
-    (0-based here; the Julia shim passes 1-based with index_base=1), cf.
-    `CHOLMODBackend(Q; ordering)` backend.jl:147-153.
+    ordering: None (own nested dissection), "natural", an explicit permutation vector (0-based here; the Julia
+    shim passes 1-based with index_base=1), a callable pattern -> permutation (where Julia passes a CliqueTrees
+    algorithm object) or `PinDenseColumns(inner, frac)` -- resolved by `gmrfx.ordering.ordering_permutation`, the
+    host logic of `CHOLMODBackend(Q; ordering)` / `ordering_permutation`, backend.jl:86-153. Unknown forms raise.
     """
 
     def __init__(self, Q, ordering=None, coords=None, device: int = -1, symbolic_only: bool = False,
@@ -69,15 +70,11 @@ class MI355XBackend:
         opts.shard_rank = shard_rank
         opts.shard_world = shard_world
         self.shard_rank, self.shard_world = shard_rank, shard_world
-        perm = None
-        if isinstance(ordering, str):
-            if ordering != "natural":
-                raise ValueError(f"unknown ordering {ordering!r}")
+        from .ordering import ordering_permutation as _resolve
+        perm = _resolve(Q, ordering, coords)
+        if isinstance(perm, str):           # "natural"
             opts.ordering = 1
-        elif ordering is not None:
-            perm = np.ascontiguousarray(ordering, dtype=np.int64)
-            if perm.shape != (self.n,):
-                raise ValueError("ordering must be a permutation of length n")
+            perm = None
         self._coords = None
         if coords is not None:
             self._coords = np.ascontiguousarray(coords, dtype=np.float64)

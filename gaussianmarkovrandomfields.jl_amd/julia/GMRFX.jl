@@ -2,8 +2,10 @@
 # it to GaussianMarkovRandomFields.jl:
 #   * seam B: `MI355XBackend <: WorkspaceBackend`            (src/workspace/backend.jl:8-30)
 #   * seam A: `MI355XCholesky` LinearSolve algorithm + hooks  (ext/GaussianMarkovRandomFieldsPardiso.jl:10-80)
-# NOTE: this image has no Julia; the file is exercised 1:1 by the Python ctypes mirror
-# (gmrfx/_lib.py, gmrfx/backend.py, gmrfx/workspace.py) which the test-suite runs. Keep both in sync.
+# NOTE: this image has no Julia; the same call sequences are exercised by the Python ctypes binding
+# (gmrfx/_lib.py, gmrfx/backend.py) and the test mirrors of the host code above the seams
+# (tests/mirror/workspace.py = seam B state machine, tests/mirror/linsolve.py = seam A: `MI355XCacheval`,
+# `solve!`, the hooks below, `deepcopy(cache)`). Keep them in sync.
 module GMRFX
 
 using LinearAlgebra, SparseArrays
@@ -27,6 +29,8 @@ Base.@kwdef struct Opts            # mirrors gmrfx_opts
     coord_dim::Int32 = 0
     reserved0::Int32 = 0
     coords::Ptr{Float64} = C_NULL
+    shard_rank::Int32 = 0          # one factorisation sharded over several GPUs (include/gmrfx.h); 0 / 1 = unsharded
+    shard_world::Int32 = 1
 end
 
 mutable struct Handle
@@ -47,10 +51,21 @@ function check(code::Int32, h::Union{Handle, Nothing} = nothing)
     error("gmrfx error $code: $msg")
 end
 
+# `ordering` (src/workspace/backend.jl:73-153): nothing -> libgmrfx's own nested dissection; :natural; a permutation
+# vector; anything else CliqueTrees accepts (an EliminationAlgorithm such as CliqueTrees.MMD(), an (order, index)
+# tuple) or a `PinDenseColumns` wrapper is resolved ONCE by the reference's own `ordering_permutation(A, ordering)`
+# (backend.jl:86-133) and reaches the library as an explicit permutation. Nothing is dropped silently: whatever
+# that resolver rejects throws there.
+resolve_ordering(Q, ordering::Nothing) = nothing
+resolve_ordering(Q, ordering::Symbol) = ordering === :natural ? nothing : throw(ArgumentError("unknown ordering $ordering"))
+resolve_ordering(Q, ordering::AbstractVector{<:Integer}) = Vector{Int}(ordering)
+resolve_ordering(Q, ordering) = Vector{Int}(G.ordering_permutation(Q, ordering))
+
 function create(Q::SparseMatrixCSC{Float64, Int}; ordering = nothing, coords = nothing, device = -1,
         check_posdef = false)
     n = size(Q, 1)
-    perm = ordering isa AbstractVector ? Vector{Int}(ordering) : nothing
+    perm = resolve_ordering(Q, ordering)
+    perm === nothing || isperm(perm) && length(perm) == n || throw(ArgumentError("ordering is not a permutation of 1:$n"))
     C = coords === nothing ? nothing : Matrix{Float64}(transpose(coords))     # dim x n == n x dim row-major
     out = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve Q perm C begin
@@ -239,44 +254,65 @@ function G.sparse_approximate_cholesky!(Θ::Matrix{Float64}, L::SparseMatrixCSC{
     return
 end
 
-function Base.deepcopy_internal(b::MI355XBackend, ::IdDict)   # deepcopy(cache) in Newton loops
+function Base.deepcopy_internal(b::MI355XBackend, stackdict::IdDict)   # deepcopy(cache) in Newton loops
+    haskey(stackdict, b) && return stackdict[b]::MI355XBackend
     out = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:gmrfx_clone, LIB), Int32, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}), b.h.ptr, out))
-    return MI355XBackend(Handle(out[]), b.n, nothing, nothing)
+    c = MI355XBackend(Handle(out[]), b.n, nothing, nothing)
+    stackdict[b] = c
+    return c
 end
 
 # ---------------------------------------------------------------------------------- seam A
-# LinearSolve algorithm: cacheval = MI355XBackend; GMRF-side hooks exactly as the Pardiso extension.
+# LinearSolve algorithm; GMRF-side hooks exactly as the Pardiso extension (ext/GaussianMarkovRandomFieldsPardiso.jl:10-80).
 import LinearSolve, SciMLBase
 struct MI355XCholesky <: LinearSolve.AbstractFactorization
     ordering::Any
 end
 MI355XCholesky() = MI355XCholesky(nothing)
-LinearSolve.init_cacheval(::MI355XCholesky, A, b, u, Pl, Pr, maxiters, abstol, reltol, verbose, assumptions) = nothing
+
+# `LinearCache`'s `cacheval` field is parameterised on the type `init_cacheval` returns, so it must be a concrete
+# MUTABLE holder from the start (returning `nothing` and assigning a backend later is a `convert` error). The
+# backend handle is created by the first `solve!`; `colptr` / `rowval` remember the pattern it was analysed for.
+mutable struct MI355XCacheval
+    be::Union{Nothing, MI355XBackend}
+    colptr::Vector{Int}
+    rowval::Vector{Int}
+end
+LinearSolve.init_cacheval(::MI355XCholesky, A, b, u, Pl, Pr, maxiters, abstol, reltol, verbose, assumptions) =
+    MI355XCacheval(nothing, Int[], Int[])
+# deepcopy(cache) (gaussian_approximation.jl:103-109): the default field-wise deepcopy of the holder reaches
+# `deepcopy_internal(::MI355XBackend)` above, i.e. gmrfx_clone -- the factor survives the fork.
+
 function SciMLBase.solve!(cache::LinearSolve.LinearCache, alg::MI355XCholesky; kwargs...)
     A = cache.A isa Symmetric ? parent(cache.A) : cache.A
+    cv = LinearSolve.@get_cacheval(cache, :MI355XCholesky)::MI355XCacheval
     if cache.isfresh
-        be = cache.cacheval
-        if be === nothing
+        cp, rv = SparseArrays.getcolptr(A), rowvals(A)
+        if cv.be === nothing || cv.colptr != cp || cv.rowval != rv        # first solve!, or cache.A got a new pattern
             h = create(A; ordering = alg.ordering, check_posdef = true)     # seam A throws PosDefException
-            be = MI355XBackend(h, size(A, 1), nothing, nothing)
+            cv.be = MI355XBackend(h, size(A, 1), nothing, nothing)
+            cv.colptr, cv.rowval = copy(cp), copy(rv)
         end
-        refactorize!(be, Symmetric(A))
-        cache.cacheval = be
+        refactorize!(cv.be, Symmetric(A))
         cache.isfresh = false
     end
-    cache.u .= backend_solve(cache.cacheval, cache.b)
+    cache.u .= backend_solve(cv.be::MI355XBackend, cache.b)
     return SciMLBase.build_linear_solution(alg, cache.u, nothing, cache)
 end
+_be(cache) = (LinearSolve.@get_cacheval(cache, :MI355XCholesky)::MI355XCacheval).be::MI355XBackend
 G.supports_selinv(::MI355XCholesky) = Val{true}()
 G.supports_backward_solve(::MI355XCholesky) = Val{true}()
-G._selinv_diag_impl(cache, ::MI355XCholesky) = get_selinv_diag(cache.cacheval)
-G._selinv_impl(cache, ::MI355XCholesky) = Symmetric(get_selinv(cache.cacheval))
-G._backward_solve_impl(cache, x, ::MI355XCholesky) = backend_backward_solve(cache.cacheval, x)
-G._logdet_cov_impl(cache, ::MI355XCholesky) = -compute_logdet(cache.cacheval)       # note the sign (logdet.jl:30)
+G._selinv_diag_impl(cache, ::MI355XCholesky) = get_selinv_diag(_be(cache))
+G._selinv_impl(cache, ::MI355XCholesky) = Symmetric(get_selinv(_be(cache)))
+G._backward_solve_impl(cache, x, ::MI355XCholesky) = backend_backward_solve(_be(cache), x)
+G._logdet_cov_impl(cache, ::MI355XCholesky) = -compute_logdet(_be(cache))       # note the sign (logdet.jl:30)
 G.prepare_for_linsolve(A::SparseMatrixCSC, ::MI355XCholesky) = Symmetric(A)
 G.configure_algorithm(alg::MI355XCholesky) = alg
-G.algorithm_applicable(::MI355XCholesky, A) = A isa Union{SparseMatrixCSC, Symmetric{<:Any, <:SparseMatrixCSC}}
+# Val{true}() / Val{false}() like every method of this predicate (linsolve_utils.jl:49-56): `_resolve_linsolve`
+# dispatches on the Val; dense or SymTridiagonal storage falls back to LinearSolve's default
+G.algorithm_applicable(::MI355XCholesky, ::Union{SparseMatrixCSC, Symmetric{<:Any, <:SparseMatrixCSC}}) = Val{true}()
+G.algorithm_applicable(::MI355XCholesky, ::AbstractMatrix) = Val{false}()
 
-export MI355XBackend, MI355XCholesky, ordering_permutation
+export MI355XBackend, MI355XCholesky, MI355XCacheval, ordering_permutation
 end # module

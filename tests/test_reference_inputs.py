@@ -55,12 +55,16 @@ def test_backend_ordering_matrix_explicit_reverse_permutation():
     assert relerr(x0, x_ref) < 1e-10 and abs(ld0 - ld_ref) < 1e-10 * abs(ld_ref) and relerr(d0, d_ref) < 1e-8
     perm = np.arange(N - 1, -1, -1)                      # collect(N:-1:1), 0-based
     ws = GMRFWorkspace(Q, ordering=perm)
-    assert np.array_equal(ws.backend.ordering_permutation(), perm)       # integer work: exact
+    # integer work, exact: the backend postorders the elimination tree of the requested ordering (as CHOLMOD does),
+    # which relabels pivots without changing the fill -- nnz(L) is that of the requested permutation
+    pb = ws.backend.ordering_permutation()
+    assert np.array_equal(np.sort(pb), np.arange(N))
+    assert ws.backend.stats()["nnz_l"] == orc.OracleFactor(Q, perm).nnz_L
     assert relerr(ws.backend.backend_solve(rhs), x0) < 1e-10
     assert abs(ws.backend.compute_logdet() - ld0) < 1e-10 * abs(ld0)
     ws.ensure_selinv()
     assert relerr(ws.backend.get_selinv_diag(), d0) < 1e-8
-    F = orc.OracleFactor(Q, perm)
+    F = orc.OracleFactor(Q, pb)
     Lg, Lo = ws.backend.factor_csc(), F.L()
     assert abs(Lg - Lo).max() <= 1e-12 * abs(Lo).max()                  # the factor of P Q P' is unique
     assert relerr(ws.backend.backend_backward_solve(rhs), F.backward_solve(rhs)) < 1e-11
