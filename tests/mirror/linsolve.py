@@ -134,10 +134,18 @@ def configure_algorithm(alg):
     return alg
 
 
+class DenseSymmetric:
+    """`Symmetric(::Matrix)`: what the generic prepare_for_linsolve (symmetrize) makes of a dense precision."""
+
+    def __init__(self, A):
+        self.parent = np.asarray(A)
+        self.shape = self.parent.shape
+
+
 def prepare_for_linsolve(A, alg):
-    if isinstance(A, Symmetric):
+    if isinstance(A, (Symmetric, DenseSymmetric)):
         return A
-    return Symmetric(A)
+    return Symmetric(A) if sp.issparse(A) else DenseSymmetric(A)
 
 
 def algorithm_applicable(alg, A) -> bool:

@@ -7,6 +7,7 @@ import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "gaussianmarkovrandomfields.jl_amd"))
 import numpy as np
+import torch    # BEFORE libgmrfx.so is loaded: torch brings its own libamdhip64; loaded second it would be a second HIP runtime
 
 ap = argparse.ArgumentParser()
 ap.add_argument("N", type=int, nargs="?", default=126)
@@ -34,8 +35,10 @@ if need > args.max_gb:
     print(json.dumps({"workload": f"cfg4 3-D {args.N}^3", "n": n, "status": "refused", "predicted_gb": need}))
     sys.exit(0)
 import torch
-be = gmrfx.MI355XBackend(Q, ordering=perm, device=0, factorize=False)
 dev = torch.device("cuda", 0)
+torch.zeros(1, device=dev)          # torch's HIP runtime initialises BEFORE libgmrfx takes most of the HBM
+torch.cuda.synchronize()
+be = gmrfx.MI355XBackend(Q, ordering=perm, device=0, factorize=False)
 d_nz = torch.from_numpy(np.ascontiguousarray(Q.data)).to(dev)
 Bh = torch.randn((args.nrhs, n), generator=torch.Generator().manual_seed(1), dtype=torch.float64)
 d_B = Bh.to(dev); d_X = torch.empty_like(d_B)
