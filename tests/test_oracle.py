@@ -158,3 +158,27 @@ def test_oracle_kl_cholesky_reference_identities():
     La = orc.kl_cholesky_inplace(K, pat, reg=1e-8)
     Lb = orc.kl_cholesky_supernodal(K, cols, rows, reg=1e-8)
     assert abs(La - Lb).max() < 1e-12 * abs(La).max()
+
+
+def test_supernodal_cpu_baseline_matches_simplicial_oracle():
+    """oracle/supernodal_cpu.c (bench.py's multi-threaded cpu_baseline: supernodal multifrontal LL' on OpenBLAS
+    kernels, on the symbolic structure libgmrfx's host analysis exports) against the simplicial oracle: factor
+    values, logdet, multi-RHS solve, backward solve -- and through it the exported supernode / relative-index /
+    scatter structures once more."""
+    import gmrfx
+    import sncpu
+    from gmrfx import spde
+    for mesh, rng_ in ((spde.grid_mesh_2d(70, 55, jitter=0.25, seed=2), 0.25), (spde.grid_mesh_3d(11, 9, 10), 0.5)):
+        Q = sp.csc_matrix(spde.matern_precision(mesh, 0, rng_))
+        n = Q.shape[0]
+        be = gmrfx.MI355XBackend(Q, coords=mesh.points, symbolic_only=True)
+        perm = be.ordering_permutation()
+        sn = sncpu.SupernodalCPU(be.symbolic(), perm, n, nthreads=4)
+        assert sn.factorize(Q.data) == -1
+        F = orc.OracleFactor(Q, perm)
+        assert abs(sn.logdet() - F.logdet()) < 1e-11 * abs(F.logdet())
+        B = np.random.default_rng(0).standard_normal((n, 7))
+        assert np.abs(sn.solve(B) - F.solve(B)).max() < 1e-10 * np.abs(F.solve(B)).max()
+        assert np.abs(sn.solve(B[:, 0], mode=1) - F.backward_solve(B[:, 0])).max() < 1e-10
+        bad = Q.copy(); bad.data = -bad.data
+        assert sn.factorize(bad.data) >= 0
