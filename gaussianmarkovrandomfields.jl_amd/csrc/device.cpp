@@ -177,6 +177,13 @@ void Device::upload(const Symbolic &S) {
         const unsigned char *op; up(op, own); d_owncol_ = op;
         HC(hipStreamSynchronize(stream));
     }
+    up(ip, S.lrow); ds_.lrow = ip;
+    {
+        const int *a; up(a, S.sw_levellist); d_sw_levellist_ = const_cast<int *>(a);
+        const int *b; up(b, S.swt_first); d_swt_first_ = const_cast<int *>(b);
+        const int *c; up(c, S.swt_last); d_swt_last_ = const_cast<int *>(c);
+        nswt_ = (int)S.swt_first.size();
+    }
     {
         const int *ll; up(ll, S.levellist); d_levellist_ = const_cast<int *>(ll);
         const int *a; up(a, S.sub_first); d_sub_first_ = const_cast<int *>(a);
@@ -186,36 +193,41 @@ void Device::upload(const Symbolic &S) {
     }
     HC(hipStreamSynchronize(stream));
 
-    levels_.clear();
-    levels_.resize(S.nlevels);
-    syrk_flops = 0;
-    for (i32 l = 0; l < S.nlevels; l++) {
-        LevelInfo &L = levels_[l];
-        L.first = (int)S.levelptr[l];
-        L.count = (int)(S.levelptr[l + 1] - S.levelptr[l]);
-        L.nsmall = S.level_nsmall[l];
-        for (int k = 0; k < 4; k++) L.ncls[k] = S.level_ncls[(size_t)l * 4 + k];
-        L.max_rows = L.max_cols = 0;
-        int max_trail = 0;
-        for (int k = L.nsmall; k < L.count; k++) {
-            i32 s = S.levellist[L.first + k];
-            L.max_rows = std::max(L.max_rows, S.nrows(s));
-            L.max_cols = std::max(L.max_cols, S.ncols(s));
-            max_trail = std::max(max_trail, S.nrows(s) - S.ncols(s));
-            const double cc = S.ncols(s), mm = S.nrows(s) - S.ncols(s);
-            syrk_flops += cc * mm * (mm + 1);   // lower triangle of the contribution block: 2 c flops per entry
-        }
-        int nblk = (L.max_cols + NB - 1) / NB;
-        L.active.assign(nblk + 1, 0);
-        for (int b = 0; b <= nblk; b++) {
-            int cnt = 0;
+    auto build_levels = [&](std::vector<LevelInfo> &LV, const std::vector<i64> &lptr, const std::vector<i32> &llist,
+                            const std::vector<i32> &lnsmall, const std::vector<i32> &lncls, bool count_flops) {
+        LV.clear();
+        LV.resize(S.nlevels);
+        for (i32 l = 0; l < S.nlevels; l++) {
+            LevelInfo &L = LV[l];
+            L.first = (int)lptr[l];
+            L.count = (int)(lptr[l + 1] - lptr[l]);
+            L.nsmall = lnsmall[l];
+            for (int k = 0; k < 4; k++) L.ncls[k] = lncls[(size_t)l * 4 + k];
+            L.max_rows = L.max_cols = 0;
+            int max_trail = 0;
             for (int k = L.nsmall; k < L.count; k++) {
-                if (S.ncols(S.levellist[L.first + k]) > b * NB) cnt++; else break;  // sorted by decreasing columns
+                i32 s = llist[L.first + k];
+                L.max_rows = std::max(L.max_rows, S.nrows(s));
+                L.max_cols = std::max(L.max_cols, S.ncols(s));
+                max_trail = std::max(max_trail, S.nrows(s) - S.ncols(s));
+                const double cc = S.ncols(s), mm = S.nrows(s) - S.ncols(s);
+                if (count_flops) syrk_flops += cc * mm * (mm + 1);   // lower triangle of the contribution block: 2 c flops per entry
             }
-            L.active[b] = cnt;
+            int nblk = (L.max_cols + NB - 1) / NB;
+            L.active.assign(nblk + 1, 0);
+            for (int b = 0; b <= nblk; b++) {
+                int cnt = 0;
+                for (int k = L.nsmall; k < L.count; k++) {
+                    if (S.ncols(llist[L.first + k]) > b * NB) cnt++; else break;  // sorted by decreasing columns
+                }
+                L.active[b] = cnt;
+            }
+            L.active.push_back(max_trail);  // stash: last element = max trailing rows of the level
         }
-        L.active.push_back(max_trail);  // stash: last element = max trailing rows of the level
-    }
+    };
+    syrk_flops = 0;
+    build_levels(levels_, S.levelptr, S.levellist, S.level_nsmall, S.level_ncls, true);
+    build_levels(swlevels_, S.sw_levelptr, S.sw_levellist, S.sw_level_nsmall, S.sw_level_ncls, false);
 
     // fronts with more than one 64-column block, by decreasing width: dense-inverse stages
     {
@@ -458,16 +470,17 @@ void Device::ensure_rhs_capacity(long long nrhs) {
 }
 
 void Device::forward(int nr, int ldx, int lo, int hi) {
+    if (lo == 0) launch_sweep_tasks(stream, ds_, 1, d_swt_first_, d_swt_last_, nswt_, d_L_, d_X_, d_W_, nr, ldx);
     if (lo == 0)
         for (int k = 0, off = 0; k < 3; off += nsub_cls_[k], k++)
             launch_subtree(stream, ds_, 1, d_sub_first_ + off, d_sub_last_ + off, nsub_cls_[k], kClsRows[k], nullptr, d_L_, nullptr,
                            nullptr, d_X_, d_W_, nr, ldx);
     for (int lev = lo; lev < hi; lev++) {
-        auto &L = levels_[lev];
+        auto &L = swlevels_[lev];
         if (lev == std::max(lo, first_multiblock_level_)) wait_inverse();
         for (int k = 0, off = 0; k < 4; off += L.ncls[k], k++)
-            launch_fwd_small(stream, ds_, d_levellist_ + L.first + off, L.ncls[k], kClsRows[k], d_L_, d_X_, d_W_, nr, ldx);
-        const int *list = d_levellist_ + L.first + L.nsmall;
+            launch_fwd_small(stream, ds_, d_sw_levellist_ + L.first + off, L.ncls[k], kClsRows[k], d_L_, d_X_, d_W_, nr, ldx);
+        const int *list = d_sw_levellist_ + L.first + L.nsmall;
         const int nf = L.count - L.nsmall;
         launch_fwd_assemble(stream, ds_, list, nf, L.max_cols, d_X_, d_W_, nr, ldx, 1);   // own rows only
         // y = L11^-1 b as one triangular product per front (dense inverse, inverse.hip), then the
@@ -490,11 +503,11 @@ void Device::forward(int nr, int ldx, int lo, int hi) {
 void Device::backward(int nr, int ldx, bool y_in_x2, int hi, int lo) {
     wait_inverse();   // (a no-op event wait once the forward sweep has passed it)
     for (int l = hi - 1; l >= lo; l--) {
-        auto &L = levels_[l];
-        const int *list = d_levellist_ + L.first + L.nsmall;
+        auto &L = swlevels_[l];
+        const int *list = d_sw_levellist_ + L.first + L.nsmall;
         const int nf = L.count - L.nsmall;
         for (int k = 0, off = 0; k < 4; off += L.ncls[k], k++)
-            launch_bwd_small(stream, ds_, d_levellist_ + L.first + off, L.ncls[k], kClsRows[k], d_L_, d_X_, nr, ldx);
+            launch_bwd_small(stream, ds_, d_sw_levellist_ + L.first + off, L.ncls[k], kClsRows[k], d_L_, d_X_, nr, ldx);
         const int nbk = std::max(1, (L.max_cols + inv_cap_ - 1) / inv_cap_);
         if (y_in_x2) {
             if (level_max_trail(L) > 0) launch_bwd_gemm(stream, ds_, list, nf, L.max_cols, d_L_, d_X_, d_X2_, nr, ldx);
@@ -519,6 +532,7 @@ void Device::backward(int nr, int ldx, bool y_in_x2, int hi, int lo) {
         for (int k = 0, off = 0; k < 3; off += nsub_cls_[k], k++)
             launch_subtree(stream, ds_, 2, d_sub_first_ + off, d_sub_last_ + off, nsub_cls_[k], kClsRows[k], nullptr, d_L_, nullptr,
                            nullptr, d_X_, nullptr, nr, ldx);
+    if (lo == 0) launch_sweep_tasks(stream, ds_, 2, d_swt_first_, d_swt_last_, nswt_, d_L_, d_X_, nullptr, nr, ldx);
 }
 
 void Device::solve_phase(const double *d_B, long long ldb, long long nrhs, double *d_Xout, long long ldx_out, int phase) {

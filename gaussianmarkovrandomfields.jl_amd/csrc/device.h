@@ -47,6 +47,7 @@ struct DevSym {
     // position in the parent is >= c_p + 32 T (the child's rows falling into the parent's 32-row
     // trailing tile T are [etile[T], etile[T+1]) -- no search at run time)
     const int *etile;
+    const int *lrow;            // sum_rows: local row (sweep tasks) of every trailing row of a task front
 };
 
 struct LevelInfo {
@@ -138,6 +139,9 @@ private:
     const Symbolic *S_ = nullptr;
     DevSym ds_{};
     std::vector<LevelInfo> levels_;
+    std::vector<LevelInfo> swlevels_;   // the sweeps' level schedule: levels_ without the fronts of the sweep tasks
+    int *d_sw_levellist_ = nullptr, *d_swt_first_ = nullptr, *d_swt_last_ = nullptr;
+    int nswt_ = 0;
     const unsigned char *d_owncol_ = nullptr;   // sharded handles: 1 for the columns of the fronts this rank factors
     const long long *d_zbptr_ = nullptr;   // arena offsets of the trailing inverse blocks (Symbolic::zbptr)
     const int *d_iperm_ = nullptr;   // inverse permutation (original row -> position), used by the RHS transposes

@@ -85,6 +85,7 @@ extern "C" int32_t gmrfx_create(int64_t n, const int64_t *colptr, const int64_t 
         if (so.coords && so.coord_dim != 2 && so.coord_dim != 3) throw std::invalid_argument("coord_dim must be 2 or 3");
         if (const char *e = std::getenv("GMRFX_SMALL_ROWS")) so.small_front_rows = std::atoi(e);   // tuning/testing knob
         if (const char *e = std::getenv("GMRFX_SUBTREE_MAX")) so.subtree_max = std::atoi(e);       // 0 disables subtree tasks
+        if (const char *e = std::getenv("GMRFX_SWEEP_TASK_ROWS")) so.sweep_task_rows = std::atoi(e);   // 0 disables sweep tasks
         if (h->opts.shard_world > 1) {
             if (h->opts.shard_rank < 0 || h->opts.shard_rank >= h->opts.shard_world) throw std::invalid_argument("shard_rank out of range");
             so.shard_rank = h->opts.shard_rank;
@@ -717,6 +718,20 @@ extern "C" int32_t gmrfx_symbolic_get(const gmrfx_handle *h, int64_t *super_firs
     if (level) for (i32 s = 0; s < ns; s++) level[s] = S.level[s];
     if (q_src) for (size_t k = 0; k < S.qsrc.size(); k++) q_src[k] = S.qsrc[k];
     if (q_dst) for (size_t k = 0; k < S.qdst.size(); k++) q_dst[k] = S.qdst[k];
+    return GMRFX_OK;
+}
+
+// Sweep tasks (symbolic.h: swt_*): bottom subtrees whose triangular sweeps run on an LDS-resident local vector.
+// ntasks / rows_cap always; first / last (ntasks each) and lrow (sum_rows) when non-null.
+extern "C" int32_t gmrfx_symbolic_sweep_tasks(const gmrfx_handle *h, int64_t *ntasks, int64_t *rows_cap, int64_t *first,
+                                              int64_t *last, int64_t *lrow) {
+    if (!h || !ntasks) return GMRFX_ERR_INVALID_ARG;
+    const Symbolic &S = h->S;
+    *ntasks = (int64_t)S.swt_first.size();
+    if (rows_cap) *rows_cap = S.swt_rows;
+    if (first) for (size_t k = 0; k < S.swt_first.size(); k++) first[k] = S.swt_first[k];
+    if (last) for (size_t k = 0; k < S.swt_last.size(); k++) last[k] = S.swt_last[k];
+    if (lrow) for (size_t k = 0; k < S.lrow.size(); k++) lrow[k] = S.lrow[k];
     return GMRFX_OK;
 }
 

@@ -529,6 +529,78 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
         S.sel_level_nsmall[l] = k;
     }
 
+    // ---- sweep tasks (see symbolic.h) -------------------------------------------------------------
+    S.in_swt.assign(ns, 0);
+    S.lrow.assign((size_t)S.sum_rows, -1);
+    {
+        const int rcap = S.shard_world > 1 ? 0 : std::min(288, opt.sweep_task_rows >= 0 ? opt.sweep_task_rows : 288);   // 288 = TASK_ROWS of sweep_task.hip
+        S.swt_rows = rcap;
+        std::vector<i32> cnt(ns, 1), ncol(ns, 0), maxc(ns, 0);
+        std::vector<double> work(ns, 0.0);
+        std::vector<uint8_t> ok(ns, 0);
+        for (i32 s = 0; s < ns; s++) {
+            ncol[s] += S.ncols(s);
+            maxc[s] = std::max(maxc[s], S.ncols(s));
+            work[s] += (double)S.nrows(s) * S.ncols(s);
+            bool good = rcap > 0;
+            for (i64 q = S.childptr[s]; q < S.childptr[s + 1]; q++) good = good && ok[S.children[q]];
+            ok[s] = good && maxc[s] <= 64 && ncol[s] + (S.nrows(s) - S.ncols(s)) <= rcap && cnt[s] <= 64;
+            const i32 p = S.sparent[s];
+            if (p != -1) { cnt[p] += cnt[s]; ncol[p] += ncol[s]; maxc[p] = std::max(maxc[p], maxc[s]); work[p] += work[s]; }
+        }
+        std::vector<i32> roots;
+        for (i32 s = 0; s < ns; s++) {
+            if (!ok[s] || cnt[s] < 2) continue;                       // a single front gains nothing over the level kernels
+            const i32 p = S.sparent[s];
+            if (p != -1 && ok[p]) continue;                           // not maximal
+            roots.push_back(s);
+        }
+        std::stable_sort(roots.begin(), roots.end(), [&](i32 a, i32 b) { return work[a] > work[b]; });
+        for (i32 t : roots) {
+            const i32 f = t - cnt[t] + 1;
+            S.swt_first.push_back(f); S.swt_last.push_back(t);
+            const i32 col0 = S.sfirst[f], col1 = S.sfirst[t + 1], nt = col1 - col0;
+            const i32 ct = S.ncols(t);
+            const i32 *rt = S.rows.data() + S.rowptr[t] + ct;          // the root's trailing rows (sorted)
+            const i32 mt = S.nrows(t) - ct;
+            for (i32 d = f; d <= t; d++) {
+                S.in_swt[d] = 1;
+                const i32 cd = S.ncols(d);
+                for (i64 k = S.rowptr[d] + cd; k < S.rowptr[d + 1]; k++) {
+                    const i32 g = S.rows[k];
+                    if (g < col1) {
+                        if (g < col0) throw std::runtime_error("internal: sweep task row below its subtree");
+                        S.lrow[k] = g - col0;
+                    } else {
+                        const i32 *it = std::lower_bound(rt, rt + mt, g);
+                        if (it == rt + mt || *it != g) throw std::runtime_error("internal: sweep task row outside the root's structure");
+                        S.lrow[k] = nt + (i32)(it - rt);
+                    }
+                }
+            }
+        }
+    }
+    S.sw_levelptr.assign(S.nlevels + 1, 0);
+    for (i32 s = 0; s < ns; s++) if (!S.in_subtree[s] && !S.in_swt[s] && mine(s)) S.sw_levelptr[S.level[s] + 1]++;
+    for (i32 l = 0; l < S.nlevels; l++) S.sw_levelptr[l + 1] += S.sw_levelptr[l];
+    S.sw_levellist.resize(S.sw_levelptr[S.nlevels]);
+    { std::vector<i64> w(S.sw_levelptr.begin(), S.sw_levelptr.end() - 1);
+      for (i32 s = 0; s < ns; s++) if (!S.in_subtree[s] && !S.in_swt[s] && mine(s)) S.sw_levellist[w[S.level[s]]++] = s; }
+    S.sw_level_nsmall.assign(S.nlevels, 0);
+    S.sw_level_ncls.assign((size_t)S.nlevels * 4, 0);
+    for (i32 l = 0; l < S.nlevels; l++) {
+        auto b = S.sw_levellist.begin() + S.sw_levelptr[l], e = S.sw_levellist.begin() + S.sw_levelptr[l + 1];
+        std::stable_sort(b, e, [&](i32 x, i32 y) {
+            const int cx = cls(x), cy = cls(y);
+            if (cx != cy) return cx < cy;
+            if (cx < 4) return x < y;
+            return S.ncols(x) != S.ncols(y) ? S.ncols(x) > S.ncols(y) : x < y;
+        });
+        i32 k = 0;
+        for (auto it = b; it != e; ++it) { const int cc = cls(*it); if (cc < 4) { k++; S.sw_level_ncls[(size_t)l * 4 + cc]++; } }
+        S.sw_level_nsmall[l] = k;
+    }
+
     // ---- contribution-block arena with lifetime reuse ------------------------------------------
     // The level schedule fixes when a block is written and when it is last read: CB_s lives from level(s) to
     // level(parent(s)) in the factorisation; in the (top-down) selected inversion the trailing inverse block

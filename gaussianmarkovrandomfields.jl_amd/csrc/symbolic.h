@@ -22,6 +22,7 @@ struct SymOptions {
     const double *coords = nullptr;
     int subtree_max = -1;      // max fronts per subtree task; -1 = default (0 = off: bit-identical, measured slower than level batching)
     int small_front_rows = -1; // fronts with r <= this (and <= 64 columns) use the fused LDS kernels; -1 = default (96), 0 = off
+    int sweep_task_rows = -1;  // LDS rows of a sweep task's local vector (Symbolic::swt_*); -1 = default, 0 = no sweep tasks
     // multi-GPU sharding of ONE factorisation along the supernodal tree (see Symbolic::owner)
     int shard_rank = 0, shard_world = 1;
 };
@@ -73,6 +74,20 @@ struct Symbolic {
     std::vector<i64> sel_levelptr;
     std::vector<i32> sel_levellist, sel_level_nsmall;
     int small_rows = 0;
+    // SWEEP TASKS (triangular solves only; the factorisation and the selected inversion keep the level schedule).
+    // A task = a maximal subtree whose fronts all have <= 64 columns and whose LOCAL VECTOR -- the subtree's own
+    // columns (contiguous in the elimination order: postorder) followed by the trailing rows of its root -- has at
+    // most swt_rows rows: ONE workgroup keeps that vector in LDS and runs the whole subtree's forward (resp.
+    // backward) substitution on it, so the update vectors between the fronts of the subtree never touch HBM (they
+    // are ~60 % of all forward-sweep hand-off traffic of a 2-D SPDE precision). lrow[k] = local row of rows[k] for
+    // the trailing rows of task fronts. The sweeps run the tasks first (forward) / last (backward) and the level
+    // schedule sw_level* (= the level lists without the task fronts) in between.
+    std::vector<i32> swt_first, swt_last;   // per task: first / last (= root) supernode, heaviest task first
+    std::vector<uint8_t> in_swt;            // per supernode
+    std::vector<i32> lrow;                  // sum_rows (-1 outside tasks / for own rows)
+    int swt_rows = 0;
+    std::vector<i64> sw_levelptr;
+    std::vector<i32> sw_levellist, sw_level_nsmall, sw_level_ncls;
     // Sharding over `shard_world` ranks (every rank runs the same analysis and gets the same answer):
     // owner[s] = rank that factors front s for the fronts inside an assigned subtree, -1 for the TOP
     // fronts (the ancestors of the assigned subtree roots), which rank 0 factors after it has received

@@ -300,6 +300,17 @@ class MI355XBackend:
             "super_first", "super_parent", "row_ptr", "rows", "rel", "panel_ptr", "panel_ld", "level", "q_src", "q_dst")]))
         return SymbolicInfo(cb_arena=cb, **a)
 
+    def sweep_tasks(self):
+        """(rows_cap, first, last, lrow): the bottom subtrees whose sweeps run on an LDS-resident local vector."""
+        nt, cap = C.c_int64(0), C.c_int64(0)
+        check(lib().gmrfx_symbolic_sweep_tasks(self._h, C.byref(nt), C.byref(cap), None, None, None))
+        sizes = np.zeros(8, np.int64)
+        check(lib().gmrfx_symbolic_sizes(self._h, ptr(sizes)))
+        first, last = np.empty(nt.value, np.int64), np.empty(nt.value, np.int64)
+        lrow = np.empty(int(sizes[1]), np.int64)
+        check(lib().gmrfx_symbolic_sweep_tasks(self._h, C.byref(nt), C.byref(cap), ptr(first), ptr(last), ptr(lrow)))
+        return int(cap.value), first, last, lrow
+
     def factor_values(self) -> np.ndarray:
         sizes = np.zeros(8, np.int64)
         check(lib().gmrfx_symbolic_sizes(self._h, ptr(sizes)))

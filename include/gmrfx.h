@@ -224,6 +224,12 @@ int32_t gmrfx_symbolic_get(const gmrfx_handle *h, int64_t *super_first, int64_t 
                            int64_t *panel_ld, int64_t *level, int64_t *q_src, int64_t *q_dst);
 /* Copy the numeric factor panels (nnz_l_stored doubles) to the host: tests compare them
  * with the oracle's L (unique for a given permutation). */
+/* Sweep tasks (host analysis; testing / inspection): maximal bottom subtrees of the supernodal tree whose forward /
+ * backward substitution one workgroup runs on an LDS-resident local vector (csrc/sweep_task.hip), so the update
+ * vectors between their fronts never touch HBM. first / last: supernode range of each task (last = root), lrow: for
+ * every entry of the supernode row lists, the local row inside its task (-1 outside tasks / for own rows). */
+int32_t gmrfx_symbolic_sweep_tasks(const gmrfx_handle *h, int64_t *ntasks, int64_t *rows_cap, int64_t *first,
+                                   int64_t *last, int64_t *lrow);
 int32_t gmrfx_get_factor_values(gmrfx_handle *h, double *out);
 
 /* KL-optimal sparse approximate Cholesky factor, L L' ~ Theta^-1: a batch of small dense problems, one

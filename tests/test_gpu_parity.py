@@ -804,3 +804,29 @@ def test_blocked_substitution_in_wide_fronts(cap, monkeypatch):
         assert relerr(ws.workspace_solve(B), F.solve(B)) < 1e-10
         ws.update_precision(sp.csc_matrix(1.5 * Q))       # refactorise: back to capped inverses
         assert relerr(ws.workspace_solve(B), F.solve(B) / 1.5) < 1e-10
+
+
+@pytest.mark.parametrize("name", ["matern64_coords", "cfg1_alpha3_65x65", "matern3d_10", "rand400", "natural_chain"])
+def test_sweep_tasks_on_and_off_agree(name, monkeypatch):
+    """Sweep tasks (whole bottom subtrees on an LDS-resident local vector, csrc/sweep_task.hip; the default) against
+    the pure level schedule (GMRFX_SWEEP_TASK_ROWS=0): same solves / backward solves to rounding (the summation order
+    of the updates differs), for full and ragged right-hand-side blocks, and both against the oracle."""
+    Q, kw = next((sp.csc_matrix(q), k) for n, q, k in CASES if n == name)
+    n = Q.shape[0]
+    rng = np.random.default_rng(5)
+    on = gmrfx.MI355XBackend(Q, **kw)
+    assert on.sweep_tasks()[1].size > 0
+    monkeypatch.setenv("GMRFX_SWEEP_TASK_ROWS", "0")
+    off = gmrfx.MI355XBackend(Q, ordering=on.ordering_permutation())
+    assert off.sweep_tasks()[1].size == 0
+    monkeypatch.delenv("GMRFX_SWEEP_TASK_ROWS")
+    F = orc.OracleFactor(Q, on.ordering_permutation())
+    for nrhs in (1, 5, 64, 70):
+        B = rng.standard_normal((n, nrhs))
+        Xo = F.solve(B)
+        assert relerr(on.backend_solve(B), Xo) < 1e-10
+        assert relerr(on.backend_solve(B), off.backend_solve(B)) < 1e-11
+        Zo = F.backward_solve(B)
+        assert relerr(on.backend_backward_solve(B), Zo) < 1e-10
+        assert relerr(on.backend_backward_solve(B), off.backend_backward_solve(B)) < 1e-11
+    assert np.array_equal(on.backend_solve(B), on.backend_solve(B))        # still bit-reproducible

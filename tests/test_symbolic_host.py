@@ -138,3 +138,83 @@ def test_threaded_symbolic_analysis_equals_serial(with_coords, monkeypatch):
                     np.asarray(sy.q_src), np.asarray(sy.q_dst)))
     for a, b in zip(*got):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("shape", ["2d", "3d", "rand"])
+def test_sweep_tasks_structure_and_local_vector_walk(shape):
+    """Sweep tasks (csrc/sweep_task.hip): maximal bottom subtrees whose triangular sweeps run on a local vector in
+    LDS. Host-side invariants, and the task algorithm itself restated in numpy on the exported structures -- forward:
+    V = [b of the subtree; 0], per front y = L11^-1 V[own], V[lrow] -= L21 y; backward the mirror image -- against the
+    level-order multifrontal walk (HostSim) front by front."""
+    from mf_hostsim import HostSim
+    if shape == "2d":
+        m = spde.grid_mesh_2d(60, 47, jitter=0.25, seed=4)
+        Q, kw = sp.csc_matrix(spde.matern_precision(m, 0, 0.3)), {"coords": m.points}
+    elif shape == "3d":
+        m = spde.grid_mesh_3d(9, 8, 10)
+        Q, kw = sp.csc_matrix(spde.matern_precision(m, 0, 0.5)), {"coords": m.points}
+    else:
+        Q, kw = spde.random_spd_precision(300, 0.01), {}
+    n = Q.shape[0]
+    b = gmrfx.MI355XBackend(Q, symbolic_only=True, **kw)
+    sy = b.symbolic()
+    cap, first, last, lrow = b.sweep_tasks()
+    ns = len(sy.super_parent)
+    c = np.diff(sy.super_first); r = np.diff(sy.row_ptr)
+    assert 0 < cap <= 288
+    seen = np.zeros(ns, bool)
+    assert len(first) > 0
+    for f, t in zip(first, last):
+        assert t - f + 1 >= 2 and t - f + 1 <= 64 and not seen[f:t + 1].any()
+        seen[f:t + 1] = True
+        # a complete subtree: every front's parent is inside, except the root's; no outside front has a parent inside
+        assert all(f < sy.super_parent[s] <= t for s in range(f, t))
+        assert not (f <= sy.super_parent[t] <= t)
+        assert c[f:t + 1].max() <= 64
+        col0, col1 = sy.super_first[f], sy.super_first[t + 1]
+        nt = col1 - col0
+        assert nt + (r[t] - c[t]) <= cap
+        root_trail = sy.rows[sy.row_ptr[t] + c[t]:sy.row_ptr[t + 1]]
+        for s in range(f, t + 1):
+            rows = sy.rows[sy.row_ptr[s]:sy.row_ptr[s + 1]]
+            lr = lrow[sy.row_ptr[s]:sy.row_ptr[s + 1]]
+            assert (lr[:c[s]] == -1).all()
+            glob = np.concatenate([np.arange(col0, col1), root_trail])
+            assert np.array_equal(glob[lr[c[s]:]], rows[c[s]:])          # local row -> the same global row
+    outside = np.flatnonzero(~seen)
+    assert all(not seen[sy.super_parent[s]] for s in outside if sy.super_parent[s] >= 0)
+    assert (lrow[np.repeat(~seen, r)] == -1).all()
+    # numeric walk of the task algorithm on the host factor
+    perm = b.ordering_permutation()
+    hs = HostSim(sy, n, Q.data).factor()
+    rng = np.random.default_rng(0)
+    Bp = rng.standard_normal((n, 3))
+    # reference: plain column-oriented forward substitution y = L^-1 b and backward x = L^-T y on the dense factor
+    Ld = hs.dense_from_panels(hs.L)
+    Yref = np.linalg.solve(Ld, Bp)
+    Xref = np.linalg.solve(Ld.T, Yref)
+    for f, t in zip(first, last):
+        col0, col1 = sy.super_first[f], sy.super_first[t + 1]
+        nt = col1 - col0
+        mroot = r[t] - c[t]
+        # forward on the task: only valid for rows whose updates all come from inside the subtree = the own rows
+        V = np.zeros((nt + mroot, 3))
+        V[:nt] = Bp[col0:col1]
+        for s in range(f, t + 1):
+            P = hs.panel(hs.L, s)
+            o = sy.super_first[s] - col0
+            y = np.linalg.solve(np.tril(P[:c[s]]), V[o:o + c[s]])
+            V[o:o + c[s]] = y
+            V[lrow[sy.row_ptr[s] + c[s]:sy.row_ptr[s + 1]]] -= P[c[s]:] @ y
+        assert np.allclose(V[:nt], Yref[col0:col1], rtol=1e-10, atol=1e-12)
+        # backward on the task, given the final x of the root's trailing rows
+        root_trail = sy.rows[sy.row_ptr[t] + c[t]:sy.row_ptr[t + 1]]
+        V = np.zeros((nt + mroot, 3))
+        V[:nt] = Yref[col0:col1]
+        V[nt:] = Xref[root_trail]
+        for s in range(t, f - 1, -1):
+            P = hs.panel(hs.L, s)
+            o = sy.super_first[s] - col0
+            tt = V[o:o + c[s]] - P[c[s]:].T @ V[lrow[sy.row_ptr[s] + c[s]:sy.row_ptr[s + 1]]]
+            V[o:o + c[s]] = np.linalg.solve(np.tril(P[:c[s]]).T, tt)
+        assert np.allclose(V[:nt], Xref[col0:col1], rtol=1e-9, atol=1e-12)
