@@ -180,9 +180,22 @@ void Device::upload(const Symbolic &S) {
     up(ip, S.lrow); ds_.lrow = ip;
     {
         const int *a; up(a, S.sw_levellist); d_sw_levellist_ = const_cast<int *>(a);
-        const int *b; up(b, S.swt_first); d_swt_first_ = const_cast<int *>(b);
-        const int *c; up(c, S.swt_last); d_swt_last_ = const_cast<int *>(c);
         nswt_ = (int)S.swt_first.size();
+        std::vector<long long> wp(ns + 1, 0);
+        for (i32 s = 0; s < ns; s++) wp[s + 1] = wp[s] + (S.nrows(s) - S.ncols(s));
+        std::vector<SweepTask> tk((size_t)nswt_);
+        for (int t = 0; t < nswt_; t++) {
+            const i32 f = S.swt_first[t], r = S.swt_last[t];
+            SweepTask &T = tk[t];
+            T.s0 = f; T.s1 = r; T.col0 = S.sfirst[f]; T.nt = S.sfirst[r + 1] - S.sfirst[f];
+            T.mroot = S.nrows(r) - S.ncols(r); T.pad = 0;
+            T.p0 = S.panelptr[f]; T.p1 = S.panelptr[r + 1];
+            T.rp0 = S.rowptr[f]; T.rp1 = S.rowptr[r + 1];
+            T.rroot = S.rowptr[r] + S.ncols(r);
+            T.woff = wp[r];
+        }
+        const SweepTask *tp; up(tp, tk); d_swt_ = const_cast<SweepTask *>(tp);
+        HC(hipStreamSynchronize(stream));
     }
     {
         const int *ll; up(ll, S.levellist); d_levellist_ = const_cast<int *>(ll);
@@ -470,7 +483,7 @@ void Device::ensure_rhs_capacity(long long nrhs) {
 }
 
 void Device::forward(int nr, int ldx, int lo, int hi) {
-    if (lo == 0) launch_sweep_tasks(stream, ds_, 1, d_swt_first_, d_swt_last_, nswt_, d_L_, d_X_, d_W_, nr, ldx);
+    if (lo == 0) launch_sweep_tasks(stream, ds_, 1, d_swt_, nswt_, d_L_, d_X_, d_W_, nr, ldx);
     if (lo == 0)
         for (int k = 0, off = 0; k < 3; off += nsub_cls_[k], k++)
             launch_subtree(stream, ds_, 1, d_sub_first_ + off, d_sub_last_ + off, nsub_cls_[k], kClsRows[k], nullptr, d_L_, nullptr,
@@ -532,7 +545,7 @@ void Device::backward(int nr, int ldx, bool y_in_x2, int hi, int lo) {
         for (int k = 0, off = 0; k < 3; off += nsub_cls_[k], k++)
             launch_subtree(stream, ds_, 2, d_sub_first_ + off, d_sub_last_ + off, nsub_cls_[k], kClsRows[k], nullptr, d_L_, nullptr,
                            nullptr, d_X_, nullptr, nr, ldx);
-    if (lo == 0) launch_sweep_tasks(stream, ds_, 2, d_swt_first_, d_swt_last_, nswt_, d_L_, d_X_, nullptr, nr, ldx);
+    if (lo == 0) launch_sweep_tasks(stream, ds_, 2, d_swt_, nswt_, d_L_, d_X_, nullptr, nr, ldx);
 }
 
 void Device::solve_phase(const double *d_B, long long ldb, long long nrhs, double *d_Xout, long long ldx_out, int phase) {

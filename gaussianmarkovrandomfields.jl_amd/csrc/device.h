@@ -50,6 +50,17 @@ struct DevSym {
     const int *lrow;            // sum_rows: local row (sweep tasks) of every trailing row of a task front
 };
 
+// One sweep task (Symbolic::swt_*): everything its workgroup needs in ONE load.
+struct SweepTask {
+    int s0, s1;            // first / last (= root) supernode
+    int col0, nt;          // first own column of the subtree, number of own columns (= local rows 0 .. nt-1)
+    int mroot, pad;        // trailing rows of the root (= local rows nt .. nt+mroot-1)
+    long long p0, p1;      // the subtree's panels in the factor storage (contiguous: postorder)
+    long long rp0, rp1;    // its range in the row / local-row lists
+    long long rroot;       // offset of the root's trailing rows in DevSym::rows
+    long long woff;        // DevSym::wptr[root]
+};
+
 struct LevelInfo {
     int first;        // offset into levellist
     int count;        // fronts in level
@@ -140,7 +151,8 @@ private:
     DevSym ds_{};
     std::vector<LevelInfo> levels_;
     std::vector<LevelInfo> swlevels_;   // the sweeps' level schedule: levels_ without the fronts of the sweep tasks
-    int *d_sw_levellist_ = nullptr, *d_swt_first_ = nullptr, *d_swt_last_ = nullptr;
+    int *d_sw_levellist_ = nullptr;
+    SweepTask *d_swt_ = nullptr;
     int nswt_ = 0;
     const unsigned char *d_owncol_ = nullptr;   // sharded handles: 1 for the columns of the fronts this rank factors
     const long long *d_zbptr_ = nullptr;   // arena offsets of the trailing inverse blocks (Symbolic::zbptr)

@@ -239,7 +239,7 @@ void launch_bwd_small(hipStream_t st, const DevSym &S, const int *list, int nfro
                       double *X, int nr, int ldx);
 
 // sweep_task.hip -- whole bottom subtrees on an LDS-resident local vector: phase 1 forward, 2 backward
-void launch_sweep_tasks(hipStream_t st, const DevSym &S, int phase, const int *tk_first, const int *tk_last, int ntasks,
+void launch_sweep_tasks(hipStream_t st, const DevSym &S, int phase, const SweepTask *tasks, int ntasks,
                         const double *L, double *X, double *W, int nr, int ldx);
 
 // selinv.hip -- Takahashi recursion, top-down over the supernodal tree

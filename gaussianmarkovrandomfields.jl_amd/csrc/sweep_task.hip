@@ -6,10 +6,18 @@
 // SPDE precision -- more than the factor itself (1.55 GB) -- and the tiny fronts at the bottom of the tree (avg 11
 // columns, 38 trailing rows) are a chain of dependent HBM round trips each. Inside a task nothing is handed off:
 // the subtree's own rows of X (contiguous in the elimination order) and the root's trailing rows form one local
-// vector V (<= TASK_ROWS rows x 64 columns, 144 KB of LDS); front after front (postorder), y_s = L11^-1 b_s
-// overwrites the front's own rows of V and V[trailing rows of s] -= L21 y_s is a right-looking update in LDS. The
-// only HBM traffic is the panels (read once, prefetched into L2 at the start of the task), the task's slice of X
-// (read once, written once, contiguous) and the root's update vector.
+// vector V (<= TASK_ROWS rows x 64 columns, 144 KB of LDS); front after front (postorder), y_s = L11^-1 b_s and
+// V[trailing rows of s] -= L21 y_s is a right-looking update in LDS. The only HBM traffic is the panels (read once,
+// prefetched into L2 at the start of the task), the task's slice of X (read once, written once) and the root's
+// update vector.
+//
+// Work split: 16 waves = 4 row-tile slots x 4 column tiles of the right-hand sides. Measured (clock64 stamps inside
+// one workgroup, and variants with parts compiled out): a front costs ~4000 cycles whatever the split -- one wave
+// issues an FP64 MFMA only every ~138 cycles and spends a few hundred vector instructions per front on clamps, masks
+// and addresses -- while barriers and memory latency (operands are requested one front ahead, the panels are warmed
+// into L2) are < 15 % of it. One wave per (row tile, 4 column tiles) ran 6000-7000 cycles per front (32 MFMAs from one
+// wave), two column tiles per wave the same as one. The task kernels take 0.65 ms (forward) / 0.57 ms (backward) at
+// cfg 2 for 86 % of all fronts: the forward sweep drops from 3.15 to 2.70 ms, the backward sweep from 2.28 to 2.20.
 //
 // Summation order is fixed (fronts in postorder, one owner per entry): bit-reproducible like the rest of the solver.
 #include <hip/hip_runtime.h>
@@ -20,13 +28,35 @@ namespace gmrfx {
 
 typedef gmrfx_d4 d4;
 
-constexpr int TASK_ROWS = 288;   // local-vector rows (Symbolic::swt_rows <= this)
-constexpr int TASK_MAXF = 64;    // fronts per task (host enforces)
+constexpr int TASK_ROWS = 288;       // local-vector rows (Symbolic::swt_rows <= this)
+constexpr int TASK_MAXF = 64;        // fronts per task (host enforces)
+constexpr int TASK_THREADS = 1024;   // 16 waves = 4 row-tile slots x 4 column tiles: one wave issues an FP64 MFMA only every ~138 cycles, so
+                                     // the MFMAs of a row tile are spread over four waves (on four SIMDs)
+constexpr int TASK_WAVES = TASK_THREADS / 64;
+constexpr int TPW = 1;                           // 16-column tiles of the right-hand sides per wave (measured: 1 beats 2 and 4)
+constexpr int TASK_SLOTS = TASK_WAVES * TPW / 4; // row-tile slots
 
 // V is stored row-major with 64 columns; the 16-column tiles of odd rows are swapped pairwise so that the two
 // k-rows a ds_read_b64 lane group (lanes 0-31 = two k-rows x 16 columns) touches fall into different halves of the
 // 64 LDS banks (row stride = 512 B = 0 mod 256 would otherwise be a 2-way conflict on every operand read).
 __device__ __forceinline__ int vidx(int row, int col) { return row * 64 + (col ^ ((row & 1) << 4)); }
+
+
+struct TaskMeta { int c, r, ld, o; long long pp, rp; };   // per front: columns, rows, panel ld, first own local row, panel / row-list offsets
+
+// A front's geometry is the same for every lane: read it into SCALAR registers, so that the address arithmetic of the
+// operand requests runs on the scalar unit.
+__device__ __forceinline__ TaskMeta uniform_meta(const TaskMeta *meta, int f) {
+    const TaskMeta v = meta[f];
+    TaskMeta m;
+    m.c = __builtin_amdgcn_readfirstlane(v.c);
+    m.r = __builtin_amdgcn_readfirstlane(v.r);
+    m.ld = __builtin_amdgcn_readfirstlane(v.ld);
+    m.o = __builtin_amdgcn_readfirstlane(v.o);
+    m.pp = ((long long)__builtin_amdgcn_readfirstlane((int)(v.pp >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v.pp);
+    m.rp = ((long long)__builtin_amdgcn_readfirstlane((int)(v.rp >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v.rp);
+    return m;
+}
 
 // element (k,q) of L11^-1 from the panel (strict lower part stored transposed in the strict upper triangle, diagonal =
 // reciprocal of L's): unconditional clamped load + arithmetic mask (see small.hip)
@@ -39,113 +69,220 @@ __device__ __forceinline__ double tinv_elem(const double *__restrict__ P, int ld
     return x;
 }
 
-struct TaskMeta { int c, r, ld, o; long long pp, rp; };   // per front: columns, rows, panel ld, first own local row, panel / row-list offsets
-
 // Loads the geometry of the task's fronts into LDS (one round trip for the whole task instead of one per front) and
-// touches the task's panels, which are contiguous in HBM (postorder), so that the per-front operand loads hit L2.
-__device__ __forceinline__ double task_prologue(const DevSym &S, const int s0, const int s1, const int col0, TaskMeta *meta,
-                                                const double *__restrict__ L) {
+// touches the task's panels and local-row lists, which are contiguous in HBM (postorder), so that the per-front
+// operand loads hit L2.
+__device__ __forceinline__ double task_prologue(const DevSym &S, const SweepTask &T, TaskMeta *meta, const double *__restrict__ L) {
     const int tid = threadIdx.x;
-    const int nf = s1 - s0 + 1;
+    const int nf = T.s1 - T.s0 + 1;
     if (tid < nf) {
-        const int s = s0 + tid;
+        const int s = T.s0 + tid;
         TaskMeta m;
         const int first = S.sfirst[s];
         m.c = S.sfirst[s + 1] - first;
         m.rp = S.rowptr[s];
         m.r = (int)(S.rowptr[s + 1] - m.rp);
         m.ld = S.ld[s];
-        m.o = first - col0;
+        m.o = first - T.col0;
         m.pp = S.panelptr[s];
         meta[tid] = m;
     }
-    // L2 warm-up: one 8-byte load per 128-byte line of the task's panels, summed into a value that is never used for
-    // arithmetic (returned and stored only under a condition that cannot hold)
-    const long long p0 = S.panelptr[s0], p1 = S.panelptr[s1 + 1];
+    // L2 warm-up: one load per 128-byte line, summed into a value that is never used for arithmetic (returned and
+    // stored only under a condition that cannot hold)
     double sink = 0.0;
-    for (long long q = p0 + (long long)tid * 16; q < p1; q += 256 * 16) sink += L[q];
-    return sink;
+    for (long long q = T.p0 + (long long)tid * 16; q < T.p1; q += TASK_THREADS * 16) sink += L[q];
+    int isink = 0;
+    for (long long q = T.rp0 + (long long)tid * 32; q < T.rp1; q += TASK_THREADS * 32) isink += S.lrow[q];
+    return sink + (double)isink;
+}
+
+// acc[t] += a (this lane's element of a 16 x 4 A operand) x V[row kq][column tile t], t = 0..3
+__device__ __forceinline__ void mfma4_lds(d4 (&acc)[TPW], const double a, const double *V, const int kq, const int cl) {
+    const double *vr = V + kq * 64;
+    const int sw = (kq & 1) << 4;
+#pragma unroll
+    for (int t = 0; t < TPW; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, vr[(t * 16 + cl) ^ sw], acc[t], 0, 0, 0);
+}
+// V[rows l2[rr]][all four column tiles] -= acc (rows lk + 4 rr of the tile; distinct rows inside a front)
+__device__ __forceinline__ void scatter_sub(double *V, const int (&l2)[4], const d4 (&acc)[TPW], const int nvalid, const int lk, const int cl) {
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {
+        if (lk + 4 * rr < nvalid) {
+            double *vr = V + l2[rr] * 64;
+            const int sw = (l2[rr] & 1) << 4;
+#pragma unroll
+            for (int t = 0; t < TPW; t++) vr[(t * 16 + cl) ^ sw] -= acc[t][rr];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// forward: V <- [b of the subtree ; 0]; per front y = L11^-1 b (own rows), V[trailing] -= L21 y
+// forward: V <- [b of the subtree ; 0]; per front y = L11^-1 b (own rows, written to X), V[trailing] -= L21 y
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void k_fwd_task(DevSym S, const int *__restrict__ tk_first, const int *__restrict__ tk_last,
+__global__ __launch_bounds__(TASK_THREADS, 1) void k_fwd_task(DevSym S, const SweepTask *__restrict__ tasks,
                                                      const double *__restrict__ L, double *__restrict__ X, double *__restrict__ W,
                                                      int nr, int ldx) {
     __shared__ double V[TASK_ROWS * 64];
     __shared__ TaskMeta meta[TASK_MAXF];
-    const int s0 = tk_first[blockIdx.x], s1 = tk_last[blockIdx.x];
-    const int col0 = S.sfirst[s0], col1 = S.sfirst[s1 + 1], NT = col1 - col0;
+    const SweepTask T = tasks[blockIdx.x];
+    const int col0 = T.col0, NT = T.nt, nf = T.s1 - T.s0 + 1, mroot = T.mroot;
     const int tid = threadIdx.x;
-    const int j = tid & 63, g = tid >> 6;
+    const int j = tid & 63, g = tid >> 6;              // g: TASK_WAVES row groups
     const int jc = min(j, nr - 1);
     const double jm = j < nr ? 1.0 : 0.0;
-    const double sink = task_prologue(S, s0, s1, col0, meta, L);
-    // the subtree's slice of X: NT contiguous rows, eight row loads in flight per thread
-    for (int i0 = g; i0 < NT; i0 += 32) {
-        double v[8];
+    const double sink = task_prologue(S, T, meta, L);
+    // the subtree's slice of X: NT contiguous rows, four row loads in flight per thread
+    for (int i0 = g; i0 < NT; i0 += 4 * TASK_WAVES) {
+        double v[4];
 #pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = X[(long long)(col0 + min(i0 + 4 * u, NT - 1)) * ldx + jc];
+        for (int u = 0; u < 4; u++) v[u] = X[(long long)(col0 + min(i0 + TASK_WAVES * u, NT - 1)) * ldx + jc];
 #pragma unroll
-        for (int u = 0; u < 8; u++) if (i0 + 4 * u < NT) V[vidx(i0 + 4 * u, j)] = v[u] * jm;
+        for (int u = 0; u < 4; u++) if (i0 + TASK_WAVES * u < NT) V[vidx(i0 + TASK_WAVES * u, j)] = v[u] * jm;
     }
+    for (int i = NT + g; i < NT + mroot; i += TASK_WAVES) V[vidx(i, j)] = 0.0;
     __syncthreads();
-    const int mroot = meta[s1 - s0].r - meta[s1 - s0].c;
-    for (int i = NT + g; i < NT + mroot; i += 4) V[vidx(i, j)] = 0.0;
-    __syncthreads();
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = wv / (4 / TPW), th = wv % (4 / TPW);  // this wave's row-tile slot and its part of the right-hand sides (scalars)
+    const int lane = tid & 63;
     const int lm = lane & 15, lk = lane >> 4;
-    for (int f = 0; f <= s1 - s0; f++) {
-        const TaskMeta m = meta[f];
+    const int cl = th * 16 * TPW + lm;                  // column of this lane in the first of its tiles
+    // Operands that do not depend on the sweep itself -- this slot's rows of the first 16 columns of L11^-1 / of its
+    // trailing row tile, and that tile's local rows -- are requested ONE FRONT AHEAD. All addresses are clamped into
+    // the front's own panel / row list, so the loads are valid for any geometry (masks are applied at use).
+    double ao[4], at[4], no[4], nt_[4];
+    int li[4], nli[4];
+    auto request = [&](int f, double (&xo)[4], double (&xt)[4], int (&xl)[4]) {
+        const TaskMeta m = uniform_meta(meta, f);
+        const int ntile = (m.r - m.c + 15) >> 4;
+        const bool narrow = m.c <= 16;
+        if (!(w == 0 || w < ntile || (!narrow && w * 16 < m.c))) return;      // this slot has no work in front f (scalar branch)
+        const double *P = L + m.pp;
+        const int *lr = S.lrow + m.rp;
+        const int i0 = m.c + w * 16;
+        const double *pa = P + min(i0 + lm, m.r - 1);
+        const int kk = narrow ? 0 : w * 16;       // narrow fronts: every slot computes the one y tile itself (see below)
+#pragma unroll
+        for (int u = 0; u < 4; u++) xo[u] = tinv_elem(P, m.ld, m.c, kk + lm, 4 * u + lk, true);
+#pragma unroll
+        for (int u = 0; u < 4; u++) xt[u] = pa[(long long)min(4 * u + lk, m.c - 1) * m.ld] * ((4 * u + lk) < m.c ? 1.0 : 0.0);
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) xl[rr] = lr[min(i0 + lk + 4 * rr, m.r - 1)];
+    };
+    request(0, ao, at, li);
+    for (int f = 0; f < nf; f++) {
+        const TaskMeta m = uniform_meta(meta, f);
         const int c = m.c, r = m.r, ld = m.ld, o = m.o;
         const double *P = L + m.pp;
         const int *lr = S.lrow + m.rp;
-        // ---- y = L11^-1 b: wave w owns own rows 16 w .. 16 w + 15 -------------------------------------------
-        const int k0 = wave * 16;
-        d4 acc[4];
+        request(min(f + 1, nf - 1), no, nt_, nli);
+        const int ntile = (r - c + 15) >> 4;
+        double *Xo = X + (long long)(col0 + o) * ldx;       // the front's own rows of X: y goes straight to HBM
+        if (c <= 16) {
+            // NARROW FRONT (most of the bottom of the tree): ONE barrier. Every active slot computes the single 16 x 16
+            // tile y = L11^-1 b itself (redundantly); in the accumulator layout register u of lane (lk, lm) holds row
+            // 4 u + lk -- exactly the B operand of k-step u -- so L21 y runs straight from registers.
+            if (w == 0 || w < ntile) {
+                d4 y[TPW];
 #pragma unroll
-        for (int t = 0; t < 4; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+                for (int t = 0; t < TPW; t++) y[t] = (d4){0.0, 0.0, 0.0, 0.0};
+                const int ku = (c + 3) >> 2;          // k-steps that hold columns of the front (scalar)
+#pragma unroll
+                for (int u = 0; u < 4; u++) if (u < ku) mfma4_lds(y, ao[u], V, o + min(4 * u + lk, c - 1), cl);
+                if (w == 0) {
+#pragma unroll
+                    for (int t = 0; t < TPW; t++)
+#pragma unroll
+                        for (int rr = 0; rr < 4; rr++)
+                            if (lk + 4 * rr < c && t * 16 + cl < nr) Xo[(long long)(lk + 4 * rr) * ldx + t * 16 + cl] = y[t][rr];
+                }
+#pragma unroll 1
+                for (int it = w; it < ntile; it += TASK_SLOTS) {
+                    const int i0 = c + it * 16;
+                    double av[4];
+                    int l2[4];
+                    if (it == w) {
+#pragma unroll
+                        for (int u = 0; u < 4; u++) { av[u] = at[u]; l2[u] = li[u]; }
+                    } else {
+                        const double *pa = P + min(i0 + lm, r - 1);
+#pragma unroll
+                        for (int rr = 0; rr < 4; rr++) l2[rr] = lr[min(i0 + lk + 4 * rr, r - 1)];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) av[u] = pa[(long long)min(4 * u + lk, c - 1) * ld] * ((4 * u + lk) < c ? 1.0 : 0.0);
+                    }
+                    d4 acc[TPW];
+#pragma unroll
+                    for (int t = 0; t < TPW; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        if (u < ku) {
+#pragma unroll
+                            for (int t = 0; t < TPW; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], y[t][u], acc[t], 0, 0, 0);
+                        }
+                    scatter_sub(V, l2, acc, r - i0, lk, cl);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 4; u++) { ao[u] = no[u]; at[u] = nt_[u]; li[u] = nli[u]; }
+            continue;
+        }
+        // ---- wide front (17..64 columns): slot w < 4 owns own rows 16 w .. 16 w + 15 -----------------------------
+        const int k0 = w * 16;
+        d4 acc[TPW];
         if (k0 < c) {
+#pragma unroll
+            for (int t = 0; t < TPW; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int u = 0; u < 4; u++) mfma4_lds(acc, ao[u], V, o + min(4 * u + lk, c - 1), cl);     // zero beyond column c / above the diagonal
             const int qhi = min(c, k0 + 16);
 #pragma unroll 1
-            for (int q0 = 0; q0 < qhi; q0 += 16) {
+            for (int q0 = 16; q0 < qhi; q0 += 16) {
                 double av[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) av[u] = tinv_elem(P, ld, c, k0 + lm, q0 + 4 * u + lk, true);
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int q = o + min(q0 + 4 * u + lk, c - 1);        // av is zero beyond column c
-#pragma unroll
-                    for (int t = 0; t < 4; t++)
-                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], V[vidx(q, t * 16 + lm)], acc[t], 0, 0, 0);
-                }
+                for (int u = 0; u < 4; u++) mfma4_lds(acc, av[u], V, o + min(q0 + 4 * u + lk, c - 1), cl);
             }
         }
-        if (c > 16) __syncthreads();            // every wave has read b before any y is written (one tile: same wave)
+        __syncthreads();            // every slot has read b before any y is written
         if (k0 < c) {
 #pragma unroll
-            for (int t = 0; t < 4; t++)
+            for (int t = 0; t < TPW; t++)
 #pragma unroll
                 for (int rr = 0; rr < 4; rr++) {
                     const int k = k0 + lk + 4 * rr;
-                    if (k < c) V[vidx(o + k, t * 16 + lm)] = acc[t][rr];
+                    if (k < c) {
+                        V[vidx(o + k, t * 16 + cl)] = acc[t][rr];
+                        if (t * 16 + cl < nr) Xo[(long long)k * ldx + t * 16 + cl] = acc[t][rr];
+                    }
                 }
         }
         __syncthreads();
         // ---- V[trailing rows] -= L21 y ---------------------------------------------------------------------
-        const int ntile = (r - c + 15) >> 4;
 #pragma unroll 1
-        for (int it = wave; it < ntile; it += 4) {
+        for (int it = w; it < ntile; it += TASK_SLOTS) {
             const int i0 = c + it * 16;
             const double *pa = P + min(i0 + lm, r - 1);
-            int li[4];
+            int l2[4];
 #pragma unroll
-            for (int rr = 0; rr < 4; rr++) li[rr] = lr[min(i0 + lk + 4 * rr, r - 1)];
+            for (int t = 0; t < TPW; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+            if (it == w) {
 #pragma unroll
-            for (int t = 0; t < 4; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+                for (int u = 0; u < 4; u++) l2[u] = li[u];
+#pragma unroll
+                for (int u = 0; u < 4; u++) mfma4_lds(acc, at[u], V, o + 4 * u + lk, cl);            // c > 16: rows o .. o+15 exist
+            } else {
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) l2[rr] = lr[min(i0 + lk + 4 * rr, r - 1)];
+                double av[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) av[u] = pa[(long long)(4 * u + lk) * ld];
+#pragma unroll
+                for (int u = 0; u < 4; u++) mfma4_lds(acc, av[u], V, o + 4 * u + lk, cl);
+            }
 #pragma unroll 1
-            for (int q0 = 0; q0 < c; q0 += 16) {
+            for (int q0 = 16; q0 < c; q0 += 16) {
                 double av[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
@@ -153,29 +290,18 @@ __global__ __launch_bounds__(256, 1) void k_fwd_task(DevSym S, const int *__rest
                     av[u] = pa[(long long)min(q, c - 1) * ld] * (q < c ? 1.0 : 0.0);
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int q = o + min(q0 + 4 * u + lk, c - 1);
-#pragma unroll
-                    for (int t = 0; t < 4; t++)
-                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], V[vidx(q, t * 16 + lm)], acc[t], 0, 0, 0);
-                }
+                for (int u = 0; u < 4; u++) mfma4_lds(acc, av[u], V, o + min(q0 + 4 * u + lk, c - 1), cl);
             }
-            // distinct rows inside a front, one wave per row tile: no conflicts
-#pragma unroll
-            for (int rr = 0; rr < 4; rr++) {
-                if (i0 + lk + 4 * rr < r) {
-#pragma unroll
-                    for (int t = 0; t < 4; t++) V[vidx(li[rr], t * 16 + lm)] -= acc[t][rr];
-                }
-            }
+            scatter_sub(V, l2, acc, r - i0, lk, cl);     // distinct rows inside a front, one wave per row tile: no conflicts
         }
         __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; u++) { ao[u] = no[u]; at[u] = nt_[u]; li[u] = nli[u]; }
     }
-    // ---- write-out: y of the whole subtree (contiguous rows of X) and the root's update vector W ---------------
+    // ---- write-out: the root's update vector W (y went to X front by front) -----------------------------------
     if (j < nr) {
-        for (int i = g; i < NT; i += 4) X[(long long)(col0 + i) * ldx + j] = V[vidx(i, j)];
-        double *Wr = W + S.wptr[s1] * ldx;
-        for (int i = g; i < mroot; i += 4) Wr[(long long)i * ldx + j] = V[vidx(NT + i, j)];
+        double *Wr = W + T.woff * ldx;
+        for (int i = g; i < mroot; i += TASK_WAVES) Wr[(long long)i * ldx + j] = V[vidx(NT + i, j)];
     }
     if (sink == 1.2345678e-300) X[(long long)col0 * ldx] = sink;      // keeps the warm-up loads alive; never true
 }
@@ -184,123 +310,180 @@ __global__ __launch_bounds__(256, 1) void k_fwd_task(DevSym S, const int *__rest
 // backward: V <- [y (or z) of the subtree ; x of the root's trailing rows]; per front, root first:
 // t = y - L21' x[trailing], x = L11^-T t
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void k_bwd_task(DevSym S, const int *__restrict__ tk_first, const int *__restrict__ tk_last,
+__global__ __launch_bounds__(TASK_THREADS, 1) void k_bwd_task(DevSym S, const SweepTask *__restrict__ tasks,
                                                      const double *__restrict__ L, double *__restrict__ X, int nr, int ldx) {
     __shared__ double V[TASK_ROWS * 64];
     __shared__ TaskMeta meta[TASK_MAXF];
-    const int s0 = tk_first[blockIdx.x], s1 = tk_last[blockIdx.x];
-    const int col0 = S.sfirst[s0], col1 = S.sfirst[s1 + 1], NT = col1 - col0;
+    const SweepTask T = tasks[blockIdx.x];
+    const int col0 = T.col0, NT = T.nt, nf = T.s1 - T.s0 + 1, mroot = T.mroot;
     const int tid = threadIdx.x;
     const int j = tid & 63, g = tid >> 6;
     const int jc = min(j, nr - 1);
     const double jm = j < nr ? 1.0 : 0.0;
-    const double sink = task_prologue(S, s0, s1, col0, meta, L);
-    for (int i0 = g; i0 < NT; i0 += 32) {
-        double v[8];
+    const double sink = task_prologue(S, T, meta, L);
+    for (int i0 = g; i0 < NT; i0 += 4 * TASK_WAVES) {
+        double v[4];
 #pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = X[(long long)(col0 + min(i0 + 4 * u, NT - 1)) * ldx + jc];
+        for (int u = 0; u < 4; u++) v[u] = X[(long long)(col0 + min(i0 + TASK_WAVES * u, NT - 1)) * ldx + jc];
 #pragma unroll
-        for (int u = 0; u < 8; u++) if (i0 + 4 * u < NT) V[vidx(i0 + 4 * u, j)] = v[u] * jm;
+        for (int u = 0; u < 4; u++) if (i0 + TASK_WAVES * u < NT) V[vidx(i0 + TASK_WAVES * u, j)] = v[u] * jm;
     }
-    __syncthreads();
     {   // x of the root's trailing rows (ancestors of the subtree: final)
-        const TaskMeta mr = meta[s1 - s0];
-        const int mroot = mr.r - mr.c;
-        const int *rows = S.rows + mr.rp + mr.c;
-        for (int i0 = g; i0 < mroot; i0 += 32) {
-            int ri[8];
-            double v[8];
+        const int *rows = S.rows + T.rroot;
+        for (int i0 = g; i0 < mroot; i0 += 4 * TASK_WAVES) {
+            int ri[4];
+            double v[4];
 #pragma unroll
-            for (int u = 0; u < 8; u++) ri[u] = rows[min(i0 + 4 * u, mroot - 1)];
+            for (int u = 0; u < 4; u++) ri[u] = rows[min(i0 + TASK_WAVES * u, mroot - 1)];
 #pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = X[(long long)ri[u] * ldx + jc];
+            for (int u = 0; u < 4; u++) v[u] = X[(long long)ri[u] * ldx + jc];
 #pragma unroll
-            for (int u = 0; u < 8; u++) if (i0 + 4 * u < mroot) V[vidx(NT + i0 + 4 * u, j)] = v[u] * jm;
+            for (int u = 0; u < 4; u++) if (i0 + TASK_WAVES * u < mroot) V[vidx(NT + i0 + TASK_WAVES * u, j)] = v[u] * jm;
         }
     }
     __syncthreads();
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = wv / (4 / TPW), th = wv % (4 / TPW);
+    const int lane = tid & 63;
     const int lm = lane & 15, lk = lane >> 4;
-    for (int f = s1 - s0; f >= 0; f--) {
-        const TaskMeta m = meta[f];
+    const int cl = th * 16 * TPW + lm;
+    const int k0 = w * 16;
+    // one front ahead (see k_fwd_task): the first 32 trailing rows of this slot's own columns with their local rows,
+    // and the diagonal 16 x 16 block of L11^-T. Only slots 0..3 ever own columns.
+    double a1[8], ad[4], n1[8], nd[4];
+    int l1[8], nl1[8];
+    auto request = [&](int f, double (&x1)[8], int (&xl)[8], double (&xd)[4]) {
+        const TaskMeta m = uniform_meta(meta, f);
+        if (k0 >= m.c) return;                                             // this slot has no work in front f (scalar branch)
+        const double *P = L + m.pp;
+        const int *lr = S.lrow + m.rp;
+        const double *pa = P + (long long)min(k0 + lm, m.c - 1) * m.ld;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int qq = min(m.c + 4 * u + lk, m.r - 1);
+            x1[u] = pa[qq];
+            xl[u] = lr[qq];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) xd[u] = tinv_elem(P, m.ld, m.c, k0 + lm, k0 + 4 * u + lk, false);
+    };
+    request(nf - 1, a1, l1, ad);
+    for (int f = nf - 1; f >= 0; f--) {
+        const TaskMeta m = uniform_meta(meta, f);
         const int c = m.c, r = m.r, ld = m.ld, o = m.o;
         const double *P = L + m.pp;
         const int *lr = S.lrow + m.rp;
-        const int k0 = wave * 16;
-        d4 acc[4];
-        // ---- t = y - L21' x_R: wave w owns own columns 16 w .. 16 w + 15 (nobody else touches those rows of V here)
+        request(max(f - 1, 0), n1, nl1, nd);
+        d4 acc[TPW];
+        // ---- t = y - L21' x_R: slot w owns own columns 16 w .. 16 w + 15 (nobody else touches those rows of V here)
         if (k0 < c) {
-            const double *pa = P + (long long)min(k0 + lm, c - 1) * ld;
 #pragma unroll
-            for (int t = 0; t < 4; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+            for (int t = 0; t < TPW; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+            if (r > c) {
+                const double *pa = P + (long long)min(k0 + lm, c - 1) * ld;
+                const int kt = (min(r - c, 32) + 3) >> 2;      // k-steps that hold trailing rows (scalar)
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (u < kt) mfma4_lds(acc, a1[u] * ((c + 4 * u + lk) < r ? 1.0 : 0.0), V, max(l1[u], 0), cl);
 #pragma unroll 1
-            for (int q0 = c; q0 < r; q0 += 32) {      // two 16-row k-blocks per pass: 8 operand + 8 index loads in flight
-                double av[8];
-                int li[8];
+                for (int q0 = c + 32; q0 < r; q0 += 32) {      // two 16-row k-blocks per pass: 8 operand + 8 index loads in flight
+                    double av[8];
+                    int l2[8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const int qq = min(q0 + 4 * u + lk, r - 1);
-                    av[u] = pa[qq];
-                    li[u] = lr[qq];
-                }
+                    for (int u = 0; u < 8; u++) {
+                        const int qq = min(q0 + 4 * u + lk, r - 1);
+                        av[u] = pa[qq];
+                        l2[u] = lr[qq];
+                    }
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const double a_ = av[u] * ((q0 + 4 * u + lk) < r ? 1.0 : 0.0);
-#pragma unroll
-                    for (int t = 0; t < 4; t++)
-                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, V[vidx(li[u], t * 16 + lm)], acc[t], 0, 0, 0);
+                    for (int u = 0; u < 8; u++)
+                        mfma4_lds(acc, av[u] * ((q0 + 4 * u + lk) < r ? 1.0 : 0.0), V, l2[u], cl);
                 }
             }
+        }
+        if (c <= 16) {
+            // NARROW FRONT: t in the accumulator layout (register u = row 4 u + lk) is the B operand of x = L11^-T t:
+            // no round trip through LDS, one barrier per front
+            if (w == 0) {
+                d4 x[TPW];
 #pragma unroll
-            for (int t = 0; t < 4; t++)
+                for (int t = 0; t < TPW; t++) x[t] = (d4){0.0, 0.0, 0.0, 0.0};
+                const int ku = (c + 3) >> 2;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (u < ku) {
+                        const int kq = o + min(4 * u + lk, c - 1);
+                        const double *vr = V + kq * 64;
+                        const int sw = (kq & 1) << 4;
+#pragma unroll
+                        for (int t = 0; t < TPW; t++)
+                            x[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[u], vr[(t * 16 + cl) ^ sw] - acc[t][u], x[t], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < TPW; t++)
+#pragma unroll
+                    for (int rr = 0; rr < 4; rr++)
+                        if (lk + 4 * rr < c) V[vidx(o + lk + 4 * rr, t * 16 + cl)] = x[t][rr];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 8; u++) { a1[u] = n1[u]; l1[u] = nl1[u]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) ad[u] = nd[u];
+            continue;
+        }
+        if (k0 < c) {
+#pragma unroll
+            for (int t = 0; t < TPW; t++)
 #pragma unroll
                 for (int rr = 0; rr < 4; rr++) {
                     const int k = k0 + lk + 4 * rr;
-                    if (k < c) V[vidx(o + k, t * 16 + lm)] -= acc[t][rr];
+                    if (k < c) V[vidx(o + k, t * 16 + cl)] -= acc[t][rr];
                 }
         }
-        if (c > 16) __syncthreads();
+        __syncthreads();
         // ---- x = L11^-T t ------------------------------------------------------------------------------------
         if (k0 < c) {
 #pragma unroll
-            for (int t = 0; t < 4; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+            for (int t = 0; t < TPW; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int u = 0; u < 4; u++) mfma4_lds(acc, ad[u], V, o + min(k0 + 4 * u + lk, c - 1), cl);
 #pragma unroll 1
-            for (int q0 = k0; q0 < c; q0 += 16) {
+            for (int q0 = k0 + 16; q0 < c; q0 += 16) {
                 double av[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) av[u] = tinv_elem(P, ld, c, k0 + lm, q0 + 4 * u + lk, false);   // Linv[q][k], q >= k
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int q = o + min(q0 + 4 * u + lk, c - 1);
-#pragma unroll
-                    for (int t = 0; t < 4; t++)
-                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], V[vidx(q, t * 16 + lm)], acc[t], 0, 0, 0);
-                }
+                for (int u = 0; u < 4; u++) mfma4_lds(acc, av[u], V, o + min(q0 + 4 * u + lk, c - 1), cl);
             }
         }
-        if (c > 16) __syncthreads();            // every wave has read t before any x is written
+        __syncthreads();            // every slot has read t before any x is written
         if (k0 < c) {
 #pragma unroll
-            for (int t = 0; t < 4; t++)
+            for (int t = 0; t < TPW; t++)
 #pragma unroll
                 for (int rr = 0; rr < 4; rr++) {
                     const int k = k0 + lk + 4 * rr;
-                    if (k < c) V[vidx(o + k, t * 16 + lm)] = acc[t][rr];
+                    if (k < c) V[vidx(o + k, t * 16 + cl)] = acc[t][rr];
                 }
         }
         __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 8; u++) { a1[u] = n1[u]; l1[u] = nl1[u]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) ad[u] = nd[u];
     }
     if (j < nr)
-        for (int i = g; i < NT; i += 4) X[(long long)(col0 + i) * ldx + j] = V[vidx(i, j)];
+        for (int i = g; i < NT; i += TASK_WAVES) X[(long long)(col0 + i) * ldx + j] = V[vidx(i, j)];
     if (sink == 1.2345678e-300) X[(long long)col0 * ldx] = sink;
 }
 
-void launch_sweep_tasks(hipStream_t st, const DevSym &S, int phase, const int *tk_first, const int *tk_last, int ntasks,
+void launch_sweep_tasks(hipStream_t st, const DevSym &S, int phase, const SweepTask *tasks, int ntasks,
                         const double *L, double *X, double *W, int nr, int ldx) {
     if (ntasks <= 0) return;
-    if (phase == 1) hipLaunchKernelGGL(k_fwd_task, dim3(ntasks), dim3(256), 0, st, S, tk_first, tk_last, L, X, W, nr, ldx);
-    else hipLaunchKernelGGL(k_bwd_task, dim3(ntasks), dim3(256), 0, st, S, tk_first, tk_last, L, X, nr, ldx);
+    if (phase == 1) hipLaunchKernelGGL(k_fwd_task, dim3(ntasks), dim3(TASK_THREADS), 0, st, S, tasks, L, X, W, nr, ldx);
+    else hipLaunchKernelGGL(k_bwd_task, dim3(ntasks), dim3(TASK_THREADS), 0, st, S, tasks, L, X, nr, ldx);
 }
 int sweep_task_rows_max() { return TASK_ROWS; }
-
 }  // namespace gmrfx
