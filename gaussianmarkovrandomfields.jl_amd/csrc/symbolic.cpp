@@ -533,7 +533,8 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
     S.in_swt.assign(ns, 0);
     S.lrow.assign((size_t)S.sum_rows, -1);
     {
-        const int rcap = S.shard_world > 1 ? 0 : std::min(288, opt.sweep_task_rows >= 0 ? opt.sweep_task_rows : 288);   // 288 = TASK_ROWS of sweep_task.hip
+        const int rcap = (S.shard_world > 1 || opt.subtree_max > 0) ? 0 : std::min(288,   // (not with the legacy subtree tasks)
+                                                                               opt.sweep_task_rows >= 0 ? opt.sweep_task_rows : 288);   // 288 = TASK_ROWS of sweep_task.hip
         S.swt_rows = rcap;
         std::vector<i32> cnt(ns, 1), ncol(ns, 0), maxc(ns, 0);
         std::vector<double> work(ns, 0.0);

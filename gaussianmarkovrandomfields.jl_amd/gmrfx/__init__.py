@@ -4,3 +4,4 @@ from .backend import MI355XBackend, SymbolicInfo  # noqa: F401
 from .ordering import PinDenseColumns, ordering_permutation  # noqa: F401
 from ._lib import GmrfxError, NoDeviceError, PosDefException  # noqa: F401
 from .kron import KroneckerWorkspace  # noqa: F401
+from .spacetime import spacetime_coords, spacetime_precision  # noqa: F401

@@ -227,3 +227,58 @@ def test_cfg4_full_size_126_cubed_on_one_gpu():
     be.refactorize(Q)
     assert be.compute_logdet() == ld1                       # bit-reproducible (no atomics anywhere)
     be.close()
+
+
+def test_cfg5_spacetime_posterior_small_matches_oracle():
+    """BASELINE.json config 5's operator at a size the oracle follows: AR(1) (rho = 0.9, ar.jl:135-148) x 2-D Matern
+    (alpha = 2) joint precision kron(Q_t, Q_s) (separable.jl:143-156) PLUS a Poisson-type diagonal likelihood term --
+    the posterior precision a Newton iterate factorises -- with the space-time nested dissection (coordinates
+    (x, y, t dt)). Factor, solve, logdet, selected-inverse diagonal, sampling map against the oracle."""
+    T = 24
+    m = spde.grid_mesh_2d(18, 15, jitter=0.2, seed=3)
+    Qt = spde.ar1_precision(T, 0.9, 1.0)
+    Qs = spde.matern_precision(m, 0, 0.4)
+    ns = Qs.shape[0]
+    rng = np.random.default_rng(9)
+    Q = gmrfx.spacetime_precision(Qt, Qs, obs_diag=np.exp(0.3 * rng.standard_normal(T * ns)))
+    n = Q.shape[0]
+    be = gmrfx.MI355XBackend(Q, coords=gmrfx.spacetime_coords(m.points, T))
+    F = orc.OracleFactor(Q, be.ordering_permutation())
+    Lg, Lo = be.factor_csc(), F.L()
+    assert abs(Lg - Lo).max() <= 1e-10 * abs(Lo).max()
+    B = rng.standard_normal((n, 3))
+    assert relerr(be.backend_solve(B), F.solve(B)) < 1e-10
+    assert abs(be.compute_logdet() - F.logdet()) < 1e-11 * abs(F.logdet())
+    assert relerr(be.get_selinv_diag(), F.selinv_diag()) < 1e-8
+    assert relerr(be.backend_backward_solve(B[:, 0]), F.backward_solve(B[:, 0])) < 1e-10
+    # the prior alone (no likelihood term) agrees with the Kronecker factor rule
+    Qp = gmrfx.spacetime_precision(Qt, Qs)
+    bp = gmrfx.MI355XBackend(Qp, coords=gmrfx.spacetime_coords(m.points, T))
+    kw = gmrfx.KroneckerWorkspace(Qt, Qs)
+    assert abs(bp.compute_logdet() - kw.logdet()) < 1e-10 * abs(kw.logdet())
+    assert relerr(bp.get_selinv_diag(), kw.selinv_diag()) < 1e-8
+
+
+def test_cfg5_spacetime_posterior_medium_properties():
+    """The same operator at 64 time steps x 100 x 100 nodes = 640 000 unknowns (block tridiagonal in time, 64 blocks
+    of 10^4): residual, sampling identity, logdet scaling, tr(Q^-1 Q) = n."""
+    T = 64
+    m = spde.grid_mesh_2d(100, 100, jitter=0.25, seed=1)
+    Qt = spde.ar1_precision(T, 0.9, 1.0)
+    Qs = spde.matern_precision(m, 0, 0.2)
+    ns = Qs.shape[0]
+    rng = np.random.default_rng(10)
+    Q = gmrfx.spacetime_precision(Qt, Qs, obs_diag=rng.uniform(0.5, 2.0, T * ns))
+    n = Q.shape[0]
+    be = gmrfx.MI355XBackend(Q, coords=gmrfx.spacetime_coords(m.points, T))
+    assert be.last_info == 0
+    ld = be.compute_logdet()
+    B = rng.standard_normal((n, 16))
+    X = be.backend_solve(B)
+    assert np.linalg.norm(Q @ X - B) / np.linalg.norm(B) < 1e-10
+    z = rng.standard_normal(n)
+    x = be.backend_backward_solve(z)
+    assert abs(x @ (Q @ x) - z @ z) < 1e-10 * (z @ z)
+    assert abs(be.selinv_dot(Q) - n) < 1e-8 * n
+    be.refactorize_values(Q.data * 2.0)
+    assert abs(be.compute_logdet() - (ld + n * np.log(2.0))) < 1e-11 * abs(ld)
