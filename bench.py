@@ -9,9 +9,11 @@ excluded from the step and reported separately.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--grid G] [--nrhs R]
 
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); the path is run as
-independent replicas (one workspace per GPU, the reference's WorkspacePool pattern), no
-data-path collective, scaling = weak. Prints ONE JSON line on rank 0.
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL). The headline is ONE
+factorisation + 64-RHS solve SHARDED over the N GPUs (strong scaling: `value` = n / step time;
+gmrfx/shard.py); the independent-replica throughput (one workspace per GPU, the reference's
+WorkspacePool pattern, weak scaling) is reported beside it under "replicas", and becomes the
+headline only if the sharded path fails or with --no-shard. Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -90,12 +92,13 @@ def cpu_baseline(Q, mesh, nrhs: int):
 
 
 def bench_sharded(args, Q, mesh, dist, rank, world, local_rank):
-    """Strong scaling of ONE refactorisation + logdet over the ranks. Not the headline line."""
+    """Strong scaling: ONE refactorisation + 64-RHS solve sharded over the ranks (gmrfx/shard.py): subtrees
+    per rank, every top front on one rank of its group, contribution blocks / update vectors point-to-point along the
+    owner-crossing tree edges (RCCL over xGMI), x of the top fronts broadcast by their owners. Returns the result dict
+    on rank 0 (None elsewhere); timed exactly like the replica loop (barrier + sync on both sides, max over ranks)."""
     import numpy as np
     import torch
     from gmrfx import shard
-    if dist is None:
-        raise SystemExit("--shard needs N > 1 ranks (torch.distributed.run)")
     dev = torch.device("cuda", local_rank)
     n = Q.shape[0]
     d_nz = torch.from_numpy(np.ascontiguousarray(Q.data)).to(dev)
@@ -106,34 +109,33 @@ def bench_sharded(args, Q, mesh, dist, rank, world, local_rank):
     sf = shard.ShardedFactor(Q, dist, device=local_rank, coords=mesh.points)
 
     def step():
-        sf.refactorize_dev(d_nz.data_ptr())
+        info = sf.refactorize_dev(d_nz.data_ptr())
         sf.solve_dev(d_B.data_ptr(), n, args.nrhs, d_X.data_ptr(), n)     # X lands on rank 0
-        return sf.logdet()
+        return info
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ld = step()
+        info = step()
     torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
     el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if args.rehearse else dev)
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    ld = sf.logdet()
+    out = None
     if rank == 0:
-        info = sf.be.shard_info()
+        plan = shard.plan_summary(sf.be)
         X = d_X.cpu().numpy().T
         resid = float(np.linalg.norm(Q @ X - Bh.numpy().T) / np.linalg.norm(Bh.numpy()))
-        print(json.dumps({"metric": "sharded factor+solve(64 RHS)+logdet (ONE factorisation over all ranks)", "value": n / (float(el.item()) / args.steps),
-                          "unit": "DoF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": 1e3 * float(el.item()) / args.steps, "higher_is_better": True, "scaling": "strong",
-                          "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                          "config": {"workload": f"cfg2 pattern ({args.grid}x{args.grid} mesh), refactorise + {args.nrhs}-RHS solve + logdet, supernodal tree cut into "
-                                                 f"subtrees per rank, {info['n_cb_blocks']} contribution blocks to rank 0, {info['n_top_fronts']} top fronts",
-                                     "exchange": "gloo + host staging (rehearsal)" if args.rehearse else "RCCL point-to-point + all-reduce"},
-                          "check": {"logdet": ld, "rel_residual": resid}}))
+        out = {"value": n / (float(el.item()) / args.steps), "ms_per_step": 1e3 * float(el.item()) / args.steps,
+               "plan": {"top_fronts": plan["top_fronts"], "cross_rank_edges": sf.info["n_edges"], "top_levels": sf.K,
+                        "flop_bound_speedup": plan["flop_bound_speedup"]},
+               "exchange": "gloo + host staging (rehearsal)" if args.rehearse else "RCCL point-to-point (batch_isend_irecv) + broadcast + all-reduce over xGMI",
+               "check": {"logdet": ld, "rel_residual": resid, "info": info}}
     dist.barrier()
     sf.close()
-    dist.destroy_process_group()
+    return out
 
 
 def main():
@@ -148,10 +150,9 @@ def main():
                     help="multi-process rehearsal on a box with ONE GPU: every rank uses cuda:0 and the "
                          "process group runs on gloo (RCCL refuses two ranks on one device)")
     ap.add_argument("--extras", action="store_true", help="also time selinv-diag and 256-sample rand (cfg 3)")
-    ap.add_argument("--shard", action="store_true",
-                    help="extra (N > 1): ONE factorisation sharded over the ranks (subtrees per rank, Schur-complement "
-                         "contribution blocks to rank 0 over the process group, all-reduced logdet; gmrfx/shard.py) "
-                         "instead of independent replicas; prints its own JSON line (strong scaling of refactorise + solve + logdet)")
+    ap.add_argument("--no-shard", action="store_true",
+                    help="N > 1: only time the independent replicas (weak scaling); by default the headline of an N > 1 run is "
+                         "ONE factorisation sharded over the N GPUs (strong scaling, gmrfx/shard.py) and the replicas are reported beside it")
     ap.add_argument("--no-logpdf", action="store_true",
                     help="skip the (untimed) logpdf loop after the timed steps: keeps kernel traces / PMC passes to whole "
                          "refactorise+solve steps (tools/prof_summary.py, tools/pmc_traffic.py)")
@@ -199,8 +200,6 @@ def main():
     mesh = spde.grid_mesh_2d(args.grid, args.grid, jitter=0.25, seed=0)
     Q = spde.matern_precision(mesh, smoothness=0, range_=0.2)   # range = 0.1 * domain width (2.0)
     n = Q.shape[0]
-    if args.shard:
-        return bench_sharded(args, Q, mesh, dist, rank, world, local_rank)
     be = gmrfx.MI355XBackend(Q, coords=mesh.points, device=local_rank, factorize=False)
     st0 = be.stats()
 
@@ -240,6 +239,13 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    sharded = None
+    if dist is not None and not args.no_shard:
+        try:
+            sharded = bench_sharded(args, Q, mesh, dist, rank, world, local_rank)
+        except Exception as e:           # the replica line must survive a failure of the sharded path
+            sharded = {"error": repr(e)} if rank == 0 else None
 
     # ---- untimed correctness evidence on this very run -------------------------------------
     X = d_X.cpu().numpy().T            # n x nrhs
@@ -407,6 +413,19 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(Q, mesh, args.nrhs)
+        if world > 1:
+            replicas = {"value": out["value"], "ms_per_step": out["ms_per_step"], "scaling": "weak",
+                        "note": "one independent workspace per GPU (the reference's WorkspacePool pattern), no data-path collective"}
+            if sharded is not None and "error" not in sharded:
+                # headline of an N > 1 run: ONE factorisation + 64-RHS solve over all N GPUs (north_star: strong scaling)
+                out.update({"value": sharded["value"], "ms_per_step": sharded["ms_per_step"], "scaling": "strong"})
+                out["config"]["parallelism"] = (f"ONE factorisation sharded over {world} GPUs: subtrees per rank, top fronts owned inside their "
+                                                f"group, Schur-complement blocks point-to-point ({sharded['exchange']})")
+                out["sharded"] = sharded
+                out["check"] = {**out["check"], "sharded": sharded["check"]}
+            else:
+                out["sharded"] = sharded
+            out["replicas"] = replicas
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -171,7 +171,7 @@ void Device::upload(const Symbolic &S) {
     if (S.shard_world > 1) {
         std::vector<unsigned char> own(S.n, 0);
         for (i32 s = 0; s < ns; s++) {
-            const bool mine = S.owner[s] == S.shard_rank || (S.owner[s] == -1 && S.shard_rank == 0);
+            const bool mine = S.owner[s] == S.shard_rank;
             if (mine) for (i32 j = S.sfirst[s]; j < S.sfirst[s + 1]; j++) own[j] = 1;
         }
         const unsigned char *op; up(op, own); d_owncol_ = op;
@@ -246,7 +246,7 @@ void Device::upload(const Symbolic &S) {
     {
         std::vector<int> il;
         for (i32 s = 0; s < ns; s++) {
-            const bool mine = S.shard_world <= 1 || S.owner[s] == S.shard_rank || (S.owner[s] == -1 && S.shard_rank == 0);
+            const bool mine = S.shard_world <= 1 || S.owner[s] == S.shard_rank;
             if (S.ncols(s) > NB && mine) il.push_back(s);     // sharded handles only hold the panels they factored
         }
         std::sort(il.begin(), il.end(), [&](int a, int b) { return S.ncols(a) != S.ncols(b) ? S.ncols(a) > S.ncols(b) : a < b; });
@@ -413,15 +413,18 @@ void Device::refactorize(const double *nzval, bool on_device) {
 void Device::refactorize_phase(const double *d_nzval, int phase) {
     HC(hipSetDevice(device));
     if (!sharded()) throw std::invalid_argument("gmrfx_refactorize_phase needs a handle created with shard_world > 1");
-    const int split = std::min<int>(S_->shard_level, (int)levels_.size());
+    const int nl = (int)levels_.size();
+    const int split = std::min<int>(S_->shard_level, nl);
     HC(hipEventRecord(ev_[0], stream));
-    if (phase == 0) {
+    if (phase == 0) {               // the subtrees this rank owns
         nz_src_ = d_nzval;
         nz_held_ = false;       // the values live in the caller's device buffer
         factorized = false;
         factor_levels(0, split);
-    } else {
-        factor_levels(split, (int)levels_.size());
+    } else {                        // top level split + phase - 1: the fronts of that level this rank owns
+        const int lev = split + phase - 1;
+        if (lev >= nl) throw std::invalid_argument("refactorize phase beyond the last level");
+        factor_levels(lev, lev + 1);
     }
     HC(hipEventRecord(ev_[1], stream));
     HC(hipStreamSynchronize(stream));
@@ -429,7 +432,7 @@ void Device::refactorize_phase(const double *d_nzval, int phase) {
     float ms = 0;
     HC(hipEventElapsedTime(&ms, ev_[0], ev_[1]));
     ms_factor = phase == 0 ? ms : ms_factor + ms;
-    if (phase != 0) { factorized = true; selinv_valid = false; inverse_pending = true; }
+    if (split + phase >= nl) { factorized = true; selinv_valid = false; inverse_pending = true; }   // last phase done
 }
 
 void Device::set_prior(const double *prior_nzval, const long long *map, long long cnt) {
@@ -556,19 +559,22 @@ void Device::solve_phase(const double *d_B, long long ldb, long long nrhs, doubl
     const int split = std::min<int>(S_->shard_level, nl);
     const long long n = S_->n;
     HC(hipEventRecord(ev_[0], stream));
-    if (phase == 0) {
+    if (phase == 0) {                                     // transpose in + forward over the own subtrees
         ensure_rhs_capacity(nrhs);
         start_inverse_async();
         launch_permute(stream, d_iperm_, (int)n, const_cast<double *>(d_B), ldb, d_X_, nr, ldx, 0);
         forward(nr, ldx, 0, split);
-    } else if (phase == 1) {
-        forward(nr, ldx, split, nl);
-        backward(nr, ldx, true, nl, split);
-    } else if (phase == 2) {
+    } else if (phase >= 100 && phase < 100 + (nl - split)) {       // forward, top level split + (phase - 100)
+        const int lev = split + phase - 100;
+        forward(nr, ldx, lev, lev + 1);
+    } else if (phase >= 200 && phase < 200 + (nl - split)) {       // backward, top level split + (phase - 200)
+        const int lev = split + phase - 200;
+        backward(nr, ldx, true, lev + 1, lev);
+    } else if (phase == 2) {                              // backward over the own subtrees
         backward(nr, ldx, true, split, 0);
-    } else if (phase == 3) {
+    } else if (phase == 3) {                              // transpose out (rank 0, after the gather)
         launch_permute(stream, d_iperm_, (int)n, d_Xout, ldx_out, d_X_, nr, ldx, 1);
-    } else throw std::invalid_argument("phase must be 0..3");
+    } else throw std::invalid_argument("solve phase must be 0, 2, 3, 100 + k or 200 + k (k = top level)");
     HC(hipEventRecord(ev_[1], stream));
     HC(hipStreamSynchronize(stream));
     HC(hipGetLastError());

@@ -186,36 +186,40 @@ extern "C" int32_t gmrfx_refactorize_phase(gmrfx_handle *h, const double *d_nzva
     return guarded(h, [&]() -> int32_t {
         if (int32_t e = need_device(h, false)) return e;
         if (phase == 0 && !d_nzval) throw std::invalid_argument("d_nzval is null");
-        if (phase != 0 && phase != 1) throw std::invalid_argument("phase must be 0 or 1");
+        if (phase < 0 || phase > h->S.nlevels - h->S.shard_level) throw std::invalid_argument("phase must be 0 (own subtrees) or 1 + k (top level k)");
         h->D->refactorize_phase(d_nzval, phase);
         return GMRFX_OK;
     });
 }
-extern "C" int32_t gmrfx_shard_info(const gmrfx_handle *h, int64_t *n_cb_blocks, int64_t *n_top_fronts, int64_t *shard_level) {
+extern "C" int32_t gmrfx_shard_info(const gmrfx_handle *h, int64_t *n_edges, int64_t *n_top_fronts, int64_t *shard_level) {
     if (!h) return GMRFX_ERR_INVALID_ARG;
     const Symbolic &S = h->S;
     int64_t ntop = 0;
-    for (i32 s = 0; s < S.nsuper; s++) ntop += S.owner[s] == -1;
-    if (n_cb_blocks) *n_cb_blocks = (int64_t)S.shard_roots.size();
+    for (i32 s = 0; s < S.nsuper; s++) ntop += S.is_top[s];
+    if (n_edges) *n_edges = (int64_t)S.shard_edges.size();
     if (n_top_fronts) *n_top_fronts = ntop;
     if (shard_level) *shard_level = S.shard_level;
     return GMRFX_OK;
 }
-extern "C" int32_t gmrfx_shard_cb_blocks(const gmrfx_handle *h, int64_t *owner, int64_t *offset, int64_t *count) {
-    if (!h || !owner || !offset || !count) return GMRFX_ERR_INVALID_ARG;
+// cross-rank tree edges child -> parent, ordered by the level of the parent: what moves between two phases
+extern "C" int32_t gmrfx_shard_edges(const gmrfx_handle *h, int64_t *child, int64_t *src, int64_t *dst, int64_t *level,
+                                     int64_t *cb_offset, int64_t *cb_count, int64_t *w_row0, int64_t *w_nrows) {
+    if (!h || !child || !src || !dst || !level || !cb_offset || !cb_count || !w_row0 || !w_nrows) return GMRFX_ERR_INVALID_ARG;
     const Symbolic &S = h->S;
-    for (size_t k = 0; k < S.shard_roots.size(); k++) {
-        const i32 d = S.shard_roots[k];
+    std::vector<int64_t> wptr(S.nsuper + 1, 0);
+    for (i32 s = 0; s < S.nsuper; s++) wptr[s + 1] = wptr[s] + (S.nrows(s) - S.ncols(s));
+    for (size_t k = 0; k < S.shard_edges.size(); k++) {
+        const i32 d = S.shard_edges[k], p = S.sparent[d];
         const int64_t m = S.nrows(d) - S.ncols(d);
-        owner[k] = S.owner[d];
-        offset[k] = S.cbptr[d];
-        count[k] = m * m;
+        child[k] = d; src[k] = S.owner[d]; dst[k] = S.owner[p]; level[k] = S.level[p];
+        cb_offset[k] = S.cbptr[d]; cb_count[k] = m * m;
+        w_row0[k] = wptr[d]; w_nrows[k] = m;
     }
     return GMRFX_OK;
 }
-extern "C" int32_t gmrfx_shard_owner(const gmrfx_handle *h, int64_t *owner) {
+extern "C" int32_t gmrfx_shard_owner(const gmrfx_handle *h, int64_t *owner, int64_t *is_top) {
     if (!h || !owner) return GMRFX_ERR_INVALID_ARG;
-    for (i32 s = 0; s < h->S.nsuper; s++) owner[s] = h->S.owner[s];
+    for (i32 s = 0; s < h->S.nsuper; s++) { owner[s] = h->S.owner[s]; if (is_top) is_top[s] = h->S.is_top[s]; }
     return GMRFX_OK;
 }
 extern "C" void *gmrfx_device_ptr(gmrfx_handle *h, int32_t which) {
@@ -241,28 +245,25 @@ extern "C" int32_t gmrfx_solve_phase(gmrfx_handle *h, const double *d_B, int64_t
         return GMRFX_OK;
     });
 }
-// kind 1: update vectors W of the subtree roots (-> rank 0), 2: X rows of the top fronts (rank 0 -> all),
-// 3: X rows of every assigned subtree (-> rank 0). owner / first row / number of rows; a row has nrhs doubles
-// (W rows index gmrfx_device_ptr(h, 3), X rows gmrfx_device_ptr(h, 2); row-major, leading dimension = nrhs).
-extern "C" int32_t gmrfx_shard_rows(const gmrfx_handle *h, int32_t kind, int64_t *nblocks, int64_t *owner, int64_t *row0, int64_t *nrows) {
+// Row blocks of the right-hand-side buffer X (gmrfx_device_ptr(h, 2); row-major, leading dimension = nrhs) that the
+// sharded solve moves: kind 2 = the own columns of every TOP front (owner broadcasts x after its backward step; level[]
+// tells in which phase), kind 3 = the columns of every assigned subtree (gathered on rank 0 at the end).
+extern "C" int32_t gmrfx_shard_rows(const gmrfx_handle *h, int32_t kind, int64_t *nblocks, int64_t *owner, int64_t *row0, int64_t *nrows,
+                                    int64_t *level) {
     if (!h || !nblocks) return GMRFX_ERR_INVALID_ARG;
     const Symbolic &S = h->S;
-    std::vector<int64_t> o, a, c;
-    if (kind == 1) {
-        std::vector<int64_t> wptr(S.nsuper + 1, 0);
-        for (i32 s = 0; s < S.nsuper; s++) wptr[s + 1] = wptr[s] + (S.nrows(s) - S.ncols(s));
-        for (i32 d : S.shard_roots) { o.push_back(S.owner[d]); a.push_back(wptr[d]); c.push_back(S.nrows(d) - S.ncols(d)); }
-    } else if (kind == 2) {
-        for (i32 s = 0; s < S.nsuper; s++) if (S.owner[s] == -1) { o.push_back(0); a.push_back(S.sfirst[s]); c.push_back(S.ncols(s)); }
+    std::vector<int64_t> o, a, c, l;
+    if (kind == 2) {
+        for (i32 s = 0; s < S.nsuper; s++) if (S.is_top[s]) { o.push_back(S.owner[s]); a.push_back(S.sfirst[s]); c.push_back(S.ncols(s)); l.push_back(S.level[s]); }
     } else if (kind == 3) {
         for (size_t k = 0; k < S.shard_sub_root.size(); k++) {
             const i32 t = S.shard_sub_root[k];
-            o.push_back(S.owner[t]); a.push_back(S.shard_sub_col0[k]); c.push_back(S.sfirst[t + 1] - S.shard_sub_col0[k]);
+            o.push_back(S.owner[t]); a.push_back(S.shard_sub_col0[k]); c.push_back(S.sfirst[t + 1] - S.shard_sub_col0[k]); l.push_back(S.level[t]);
         }
     } else return GMRFX_ERR_INVALID_ARG;
     *nblocks = (int64_t)o.size();
     if (owner && row0 && nrows)
-        for (size_t k = 0; k < o.size(); k++) { owner[k] = o[k]; row0[k] = a[k]; nrows[k] = c[k]; }
+        for (size_t k = 0; k < o.size(); k++) { owner[k] = o[k]; row0[k] = a[k]; nrows[k] = c[k]; if (level) level[k] = l[k]; }
     return GMRFX_OK;
 }
 extern "C" int32_t gmrfx_logdet_partial(gmrfx_handle *h, double *out) {

@@ -362,6 +362,7 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
     S.shard_rank = opt.shard_rank;
     S.shard_world = std::max(1, opt.shard_world);
     S.owner.assign(ns, 0);
+    S.is_top.assign(ns, 0);
     S.shard_level = S.nlevels;
     if (S.shard_world > 1) {
         const int W = S.shard_world;
@@ -376,10 +377,10 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
         std::vector<i32> T;                     // current subtree roots
         std::vector<uint8_t> top(ns, 0);
         for (i32 s = 0; s < ns; s++) if (S.sparent[s] == -1) T.push_back(s);
-        // LPT deal of the current subtrees; returns the largest local load. The top runs on rank 0 AFTER all
-        // local work (it needs every subtree root's contribution block), so a plan costs
-        //     max_r local_r + (flops of the top fronts):
-        // splitting the heaviest subtree lowers the first term and raises the second.
+        // LPT deal of the current subtrees; returns the largest local load. The top fronts run after the local work,
+        // each on one rank of its group, independent ones concurrently: a plan costs about
+        //     max_r local_r + (heaviest root-to-leaf chain of top fronts),
+        // and splitting the heaviest subtree lowers the first term and may raise the second.
         auto makespan = [&](std::vector<i32> &assign_out) {
             std::vector<i32> ord(T);
             std::sort(ord.begin(), ord.end(), [&](i32 a, i32 b) { return wsub[a] != wsub[b] ? wsub[a] > wsub[b] : a < b; });
@@ -393,9 +394,20 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
             return *std::max_element(load.begin(), load.end());
         };
         std::vector<i32> asg;
-        double wtop = 0;
+        auto top_chain = [&]() {          // heaviest chain inside the top set (children have smaller ids)
+            std::vector<double> cp(ns, 0.0);
+            double best = 0.0;
+            for (i32 s = 0; s < ns; s++) {
+                if (!top[s]) continue;
+                double m = 0.0;
+                for (i64 q = S.childptr[s]; q < S.childptr[s + 1]; q++) m = std::max(m, cp[S.children[q]]);
+                cp[s] = m + wown[s];
+                best = std::max(best, cp[s]);
+            }
+            return best;
+        };
         for (int it = 0; it < 256; it++) {
-            const double cost = makespan(asg) + wtop;
+            const double cost = makespan(asg) + top_chain();
             i32 best = -1;
             for (i32 s : T) if (S.childptr[s + 1] > S.childptr[s] && (best == -1 || wsub[s] > wsub[best])) best = s;
             if (best == -1) break;
@@ -403,41 +415,63 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
             std::vector<i32> T0 = T;
             T.erase(std::find(T.begin(), T.end(), best));
             for (i64 q = S.childptr[best]; q < S.childptr[best + 1]; q++) T.push_back(S.children[q]);
-            std::vector<i32> asg2;
-            const double cost2 = makespan(asg2) + wtop + wown[best];
-            if ((int)T0.size() >= W && cost2 >= 0.98 * cost) { T = T0; break; }     // no longer pays
             top[best] = 1;
-            wtop += wown[best];
+            std::vector<i32> asg2;
+            const double cost2 = makespan(asg2) + top_chain();
+            if ((int)T0.size() >= W && cost2 >= 0.98 * cost) { T = T0; top[best] = 0; break; }     // no longer pays
         }
         makespan(asg);
         // owner: subtree root's rank for everything below it (postorder: parents after children)
+        S.is_top.assign(ns, 0);
         for (i32 s = ns - 1; s >= 0; s--) {
-            if (top[s]) S.owner[s] = -1;
+            if (top[s]) { S.is_top[s] = 1; S.owner[s] = -1; }
             else if (asg[s] >= 0) S.owner[s] = asg[s];
             else S.owner[s] = S.owner[S.sparent[s]];     // inside a subtree: same as the parent (processed first)
         }
+        // top fronts, children first: the least loaded (in top flops) of the owners of the children -- one child's
+        // contribution block stays where it is, independent top fronts spread over the ranks of their group
+        {
+            std::vector<double> topload(W, 0.0);
+            for (i32 s = 0; s < ns; s++) {
+                if (!S.is_top[s]) continue;
+                i32 best = -1;
+                for (i64 q = S.childptr[s]; q < S.childptr[s + 1]; q++) {
+                    const i32 r = S.owner[S.children[q]];
+                    if (best == -1 || topload[r] < topload[best] || (topload[r] == topload[best] && r < best)) best = r;
+                }
+                if (best == -1) best = 0;       // (a top front always has children: it was split)
+                S.owner[s] = best;
+                topload[best] += wown[s];
+            }
+        }
         // top fronts go to levels >= shard_level = 1 + highest level of any assigned front
         i32 lmax = -1;
-        for (i32 s = 0; s < ns; s++) if (S.owner[s] >= 0) lmax = std::max(lmax, S.level[s]);
+        for (i32 s = 0; s < ns; s++) if (!S.is_top[s]) lmax = std::max(lmax, S.level[s]);
         S.shard_level = lmax + 1;
         for (i32 s = 0; s < ns; s++) {
-            if (S.owner[s] != -1) continue;
+            if (!S.is_top[s]) continue;
             i32 lv = S.shard_level;
             for (i64 q = S.childptr[s]; q < S.childptr[s + 1]; q++) {
                 const i32 d = S.children[q];
-                if (S.owner[d] == -1) lv = std::max(lv, S.level[d] + 1);    // children have smaller ids: already final
-                else S.shard_roots.push_back(d);
+                if (S.is_top[d]) lv = std::max(lv, S.level[d] + 1);    // children have smaller ids: already final
             }
             S.level[s] = lv;
         }
-        std::sort(S.shard_roots.begin(), S.shard_roots.end());
+        for (i32 d = 0; d < ns; d++) {
+            const i32 p = S.sparent[d];
+            if (p != -1 && S.owner[p] != S.owner[d]) S.shard_edges.push_back(d);
+        }
+        std::stable_sort(S.shard_edges.begin(), S.shard_edges.end(), [&](i32 a, i32 b) {
+            const i32 la = S.level[S.sparent[a]], lb = S.level[S.sparent[b]];
+            return la != lb ? la < lb : a < b;
+        });
         {   // every assigned subtree (postorder: a subtree is a contiguous id range ending at its root)
             std::vector<i32> cnt(ns, 1);
             for (i32 s = 0; s < ns; s++) if (S.sparent[s] != -1) cnt[S.sparent[s]] += cnt[s];
             for (i32 s = 0; s < ns; s++) {
-                if (S.owner[s] < 0) continue;
+                if (S.is_top[s]) continue;
                 const i32 p = S.sparent[s];
-                if (p != -1 && S.owner[p] != -1) continue;      // not a subtree root
+                if (p != -1 && !S.is_top[p]) continue;          // not a subtree root
                 S.shard_sub_root.push_back(s);
                 S.shard_sub_col0.push_back(S.sfirst[s - cnt[s] + 1]);
             }
@@ -447,7 +481,7 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
         S.nlevels = std::max(S.nlevels, S.shard_level);
     }
     // does this rank execute front s?  (top fronts: rank 0)
-    auto mine = [&](i32 s) { return S.shard_world == 1 || S.owner[s] == S.shard_rank || (S.owner[s] == -1 && S.shard_rank == 0); };
+    auto mine = [&](i32 s) { return S.shard_world == 1 || S.owner[s] == S.shard_rank; };
     // small fronts (fused LDS kernels, small.hip): r <= 96 or r <= 128 rows and <= 64 columns
     S.small_rows = opt.small_front_rows >= 0 ? opt.small_front_rows : 96;    // measured on cfg 2: 96 beats 128 and 64 (tools/sweep notes in DESIGN.md)
     S.is_small.resize(ns);
@@ -533,7 +567,7 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
     S.in_swt.assign(ns, 0);
     S.lrow.assign((size_t)S.sum_rows, -1);
     {
-        const int rcap = (S.shard_world > 1 || opt.subtree_max > 0) ? 0 : std::min(288,   // (not with the legacy subtree tasks)
+        const int rcap = opt.subtree_max > 0 ? 0 : std::min(288,   // (not with the legacy subtree tasks)
                                                                                opt.sweep_task_rows >= 0 ? opt.sweep_task_rows : 288);   // 288 = TASK_ROWS of sweep_task.hip
         S.swt_rows = rcap;
         std::vector<i32> cnt(ns, 1), ncol(ns, 0), maxc(ns, 0);
@@ -545,7 +579,7 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
             work[s] += (double)S.nrows(s) * S.ncols(s);
             bool good = rcap > 0;
             for (i64 q = S.childptr[s]; q < S.childptr[s + 1]; q++) good = good && ok[S.children[q]];
-            ok[s] = good && maxc[s] <= 64 && ncol[s] + (S.nrows(s) - S.ncols(s)) <= rcap && cnt[s] <= 64;
+            ok[s] = good && !S.is_top[s] && maxc[s] <= 64 && ncol[s] + (S.nrows(s) - S.ncols(s)) <= rcap && cnt[s] <= 64;
             const i32 p = S.sparent[s];
             if (p != -1) { cnt[p] += cnt[s]; ncol[p] += ncol[s]; maxc[p] = std::max(maxc[p], maxc[s]); work[p] += work[s]; }
         }
@@ -559,6 +593,8 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
         std::stable_sort(roots.begin(), roots.end(), [&](i32 a, i32 b) { return work[a] > work[b]; });
         for (i32 t : roots) {
             const i32 f = t - cnt[t] + 1;
+            for (i32 d = f; d <= t; d++) S.in_swt[d] = 1;      // (a task lies inside ONE assigned subtree: one owner)
+            if (!mine(t)) continue;                            // sharded handles keep the tasks of their own subtrees
             S.swt_first.push_back(f); S.swt_last.push_back(t);
             const i32 col0 = S.sfirst[f], col1 = S.sfirst[t + 1], nt = col1 - col0;
             const i32 ct = S.ncols(t);

@@ -88,14 +88,18 @@ struct Symbolic {
     int swt_rows = 0;
     std::vector<i64> sw_levelptr;
     std::vector<i32> sw_levellist, sw_level_nsmall, sw_level_ncls;
-    // Sharding over `shard_world` ranks (every rank runs the same analysis and gets the same answer):
-    // owner[s] = rank that factors front s for the fronts inside an assigned subtree, -1 for the TOP
-    // fronts (the ancestors of the assigned subtree roots), which rank 0 factors after it has received
-    // the contribution blocks of the subtree roots. Top fronts are pushed to levels >= shard_level, all
-    // assigned subtrees live below it, and the level lists of a rank only hold the fronts it executes.
+    // Sharding over `shard_world` ranks (every rank runs the same analysis and gets the same answer). The supernodal
+    // tree is cut top-down into subtrees dealt to the ranks (LPT on factorisation flops); the fronts above them -- the
+    // TOP, is_top[s] -- are owned ONE BY ONE by a rank of the group whose subtrees they join (the least loaded owner of
+    // their children), so independent top fronts run on different GPUs and a contribution block crosses ranks only
+    // along a tree edge whose two ends have different owners (shard_edges: the pairwise 4+2+1 pattern of SURVEY 8e).
+    // owner[s] >= 0 for every front. Top fronts are pushed to levels >= shard_level, all assigned subtrees live
+    // below it, and the level lists of a rank only hold the fronts it executes; the top levels are run one level per
+    // phase with the cross-rank edges of that level exchanged in between.
     std::vector<i32> owner;       // nsuper
+    std::vector<uint8_t> is_top;  // nsuper
     i32 shard_rank = 0, shard_world = 1, shard_level = 0;   // shard_level = nlevels when world == 1
-    std::vector<i32> shard_roots; // assigned subtree roots whose parent is a top front (their CBs travel to rank 0)
+    std::vector<i32> shard_edges; // children d with owner[d] != owner[parent(d)], ordered by (level of the parent, d)
     std::vector<i32> shard_sub_root, shard_sub_col0;   // ALL assigned subtrees: root supernode, first column (columns [col0, sfirst[root+1]) are theirs)
     // the caller's pattern (0-based) and which stored triangle defines Q: kept for the quadratic form
     // x'Qx (sqmahal / logpdf), which runs on the caller's CSC values, not on the factor

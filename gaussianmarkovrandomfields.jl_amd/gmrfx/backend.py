@@ -371,33 +371,38 @@ class MI355XBackend:
     def shard_info(self) -> dict:
         a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
         check(lib().gmrfx_shard_info(self._h, C.byref(a), C.byref(b), C.byref(c)), self._h)
-        return {"n_cb_blocks": a.value, "n_top_fronts": b.value, "shard_level": c.value}
+        st = self.stats()
+        return {"n_edges": a.value, "n_top_fronts": b.value, "shard_level": c.value, "n_top_levels": int(st["nlevels"] - c.value)}
 
-    def shard_cb_blocks(self):
-        """(owner, offset, count) of the contribution blocks that travel to rank 0; offsets in doubles
-        into the contribution-block arena (device_ptr(0))."""
-        k = self.shard_info()["n_cb_blocks"]
-        owner, off, cnt = (np.zeros(k, np.int64) for _ in range(3))
+    def shard_edges(self) -> dict:
+        """Cross-rank tree edges child -> parent, ordered by the level of the parent: child, src (owner of the
+        child), dst (owner of the parent), level, and where the child's contribution block / update vector live
+        (offset + count in doubles into device_ptr(0); first row + rows of device_ptr(3))."""
+        k = self.shard_info()["n_edges"]
+        names = ("child", "src", "dst", "level", "cb_offset", "cb_count", "w_row0", "w_nrows")
+        arr = {nm: np.zeros(k, np.int64) for nm in names}
         if k:
-            check(lib().gmrfx_shard_cb_blocks(self._h, ptr(owner), ptr(off), ptr(cnt)), self._h)
-        return owner, off, cnt
+            check(lib().gmrfx_shard_edges(self._h, *[ptr(arr[nm]) for nm in names]), self._h)
+        return arr
 
-    def shard_owner(self) -> np.ndarray:
-        out = np.zeros(self.stats()["nsuper"], np.int64)
-        check(lib().gmrfx_shard_owner(self._h, ptr(out)), self._h)
-        return out
+    def shard_owner(self, with_top: bool = False):
+        ns = self.stats()["nsuper"]
+        out, top = np.zeros(ns, np.int64), np.zeros(ns, np.int64)
+        check(lib().gmrfx_shard_owner(self._h, ptr(out), ptr(top)), self._h)
+        return (out, top.astype(bool)) if with_top else out
 
     def solve_phase_dev(self, d_B: int, ldb: int, nrhs: int, d_X: int, ldx: int, phase: int) -> None:
         check(lib().gmrfx_solve_phase(self._h, d_B, ldb, nrhs, d_X, ldx, phase), self._h)
 
     def shard_rows(self, kind: int):
-        """(owner, first row, rows) of the row blocks of exchange `kind` (1: W up, 2: X top down, 3: X owned up)."""
+        """(owner, first row, rows, level) of the X row blocks the sharded solve moves (2: own columns of the top
+        fronts, broadcast by their owners; 3: columns of the assigned subtrees, gathered on rank 0)."""
         k = C.c_int64(0)
-        check(lib().gmrfx_shard_rows(self._h, kind, C.byref(k), None, None, None), self._h)
-        owner, r0, nr = (np.zeros(k.value, np.int64) for _ in range(3))
+        check(lib().gmrfx_shard_rows(self._h, kind, C.byref(k), None, None, None, None), self._h)
+        owner, r0, nr, lv = (np.zeros(k.value, np.int64) for _ in range(4))
         if k.value:
-            check(lib().gmrfx_shard_rows(self._h, kind, C.byref(k), ptr(owner), ptr(r0), ptr(nr)), self._h)
-        return owner, r0, nr
+            check(lib().gmrfx_shard_rows(self._h, kind, C.byref(k), ptr(owner), ptr(r0), ptr(nr), ptr(lv)), self._h)
+        return owner, r0, nr, lv
 
     def device_ptr(self, which: int) -> int:
         return int(lib().gmrfx_device_ptr(self._h, which) or 0)

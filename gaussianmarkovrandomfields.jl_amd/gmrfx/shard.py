@@ -1,16 +1,17 @@
 """One factorisation sharded over the ranks of a torch.distributed process group (one GPU each).
 
-SURVEY section 8(e): the supernodal tree is cut top-down into subtrees that are dealt to the ranks
-(`Symbolic::owner`, csrc/symbolic.cpp); every rank factors its subtrees, the contribution blocks of
-the subtree roots -- the Schur complements the fronts above them assemble -- travel to rank 0 over the
-process group (RCCL point-to-point on MI355X nodes, gloo in the CPU-side rehearsal), rank 0 factors the
-top fronts, and log det Q is an all-reduce of the ranks' partial sums. This is the exchange step the
-reference's multifrontal solvers (CHOLMOD behind src/workspace/backend.jl:165-189) do inside one
-address space.
+SURVEY section 8(e): the supernodal tree is cut top-down into subtrees that are dealt to the ranks; every front above
+them (the "top") is owned by ONE rank of the group whose subtrees it joins (`Symbolic::owner`, csrc/symbolic.cpp), so
+independent top fronts run on different GPUs. Data crosses ranks only along tree edges whose ends have different owners
+-- the Schur-complement contribution block of the child in the factorisation, its update vector in the forward sweep --
+and goes point-to-point, src -> dst, into the same offset of the destination's buffers (all ranks share one layout);
+after its backward step the owner of a top front broadcasts the front's x. log det Q is an all-reduce of partial sums,
+a non-positive pivot an all-reduce (min). The top levels run one level per phase; all transfers of a phase are posted
+as ONE batch (batch_isend_irecv). This is the exchange the reference's CPU solver (CHOLMOD behind
+src/workspace/backend.jl:165-189) never needs: it has one address space.
 
-Device buffers are handed to torch.distributed without copies: the contribution-block arena of the
-library is wrapped as a torch tensor through __cuda_array_interface__.
-"""
+Device buffers are handed to torch.distributed without copies: the library's arena / X / W buffers are wrapped as torch
+tensors through __cuda_array_interface__ (RCCL on MI355X nodes); the gloo rehearsal stages through host tensors."""
 from __future__ import annotations
 
 import numpy as np
@@ -32,90 +33,105 @@ class ShardedFactor:
         self.dev = torch.device("cuda", device)
         self.be = MI355XBackend(Q, coords=coords, device=device, factorize=False, shard_rank=self.rank,
                                 shard_world=self.world, **kw)
-        self.owner, self.off, self.cnt = self.be.shard_cb_blocks()
+        self.info = self.be.shard_info()
+        self.K = self.info["n_top_levels"]
+        self.L0 = self.info["shard_level"]
+        self.edges = self.be.shard_edges()
+        self.top_rows = self.be.shard_rows(2)
+        self.sub_rows = self.be.shard_rows(3)
         self.host_staging = dist.get_backend() == "gloo"      # rehearsal: gloo moves host tensors only
-        self._rows = None
+        self.last_info = 0
 
-    def _cb_view(self, off: int, cnt: int):
-        base = self.be.device_ptr(0)
+    # ---- transfers ----------------------------------------------------------------------------------
+    def _view(self, which: int, off: int, cnt: int):
+        base = self.be.device_ptr(which)
         return self.torch.as_tensor(_DevView(base + 8 * int(off), int(cnt)), device=self.dev)
 
-    def _exchange_cb(self):
-        """Subtree-root contribution blocks -> rank 0, written in place into its arena."""
+    def _p2p(self, items):
+        """items: (src, dst, which buffer, offset, count) -- every rank passes the same list; the transfers this rank
+        takes part in are posted as one batch."""
         t, dist = self.torch, self.dist
-        reqs = []
-        for k in range(len(self.owner)):
-            src = int(self.owner[k])
-            if src == 0:
+        ops, post = [], []
+        for tag, (src, dst, which, off, cnt) in enumerate(items):
+            if src == dst or self.rank not in (src, dst) or cnt == 0:
                 continue
+            v = self._view(which, off, cnt)
             if self.rank == src:
-                v = self._cb_view(self.off[k], self.cnt[k])
-                dist.send(v.cpu() if self.host_staging else v, dst=0, tag=k)
-            elif self.rank == 0:
-                v = self._cb_view(self.off[k], self.cnt[k])
-                if self.host_staging:
-                    buf = t.empty(int(self.cnt[k]), dtype=t.float64)
-                    dist.recv(buf, src=src, tag=k)
-                    v.copy_(buf)
-                else:
-                    dist.recv(v, src=src, tag=k)
-        t.cuda.synchronize(self.dev)
-        return reqs
-
-    def refactorize_dev(self, d_nzval_ptr: int) -> None:
-        self.be.refactorize_phase_dev(d_nzval_ptr, 0)
-        self._exchange_cb()
-        self.be.refactorize_phase_dev(d_nzval_ptr, 1)
-
-    # ---- sharded solve ---------------------------------------------------------------------------
-    def _rows_view(self, which: int, row0: int, nrows: int, nrhs: int):
-        base = self.be.device_ptr(which)
-        return self.torch.as_tensor(_DevView(base + 8 * int(row0) * nrhs, int(nrows) * nrhs), device=self.dev)
-
-    def _move_rows(self, which: int, blocks, nrhs: int, to_root: bool):
-        """to_root: every owner sends its row blocks to rank 0 (in place, same rows of rank 0's buffer);
-        otherwise rank 0 broadcasts its row blocks to everybody."""
-        t, dist = self.torch, self.dist
-        owner, r0, nr = blocks
-        for k in range(len(owner)):
-            if to_root:
-                src = int(owner[k])
-                if src == 0 or self.rank not in (0, src):
-                    continue
-                v = self._rows_view(which, r0[k], nr[k], nrhs)
-                if self.rank == src:
-                    dist.send(v.cpu() if self.host_staging else v, dst=0, tag=k)
-                elif self.host_staging:
-                    buf = t.empty(v.numel(), dtype=t.float64)
-                    dist.recv(buf, src=src, tag=k)
-                    v.copy_(buf)
-                else:
-                    dist.recv(v, src=src, tag=k)
+                ops.append(dist.P2POp(dist.isend, v.cpu() if self.host_staging else v, dst, tag=tag))
+            elif self.host_staging:
+                buf = t.empty(int(cnt), dtype=t.float64)
+                ops.append(dist.P2POp(dist.irecv, buf, src, tag=tag))
+                post.append((v, buf))
             else:
-                v = self._rows_view(which, r0[k], nr[k], nrhs)
-                if self.host_staging:
-                    buf = v.cpu() if self.rank == 0 else t.empty(v.numel(), dtype=t.float64)
-                    dist.broadcast(buf, src=0)
-                    if self.rank != 0:
-                        v.copy_(buf)
-                else:
-                    dist.broadcast(v, src=0)
+                ops.append(dist.P2POp(dist.irecv, v, src, tag=tag))
+        if ops:
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
+        for v, buf in post:
+            v.copy_(buf)
         t.cuda.synchronize(self.dev)
 
+    def _bcast_rows(self, blocks, nrhs: int):
+        """blocks: (owner, first row, rows) of X row blocks; every owner broadcasts its blocks (one fused buffer per
+        owner and call)."""
+        t, dist = self.torch, self.dist
+        for src in sorted({int(o) for o, _, _ in blocks}):
+            mine = [(int(r0), int(nr)) for o, r0, nr in blocks if int(o) == src]
+            views = [self._view(2, r0 * nrhs, nr * nrhs) for r0, nr in mine]
+            total = sum(v.numel() for v in views)
+            if self.rank == src:
+                buf = t.cat([v.cpu() if self.host_staging else v for v in views]) if len(views) > 1 else (views[0].cpu() if self.host_staging else views[0])
+            else:
+                buf = t.empty(total, dtype=t.float64, device="cpu" if self.host_staging else self.dev)
+            dist.broadcast(buf, src=src)
+            if self.rank != src:
+                o = 0
+                for v in views:
+                    v.copy_(buf[o:o + v.numel()])
+                    o += v.numel()
+        t.cuda.synchronize(self.dev)
+
+    def _edges_of_level(self, lev: int):
+        e = self.edges
+        return np.flatnonzero(e["level"] == lev)
+
+    # ---- factorisation ------------------------------------------------------------------------------
+    def refactorize_dev(self, d_nzval_ptr: int) -> int:
+        be, e = self.be, self.edges
+        be.refactorize_phase_dev(d_nzval_ptr, 0)
+        for k in range(self.K):
+            idx = self._edges_of_level(self.L0 + k)
+            self._p2p([(int(e["src"][i]), int(e["dst"][i]), 0, int(e["cb_offset"][i]), int(e["cb_count"][i])) for i in idx])
+            be.refactorize_phase_dev(d_nzval_ptr, 1 + k)
+        # first non-positive pivot over all ranks (0 = none), like the `info` of gmrfx_refactorize
+        t = self.torch
+        fc = int(be.stats()["fail_col"])
+        v = t.tensor([fc if fc >= 0 else 2 ** 62], dtype=t.int64, device="cpu" if self.host_staging else self.dev)
+        self.dist.all_reduce(v, op=self.dist.ReduceOp.MIN)
+        self.last_info = 0 if int(v.item()) >= 2 ** 62 else int(v.item()) + 1
+        return self.last_info
+
+    # ---- solve --------------------------------------------------------------------------------------
     def solve_dev(self, d_B: int, ldb: int, nrhs: int, d_X: int, ldx: int) -> None:
         """Q X = B with the factor sharded over the ranks; B (full, column-major n x nrhs) on every rank,
         X (full) is produced on rank 0. 1..64 right-hand sides per call."""
-        be = self.be
-        if self._rows is None:
-            self._rows = {k: be.shard_rows(k) for k in (1, 2, 3)}
-        be.solve_phase_dev(d_B, ldb, nrhs, d_X, ldx, 0)          # transpose in + own forward
-        self._move_rows(3, self._rows[1], nrhs, True)            # W of the subtree roots -> rank 0
-        be.solve_phase_dev(d_B, ldb, nrhs, d_X, ldx, 1)          # the top: forward, backward (rank 0)
-        self._move_rows(2, self._rows[2], nrhs, False)           # x of the top fronts -> everybody
-        be.solve_phase_dev(d_B, ldb, nrhs, d_X, ldx, 2)          # own backward
-        self._move_rows(2, self._rows[3], nrhs, True)            # x of the owned subtrees -> rank 0
+        be, e = self.be, self.edges
+        be.solve_phase_dev(d_B, ldb, nrhs, d_X, ldx, 0)                      # transpose in + own forward
+        for k in range(self.K):
+            idx = self._edges_of_level(self.L0 + k)
+            self._p2p([(int(e["src"][i]), int(e["dst"][i]), 3, int(e["w_row0"][i]) * nrhs, int(e["w_nrows"][i]) * nrhs) for i in idx])
+            be.solve_phase_dev(d_B, ldb, nrhs, d_X, ldx, 100 + k)            # forward, top level k
+        owner, r0, nr, lv = self.top_rows
+        for k in range(self.K - 1, -1, -1):
+            be.solve_phase_dev(d_B, ldb, nrhs, d_X, ldx, 200 + k)            # backward, top level k
+            sel = np.flatnonzero(lv == self.L0 + k)
+            self._bcast_rows([(owner[i], r0[i], nr[i]) for i in sel], nrhs)  # x of that level's fronts -> everybody
+        be.solve_phase_dev(d_B, ldb, nrhs, d_X, ldx, 2)                      # own backward
+        so, sr0, snr, _ = self.sub_rows
+        items = [(int(so[i]), 0, 2, int(sr0[i]) * nrhs, int(snr[i]) * nrhs) for i in range(len(so))]
+        self._p2p(items)                                                     # x of the owned subtrees -> rank 0
         if self.rank == 0:
-            be.solve_phase_dev(d_B, ldb, nrhs, d_X, ldx, 3)      # transpose out
+            be.solve_phase_dev(d_B, ldb, nrhs, d_X, ldx, 3)                  # transpose out
 
     def logdet(self) -> float:
         """log det Q: all-reduce (sum) of the ranks' partial sums over their own pivots."""
@@ -129,14 +145,20 @@ class ShardedFactor:
 
 
 def plan_summary(be) -> dict:
-    """Who owns how much (host-side, works on symbolic_only handles too)."""
-    owner = be.shard_owner()
+    """Who owns how much, and the flop-count bound on the speed-up (host-side, works on symbolic_only handles):
+    time ~ max_r (flops of rank r's subtrees) + sum over top levels of the heaviest rank's flops in that level."""
+    owner, top = be.shard_owner(with_top=True)
     sy = be.symbolic()
     c = np.diff(sy.super_first).astype(np.float64)
     r = np.diff(sy.row_ptr).astype(np.float64)
     m = r - c
     fl = c ** 3 / 3 + c * c * m + c * m * m
-    out = {"top_fronts": int((owner == -1).sum()), "top_flops": float(fl[owner == -1].sum())}
-    for k in range(int(owner.max()) + 1):
-        out[f"rank{k}_flops"] = float(fl[owner == k].sum())
-    return out
+    W = int(owner.max()) + 1
+    local = [float(fl[(owner == k) & ~top].sum()) for k in range(W)]
+    t_top = 0.0
+    for lv in np.unique(sy.level[top]):
+        sel = top & (sy.level == lv)
+        t_top += max(float(fl[sel & (owner == k)].sum()) for k in range(W))
+    total = float(fl.sum())
+    return {"world": W, "top_fronts": int(top.sum()), "top_flops": float(fl[top].sum()), "local_flops": local,
+            "top_critical_flops": t_top, "flop_bound_speedup": total / (max(local) + t_top)}

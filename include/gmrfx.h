@@ -125,26 +125,35 @@ int32_t gmrfx_refactorize_update(gmrfx_handle *h, const double *hvals, int64_t *
 int32_t gmrfx_refactorize_update_dev(gmrfx_handle *h, const double *d_hvals, int64_t *info);
 
 /* ---- sharded factorisation (opts.shard_world > 1); SURVEY section 8(e) -------------------------------
- * A refactorisation is then two phases with one exchange in between, driven by the host language over
- * its collective library (RCCL through torch.distributed in the Python mirror, gmrfx/shard.py):
- *   gmrfx_refactorize_phase(h, nzval, 0)   every rank: the subtrees it owns
- *   [ranks != 0 send the contribution blocks of their subtree roots to rank 0: gmrfx_shard_cb_blocks
- *    lists them as (owner, offset, count) into the contribution-block arena gmrfx_device_ptr(h, 0)]
- *   gmrfx_refactorize_phase(h, nzval, 1)   rank 0: the top fronts (no-op elsewhere)
- * gmrfx_logdet_partial returns this rank's share of log det Q (sum over the ranks = log det Q).
- * A solve (device buffers, 1..64 right-hand sides) is four phases: 0 transpose-in + forward sweep over the
- * own subtrees; [update vectors W of the subtree roots -> rank 0]; 1 the top, forward then backward (rank 0);
- * [X rows of the top fronts: rank 0 -> all]; 2 backward sweep over the own subtrees; [X rows of the owned
- * subtrees -> rank 0]; 3 transpose-out on rank 0. gmrfx_shard_rows lists the row blocks of each exchange
- * (rows of the row-major n x nrhs buffers gmrfx_device_ptr(h, 2) = X and (h, 3) = W).
+ * ONE factorisation over several GPUs, one process each, driven by the host language over its collective library
+ * (RCCL through torch.distributed in the Python binding, gmrfx/shard.py). Every process runs the same analysis: the
+ * supernodal tree is cut into subtrees dealt to the ranks, and every front ABOVE them (the "top") is owned by one
+ * rank of the group whose subtrees it joins -- independent top fronts run on different GPUs, and data crosses ranks
+ * only along the tree edges whose two ends have different owners (gmrfx_shard_edges: child, src, dst, level of the
+ * parent, the contribution block's place in the arena gmrfx_device_ptr(h, 0), the update vector's rows in
+ * gmrfx_device_ptr(h, 3)). All ranks share one layout of the arena / X / W buffers, so a block is sent to the same
+ * offset it came from. K = nlevels - shard_level top levels.
+ *   refactorisation  gmrfx_refactorize_phase(h, nzval, 0)      the subtrees this rank owns
+ *                    for k = 0 .. K-1:  [contribution blocks of the edges with level = shard_level + k: src -> dst]
+ *                                       gmrfx_refactorize_phase(h, nzval, 1 + k)   this rank's fronts of top level k
+ *   log det Q        all-reduce (sum) of gmrfx_logdet_partial; pivot failures: all-reduce (min) of gmrfx_stats.fail_col
+ *   solve (1..64 right-hand sides, device buffers)
+ *                    gmrfx_solve_phase(.., 0)                  transpose in + forward sweep over the own subtrees
+ *                    for k = 0 .. K-1:  [update vectors W of the level's edges: src -> dst]   gmrfx_solve_phase(.., 100 + k)
+ *                    for k = K-1 .. 0:  gmrfx_solve_phase(.., 200 + k)   [x of that level's top fronts: owner -> all,
+ *                                       gmrfx_shard_rows(kind 2)]
+ *                    gmrfx_solve_phase(.., 2)                  backward sweep over the own subtrees
+ *                    [x of every assigned subtree -> rank 0, gmrfx_shard_rows(kind 3)]   gmrfx_solve_phase(.., 3) on rank 0
  * Selected inversion on a sharded handle is not implemented yet (GMRFX_ERR_INVALID_ARG). */
 int32_t gmrfx_refactorize_phase(gmrfx_handle *h, const double *d_nzval, int32_t phase);
-int32_t gmrfx_shard_info(const gmrfx_handle *h, int64_t *n_cb_blocks, int64_t *n_top_fronts, int64_t *shard_level);
-int32_t gmrfx_shard_cb_blocks(const gmrfx_handle *h, int64_t *owner, int64_t *offset, int64_t *count);
-int32_t gmrfx_shard_owner(const gmrfx_handle *h, int64_t *owner /* nsuper; -1 = top */);
+int32_t gmrfx_shard_info(const gmrfx_handle *h, int64_t *n_edges, int64_t *n_top_fronts, int64_t *shard_level);
+int32_t gmrfx_shard_edges(const gmrfx_handle *h, int64_t *child, int64_t *src, int64_t *dst, int64_t *level,
+                          int64_t *cb_offset, int64_t *cb_count, int64_t *w_row0, int64_t *w_nrows);
+int32_t gmrfx_shard_owner(const gmrfx_handle *h, int64_t *owner /* nsuper, >= 0 */, int64_t *is_top /* nsuper, nullable */);
 void   *gmrfx_device_ptr(gmrfx_handle *h, int32_t which /* 0: contribution-block arena, 1: factor panels, 2: X, 3: W */);
 int32_t gmrfx_solve_phase(gmrfx_handle *h, const double *d_B, int64_t ldb, int64_t nrhs, double *d_X, int64_t ldx, int32_t phase);
-int32_t gmrfx_shard_rows(const gmrfx_handle *h, int32_t kind, int64_t *nblocks, int64_t *owner, int64_t *row0, int64_t *nrows);
+int32_t gmrfx_shard_rows(const gmrfx_handle *h, int32_t kind, int64_t *nblocks, int64_t *owner, int64_t *row0, int64_t *nrows,
+                         int64_t *level);
 int32_t gmrfx_logdet_partial(gmrfx_handle *h, double *out);
 
 /* Q X = B. Replaces `F \ b` / `F \ B`: src/workspace/backend.jl:191-209. */

@@ -549,7 +549,7 @@ def _shard_gpu_worker(rank, world, port, q):
         d_nz = torch.from_numpy(np.ascontiguousarray(Q.data)).to(dev)
         sf = shard.ShardedFactor(Q, dist, device=0, coords=m.points)
         for _ in range(2):                               # twice: the second run reuses every buffer
-            sf.refactorize_dev(d_nz.data_ptr())
+            assert sf.refactorize_dev(d_nz.data_ptr()) == 0
         ld = sf.logdet()
         # sharded solve: B on every rank, X on rank 0; must equal the unsharded solve bit for bit
         nrhs = 64 if world == 2 else 7
@@ -558,7 +558,7 @@ def _shard_gpu_worker(rank, world, port, q):
         torch.cuda.synchronize()      # torch's fill kernel runs on torch's stream, the library on its own ones
         sf.solve_dev(d_B.data_ptr(), Q.shape[0], nrhs, d_X.data_ptr(), Q.shape[0])
         owner = sf.be.shard_owner()
-        mine = (owner == rank) | ((owner == -1) & (rank == 0))
+        mine = owner == rank
         sy = sf.be.symbolic()
         vals = sf.be.factor_values()
         # compare the panels this rank factored with an unsharded handle, bit for bit
@@ -600,9 +600,10 @@ def _shard_gpu_worker(rank, world, port, q):
 
 @pytest.mark.parametrize("world", [2, 4])
 def test_sharded_factorisation_rehearsal_on_one_gpu(world):
-    """ONE factorisation sharded over `world` processes (subtrees per rank, Schur-complement
-    contribution blocks to rank 0, top fronts on rank 0, all-reduced logdet) -- rehearsed with all ranks on
-    this one GPU. Every rank's panels must equal the unsharded factor bit for bit."""
+    """ONE factorisation sharded over `world` processes (subtrees per rank, every top front on one rank
+    of its group, Schur-complement contribution blocks / update vectors point-to-point along the owner-crossing tree
+    edges, x of the top fronts broadcast by their owners, all-reduced logdet and pivot check) -- rehearsed with all
+    ranks on this one GPU. Every rank's panels and the solution must equal the unsharded ones bit for bit."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -1,8 +1,10 @@
-"""CPU, gloo, world_size 2 and 3: the SHARDED-factorisation path (gmrfx/shard.py). Every rank
-runs the same symbolic analysis with its own shard_rank, factors the fronts it owns with the test's host
-walk (tests/mf_hostsim.py -- this container has no GPU), the contribution blocks of the subtree roots
-travel to rank 0 over the process group, rank 0 factors the top fronts, and log det Q is an all-reduce of
-the partial sums. Checks the plan invariants and the result against the unsharded walk."""
+"""CPU, gloo, world_size 2, 3 and 5: the SHARDED-factorisation path (gmrfx/shard.py). Every rank runs the
+same symbolic analysis with its own shard_rank and factors the fronts it owns with the test's host walk
+(tests/mf_hostsim.py -- this container has no GPU): its subtrees first, then the top one level per phase, each top
+front on its one owner, the contribution blocks / update vectors of the cross-rank tree edges (gmrfx_shard_edges)
+travelling point-to-point src -> dst before the phase that needs them, x of the top fronts broadcast by their
+owners, log det Q an all-reduce of the partial sums. Checks the plan invariants (group ownership, edges = exactly
+the owner-crossing tree edges, levels) and the results against the unsharded walk and dense LAPACK."""
 import os
 import sys
 
@@ -30,28 +32,40 @@ def _worker(rank, world, port, q):
     n = Q.shape[0]
     be = gmrfx.MI355XBackend(Q, coords=mesh.points, symbolic_only=True, shard_rank=rank, shard_world=world)
     sy = be.symbolic()
-    owner = be.shard_owner()
+    owner, is_top = be.shard_owner(with_top=True)
     par = sy.super_parent
     ns = len(par)
     info = be.shard_info()
+    E = be.shard_edges()
+    L0, K = info["shard_level"], info["n_top_levels"]
     # ---- plan invariants -------------------------------------------------------------------------
-    assert ((owner >= -1) & (owner < world)).all() and (owner == -1).sum() == info["n_top_fronts"]
+    assert ((owner >= 0) & (owner < world)).all() and is_top.sum() == info["n_top_fronts"]
+    kids = [[] for _ in range(ns)]
+    for s in range(ns):
+        if par[s] >= 0:
+            kids[par[s]].append(s)
     for s in range(ns):
         p = par[s]
         if p >= 0:
             assert sy.level[p] > sy.level[s]
-            assert owner[p] == -1 or owner[p] == owner[s]        # subtrees are closed downwards
-            if owner[s] == -1:
-                assert owner[p] == -1                            # the top is closed upwards
-        if owner[s] == -1:
-            assert sy.level[s] >= info["shard_level"]
+            assert is_top[p] or owner[p] == owner[s]             # subtrees are closed downwards: one owner
+            if is_top[s]:
+                assert is_top[p]                                 # the top is closed upwards
+        if is_top[s]:
+            assert sy.level[s] >= L0 and kids[s]
+            assert owner[s] in {owner[d] for d in kids[s]}       # owned inside the group of ranks it joins
         else:
-            assert sy.level[s] < info["shard_level"]
-    roots = [s for s in range(ns) if owner[s] >= 0 and par[s] >= 0 and owner[par[s]] == -1]
-    assert len(roots) == info["n_cb_blocks"]
+            assert sy.level[s] < L0
+    cross = sorted(d for d in range(ns) if par[d] >= 0 and owner[par[d]] != owner[d])
+    assert sorted(E["child"].tolist()) == cross and len(cross) == info["n_edges"]
+    for i, d in enumerate(E["child"]):
+        assert E["src"][i] == owner[d] and E["dst"][i] == owner[par[d]] and E["level"][i] == sy.level[par[d]] >= L0
+        assert E["cb_count"][i] == (sy.row_ptr[d + 1] - sy.row_ptr[d] - (sy.super_first[d + 1] - sy.super_first[d])) ** 2
+    assert (np.diff(E["level"]) >= 0).all()
+    assert sy.level.max() + 1 == L0 + K
     # ---- sharded host walk -----------------------------------------------------------------------
     sim = HostSim(sy, n, np.asarray(Q.data))
-    mine = lambda s: owner[s] == rank or (owner[s] == -1 and rank == 0)
+    mine = lambda s: owner[s] == rank
     cb = {}
 
     def factor_front(s):
@@ -68,32 +82,35 @@ def _worker(rank, world, port, q):
         P[:c, :] = np.tril(L11); P[c:, :] = L21
         cb[s] = F[c:, c:] - L21 @ L21.T
 
+    def exchange(store, lev, width, tagbase):
+        """the cross-rank edges whose parent sits at level `lev`: src -> dst"""
+        for i in np.flatnonzero(E["level"] == lev):
+            d, src, dst = int(E["child"][i]), int(E["src"][i]), int(E["dst"][i])
+            m = int(sim.r[d] - sim.c[d])
+            if rank == src:
+                dist.send(torch.from_numpy(np.ascontiguousarray(store.pop(d))), dst=dst, tag=tagbase + i)
+            elif rank == dst:
+                buf = torch.empty((m, m if width is None else width), dtype=torch.float64)
+                dist.recv(buf, src=src, tag=tagbase + i)
+                store[d] = buf.numpy()
+
     for s in sim.order:                                   # phase 0: own subtrees (levels < shard_level)
-        if owner[s] >= 0 and mine(s):
+        if not is_top[s] and mine(s):
             factor_front(s)
-    for d in roots:                                       # exchange: subtree-root CBs -> rank 0
-        m = int(sim.r[d] - sim.c[d])
-        if owner[d] == 0:
-            continue
-        if rank == owner[d]:
-            dist.send(torch.from_numpy(np.ascontiguousarray(cb.pop(d))), dst=0, tag=int(d))
-        elif rank == 0:
-            buf = torch.empty((m, m), dtype=torch.float64)
-            dist.recv(buf, src=int(owner[d]), tag=int(d))
-            cb[d] = buf.numpy()
-    for s in sim.order:                                   # phase 1: the top (rank 0)
-        if owner[s] == -1 and mine(s):
-            factor_front(s)
-    # ---- sharded solve: own forward, W of the subtree roots -> rank 0, the top on rank 0, x of the top
-    #      fronts -> everybody, own backward, owned x -> rank 0 -----------------------------------------
-    k = 3
-    Bp = np.random.default_rng(5).standard_normal((n, k))          # right-hand sides in elimination order
+    for k in range(K):                                    # top levels, one phase each
+        exchange(cb, L0 + k, None, 0)
+        for s in sim.order:
+            if is_top[s] and sy.level[s] == L0 + k and mine(s):
+                factor_front(s)
+    # ---- sharded solve ---------------------------------------------------------------------------
+    k_rhs = 3
+    Bp = np.random.default_rng(5).standard_normal((n, k_rhs))      # right-hand sides in elimination order
     X = Bp.copy()
     W = {}
 
     def fwd_front(s):
         c, r = sim.c[s], sim.r[s]
-        f = np.zeros((r, k)); rows = sim.rows(s)
+        f = np.zeros((r, k_rhs)); rows = sim.rows(s)
         f[:c] = X[rows[:c]]
         for d in sim.children[s]:
             f[sim.rel(d)] += W.pop(d)
@@ -107,40 +124,34 @@ def _worker(rank, world, port, q):
         X[rows[:c]] = np.linalg.solve(np.tril(P[:c]).T, X[rows[:c]] - P[c:].T @ X[rows[c:]])
 
     for s in sim.order:
-        if owner[s] >= 0 and mine(s):
+        if not is_top[s] and mine(s):
             fwd_front(s)
-    for d in roots:
-        m = int(sim.r[d] - sim.c[d])
-        if owner[d] == 0:
-            continue
-        if rank == owner[d]:
-            dist.send(torch.from_numpy(np.ascontiguousarray(W.pop(d))), dst=0, tag=1000 + int(d))
-        elif rank == 0:
-            buf = torch.empty((m, k), dtype=torch.float64)
-            dist.recv(buf, src=int(owner[d]), tag=1000 + int(d))
-            W[d] = buf.numpy()
-    tops = [s for s in sim.order if owner[s] == -1]
-    if rank == 0:
-        for s in tops:
-            fwd_front(s)
-        for s in tops[::-1]:
-            bwd_front(s)
-    for s in tops:                                        # x of the top fronts' columns: rank 0 -> all
-        rows = sim.rows(s)[:sim.c[s]]
-        buf = torch.from_numpy(np.ascontiguousarray(X[rows]))
-        dist.broadcast(buf, src=0)
-        X[rows] = buf.numpy()
+    for k in range(K):
+        exchange(W, L0 + k, k_rhs, 1000)
+        for s in sim.order:
+            if is_top[s] and sy.level[s] == L0 + k and mine(s):
+                fwd_front(s)
+    for k in range(K - 1, -1, -1):
+        lev_fronts = [s for s in sim.order if is_top[s] and sy.level[s] == L0 + k]
+        for s in lev_fronts[::-1]:
+            if mine(s):
+                bwd_front(s)
+        for s in lev_fronts:                              # x of the level's fronts: owner -> all
+            rows = sim.rows(s)[:sim.c[s]]
+            buf = torch.from_numpy(np.ascontiguousarray(X[rows]))
+            dist.broadcast(buf, src=int(owner[s]))
+            X[rows] = buf.numpy()
     for s in sim.order[::-1]:
-        if owner[s] >= 0 and mine(s):
+        if not is_top[s] and mine(s):
             bwd_front(s)
     for s in range(ns):                                   # owned x -> rank 0 (per front here; per subtree on the device)
-        if owner[s] <= 0:
+        if is_top[s] or owner[s] == 0:
             continue
         rows = sim.rows(s)[:sim.c[s]]
         if rank == owner[s]:
             dist.send(torch.from_numpy(np.ascontiguousarray(X[rows])), dst=0, tag=2000 + s)
         elif rank == 0:
-            buf = torch.empty((len(rows), k), dtype=torch.float64)
+            buf = torch.empty((len(rows), k_rhs), dtype=torch.float64)
             dist.recv(buf, src=int(owner[s]), tag=2000 + s)
             X[rows] = buf.numpy()
     solve_err = None
@@ -154,12 +165,12 @@ def _worker(rank, world, port, q):
     if rank == 0:
         ref = HostSim(gmrfx.MI355XBackend(Q, coords=mesh.points, symbolic_only=True).symbolic(), n, np.asarray(Q.data)).factor().logdet()
         dense = np.linalg.slogdet(Q.toarray())[1]
-        q.put((float(t.item()), ref, dense, info, [int((owner == kk).sum()) for kk in range(-1, world)], solve_err))
+        q.put((float(t.item()), ref, dense, info, [int(is_top.sum())] + [int((owner == kk).sum()) for kk in range(world)], solve_err))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 5])
 def test_sharded_factor_plan_and_logdet_gloo(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
