@@ -176,6 +176,26 @@ void Device::upload(const Symbolic &S) {
         }
         const unsigned char *op; up(op, own); d_owncol_ = op;
         HC(hipStreamSynchronize(stream));
+        // selected inversion across ranks: which of my fronts get their trailing inverse block from another rank, and
+        // which fronts of other ranks get theirs from me (gathered here, level by level, then sent)
+        std::vector<unsigned char> fp(ns, 0);
+        std::vector<std::vector<int>> fc(S.nlevels);
+        for (i32 s = 0; s < ns; s++) {
+            const i32 pr = S.sparent[s];
+            if (pr < 0) continue;
+            if (S.owner[pr] != S.shard_rank) fp[s] = 1;
+            if (S.owner[pr] == S.shard_rank && S.owner[s] != S.shard_rank) fc[S.level[s]].push_back(s);
+        }
+        const unsigned char *fpp; up(fpp, fp); ds_.foreign_parent = fpp;
+        std::vector<int> flat;
+        fc_levelptr_.assign(S.nlevels + 1, 0);
+        fc_maxtrail_.assign(S.nlevels, 0);
+        for (i32 l = 0; l < S.nlevels; l++) {
+            for (int s : fc[l]) { flat.push_back(s); fc_maxtrail_[l] = std::max(fc_maxtrail_[l], S.nrows(s) - S.ncols(s)); }
+            fc_levelptr_[l + 1] = (int)flat.size();
+        }
+        const int *fl; up(fl, flat); d_fchild_ = const_cast<int *>(fl);
+        HC(hipStreamSynchronize(stream));
     }
     up(ip, S.lrow); ds_.lrow = ip;
     {
@@ -720,13 +740,8 @@ void Device::quadform(const double *d_nz, const double *d_X, long long ldx, long
     float ms; HC(hipEventElapsedTime(&ms, ev_[0], ev_[1])); ms_quadform = ms;
 }
 
-void Device::selinv_compute() {
-    HC(hipSetDevice(device));
-    if (sharded()) throw std::invalid_argument("selected inversion on a sharded handle is not implemented yet");
-    if (selinv_valid) return;
+void Device::selinv_begin() {
     const Symbolic &S = *S_;
-    DevSym dsz = ds_;            // the selected inversion has its own slot layout in the contribution-block arena
-    dsz.cbptr = d_zbptr_;
     start_inverse_async();
     wait_inverse();
     if (!inverse_full_) {      // the sweeps only need inv_cap_-column inverses; the Takahashi step needs all of L11^-1
@@ -735,8 +750,7 @@ void Device::selinv_compute() {
     }
     if (!d_Z_) d_Z_ = dalloc<double>((size_t)l_size_);
     // workspaces: small fronts: Yh = r x 64 per front; big fronts: Yt and Z21t = (r-c) x c each
-    long long *d_yoff = nullptr;
-    {
+    if (!d_yoff_) {
         std::vector<long long> yoff(S.nsuper, 0);
         long long mx = 0;
         for (i32 l = 0; l < S.nlevels; l++) {
@@ -750,13 +764,18 @@ void Device::selinv_compute() {
             mx = std::max(mx, off);
         }
         if (mx > tmp_cap_) { d_tmp_ = dregrow(d_tmp_, (size_t)mx); tmp_cap_ = mx; }
-        HC(hipMalloc((void **)&d_yoff, std::max<size_t>(yoff.size(), 1) * sizeof(long long)));
-        HC(hipMemcpyAsync(d_yoff, yoff.data(), yoff.size() * sizeof(long long), hipMemcpyHostToDevice, stream));
+        d_yoff_ = dalloc<long long>(std::max<size_t>(yoff.size(), 1));
+        HC(hipMemcpyAsync(d_yoff_, yoff.data(), yoff.size() * sizeof(long long), hipMemcpyHostToDevice, stream));
         HC(hipStreamSynchronize(stream));
     }
-    HC(hipEventRecord(ev_[0], stream));
     HC(hipMemsetAsync(d_Z_, 0, (size_t)l_size_ * sizeof(double), stream));
-    for (int l = (int)levels_.size() - 1; l >= 0; l--) {
+}
+
+void Device::selinv_levels(int hi, int lo) {
+    const Symbolic &S = *S_;
+    DevSym dsz = ds_;            // the selected inversion has its own slot layout in the contribution-block arena
+    dsz.cbptr = d_zbptr_;
+    for (int l = hi - 1; l >= lo; l--) {
         auto &L = levels_[l];
         // all fronts of the level (subtree members included): small first, then big
         const int sfirst = (int)S.sel_levelptr[l], scount = (int)(S.sel_levelptr[l + 1] - S.sel_levelptr[l]);
@@ -768,22 +787,58 @@ void Device::selinv_compute() {
         launch_sel_gather(stream, dsz, list, nf, level_max_trail(L), d_Z_, d_cb_);
         for (int phase = 0; phase < 3; phase++)
             launch_sel_dense(stream, dsz, list, nf, phase, L.max_cols, level_max_trail(L), d_L_, d_Z_, d_cb_, d_tmp_,
-                             d_tmp_, d_yoff);
+                             d_tmp_, d_yoff_);
         // small fronts of the level (<= 128 rows, <= 64 columns: one block step)
         if (snsmall > 0) {
             const int *sl = d_sel_levellist_ + sfirst;
             launch_sel_gather(stream, dsz, sl, snsmall, 128, d_Z_, d_cb_);
-            launch_trsm(stream, dsz, sl, snsmall, 0, 1, 128, d_L_, d_tmp_, d_yoff, FrontArg{0, 0, 0, 0, 0, 0, 0});
-            launch_sel_symm(stream, dsz, sl, snsmall, 0, 128, d_Z_, d_cb_, d_tmp_, d_yoff);
-            launch_sel_diag(stream, dsz, sl, snsmall, 0, d_L_, d_Z_, d_tmp_, d_yoff);
+            launch_trsm(stream, dsz, sl, snsmall, 0, 1, 128, d_L_, d_tmp_, d_yoff_, FrontArg{0, 0, 0, 0, 0, 0, 0});
+            launch_sel_symm(stream, dsz, sl, snsmall, 0, 128, d_Z_, d_cb_, d_tmp_, d_yoff_);
+            launch_sel_diag(stream, dsz, sl, snsmall, 0, d_L_, d_Z_, d_tmp_, d_yoff_);
         }
     }
+}
+
+void Device::selinv_compute() {
+    HC(hipSetDevice(device));
+    if (selinv_valid) return;
+    if (sharded()) throw std::invalid_argument("sharded handle: the selected inversion runs in phases with exchanges in between (gmrfx_selinv_phase, gmrfx/shard.py)");
+    selinv_begin();
+    HC(hipEventRecord(ev_[0], stream));
+    selinv_levels((int)levels_.size(), 0);
     HC(hipEventRecord(ev_[1], stream));
     HC(hipStreamSynchronize(stream));
     HC(hipGetLastError());
-    (void)hipFree(d_yoff);
     float ms; HC(hipEventElapsedTime(&ms, ev_[0], ev_[1])); ms_selinv = ms;
     selinv_valid = true;
+}
+
+void Device::selinv_phase(int what, int hi, int lo) {
+    HC(hipSetDevice(device));
+    if (!sharded()) throw std::invalid_argument("gmrfx_selinv_phase needs a handle created with shard_world > 1");
+    const int nl = (int)levels_.size();
+    if (what == 0) {
+        selinv_valid = false;
+        selinv_begin();
+        ms_selinv = 0;
+    } else if (what == 1) {
+        if (hi < 0 || hi >= nl) throw std::invalid_argument("selinv phase: level out of range");
+        DevSym dsz = ds_;
+        dsz.cbptr = d_zbptr_;
+        const int a = fc_levelptr_[hi], b = fc_levelptr_[hi + 1];
+        launch_sel_gather(stream, dsz, d_fchild_ + a, b - a, fc_maxtrail_[hi], d_Z_, d_cb_);
+    } else if (what == 2) {
+        if (lo < 0 || hi > nl || lo > hi) throw std::invalid_argument("selinv phase: level range out of bounds");
+        HC(hipEventRecord(ev_[0], stream));
+        selinv_levels(hi, lo);
+        HC(hipEventRecord(ev_[1], stream));
+        HC(hipStreamSynchronize(stream));
+        float ms; HC(hipEventElapsedTime(&ms, ev_[0], ev_[1])); ms_selinv += ms;
+    } else if (what == 3) {
+        selinv_valid = true;
+    } else throw std::invalid_argument("selinv phase must be 0 (begin), 1 (gather for other ranks), 2 (own levels) or 3 (end)");
+    HC(hipStreamSynchronize(stream));
+    HC(hipGetLastError());
 }
 
 void Device::selinv_diag(double *out_host) {

@@ -48,6 +48,8 @@ struct DevSym {
     // trailing tile T are [etile[T], etile[T+1]) -- no search at run time)
     const int *etile;
     const int *lrow;            // sum_rows: local row (sweep tasks) of every trailing row of a task front
+    const unsigned char *foreign_parent;   // sharded handles: 1 = the parent of this front is owned by another rank
+                                           // (its trailing inverse block arrives over the wire: no local gather); else null
 };
 
 // One sweep task (Symbolic::swt_*): everything its workgroup needs in ONE load.
@@ -109,6 +111,10 @@ public:
     // when the handle holds them itself (host-pointer refactorize / refactorize_update).
     void quadform(const double *d_nz, const double *d_X, long long ldx, long long nvec, const double *d_mu, double *out_host);
     void selinv_compute();
+    // sharded selected inversion, top-down (include/gmrfx.h): 0 = begin, 1 = gather the trailing inverse blocks of the
+    // OTHER ranks' fronts at level `hi` whose parents this rank owns (they are then sent to their owners),
+    // 2 = this rank's fronts of levels hi-1 .. lo, 3 = end
+    void selinv_phase(int what, int hi, int lo);
     void selinv_diag(double *out_host);
     void gather_z(const long long *offsets_host, long long cnt, double *out_host);  // offsets into panel storage, -1 -> 0.0
     // out[g] = sum_{t in segment g} w[t] * Z[off[t]] (off = -1 -> 0), all arrays on the host; Z = selected inverse panels
@@ -182,6 +188,11 @@ private:
     void wait_inverse();
     int first_multiblock_level_ = 0;
     long long rhs_cap_ = 0, io_cap_ = 0, tmp_cap_ = 0;
+    long long *d_yoff_ = nullptr;                 // selected inversion: per-front offsets of the Yh / Yt workspaces
+    int *d_fchild_ = nullptr;                     // sharded: other ranks' children of this rank's fronts, by level
+    std::vector<int> fc_levelptr_, fc_maxtrail_;  // ranges of d_fchild_ per level, max trailing rows per level
+    void selinv_begin();
+    void selinv_levels(int hi, int lo);
     // Solves with more than 64 right-hand sides run their 64-column passes on TWO lanes (stream + buffers each):
     // one pass is launch-latency bound (4.6 ms for 1 column, 5.9 for 64), two interleave on the idle CUs.
     double *d_Xb_ = nullptr, *d_X2b_ = nullptr, *d_Wb_ = nullptr;   // lane 1 (lane 0 = d_X_ / d_X2_ / d_W_ on `stream`)

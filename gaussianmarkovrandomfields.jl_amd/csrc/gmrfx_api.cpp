@@ -203,7 +203,8 @@ extern "C" int32_t gmrfx_shard_info(const gmrfx_handle *h, int64_t *n_edges, int
 }
 // cross-rank tree edges child -> parent, ordered by the level of the parent: what moves between two phases
 extern "C" int32_t gmrfx_shard_edges(const gmrfx_handle *h, int64_t *child, int64_t *src, int64_t *dst, int64_t *level,
-                                     int64_t *cb_offset, int64_t *cb_count, int64_t *w_row0, int64_t *w_nrows) {
+                                     int64_t *cb_offset, int64_t *cb_count, int64_t *w_row0, int64_t *w_nrows, int64_t *zb_offset,
+                                     int64_t *child_level) {
     if (!h || !child || !src || !dst || !level || !cb_offset || !cb_count || !w_row0 || !w_nrows) return GMRFX_ERR_INVALID_ARG;
     const Symbolic &S = h->S;
     std::vector<int64_t> wptr(S.nsuper + 1, 0);
@@ -214,6 +215,8 @@ extern "C" int32_t gmrfx_shard_edges(const gmrfx_handle *h, int64_t *child, int6
         child[k] = d; src[k] = S.owner[d]; dst[k] = S.owner[p]; level[k] = S.level[p];
         cb_offset[k] = S.cbptr[d]; cb_count[k] = m * m;
         w_row0[k] = wptr[d]; w_nrows[k] = m;
+        if (zb_offset) zb_offset[k] = S.zbptr[d];
+        if (child_level) child_level[k] = S.level[d];
     }
     return GMRFX_OK;
 }
@@ -305,6 +308,16 @@ extern "C" int32_t gmrfx_selinv_compute(gmrfx_handle *h) {
     return guarded(h, [&]() -> int32_t {
         if (int32_t e = need_device(h, true)) return e;
         h->D->selinv_compute();
+        return GMRFX_OK;
+    });
+}
+
+// sharded selected inversion (include/gmrfx.h): what = 0 begin, 1 gather the trailing inverse blocks of other ranks'
+// fronts at level hi (parents owned here), 2 this rank's fronts of levels hi-1 .. lo, 3 end
+extern "C" int32_t gmrfx_selinv_phase(gmrfx_handle *h, int32_t what, int32_t hi, int32_t lo) {
+    return guarded(h, [&]() -> int32_t {
+        if (int32_t e = need_device(h, true)) return e;
+        h->D->selinv_phase(what, hi, lo);
         return GMRFX_OK;
     });
 }

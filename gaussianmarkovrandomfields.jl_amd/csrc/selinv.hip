@@ -25,6 +25,7 @@ __global__ __launch_bounds__(256) void k_sel_gather(DevSym S, const int *__restr
     const int s = list[blockIdx.y];
     const int p = S.sparent[s];
     if (p < 0) return;
+    if (S.foreign_parent && S.foreign_parent[s]) return;     // sharded: the block was gathered by the parent's owner and sent here
     const int c = S.sfirst[s + 1] - S.sfirst[s];
     const int r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
     const int m = r - c;

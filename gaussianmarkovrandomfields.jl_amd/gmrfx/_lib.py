@@ -62,7 +62,7 @@ EXPORTS = [
     "gmrfx_shard_rows", "gmrfx_set_prior", "gmrfx_refactorize_update", "gmrfx_refactorize_update_dev",
     "gmrfx_quadform", "gmrfx_quadform_dev", "gmrfx_selinv_dot", "gmrfx_selinv_row_diag", "gmrfx_kl_cholesky",
     "gmrfx_selinv_row_diag_plan", "gmrfx_selinv_row_diag_apply", "gmrfx_selinv_row_diag_free",
-    "gmrfx_symbolic_sweep_tasks",
+    "gmrfx_symbolic_sweep_tasks", "gmrfx_selinv_phase",
 ]
 
 
@@ -100,7 +100,8 @@ def lib():
         L.gmrfx_get_factor_values.argtypes = [vp, vp]
         L.gmrfx_refactorize_phase.argtypes = [vp, vp, i32]
         L.gmrfx_shard_info.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
-        L.gmrfx_shard_edges.argtypes = [vp] + [vp] * 8
+        L.gmrfx_shard_edges.argtypes = [vp] + [vp] * 10
+        L.gmrfx_selinv_phase.argtypes = [vp, i32, i32, i32]
         L.gmrfx_shard_owner.argtypes = [vp, vp, vp]
         L.gmrfx_device_ptr.argtypes = [vp, i32]
         L.gmrfx_device_ptr.restype = C.c_void_p

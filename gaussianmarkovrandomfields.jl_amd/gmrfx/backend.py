@@ -379,11 +379,17 @@ class MI355XBackend:
         child), dst (owner of the parent), level, and where the child's contribution block / update vector live
         (offset + count in doubles into device_ptr(0); first row + rows of device_ptr(3))."""
         k = self.shard_info()["n_edges"]
-        names = ("child", "src", "dst", "level", "cb_offset", "cb_count", "w_row0", "w_nrows")
+        names = ("child", "src", "dst", "level", "cb_offset", "cb_count", "w_row0", "w_nrows", "zb_offset", "child_level")
         arr = {nm: np.zeros(k, np.int64) for nm in names}
         if k:
             check(lib().gmrfx_shard_edges(self._h, *[ptr(arr[nm]) for nm in names]), self._h)
         return arr
+
+    def selinv_phase(self, what: int, hi: int = 0, lo: int = 0) -> None:
+        """Sharded selected inversion (include/gmrfx.h): 0 begin, 1 gather for other ranks at level hi, 2 own levels hi-1..lo, 3 end."""
+        self._selinv_cache = None
+        self._selinv_diag_cache = None
+        check(lib().gmrfx_selinv_phase(self._h, what, hi, lo), self._h)
 
     def shard_owner(self, with_top: bool = False):
         ns = self.stats()["nsuper"]

@@ -133,6 +133,37 @@ class ShardedFactor:
         if self.rank == 0:
             be.solve_phase_dev(d_B, ldb, nrhs, d_X, ldx, 3)                  # transpose out
 
+    # ---- selected inversion -------------------------------------------------------------------------
+    def selinv_compute(self) -> None:
+        """Takahashi recursion, top-down over the sharded tree: a front needs the trailing block of its PARENT's inverse
+        front; for an owner-crossing edge the parent's owner gathers that block (it holds both sources) into the
+        shared arena layout and sends it to the child's owner. Levels without such edges run as one range."""
+        be, e = self.be, self.edges
+        nl = self.L0 + self.K
+        be.selinv_phase(0)
+        cut = sorted({int(l) for l in e["child_level"]}, reverse=True)     # levels that receive blocks
+        hi = nl
+        for l in cut:
+            if hi > l + 1:
+                be.selinv_phase(2, hi, l + 1)                    # my fronts of the levels above l
+            be.selinv_phase(1, l)                                # gather for the other ranks' fronts of level l
+            idx = np.flatnonzero(e["child_level"] == l)
+            self._p2p([(int(e["dst"][i]), int(e["src"][i]), 0, int(e["zb_offset"][i]), int(e["cb_count"][i])) for i in idx])
+            be.selinv_phase(2, l + 1, l)
+            hi = l
+        if hi > 0:
+            be.selinv_phase(2, hi, 0)
+        be.selinv_phase(3)
+
+    def selinv_diag(self):
+        """diag(Q^-1) in original ordering on every rank: all-reduce (sum) of the ranks' parts."""
+        t = self.torch
+        part = t.from_numpy(self.be.get_selinv_diag().copy())
+        if not self.host_staging:
+            part = part.to(self.dev)
+        self.dist.all_reduce(part, op=self.dist.ReduceOp.SUM)
+        return part.cpu().numpy()
+
     def logdet(self) -> float:
         """log det Q: all-reduce (sum) of the ranks' partial sums over their own pivots."""
         t = self.torch

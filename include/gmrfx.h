@@ -144,11 +144,19 @@ int32_t gmrfx_refactorize_update_dev(gmrfx_handle *h, const double *d_hvals, int
  *                                       gmrfx_shard_rows(kind 2)]
  *                    gmrfx_solve_phase(.., 2)                  backward sweep over the own subtrees
  *                    [x of every assigned subtree -> rank 0, gmrfx_shard_rows(kind 3)]   gmrfx_solve_phase(.., 3) on rank 0
- * Selected inversion on a sharded handle is not implemented yet (GMRFX_ERR_INVALID_ARG). */
+ *   selected inversion (top-down)   gmrfx_selinv_phase(h, 0, 0, 0) begin; for every level l from the top: (h, 1, l, 0) the
+ *                    owners of the PARENTS gather the trailing inverse blocks of the other ranks' fronts at level l;
+ *                    [those blocks (zb_offset / cb_count of the edges with child_level = l, in gmrfx_device_ptr(h, 0)):
+ *                    owner of the parent -> owner of the child]; (h, 2, l + 1, l) this rank's fronts of level l
+ *                    (levels without cross-rank edges may be run as one range); (h, 3, 0, 0) end. The getters
+ *                    (gmrfx_selinv_diag / _extract / _dot ...) then return this rank's PART (zeros for the entries of
+ *                    other ranks' fronts): sum over the ranks = the selected inverse. */
 int32_t gmrfx_refactorize_phase(gmrfx_handle *h, const double *d_nzval, int32_t phase);
 int32_t gmrfx_shard_info(const gmrfx_handle *h, int64_t *n_edges, int64_t *n_top_fronts, int64_t *shard_level);
 int32_t gmrfx_shard_edges(const gmrfx_handle *h, int64_t *child, int64_t *src, int64_t *dst, int64_t *level,
-                          int64_t *cb_offset, int64_t *cb_count, int64_t *w_row0, int64_t *w_nrows);
+                          int64_t *cb_offset, int64_t *cb_count, int64_t *w_row0, int64_t *w_nrows,
+                          int64_t *zb_offset /* nullable */, int64_t *child_level /* nullable */);
+int32_t gmrfx_selinv_phase(gmrfx_handle *h, int32_t what, int32_t level_hi, int32_t level_lo);
 int32_t gmrfx_shard_owner(const gmrfx_handle *h, int64_t *owner /* nsuper, >= 0 */, int64_t *is_top /* nsuper, nullable */);
 void   *gmrfx_device_ptr(gmrfx_handle *h, int32_t which /* 0: contribution-block arena, 1: factor panels, 2: X, 3: W */);
 int32_t gmrfx_solve_phase(gmrfx_handle *h, const double *d_B, int64_t ldb, int64_t nrhs, double *d_X, int64_t ldx, int32_t phase);

@@ -587,6 +587,13 @@ def _shard_gpu_worker(rank, world, port, q):
             if not resid < 1e-10:
                 same = False
                 why.append(f"residual {resid:.3e}")
+        # sharded selected inversion: the all-reduced diagonal equals the unsharded one bit for bit
+        sf.selinv_compute()
+        dsh = sf.selinv_diag()
+        dref = ref.get_selinv_diag()
+        if not np.array_equal(dsh, dref):
+            same = False
+            why.append(f"sharded selinv diagonal differs from the unsharded one by {np.abs(dsh - dref).max():.3e} (rel {np.abs(dsh / dref - 1).max():.3e})")
         info = dict(sf.be.shard_info()); info["why"] = why[:5]
         q.put((rank, ld, ref.compute_logdet(), bool(same), int(mine.sum()), info))
         dist.barrier()
