@@ -182,3 +182,33 @@ def test_supernodal_cpu_baseline_matches_simplicial_oracle():
         assert np.abs(sn.solve(B[:, 0], mode=1) - F.backward_solve(B[:, 0])).max() < 1e-10
         bad = Q.copy(); bad.data = -bad.data
         assert sn.factorize(bad.data) >= 0
+
+
+def test_oracle_on_the_references_deterministic_inputs():
+    """The oracle itself on the inputs the reference's tests fully specify (no RNG in Q): the 145 x 145 grid Laplacian +
+    dense border of test/workspace/test_backend_ordering.jl:9-17 under `perm = N:-1:1`, the natural order and a random
+    one (answers must not depend on the ordering, :25-31: solve / logdet rtol 1e-10, selinv diagonal 1e-8), and the AR(1)
+    precision of src/latent_models/ar.jl:135-148 against its closed forms det = tau^n (1 - rho^2),
+    Sigma_ij = rho^|i-j| / (tau (1 - rho^2))."""
+    from test_reference_inputs import backend_ordering_matrix
+    from gmrfx import spde
+    _, Q = backend_ordering_matrix()
+    N = Q.shape[0]
+    Qd = Q.toarray()
+    rhs = np.random.default_rng(0).standard_normal(N)
+    x_ref, ld_ref, d_ref = np.linalg.solve(Qd, rhs), np.linalg.slogdet(Qd)[1], np.diag(np.linalg.inv(Qd))
+    for perm in (np.arange(N - 1, -1, -1), np.arange(N), np.random.default_rng(1).permutation(N)):
+        F = orc.OracleFactor(Q, perm)
+        assert np.abs(F.solve(rhs) - x_ref).max() < 1e-10 * np.abs(x_ref).max()
+        assert abs(F.logdet() - ld_ref) < 1e-10 * abs(ld_ref)
+        assert np.abs(F.selinv_diag() - d_ref).max() < 1e-8 * d_ref.max()
+        L = F.L().toarray()
+        assert np.abs(L @ L.T - Qd[np.ix_(perm, perm)]).max() < 1e-12 * np.abs(Qd).max()
+    n, rho, tau = 400, 0.9, 2.5
+    Qa = sp.csc_matrix(spde.ar1_precision(n, rho, tau))
+    F = orc.OracleFactor(Qa, np.arange(n))
+    s2 = 1.0 / (tau * (1.0 - rho * rho))
+    assert abs(F.logdet() - (n * np.log(tau) + np.log1p(-rho * rho))) < 1e-11 * n
+    assert np.abs(F.selinv_diag() - s2).max() < 1e-9 * s2
+    e = np.zeros(n); e[137] = 1.0
+    assert np.allclose(F.solve(e), s2 * rho ** np.abs(np.arange(n) - 137), rtol=1e-9, atol=1e-14)
