@@ -219,6 +219,17 @@ void Device::upload(const Symbolic &S) {
     }
     {
         const int *ll; up(ll, S.levellist); d_levellist_ = const_cast<int *>(ll);
+        {   // the same lists with every level's big fronts split into their even / odd positions
+            std::vector<int> l2(S.levellist.begin(), S.levellist.end());
+            for (i32 l = 0; l < S.nlevels; l++) {
+                const i64 f = S.levelptr[l] + S.level_nsmall[l], e = S.levelptr[l + 1];
+                i64 w = f;
+                for (i64 k = f; k < e; k += 2) l2[w++] = S.levellist[k];
+                for (i64 k = f + 1; k < e; k += 2) l2[w++] = S.levellist[k];
+            }
+            const int *l2p; up(l2p, l2); d_levellist2_ = const_cast<int *>(l2p);
+            if (const char *e = std::getenv("GMRFX_TWO_CHAINS")) two_chains_ = std::atoi(e) != 0;
+        }
         const int *a; up(a, S.sub_first); d_sub_first_ = const_cast<int *>(a);
         const int *b; up(b, S.sub_last); d_sub_last_ = const_cast<int *>(b);
         for (int k = 0; k < 3; k++) nsub_cls_[k] = S.nsub_cls[k];
@@ -342,26 +353,47 @@ void Device::factor_levels(int lo, int hi) {
         const int nf = L.count - L.nsmall;
         launch_assemble(stream, ds_, list, nf, L.max_cols, L.max_rows, nz_src_, d_L_, d_cb_);
         const int nblk = level_nblk(L);
-        // geometry of the widest front of the level (fronts are sorted by decreasing width): when it is
-        // the only one still active, the panel kernels get it in their arguments (kernels.h, FrontArg)
-        FrontArg f1{0, 0, 0, 0, 0, 0, 0}, f0{0, 0, 0, 0, 0, 0, 0};
-        if (nf > 0) {
-            const i32 s1 = S_->levellist[L.first + L.nsmall];
-            f1 = FrontArg{1, (int)s1, S_->ncols(s1), S_->nrows(s1), (int)S_->ld[s1], (int)S_->sfirst[s1], (long long)S_->panelptr[s1]};
+        // The panel factorisation of a level is a chain of small dependent launches per 64-column block (potrf64 on ONE
+        // workgroup per front -> trsm -> gemm): while the diagonal blocks factor, the chip idles. Levels with several
+        // wide fronts run TWO independent chains -- the fronts at even / odd positions of the width-sorted list -- on two
+        // streams, so one half's trsm / gemm fills the chip while the other half sits in potrf64. Same arithmetic per
+        // front: bit-identical factor.
+        const bool two = two_chains_ && nf >= 2 && nblk >= 4 && !sharded();
+        const int nhalf = two ? 2 : 1;
+        if (two) {
+            HC(hipEventRecord(ev_ready_, stream));
+            HC(hipStreamWaitEvent(stream3, ev_ready_, 0));
         }
-        for (int b = 0; b < nblk; b++) {
-            const int kb = b * NB;
-            launch_potrf64(stream, ds_, list, L.active[b], kb, d_L_, d_info_, L.active[b] == 1 ? f1 : f0);
-            launch_trsm(stream, ds_, list, L.active[b], kb, 0, L.max_rows - kb - 1, d_L_, nullptr, nullptr, L.active[b] == 1 ? f1 : f0);
-            // two-level blocking: K = 64 updates only inside the current 256-column block, the
-            // rest of the panel once per block with K = 256
-            const int J1 = (b / OBK + 1) * OBK;   // first 64-block of the next 256-column block
-            if (b + 1 < nblk && b + 1 < J1)
-                launch_gemm_nt(stream, ds_, list, L.active[b + 1], kb, NB, kb + NB, J1 * NB, L.max_rows - kb - NB,
-                               std::min(J1 * NB, L.max_cols) - kb - NB, d_L_, L.active[b + 1] == 1 ? f1 : f0);
-            if (b + 1 == J1 && J1 < nblk)
-                launch_gemm_nt(stream, ds_, list, L.active[J1], (J1 - OBK) * NB, OBK * NB, J1 * NB, INT_MAX,
-                               L.max_rows - J1 * NB, L.max_cols - J1 * NB, d_L_, L.active[J1] == 1 ? f1 : f0);
+        for (int hf = 0; hf < nhalf; hf++) {
+            hipStream_t st = hf == 0 ? stream : stream3;
+            const int *hl = two ? d_levellist2_ + L.first + L.nsmall + (hf == 0 ? 0 : (nf + 1) / 2) : list;
+            auto act = [&](int b) { const int a = L.active[b]; return two ? (hf == 0 ? (a + 1) / 2 : a / 2) : a; };
+            // geometry of the widest front of the (half-)list (fronts are sorted by decreasing width): when it is
+            // the only one still active, the panel kernels get it in their arguments (kernels.h, FrontArg)
+            FrontArg f1{0, 0, 0, 0, 0, 0, 0}, f0{0, 0, 0, 0, 0, 0, 0};
+            if (nf > hf) {
+                const i32 s1 = S_->levellist[L.first + L.nsmall + hf];
+                f1 = FrontArg{1, (int)s1, S_->ncols(s1), S_->nrows(s1), (int)S_->ld[s1], (int)S_->sfirst[s1], (long long)S_->panelptr[s1]};
+            }
+            for (int b = 0; b < nblk; b++) {
+                const int kb = b * NB;
+                if (act(b) <= 0) break;
+                launch_potrf64(st, ds_, hl, act(b), kb, d_L_, d_info_, act(b) == 1 ? f1 : f0);
+                launch_trsm(st, ds_, hl, act(b), kb, 0, L.max_rows - kb - 1, d_L_, nullptr, nullptr, act(b) == 1 ? f1 : f0);
+                // two-level blocking: K = 64 updates only inside the current 256-column block, the
+                // rest of the panel once per block with K = 256
+                const int J1 = (b / OBK + 1) * OBK;   // first 64-block of the next 256-column block
+                if (b + 1 < nblk && b + 1 < J1)
+                    launch_gemm_nt(st, ds_, hl, act(b + 1), kb, NB, kb + NB, J1 * NB, L.max_rows - kb - NB,
+                                   std::min(J1 * NB, L.max_cols) - kb - NB, d_L_, act(b + 1) == 1 ? f1 : f0);
+                if (b + 1 == J1 && J1 < nblk)
+                    launch_gemm_nt(st, ds_, hl, act(J1), (J1 - OBK) * NB, OBK * NB, J1 * NB, INT_MAX,
+                                   L.max_rows - J1 * NB, L.max_cols - J1 * NB, d_L_, act(J1) == 1 ? f1 : f0);
+            }
+        }
+        if (two) {
+            HC(hipEventRecord(ev_done1_, stream3));
+            HC(hipStreamWaitEvent(stream, ev_done1_, 0));
         }
         if (nf > 0 && level_max_trail(L) > 0) {
             HC(hipEventRecord(ev_syrk_[2 * nsy], stream));

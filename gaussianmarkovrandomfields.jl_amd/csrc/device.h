@@ -164,6 +164,8 @@ private:
     const long long *d_zbptr_ = nullptr;   // arena offsets of the trailing inverse blocks (Symbolic::zbptr)
     const int *d_iperm_ = nullptr;   // inverse permutation (original row -> position), used by the RHS transposes
     int *d_levellist_ = nullptr;
+    int *d_levellist2_ = nullptr;   // per level: the big fronts re-ordered [even positions..., odd positions...] (two-stream panel chains)
+    bool two_chains_ = true;
     int *d_sub_first_ = nullptr, *d_sub_last_ = nullptr, *d_sel_levellist_ = nullptr;
     int nsub_cls_[3] = {0, 0, 0};
     double *d_L_ = nullptr, *d_Z_ = nullptr, *d_cb_ = nullptr, *d_nz_ = nullptr;
