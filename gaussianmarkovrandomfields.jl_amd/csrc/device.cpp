@@ -164,6 +164,8 @@ void Device::upload(const Symbolic &S) {
         if (etile.empty()) etile.push_back(0);
         up(ip, etile); ds_.etile = ip;
         HC(hipStreamSynchronize(stream));
+        h_edges_.swap(edges);      // read once more by the tile records of the contribution-block SYRK (init)
+        h_etile_.swap(etile);
     }
     tmp64 = conv<long long>(S.diagoff); up(lp, tmp64); ds_.diagoff = lp; HC(hipStreamSynchronize(stream));
     up(ip, S.perm); ds_.perm = ip;
@@ -303,6 +305,66 @@ void Device::upload(const Symbolic &S) {
         HC(hipStreamSynchronize(stream));
     }
 
+    // Contribution-block tiles of every level in hand-out order: front by front (the level list's order), inside a
+    // front by 8 x 8-tile squares of the lower triangle (row-major inside a square), then cut into 8 runs of equal
+    // estimated cost -- one per XCD. One self-contained record per tile (kernels.hip, k_syrk_cb_rec).
+    {
+        if (const char *e = std::getenv("GMRFX_SYRK_XCD")) syrk_xcd_ = std::atoi(e) != 0;
+        std::vector<SyrkTile> recs;
+        std::vector<double> cost;
+        constexpr int SQ = 8;
+        for (i32 l = 0; l < S.nlevels; l++) {
+            LevelInfo &L = levels_[l];
+            cost.clear();
+            L.syrk_off = (long long)recs.size();
+            for (int k = L.nsmall; syrk_xcd_ && k < L.count; k++) {
+                const i32 s = S.levellist[L.first + k];
+                const int c = S.ncols(s), m = S.nrows(s) - c;
+                const int T = (m + 63) / 64, nT = (m + 31) / 32;
+                const i64 ch0 = S.childptr[s];
+                const int nch = (int)(S.childptr[s + 1] - ch0);
+                for (int I = 0; I < T; I += SQ)
+                    for (int J = 0; J <= I; J += SQ)
+                        for (int bi = I; bi < std::min(I + SQ, T); bi++)
+                            for (int bj = J; bj < std::min(J + SQ, bi + 1); bj++) {
+                                // k-loop of 3 (diagonal tile) or 4 waves + the gather / epilogue of a tile, in columns of K
+                                cost.push_back((double)(c + 48) * (bi == bj ? 3 : 4));
+                                SyrkTile t{};
+                                t.pa = (long long)S.panelptr[s] + c;
+                                t.cb = (long long)S.cbptr[s];
+                                t.ch0 = (long long)ch0;
+                                t.c = c; t.m = m; t.ld = (int)S.ld[s]; t.nch = nch;
+                                t.bi = bi; t.bj = bj;
+                                for (int q = 0; q < std::min(nch, 2); q++) {
+                                    const EdgeRec &e = h_edges_[ch0 + q];
+                                    const int *et = h_etile_.data() + e.tptr;
+                                    t.reloff[q] = e.reloff; t.cboff[q] = e.cboff; t.md[q] = e.md;
+                                    t.a0[q] = et[2 * bi]; t.a1[q] = et[std::min(2 * bi + 2, nT)];
+                                    t.b0[q] = et[2 * bj]; t.b1[q] = et[std::min(2 * bj + 2, nT)];
+                                }
+                                recs.push_back(t);
+                            }
+            }
+            const size_t nt = cost.size();
+            if (nt >= (size_t)INT_MAX / 8) throw std::runtime_error("too many contribution-block tiles in one level");
+            double tot = 0, acc = 0;
+            for (size_t t = 0; t < nt; t++) tot += cost[t];
+            int x = 0;
+            L.syrk_split.start[0] = 0;
+            for (size_t t = 0; t < nt; t++) {
+                while (x < 7 && acc >= tot * (x + 1) / 8) L.syrk_split.start[++x] = (int)t;
+                acc += cost[t];
+            }
+            while (x < 8) L.syrk_split.start[++x] = (int)nt;
+            L.syrk_per = 0;
+            for (int q = 0; q < 8; q++) L.syrk_per = std::max(L.syrk_per, L.syrk_split.start[q + 1] - L.syrk_split.start[q]);
+        }
+        if (recs.empty()) recs.push_back(SyrkTile{});
+        const SyrkTile *rp; up(rp, recs); d_syrk_recs_ = const_cast<SyrkTile *>(rp);
+        HC(hipStreamSynchronize(stream));
+        std::vector<EdgeRec>().swap(h_edges_);
+        std::vector<int>().swap(h_etile_);
+    }
     ev_syrk_.resize(2 * (size_t)S.nlevels);
     for (auto &e : ev_syrk_) HC(hipEventCreate(&e));
     first_multiblock_level_ = S.nlevels;
@@ -397,7 +459,8 @@ void Device::factor_levels(int lo, int hi) {
         }
         if (nf > 0 && level_max_trail(L) > 0) {
             HC(hipEventRecord(ev_syrk_[2 * nsy], stream));
-            launch_syrk_cb(stream, ds_, list, nf, level_max_trail(L), d_L_, d_cb_);
+            if (syrk_xcd_) launch_syrk_cb_recs(stream, ds_, d_syrk_recs_ + L.syrk_off, L.syrk_split, L.syrk_per, d_L_, d_cb_);
+            else launch_syrk_cb(stream, ds_, list, nf, level_max_trail(L), d_L_, d_cb_);
             HC(hipEventRecord(ev_syrk_[2 * nsy + 1], stream));
             nsy++;
         }

@@ -63,6 +63,23 @@ struct SweepTask {
     long long woff;        // DevSym::wptr[root]
 };
 
+struct SyrkSplit { int start[9]; };   // tile runs of the 8 XCDs inside a level's tile list
+
+// Everything a workgroup of k_syrk_cb_rec needs for one 64 x 64 contribution-block tile, in ONE 128-byte record (one
+// scalar load) instead of four rounds of dependent index loads (tile -> front geometry -> edge records -> tile ranges):
+// the levels with narrow fronts spend their time in exactly that chain.
+struct SyrkTile {
+    long long pa;            // offset of L21 (panel + c rows down) in the factor storage
+    long long cb;            // offset of the front's contribution block in the arena
+    long long ch0;           // first child edge of the front (children beyond the second go the long way)
+    int c, m, ld, nch;       // columns, trailing rows, leading dimension, number of children
+    int bi, bj, pad0, pad1;  // tile row / column
+    long long reloff[2], cboff[2];   // first two children: relative-row list, contribution block
+    int md[2];                       //   trailing rows of the child
+    int a0[2], a1[2], b0[2], b1[2];  //   the child's rows that fall into the tile's rows [a0, a1) / columns [b0, b1)
+};
+static_assert(sizeof(SyrkTile) == 128, "SyrkTile is one 128-byte record");
+
 struct LevelInfo {
     int first;        // offset into levellist
     int count;        // fronts in level
@@ -71,6 +88,10 @@ struct LevelInfo {
     int max_rows;     // over big fronts
     int max_cols;     // over big fronts (they are sorted by decreasing column count)
     std::vector<int> active;  // active[k] = number of big fronts with ncols > k*NB
+    // contribution-block SYRK: the level's 64 x 64 tiles in the order they are handed out, cut into one run per XCD
+    long long syrk_off = 0;   // offset of the level's tiles in Device::d_syrk_recs_
+    SyrkSplit syrk_split{};   // run of XCD x = [start[x], start[x + 1])
+    int syrk_per = 0;         // longest run: the grid is 8 * syrk_per workgroups
 };
 
 class Device {
@@ -164,6 +185,10 @@ private:
     const long long *d_zbptr_ = nullptr;   // arena offsets of the trailing inverse blocks (Symbolic::zbptr)
     const int *d_iperm_ = nullptr;   // inverse permutation (original row -> position), used by the RHS transposes
     int *d_levellist_ = nullptr;
+    SyrkTile *d_syrk_recs_ = nullptr;   // one record per contribution-block tile, level by level, in hand-out order
+    std::vector<EdgeRec> h_edges_;      // host copies of the edge records / tile tables between upload() and init()
+    std::vector<int> h_etile_;
+    bool syrk_xcd_ = true;          // GMRFX_SYRK_XCD=0: k_syrk_cb on a plain 3-D grid (front, tile row, tile column) instead
     int *d_levellist2_ = nullptr;   // per level: the big fronts re-ordered [even positions..., odd positions...] (two-stream panel chains)
     bool two_chains_ = true;
     int *d_sub_first_ = nullptr, *d_sub_last_ = nullptr, *d_sel_levellist_ = nullptr;

@@ -13,11 +13,16 @@ constexpr int FWD_RB = 32;    // front rows owned by one forward-assembly workgr
 // Geometry of one front. Normally read through list[z] -> sfirst / rowptr / ld / panelptr: two
 // dependent round trips at the start of every kernel. The panel chain at the top of the tree
 // (potrf -> trsm -> gemm, ~120 dependent launches on a single front) gets it in the kernel arguments.
+// two doubles that are only known to be 8-byte aligned (one 16-byte load; the hardware takes unaligned addresses)
+typedef double gmrfx_d2u __attribute__((ext_vector_type(2), aligned(8)));
+
 struct FrontArg { int on, s, c, r, ld, first; long long pp; };
 struct FrontView { int s, c, r, ld, first; long long pp; };
 void launch_assemble(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, int max_rows,
                      const double *nzval, double *L, double *CB);
 void launch_syrk_cb(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_trail, const double *L, double *CB);
+// The same tiles from self-contained records, one contiguous run per XCD (workgroup id mod 8 = XCD): see k_syrk_cb_rec.
+void launch_syrk_cb_recs(hipStream_t st, const DevSym &S, const SyrkTile *recs, const SyrkSplit &split, int per_xcd, const double *L, double *CB);
 void launch_trsm(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int mode, int max_rows_below,
                  double *L, double *Yh, const long long *yoff, const FrontArg &fa);
 void launch_gemm_nt(hipStream_t st, const DevSym &S, const int *list, int nactive, int k0, int K, int c0, int c1,

@@ -22,6 +22,7 @@
 namespace gmrfx {
 
 typedef gmrfx_d4 d4;
+typedef gmrfx_d2u d2u;
 
 // Two lower bounds in the sorted array a[0..n) at once, by all 64 lanes of a wave together
 // (64-ary search: 2 rounds of one load each for n <= 4096 instead of 12 dependent loads each).
@@ -342,14 +343,15 @@ __global__ __launch_bounds__(256) void k_gemm_nt(DevSym S, const int *__restrict
 // One workgroup per 64x64 lower tile: the children's entries that fall into the tile are gathered
 // into an LDS tile (fixed child order, no atomics), the product runs on the FP64 MFMA, the
 // epilogue stores LDS tile minus accumulators. No zero-fill, no read-modify-write of CB in HBM.
+// (Reference form on a plain 3-D grid, front x tile row x tile column: GMRFX_SYRK_XCD=0. The product path is
+// k_syrk_cb_rec below -- same arithmetic, tiles handed out per XCD from self-contained records.)
 __global__ __launch_bounds__(256) void k_syrk_cb(DevSym S, const int *__restrict__ list, const double *__restrict__ L,
                                                  double *__restrict__ CB) {
     __shared__ double Tl[64 * 65];
-    const int s = list[blockIdx.z];
+    const int s = list[blockIdx.z], bi = blockIdx.x, bj = blockIdx.y;
     const int c = S.sfirst[s + 1] - S.sfirst[s];
     const int r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
     const int m = r - c;
-    const int bi = blockIdx.x, bj = blockIdx.y;
     if (bj > bi || bi * 64 >= m) return;
     const int ld = S.ld[s];
     const double *A = L + S.panelptr[s] + c;
@@ -422,6 +424,159 @@ __global__ __launch_bounds__(256) void k_syrk_cb(DevSym S, const int *__restrict
 #pragma unroll
             for (int rr = 0; rr < 4; rr++) {
                 const int j = j0 + a * 16 + lk + 4 * rr, i = i0 + b * 16 + lm;
+                if (i < m && j < m && i >= j) C[i + (long long)j * m] = Tl[(i - ti0) + (j - tj0) * 65] - acc[a][b][rr];
+            }
+}
+
+// The product form of the same tile, driven by one 128-byte record per tile (SyrkTile, device.h) and handed out per
+// XCD: workgroups go to the 8 XCDs round-robin by linear id, so id & 7 is the XCD and id >> 3 the position in that
+// XCD's run of the level's tile list. A run holds whole fronts or compact 8 x 8-tile squares of one front, so the L21
+// row blocks its tiles share are fetched into ONE L2 instead of all eight (L2-miss traffic of the launches of one
+// factorisation: 17.2 GB on the 3-D grid, 6.95 GB here, 5.77 GB algorithmic -- tools/syrk_levels.py traffic).
+// A tile of a narrow front is a chain of round trips, not arithmetic: the record arrives in one scalar load (instead of
+// tile -> front geometry -> edge records -> tile ranges), the first k-batch of the product and the first child's entries
+// are requested right behind it, and only then does anything wait. Children are still added one after the other, the k
+// order is unchanged: bit-identical to k_syrk_cb.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_syrk_cb_rec(DevSym S, const SyrkTile *__restrict__ recs, const SyrkSplit split,
+                                                     const double *__restrict__ L, double *__restrict__ CB) {
+    __shared__ double Tl[64 * 65];
+    const int x = blockIdx.x & 7;
+    const int t = split.start[x] + (int)(blockIdx.x >> 3);
+    if (t >= split.start[x + 1]) return;
+    const SyrkTile T = recs[t];
+    const int c = T.c, m = T.m, ld = T.ld, bi = T.bi, bj = T.bj;
+    const double *A = L + T.pa;
+    double *C = CB + T.cb;
+    const int tid = threadIdx.x;
+    const int ti0 = bi * 64, tj0 = bj * 64;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int lm = lane & 15, lk = lane >> 4;
+    const int i0 = ti0 + (wave & 1) * 32, j0 = tj0 + (wave >> 1) * 32;
+    const bool live = !(i0 >= m || j0 >= m || j0 > i0 + 31);       // this wave's 32 x 32 part reaches the lower triangle
+    constexpr int KU = 4;
+    // Operand rows in PAIRS: MFMA row lm of tile 0 / tile 1 is row 2 lm / 2 lm + 1 of the wave's 32 (not lm / 16 + lm),
+    // so one 16-byte load per lane feeds both tiles -- half the vector memory instructions of the k-loop, which is
+    // what these kernels are bound by (see above). Lanes past the last row re-read the last pair (never stored); the
+    // odd row after an odd m is padding or the next column's first entry (never stored either).
+    const int mlast = (m - 1) & ~1;
+    const double *pa2 = A + min(j0 + 2 * lm, mlast);
+    const double *pb2 = A + min(i0 + 2 * lm, mlast);
+    double av[KU][2], bv[KU][2];
+    auto request = [&](int q0) {
+#pragma unroll
+        for (int u = 0; u < KU; u++) {
+            const long long ko = (long long)min(q0 + 4 * u + lk, c - 1) * ld;
+            const d2u xa = *(const d2u *)(pa2 + ko), xb = *(const d2u *)(pb2 + ko);
+            av[u][0] = xa.x; av[u][1] = xa.y;
+            bv[u][0] = xb.x; bv[u][1] = xb.y;
+        }
+    };
+    if (live) request(0);
+    // the first two children's entries: (row la, column lb + 4 u) of the child's rows / columns inside this tile.
+    // Round trips: record -> [k-batch 0 + child 0] -> child 1 -> k-batch 1 ...
+    // Every vector memory instruction costs the CU's address unit ~16 cycles whatever its lanes do, and these levels
+    // are bound by exactly that (TA busy 87 %): so the child's column indices come in ONE load (lane l holds the
+    // index of column b0 + l; each use reads its lane), columns beyond the tile's range issue nothing at all, and
+    // neither do lanes beyond its row range.
+    const int la = lane;
+    const int lb = __builtin_amdgcn_readfirstlane(wave);
+    int ti, rb;
+    double uv[16];
+    auto fetch = [&](int q) {
+        const int md = T.md[q];
+        const int *reld = S.rel + T.reloff[q];
+        const double *Ud = CB + T.cboff[q];
+        const int a = T.a0[q] + la;
+        const int ac = min(a, md - 1);
+        ti = reld[ac];
+        rb = reld[min(T.b0[q] + la, md - 1)];
+        const int nb = T.b1[q] - T.b0[q] - lb;          // this wave's columns: b0 + lb + 4 u < b1  <=>  4 u < nb
+        if (a < T.a1[q]) {
+#pragma unroll
+            for (int u = 0; u < 16; u++)
+                if (4 * u < nb) uv[u] = Ud[ac + (long long)(T.b0[q] + lb + 4 * u) * md];
+        }
+    };
+    auto add = [&](int q) {
+        const int a = T.a0[q] + la;
+        const int nb = T.b1[q] - T.b0[q] - lb;
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            if (4 * u < nb) {
+                const int tc = __builtin_amdgcn_readlane(rb, lb + 4 * u) - c - tj0;
+                if (a < T.a1[q] && a >= T.b0[q] + lb + 4 * u) Tl[(ti - c - ti0) + tc * 65] += uv[u];
+            }
+        }
+    };
+    d4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+    auto mfma_batch = [&](int q0) {
+#pragma unroll
+        for (int u = 0; u < KU; u++) {
+            const double mk = (q0 + 4 * u + lk) < c ? 1.0 : 0.0;
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++)
+                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][a] * mk, bv[u][b], acc[a][b], 0, 0, 0);
+        }
+    };
+    if (T.nch > 0) fetch(0);
+    for (int idx = tid; idx < 64 * 65; idx += 256) Tl[idx] = 0.0;
+    __syncthreads();
+    if (T.nch > 0) {
+        add(0);
+        __syncthreads();
+    }
+    if (T.nch > 1) {
+        fetch(1);
+        add(1);
+        __syncthreads();
+    }
+    if (T.nch > 2) {       // further children: edge record -> tile ranges -> entries, one child at a time
+        const int nT = (m + 31) >> 5;
+        for (long long cb = T.ch0 + 2; cb < T.ch0 + T.nch; cb++) {
+            const EdgeRec er = S.edge[cb];
+            const int *et = S.etile + er.tptr;
+            const int a0 = et[2 * bi], a1 = et[min(2 * bi + 2, nT)], b0 = et[2 * bj], b1 = et[min(2 * bj + 2, nT)];
+            const int md = er.md;
+            const int *reld = S.rel + er.reloff;
+            const double *Ud = CB + er.cboff;
+            const int a = a0 + la, ac = min(a, md - 1);
+            const int tr = reld[ac] - c - ti0;
+            int tc[16];
+            double w[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const int b = min(b0 + lb + 4 * u, md - 1);
+                tc[u] = reld[b];
+                w[u] = Ud[ac + (long long)b * md];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const int b = b0 + lb + 4 * u;
+                if (a < a1 && b < b1 && a >= b) Tl[tr + (tc[u] - c - tj0) * 65] += w[u];
+            }
+            __syncthreads();
+        }
+    }
+    if (!live) return;
+    // D[m_ = j][n = i] = sum_q L21[j][q] L21[i][q]: rows i on the lanes (contiguous in column-major CB); the first
+    // batch arrived long ago
+    for (int q0 = 0; q0 < c; q0 += 4 * KU) {
+        if (q0 > 0) request(q0);
+        mfma_batch(q0);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                const int j = j0 + 2 * (lk + 4 * rr) + a, i = i0 + 2 * lm + b;
                 if (i < m && j < m && i >= j) C[i + (long long)j * m] = Tl[(i - ti0) + (j - tj0) * 65] - acc[a][b][rr];
             }
 }
@@ -963,6 +1118,10 @@ void launch_assemble(hipStream_t st, const DevSym &S, const int *list, int nfron
 void launch_syrk_cb(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_trail, const double *L, double *CB) {
     if (nfronts <= 0 || max_trail <= 0) return;
     hipLaunchKernelGGL(k_syrk_cb, dim3(odd(cdiv(max_trail, 64)), odd(cdiv(max_trail, 64)), nfronts), dim3(256), 0, st, S, list, L, CB);
+}
+void launch_syrk_cb_recs(hipStream_t st, const DevSym &S, const SyrkTile *recs, const SyrkSplit &split, int per_xcd, const double *L, double *CB) {
+    if (per_xcd <= 0) return;
+    hipLaunchKernelGGL(k_syrk_cb_rec, dim3(8 * (unsigned)per_xcd), dim3(256), 0, st, S, recs, split, L, CB);
 }
 void launch_trsm(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int mode, int max_rows_below,
                  double *L, double *Yh, const long long *yoff, const FrontArg &fa) {

@@ -149,8 +149,10 @@ __global__ __launch_bounds__(TASK_THREADS, 1) void k_fwd_task(DevSym S, const Sw
     // Operands that do not depend on the sweep itself -- this slot's rows of the first 16 columns of L11^-1 / of its
     // trailing row tile, and that tile's local rows -- are requested ONE FRONT AHEAD. All addresses are clamped into
     // the front's own panel / row list, so the loads are valid for any geometry (masks are applied at use).
-    double ao[4], at[4], no[4], nt_[4];
-    int li[4], nli[4];
+    // (two operand sets used alternately, the front loop unrolled by two: rotating ONE set through a copy at the end of
+    //  an iteration would make the copy wait for the loads just requested -- and with it the whole prefetch)
+    double opA_o[4], opA_t[4], opB_o[4], opB_t[4];
+    int opA_l[4], opB_l[4];
     auto request = [&](int f, double (&xo)[4], double (&xt)[4], int (&xl)[4]) {
         const TaskMeta m = uniform_meta(meta, f);
         const int ntile = (m.r - m.c + 15) >> 4;
@@ -168,8 +170,8 @@ __global__ __launch_bounds__(TASK_THREADS, 1) void k_fwd_task(DevSym S, const Sw
 #pragma unroll
         for (int rr = 0; rr < 4; rr++) xl[rr] = lr[min(i0 + lk + 4 * rr, m.r - 1)];
     };
-    request(0, ao, at, li);
-    for (int f = 0; f < nf; f++) {
+    request(0, opA_o, opA_t, opA_l);
+    auto front = [&](const int f, double (&ao)[4], double (&at)[4], int (&li)[4], double (&no)[4], double (&nt_)[4], int (&nli)[4]) {
         const TaskMeta m = uniform_meta(meta, f);
         const int c = m.c, r = m.r, ld = m.ld, o = m.o;
         const double *P = L + m.pp;
@@ -223,9 +225,7 @@ __global__ __launch_bounds__(TASK_THREADS, 1) void k_fwd_task(DevSym S, const Sw
                 }
             }
             __syncthreads();
-#pragma unroll
-            for (int u = 0; u < 4; u++) { ao[u] = no[u]; at[u] = nt_[u]; li[u] = nli[u]; }
-            continue;
+            return;
         }
         // ---- wide front (17..64 columns): slot w < 4 owns own rows 16 w .. 16 w + 15 -----------------------------
         const int k0 = w * 16;
@@ -295,8 +295,14 @@ __global__ __launch_bounds__(TASK_THREADS, 1) void k_fwd_task(DevSym S, const Sw
             scatter_sub(V, l2, acc, r - i0, lk, cl);     // distinct rows inside a front, one wave per row tile: no conflicts
         }
         __syncthreads();
-#pragma unroll
-        for (int u = 0; u < 4; u++) { ao[u] = no[u]; at[u] = nt_[u]; li[u] = nli[u]; }
+    };
+    {
+        int f = 0;
+        for (; f + 1 < nf; f += 2) {
+            front(f, opA_o, opA_t, opA_l, opB_o, opB_t, opB_l);
+            front(f + 1, opB_o, opB_t, opB_l, opA_o, opA_t, opA_l);
+        }
+        if (f < nf) front(f, opA_o, opA_t, opA_l, opB_o, opB_t, opB_l);
     }
     // ---- write-out: the root's update vector W (y went to X front by front) -----------------------------------
     if (j < nr) {
@@ -350,8 +356,8 @@ __global__ __launch_bounds__(TASK_THREADS, 1) void k_bwd_task(DevSym S, const Sw
     const int k0 = w * 16;
     // one front ahead (see k_fwd_task): the first 32 trailing rows of this slot's own columns with their local rows,
     // and the diagonal 16 x 16 block of L11^-T. Only slots 0..3 ever own columns.
-    double a1[8], ad[4], n1[8], nd[4];
-    int l1[8], nl1[8];
+    double opA_1[8], opA_d[4], opB_1[8], opB_d[4];
+    int opA_l[8], opB_l[8];
     auto request = [&](int f, double (&x1)[8], int (&xl)[8], double (&xd)[4]) {
         const TaskMeta m = uniform_meta(meta, f);
         if (k0 >= m.c) return;                                             // this slot has no work in front f (scalar branch)
@@ -367,8 +373,8 @@ __global__ __launch_bounds__(TASK_THREADS, 1) void k_bwd_task(DevSym S, const Sw
 #pragma unroll
         for (int u = 0; u < 4; u++) xd[u] = tinv_elem(P, m.ld, m.c, k0 + lm, k0 + 4 * u + lk, false);
     };
-    request(nf - 1, a1, l1, ad);
-    for (int f = nf - 1; f >= 0; f--) {
+    request(nf - 1, opA_1, opA_l, opA_d);
+    auto front = [&](const int f, double (&a1)[8], int (&l1)[8], double (&ad)[4], double (&n1)[8], int (&nl1)[8], double (&nd)[4]) {
         const TaskMeta m = uniform_meta(meta, f);
         const int c = m.c, r = m.r, ld = m.ld, o = m.o;
         const double *P = L + m.pp;
@@ -386,17 +392,17 @@ __global__ __launch_bounds__(TASK_THREADS, 1) void k_bwd_task(DevSym S, const Sw
                 for (int u = 0; u < 8; u++)
                     if (u < kt) mfma4_lds(acc, a1[u] * ((c + 4 * u + lk) < r ? 1.0 : 0.0), V, max(l1[u], 0), cl);
 #pragma unroll 1
-                for (int q0 = c + 32; q0 < r; q0 += 32) {      // two 16-row k-blocks per pass: 8 operand + 8 index loads in flight
-                    double av[8];
-                    int l2[8];
+                for (int q0 = c + 32; q0 < r; q0 += 16) {      // rare in a task (r - c > 32): one 16-row k-block per pass
+                    double av[4];
+                    int l2[4];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) {
+                    for (int u = 0; u < 4; u++) {
                         const int qq = min(q0 + 4 * u + lk, r - 1);
                         av[u] = pa[qq];
                         l2[u] = lr[qq];
                     }
 #pragma unroll
-                    for (int u = 0; u < 8; u++)
+                    for (int u = 0; u < 4; u++)
                         mfma4_lds(acc, av[u] * ((q0 + 4 * u + lk) < r ? 1.0 : 0.0), V, l2[u], cl);
                 }
             }
@@ -427,11 +433,7 @@ __global__ __launch_bounds__(TASK_THREADS, 1) void k_bwd_task(DevSym S, const Sw
                         if (lk + 4 * rr < c) V[vidx(o + lk + 4 * rr, t * 16 + cl)] = x[t][rr];
             }
             __syncthreads();
-#pragma unroll
-            for (int u = 0; u < 8; u++) { a1[u] = n1[u]; l1[u] = nl1[u]; }
-#pragma unroll
-            for (int u = 0; u < 4; u++) ad[u] = nd[u];
-            continue;
+            return;
         }
         if (k0 < c) {
 #pragma unroll
@@ -469,10 +471,14 @@ __global__ __launch_bounds__(TASK_THREADS, 1) void k_bwd_task(DevSym S, const Sw
                 }
         }
         __syncthreads();
-#pragma unroll
-        for (int u = 0; u < 8; u++) { a1[u] = n1[u]; l1[u] = nl1[u]; }
-#pragma unroll
-        for (int u = 0; u < 4; u++) ad[u] = nd[u];
+    };
+    {
+        int f = nf - 1;
+        for (; f >= 1; f -= 2) {
+            front(f, opA_1, opA_l, opA_d, opB_1, opB_l, opB_d);
+            front(f - 1, opB_1, opB_l, opB_d, opA_1, opA_l, opA_d);
+        }
+        if (f == 0) front(0, opA_1, opA_l, opA_d, opB_1, opB_l, opB_d);
     }
     if (j < nr)
         for (int i = g; i < NT; i += TASK_WAVES) X[(long long)(col0 + i) * ldx + j] = V[vidx(i, j)];
