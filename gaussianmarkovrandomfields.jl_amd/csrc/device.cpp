@@ -18,10 +18,13 @@ void hip_check(hipError_t e, const char *what) {
 #define HC(x) hip_check((x), #x)
 
 template <class T> T *Device::dalloc(size_t count) {
+    // 16 bytes of slack behind every array: kernels that load rows in pairs (16 bytes per lane) may read one element
+    // past the last one; the value is never used, but the address must be mapped
     void *p = nullptr;
-    HC(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
-    allocs_.push_back({p, std::max<size_t>(count, 1) * sizeof(T)});
-    bytes_total += (double)(std::max<size_t>(count, 1) * sizeof(T));
+    const size_t bytes = std::max<size_t>(count, 1) * sizeof(T) + 16;
+    HC(hipMalloc(&p, bytes));
+    allocs_.push_back({p, bytes});
+    bytes_total += (double)bytes;
     return (T *)p;
 }
 

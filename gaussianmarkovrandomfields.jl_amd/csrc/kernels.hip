@@ -23,6 +23,7 @@ namespace gmrfx {
 
 typedef gmrfx_d4 d4;
 typedef gmrfx_d2u d2u;
+typedef int i2u __attribute__((ext_vector_type(2), aligned(4)));   // two ints, 4-byte aligned: one 8-byte load
 
 // Two lower bounds in the sorted array a[0..n) at once, by all 64 lanes of a wave together
 // (64-ary search: 2 rounds of one load each for n <= 4096 instead of 12 dependent loads each).
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256) void k_assemble(DevSym S, const int *__restric
     if (tc >= c) return;
     const int ld = S.ld[s];
     double *Pc = L + S.panelptr[s] + (long long)tc * ld;
-    for (int i = tl; i < ld; i += NL) Pc[i] = 0.0;
+    for (int i = 2 * tl; i < ld; i += 2 * NL) *(d2u *)(Pc + i) = (d2u){0.0, 0.0};      // ld is even
     if (WIDE) __syncthreads();
     {
         const long long q0 = S.qptr[s];
@@ -96,7 +97,8 @@ __global__ __launch_bounds__(256) void k_assemble(DevSym S, const int *__restric
         wave_lower_bound2(reld, er.nown, tc, tc + 1, lane, j, j1);   // only rows mapped into own columns
         if (j1 == j) continue;                    // this child has no row mapped to column tc (workgroup-uniform)
         const double *Uc = CB + er.cboff + (long long)j * md;
-        // four independent row chunks in flight per lane (rel -> P read-modify-write chain)
+        // four independent row chunks in flight per lane (rel -> P read-modify-write chain; row pairs per lane as in
+        // k_assemble_lds were measured slower here: the scattered read-modify-write of P is the long pole, not the loads)
         for (int i0 = j + tl; i0 < md; i0 += 4 * NL) {
             int ri[4];
             double u[4], pv[4];
@@ -264,23 +266,33 @@ __global__ __launch_bounds__(256) void k_gemm_nt(DevSym S, const int *__restrict
     // loads of a whole batch of KU k-steps issue back to back; the next batch is fetched into
     // a second register set before the current batch's MFMAs (software double buffering).
     constexpr int KU = TW == 2 ? 4 : 8;
+    // TW = 2: operand rows in PAIRS -- MFMA row lm of tile 0 / 1 is row 2 lm / 2 lm + 1 of the wave's 32 -- so one 16-byte
+    // load per lane feeds both tiles, and C is read and written 16 bytes at a time as well: half the vector memory
+    // instructions (the CU's address unit, not the MFMA pipe, is the busiest unit of this kernel). Lanes past the last
+    // row re-read the last pair; the odd row after an odd count is padding or the next column's first entry.
+    const int Mlast = (M - 1) & ~1, Nlast = (N - 1) & ~1;
     const double *pa[TW], *pb[TW];
 #pragma unroll
-    for (int a = 0; a < TW; a++) pa[a] = A + min(i0 + a * 16 + lm, M - 1);
+    for (int a = 0; a < TW; a++) pa[a] = A + (TW == 2 ? min(i0 + 2 * lm, Mlast) : min(i0 + a * 16 + lm, M - 1));
 #pragma unroll
-    for (int b = 0; b < TW; b++) pb[b] = A + min(j0 + b * 16 + lm, N - 1);
+    for (int b = 0; b < TW; b++) pb[b] = A + (TW == 2 ? min(j0 + 2 * lm, Nlast) : min(j0 + b * 16 + lm, N - 1));
     double ca[KU][TW], cb[KU][TW];
+    auto load_step = [&](long long off, double (&xa)[TW], double (&xb)[TW]) {
+        if constexpr (TW == 2) {
+            const d2u va = *(const d2u *)(pa[0] + off), vb = *(const d2u *)(pb[0] + off);
+            xa[0] = va.x; xa[1] = va.y; xb[0] = vb.x; xb[1] = vb.y;
+        } else {
+#pragma unroll
+            for (int a = 0; a < TW; a++) xa[a] = pa[a][off];
+#pragma unroll
+            for (int b = 0; b < TW; b++) xb[b] = pb[b][off];
+        }
+    };
     // full batches: no masking at all, so the prefetch of batch k+1 really overlaps the MFMAs of
     // batch k (nothing consumes the loaded registers before the MFMAs that need them)
     auto fetch = [&](int k0, double (&xa)[KU][TW], double (&xb)[KU][TW]) {
 #pragma unroll
-        for (int u = 0; u < KU; u++) {
-            const long long off = (long long)(k0 + 4 * u + lk) * ld;
-#pragma unroll
-            for (int a = 0; a < TW; a++) xa[u][a] = pa[a][off];
-#pragma unroll
-            for (int b = 0; b < TW; b++) xb[u][b] = pb[b][off];
-        }
+        for (int u = 0; u < KU; u++) load_step((long long)(k0 + 4 * u + lk) * ld, xa[u], xb[u]);
     };
     auto mma = [&](double (&xa)[KU][TW], double (&xb)[KU][TW]) {
 #pragma unroll
@@ -304,39 +316,63 @@ __global__ __launch_bounds__(256) void k_gemm_nt(DevSym S, const int *__restrict
 #pragma unroll
         for (int u = 0; u < KU; u++) {
             const int kk = kfull + 4 * u + lk;
-            const long long off = (long long)min(kk, K - 1) * ld;
             const double mk = kk < K ? 1.0 : 0.0;
+            load_step((long long)min(kk, K - 1) * ld, ca[u], cb[u]);
 #pragma unroll
-            for (int a = 0; a < TW; a++) ca[u][a] = pa[a][off] * mk;
-#pragma unroll
-            for (int b = 0; b < TW; b++) cb[u][b] = pb[b][off];
+            for (int a = 0; a < TW; a++) ca[u][a] *= mk;
         }
         mma(ca, cb);
     }
     // D[m][n]: m (rows of the first operand = C's column) = lk + 4*reg, n = lm = C's row
     // read-modify-write of C in two passes (all loads, then all stores): one round trip instead of
     // a chain of 4 TW^2 (the compiler cannot reorder a load of C past the previous store to C)
-    double cv[TW][TW][4];
+    if constexpr (TW == 2) {
+        // tile a of the rows = row i0 + 2 lm + a, tile b of the columns = column j0 + 2 (lk + 4 rr) + b
+        d2u cv[2][4];
 #pragma unroll
-    for (int a = 0; a < TW; a++)
-#pragma unroll
-        for (int b = 0; b < TW; b++)
-#pragma unroll
-            for (int rr = 0; rr < 4; rr++) {
-                const int i = min(i0 + a * 16 + lm, M - 1);
-                const int j = min(j0 + b * 16 + lk + 4 * rr, N - 1);
-                cv[a][b][rr] = C[i + (long long)j * ldc];
-            }
-#pragma unroll
-    for (int a = 0; a < TW; a++)
-#pragma unroll
-        for (int b = 0; b < TW; b++)
+        for (int b = 0; b < 2; b++)
 #pragma unroll
             for (int rr = 0; rr < 4; rr++) {
-                const int i = i0 + a * 16 + lm;
-                const int j = j0 + b * 16 + lk + 4 * rr;
-                if (i < M && j < N && i >= j) C[i + (long long)j * ldc] = cv[a][b][rr] - acc[a][b][rr];
+                const int j = min(j0 + 2 * (lk + 4 * rr) + b, N - 1);
+                cv[b][rr] = *(const d2u *)(C + min(i0 + 2 * lm, Mlast) + (long long)j * ldc);
             }
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                const int i = i0 + 2 * lm, j = j0 + 2 * (lk + 4 * rr) + b;
+                const bool v0 = i < M && j < N && i >= j, v1 = i + 1 < M && j < N && i + 1 >= j;
+                double *dst = C + i + (long long)j * ldc;
+                const double x0 = cv[b][rr].x - acc[0][b][rr], x1 = cv[b][rr].y - acc[1][b][rr];
+                if (v0 && v1) *(d2u *)dst = (d2u){x0, x1};
+                else {
+                    if (v0) dst[0] = x0;
+                    if (v1) dst[1] = x1;
+                }
+            }
+    } else {
+        double cv[TW][TW][4];
+#pragma unroll
+        for (int a = 0; a < TW; a++)
+#pragma unroll
+            for (int b = 0; b < TW; b++)
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) {
+                    const int i = min(i0 + a * 16 + lm, M - 1);
+                    const int j = min(j0 + b * 16 + lk + 4 * rr, N - 1);
+                    cv[a][b][rr] = C[i + (long long)j * ldc];
+                }
+#pragma unroll
+        for (int a = 0; a < TW; a++)
+#pragma unroll
+            for (int b = 0; b < TW; b++)
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) {
+                    const int i = i0 + a * 16 + lm;
+                    const int j = j0 + b * 16 + lk + 4 * rr;
+                    if (i < M && j < N && i >= j) C[i + (long long)j * ldc] = cv[a][b][rr] - acc[a][b][rr];
+                }
+    }
 }
 
 // Contribution block of a big front, written ONCE:  CB = (extend-add of the children's CBs) - L21 L21'.
@@ -1078,19 +1114,31 @@ __global__ __launch_bounds__(256) void k_assemble_lds(DevSym S, const int *__res
         wave_lower_bound2(reld, er.nown, tc, tc + 1, lane, j, j1);   // only rows mapped into own columns
         if (j1 == j) continue;                    // this child has no row mapped to column tc
         const double *Uc = CB + er.cboff + (long long)j * md;
-        for (int i0 = j + lane; i0 < md; i0 += 512) {   // eight independent row chunks in flight per lane
-            int ri[8];
-            double u[8];
+        // Rows in PAIRS per lane (one 16-byte value load + one 8-byte index load cover 128 rows of the column), four
+        // chunks in flight, and chunks past the end of the child's column issue nothing: the kernel is bound by the
+        // CU's address unit (a vector memory instruction costs it ~16 cycles whatever its lanes do), not by HBM.
+        // The pair that starts at the last row reads one element past the column: the next column, or the 16 bytes of
+        // slack every device array ends in (Device::dalloc); never used.
+        for (int base = j; base < md; base += 512) {
+            i2u ri[4];
+            d2u u[4];
 #pragma unroll
-            for (int q = 0; q < 8; q++) ri[q] = reld[min(i0 + 64 * q, md - 1)];
+            for (int q = 0; q < 4; q++)
+                if (base + 128 * q < md) {
+                    const int ic = min(base + 128 * q + 2 * lane, md - 1);
+                    ri[q] = *(const i2u *)(reld + ic);
+                    u[q] = *(const d2u *)(Uc + ic);
+                }
 #pragma unroll
-            for (int q = 0; q < 8; q++) u[q] = Uc[min(i0 + 64 * q, md - 1)];
-#pragma unroll
-            for (int q = 0; q < 8; q++)
-                if (i0 + 64 * q < md) Cw[ri[q]] += u[q];      // distinct rows within a child: no conflicts
+            for (int q = 0; q < 4; q++)
+                if (base + 128 * q < md) {
+                    const int i = base + 128 * q + 2 * lane;
+                    if (i < md) Cw[ri[q].x] += u[q].x;          // distinct rows within a child: no conflicts
+                    if (i + 1 < md) Cw[ri[q].y] += u[q].y;
+                }
         }
     }
-    for (int i = lane; i < ld; i += 64) Pc[i] = Cw[i];
+    for (int i = 2 * lane; i < ld; i += 128) *(d2u *)(Pc + i) = (d2u){Cw[i], Cw[i + 1]};      // ld is even
 }
 
 // Workgroups are handed to the 8 XCDs round-robin by linear id (x fastest). Rectangular grids whose
