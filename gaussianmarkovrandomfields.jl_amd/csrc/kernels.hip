@@ -146,43 +146,45 @@ __device__ __forceinline__ void stage_linv(const double *__restrict__ Dg, int ld
 //   mode 1 (selected inversion): Yh[i, :]  <- L[i, blk] * Linv
 // One wave owns 16 rows (reads all of them before it writes), a workgroup 64 rows.
 template <int MODE, int SPLIT>
-__global__ __launch_bounds__(256) void k_trsm(DevSym S, const int *__restrict__ list, int kb,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k_trsm(DevSym S, const int *__restrict__ list, int kb,
                                               double *__restrict__ L, double *__restrict__ Yh,
                                               const long long *__restrict__ yoff, FrontArg fa) {
-    // SPLIT = 0: a workgroup owns 64 rows, each wave 16 of them (all four 16-column tiles);
+    // SPLIT = 0: a workgroup owns 128 rows, each wave 32 of them (all four 16-column tiles) as 16 row PAIRS: MFMA
+    // row lm of tile 0 / 1 is row 2 lm / 2 lm + 1 of the wave's 32, so one 16-byte load per lane and k-step feeds both
+    // tiles and the results leave 16 bytes at a time (half the vector memory instructions, half the LDS reads and half
+    // the stagings of the inverse block per row; the kernel streams the block column once in, once out);
     // SPLIT = 1 (latency variant for levels with a handful of fronts): a workgroup owns 16 rows
-    // and each wave ONE column tile of them -- four times the workgroups, a quarter of the MFMA
+    // and each wave ONE column tile of them -- many more workgroups, a quarter of the MFMA
     // chain per wave (a single CU sustains only ~0.14 TFLOP/s of FP64 MFMA).
     __shared__ double Ti[NB * NB];
     const FrontView fv = front_view(S, list, blockIdx.y, fa);
     const int s = fv.s, c = fv.c, r = fv.r;
     if (kb >= c) return;
     const int w = min(NB, c - kb);
-    const int row0 = kb + w + blockIdx.x * (SPLIT ? 16 : 64);
+    const int row0 = kb + w + blockIdx.x * (SPLIT ? 16 : 128);
     if (row0 >= r) return;
     const int ld = fv.ld;
     double *Pp = L + fv.pp;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int lm = lane & 15, lk = lane >> 4;
-    const int i0 = SPLIT ? row0 : row0 + wave * 16;
-    const int i = i0 + lm;
     const double *A = Pp + (long long)kb * ld;
-    const double *pa = A + min(i, r - 1);
-    // this wave's rows of the block column are requested BEFORE the inverse block is staged: the two global
-    // round trips of this latency-bound kernel overlap instead of following each other
-    double bv[16];
-#pragma unroll
-    for (int u = 0; u < 16; u++) {
-        const int q = 4 * u + lk;
-        bv[u] = pa[(long long)min(q, w - 1) * ld];   // B[kk=q][n=i]; Ti is zero for q >= w, rows >= r never stored
-    }
-    stage_linv(Pp + kb + (long long)kb * ld, ld, w, Ti, threadIdx.x);
-    __syncthreads();
-    if (i0 >= r) return;
     double *out = MODE == 0 ? Pp + (long long)kb * ld : Yh + yoff[s];
     const int ldo = MODE == 0 ? ld : r;
     // Linv is lower triangular: MODE 0 (A Linv') needs q <= k, MODE 1 (L Linv) needs q >= k
     if (SPLIT) {
+        const int i0 = row0;
+        const int i = i0 + lm;
+        const double *pa = A + min(i, r - 1);
+        // this wave's rows of the block column are requested BEFORE the inverse block is staged: the two global
+        // round trips of this latency-bound kernel overlap instead of following each other
+        double bv[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const int q = 4 * u + lk;
+            bv[u] = pa[(long long)min(q, w - 1) * ld];   // B[kk=q][n=i]; Ti is zero for q >= w, rows >= r never stored
+        }
+        stage_linv(Pp + kb + (long long)kb * ld, ld, w, Ti, threadIdx.x);
+        __syncthreads();
         const int t = wave;
         d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
         const int k = t * 16 + lm;
@@ -201,9 +203,25 @@ __global__ __launch_bounds__(256) void k_trsm(DevSym S, const int *__restrict__ 
             if (kk < w) out[i + (long long)kk * ldo] = acc[rr];
         }
     } else {
-        d4 acc[4];
+        const int i0 = row0 + wave * 32;
+        const int i = i0 + 2 * lm;                     // this lane's row pair: i, i + 1
+        // (lanes past the last row re-read the last row's pair; its second half is padding, the next column's first
+        //  entry or the slack behind the array -- never stored)
+        const double *pa = A + min(i, r - 1);
+        d2u bv[16];
 #pragma unroll
-        for (int t = 0; t < 4; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int u = 0; u < 16; u++) {
+            const int q = 4 * u + lk;
+            bv[u] = *(const d2u *)(pa + (long long)min(q, w - 1) * ld);
+        }
+        stage_linv(Pp + kb + (long long)kb * ld, ld, w, Ti, threadIdx.x);
+        __syncthreads();
+        if (i0 >= r) return;
+        d4 acc[2][4];
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) acc[a][t] = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int u = 0; u < 16; u++) {
             const int q = 4 * u + lk;
@@ -213,7 +231,8 @@ __global__ __launch_bounds__(256) void k_trsm(DevSym S, const int *__restrict__ 
                     if (MODE == 0 ? (u <= 4 * t + 3) : (u >= 4 * t)) {
                         const int k = t * 16 + lm;                                    // A[m=k][kk=q]
                         const double av = MODE == 0 ? Ti[k * NB + q] : Ti[q * NB + k];
-                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[u], acc[t], 0, 0, 0);
+                        acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[u].x, acc[0][t], 0, 0, 0);
+                        acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[u].y, acc[1][t], 0, 0, 0);
                     }
                 }
             }
@@ -224,7 +243,11 @@ __global__ __launch_bounds__(256) void k_trsm(DevSym S, const int *__restrict__ 
 #pragma unroll
             for (int rr = 0; rr < 4; rr++) {
                 const int k = t * 16 + lk + 4 * rr;
-                if (k < w) out[i + (long long)k * ldo] = acc[t][rr];
+                if (k < w) {
+                    double *dst = out + i + (long long)k * ldo;
+                    if (i + 1 < r) *(d2u *)dst = (d2u){acc[0][t][rr], acc[1][t][rr]};
+                    else dst[0] = acc[0][t][rr];
+                }
             }
     }
 }
@@ -606,15 +629,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
         if (q0 > 0) request(q0);
         mfma_batch(q0);
     }
+    // rows i, i + 1 of column j leave together (16 bytes) wherever both lie inside the lower triangle
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
-        for (int b = 0; b < 2; b++)
-#pragma unroll
-            for (int rr = 0; rr < 4; rr++) {
-                const int j = j0 + 2 * (lk + 4 * rr) + a, i = i0 + 2 * lm + b;
-                if (i < m && j < m && i >= j) C[i + (long long)j * m] = Tl[(i - ti0) + (j - tj0) * 65] - acc[a][b][rr];
+        for (int rr = 0; rr < 4; rr++) {
+            const int j = j0 + 2 * (lk + 4 * rr) + a, i = i0 + 2 * lm;
+            if (j < m) {
+                const double *tl = Tl + (i - ti0) + (j - tj0) * 65;
+                double *dst = C + i + (long long)j * m;
+                const bool v0 = i < m && i >= j, v1 = i + 1 < m && i + 1 >= j;
+                if (v0 && v1) *(d2u *)dst = (d2u){tl[0] - acc[a][0][rr], tl[1] - acc[a][1][rr]};
+                else {
+                    if (v0) dst[0] = tl[0] - acc[a][0][rr];
+                    if (v1) dst[1] = tl[1] - acc[a][1][rr];
+                }
             }
+        }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1175,7 +1206,7 @@ void launch_trsm(hipStream_t st, const DevSym &S, const int *list, int nactive, 
                  double *L, double *Yh, const long long *yoff, const FrontArg &fa) {
     if (nactive <= 0 || max_rows_below <= 0) return;
     const bool split = (long long)cdiv(max_rows_below, 64) * nactive <= 128;
-    const dim3 grid(odd(cdiv(max_rows_below, split ? 16 : 64)), nactive);
+    const dim3 grid(odd(cdiv(max_rows_below, split ? 16 : 128)), nactive);
     if (mode == 0) {
         if (split) hipLaunchKernelGGL((k_trsm<0, 1>), grid, dim3(256), 0, st, S, list, kb, L, Yh, yoff, fa);
         else hipLaunchKernelGGL((k_trsm<0, 0>), grid, dim3(256), 0, st, S, list, kb, L, Yh, yoff, fa);
