@@ -164,7 +164,6 @@ __global__ __launch_bounds__(64 * NW) void k_xmul(DevSym S, const int *__restric
     const double *P = L + S.panelptr[s] + col0 + (long long)col0 * ld;
     const double *Bb = Xin + (long long)first * ldx;
     const int lm = lane & 15, lk = lane >> 4;
-    const int nt = (nr + 15) >> 4;
     d4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
@@ -177,8 +176,13 @@ __global__ __launch_bounds__(64 * NW) void k_xmul(DevSym S, const int *__restric
         for (int u = 0; u < KU; u++) {
             const int q = q0 + 4 * u + lk;
             av[u] = trans ? xinv_elem(P, ld, c, q, k0 + lm) : xinv_elem(P, ld, c, k0 + lm, q);
+            // right-hand sides in pairs: column tile t is right-hand side 32 (t >> 1) + 2 lm + (t & 1), one 16-byte load
+            // feeds two tiles (the pair behind the last right-hand side reads into the next row; never stored)
 #pragma unroll
-            for (int t = 0; t < 4; t++) bv[u][t] = Bb[(long long)min(q, c - 1) * ldx + min(t * 16 + lm, nr - 1)];
+            for (int t2 = 0; t2 < 2; t2++) {
+                const gmrfx_d2u y = *(const gmrfx_d2u *)(Bb + (long long)min(q, c - 1) * ldx + min(32 * t2 + 2 * lm, nr - 1));
+                bv[u][2 * t2] = y.x; bv[u][2 * t2 + 1] = y.y;
+            }
         }
 #pragma unroll
         for (int u = 0; u < KU; u++)
@@ -194,8 +198,8 @@ __global__ __launch_bounds__(64 * NW) void k_xmul(DevSym S, const int *__restric
     double *Yb = Xout + (long long)first * ldx;
 #pragma unroll
     for (int t = 0; t < 4; t++)
-        if (t == wave && t < nt) {
-            const int j = t * 16 + lm;
+        if (t == wave) {
+            const int j = 32 * (t >> 1) + 2 * lm + (t & 1);
 #pragma unroll
             for (int rr = 0; rr < 4; rr++) {
                 const int k = k0 + lk + 4 * rr;

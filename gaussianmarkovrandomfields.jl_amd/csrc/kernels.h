@@ -200,6 +200,49 @@ __device__ __forceinline__ void splitk_reduce4(gmrfx_d4 (&acc)[NA][4], double *r
         }
     }
 }
+// The same for two row tiles with PAIR ownership: after the call wave w holds the complete tiles acc[w >> 1][2 (w & 1)]
+// and acc[w >> 1][2 (w & 1) + 1] -- two column tiles of ONE row tile, which the kernels that load right-hand sides in
+// pairs (column tile t = right-hand sides 32 (t >> 1) + 2 lm + (t & 1)) then store 16 bytes per lane. Two passes (one
+// per column-tile pair), partial sums added in wave order 0..3. red: 12 tiles = 24 KB, as above.
+__device__ __forceinline__ void splitk_reduce4_pairs(gmrfx_d4 (&acc)[2][4], double *red, int wave, int lane) {
+#pragma unroll
+    for (int hc = 0; hc < 2; hc++) {
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+            const int owner = 2 * a + hc;
+            if (wave != owner) {
+                const int rank = wave < owner ? wave : wave - 1;
+#pragma unroll
+                for (int e = 0; e < 2; e++)
+#pragma unroll
+                    for (int rr = 0; rr < 4; rr++) red[(((a * 3 + rank) * 2 + e) * 4 + rr) * 64 + lane] = acc[a][2 * hc + e][rr];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+            const int owner = 2 * a + hc;
+            if (wave == owner) {
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    gmrfx_d4 part[4];
+#pragma unroll
+                    for (int w = 0; w < 4; w++) {
+                        if (w == owner) part[w] = acc[a][2 * hc + e];
+                        else {
+                            const int rank = w < owner ? w : w - 1;
+#pragma unroll
+                            for (int rr = 0; rr < 4; rr++) part[w][rr] = red[(((a * 3 + rank) * 2 + e) * 4 + rr) * 64 + lane];
+                        }
+                    }
+#pragma unroll
+                    for (int rr = 0; rr < 4; rr++) acc[a][2 * hc + e][rr] = ((part[0][rr] + part[1][rr]) + part[2][rr]) + part[3][rr];
+                }
+            }
+        }
+    }
+}
 #endif
 
 // inverse.hip -- dense L11^-1 of big fronts (recursive doubling) and the sweeps that use it

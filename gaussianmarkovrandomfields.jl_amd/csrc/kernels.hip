@@ -731,17 +731,18 @@ __global__ __launch_bounds__(256) void k_fwd_update_longk(DevSym S, const int *_
     const double *P = L + S.panelptr[s];
     const double *Yb = X + (long long)S.sfirst[s] * ldx;
     double *Ws = W + S.wptr[s] * ldx;
-    const int nt = (nr + 15) >> 4;
     // ---- gather the children's update vectors for these rows into LDS (fixed child order, no
     //      atomics): W_s is then written exactly once, with no zero-fill / read-modify-write passes
     {
-        const int j = threadIdx.x & 63, g = threadIdx.x >> 6;
+        const int j = threadIdx.x & 63, g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         const int jcl = min(j, nr - 1);
         const double jm = j < nr ? 1.0 : 0.0;
         for (int i = g; i < RT; i += 4) Tl[i * 64 + j] = 0.0;
         __syncthreads();
         // children two at a time (see k_syrk_cb): records + tile ranges first, then at most 32
-        // child rows per tile and child, all loads in flight at once; added in child order
+        // child rows per tile and child, all loads in flight at once; added in child order. The target rows of a
+        // child come in ONE load (lane l: row a0 + l; each use reads its lane) and rows past the tile's range issue
+        // nothing: a vector memory instruction costs the address unit ~16 cycles whatever its lanes do.
         const long long ch0 = S.childptr[s], ch1 = S.childptr[s + 1];
         const int T = (blockIdx.x * RT) >> 5;   // 32-row granularity of the tile table
         for (long long cb = ch0; cb < ch1; cb += 2) {
@@ -759,17 +760,18 @@ __global__ __launch_bounds__(256) void k_fwd_update_longk(DevSym S, const int *_
                 if (cb + q < ch1) {
                     const int *reld = S.rel + er[q].reloff;
                     const double *Wd = W + er[q].woff * ldx;
-                    int tr[8];
+                    const int rt = reld[min(a0[q] + j, er[q].md - 1)];
+                    const int na = a1[q] - a0[q] - g;            // this wave's rows: a0 + g + 4 u < a1  <=>  4 u < na
                     double wv[8];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        const int a = min(a0[q] + g + 4 * u, er[q].md - 1);
-                        tr[u] = reld[a];
-                        wv[u] = Wd[(long long)a * ldx + jcl];
-                    }
+                    for (int u = 0; u < 8; u++)
+                        if (4 * u < na) wv[u] = Wd[(long long)(a0[q] + g + 4 * u) * ldx + jcl];
 #pragma unroll
                     for (int u = 0; u < 8; u++)
-                        if (a0[q] + g + 4 * u < a1[q] && tr[u] >= i0 && tr[u] < i0 + RT) Tl[(tr[u] - i0) * 64 + j] += wv[u] * jm;
+                        if (4 * u < na) {
+                            const int tr = __builtin_amdgcn_readlane(rt, g + 4 * u);
+                            if (tr >= i0 && tr < i0 + RT) Tl[(tr - i0) * 64 + j] += wv[u] * jm;
+                        }
                     __syncthreads();
                 }
             }
@@ -780,10 +782,11 @@ __global__ __launch_bounds__(256) void k_fwd_update_longk(DevSym S, const int *_
     for (int a = 0; a < NA; a++)
 #pragma unroll
         for (int t = 0; t < 4; t++) acc[a][t] = (d4){0.0, 0.0, 0.0, 0.0};
-    const double *pa[NA];
-#pragma unroll
-    for (int a = 0; a < NA; a++) pa[a] = P + min(i0 + a * 16 + lm, r - 1);
-    const int jc[4] = {min(lm, nr - 1), min(16 + lm, nr - 1), min(32 + lm, nr - 1), min(48 + lm, nr - 1)};
+    // Operands in PAIRS (16-byte loads): NA = 2: MFMA row lm of row tile 0 / 1 is row 2 lm / 2 lm + 1 of the 32; column
+    // tile t is right-hand side 32 (t >> 1) + 2 lm + (t & 1): one load feeds two tiles, three loads per k-step instead
+    // of six. Lanes past the last row / right-hand side re-read the last one's pair (results never stored).
+    const double *pa = P + (NA == 2 ? min(i0 + 2 * lm, r - 1) : min(i0 + lm, r - 1));
+    const int jb[2] = {min(2 * lm, nr - 1), min(32 + 2 * lm, nr - 1)};
     constexpr int KU = 4;
     for (int k0 = wave * 4 * KU; k0 < c; k0 += 16 * KU) {
         double av[KU][NA], bv[KU][4];
@@ -792,10 +795,17 @@ __global__ __launch_bounds__(256) void k_fwd_update_longk(DevSym S, const int *_
             const int kk = k0 + 4 * u + lk;
             const int kc = min(kk, c - 1);
             const double mk = kk < c ? 1.0 : 0.0;
+            if constexpr (NA == 2) {
+                const d2u x = *(const d2u *)(pa + (long long)kc * ld);
+                av[u][0] = x.x * mk; av[u][1] = x.y * mk;
+            } else {
+                av[u][0] = pa[(long long)kc * ld] * mk;
+            }
 #pragma unroll
-            for (int a = 0; a < NA; a++) av[u][a] = pa[a][(long long)kc * ld] * mk;
-#pragma unroll
-            for (int t = 0; t < 4; t++) bv[u][t] = Yb[(long long)kc * ldx + jc[t]];
+            for (int t2 = 0; t2 < 2; t2++) {
+                const d2u y = *(const d2u *)(Yb + (long long)kc * ldx + jb[t2]);
+                bv[u][2 * t2] = y.x; bv[u][2 * t2 + 1] = y.y;
+            }
         }
 #pragma unroll
         for (int u = 0; u < KU; u++)
@@ -805,18 +815,39 @@ __global__ __launch_bounds__(256) void k_fwd_update_longk(DevSym S, const int *_
                 for (int t = 0; t < 4; t++)
                     acc[a][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][a], bv[u][t], acc[a][t], 0, 0, 0);
     }
-    splitk_reduce4<NA>(acc, red, wave, lane);
-    // wave w owns the 16 right-hand sides 16 w .. 16 w + 15 of every row tile
+    if constexpr (NA == 2) {
+        // wave w owns row tile w >> 1 (rows i0 + 2 (lk + 4 rr) + (w >> 1)) x right-hand sides 32 (w & 1) + 2 lm, + 1:
+        // W leaves 16 bytes per lane
+        splitk_reduce4_pairs(acc, red, wave, lane);
+        const int a = wave >> 1, hc = wave & 1;
+        const int j = 32 * hc + 2 * lm;
 #pragma unroll
-    for (int a = 0; a < NA; a++) {
+        for (int rr = 0; rr < 4; rr++) {
+            const int i = i0 + 2 * (lk + 4 * rr) + a;
+            if (i < r && j < nr) {
+                double *dst = Ws + (long long)(i - c) * ldx + j;
+                const double *tl = Tl + (i - i0) * 64 + j;
+                double x0 = 0.0, x1 = 0.0;
+#pragma unroll
+                for (int aa = 0; aa < 2; aa++)          // (a is wave-uniform; the accumulator index must be a constant)
+#pragma unroll
+                    for (int h = 0; h < 2; h++)
+                        if (aa == a && h == hc) { x0 = tl[0] - acc[aa][2 * h][rr]; x1 = tl[1] - acc[aa][2 * h + 1][rr]; }
+                if (j + 1 < nr) *(d2u *)dst = (d2u){x0, x1};
+                else dst[0] = x0;
+            }
+        }
+    } else {
+        splitk_reduce4<NA>(acc, red, wave, lane);
+        // wave w owns column tile w (right-hand sides 32 (w >> 1) + 2 lm + (w & 1))
 #pragma unroll
         for (int t = 0; t < 4; t++) {
-            if (t == wave && t < nt) {
-                const int j = t * 16 + lm;
+            if (t == wave) {
+                const int j = 32 * (t >> 1) + 2 * lm + (t & 1);
 #pragma unroll
                 for (int rr = 0; rr < 4; rr++) {
-                    const int i = i0 + a * 16 + lk + 4 * rr;
-                    if (i < r && j < nr) Ws[(long long)(i - c) * ldx + j] = Tl[(i - i0) * 64 + j] - acc[a][t][rr];
+                    const int i = i0 + lk + 4 * rr;
+                    if (i < r && j < nr) Ws[(long long)(i - c) * ldx + j] = Tl[(i - i0) * 64 + j] - acc[0][t][rr];
                 }
             }
         }
@@ -918,7 +949,6 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_gemm_longk(DevSym S, const int 
     const int first = S.sfirst[s];
     const double *P = L + S.panelptr[s];
     const int *rows = S.rows + S.rowptr[s];
-    const int nt = (nr + 15) >> 4;
     d4 acc[NA][4];
 #pragma unroll
     for (int a = 0; a < NA; a++)
@@ -927,34 +957,50 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_gemm_longk(DevSym S, const int 
     const double *pa[NA];
 #pragma unroll
     for (int a = 0; a < NA; a++) pa[a] = P + (long long)min(i0 + a * 16 + lm, c - 1) * ld;
-    const int jc[4] = {min(lm, nr - 1), min(16 + lm, nr - 1), min(32 + lm, nr - 1), min(48 + lm, nr - 1)};
+    // Everything in PAIRS (16-byte / 8-byte loads; the CU's address unit is what this kernel keeps busiest):
+    //  * the panel along k: a lane loads rows q, q + 1 of its column, q = batch + 8 h + 2 lk, and feeds k-steps 2 h and
+    //    2 h + 1 with them (k-step 2 h + e covers rows batch + 8 h + 2 lk + e, lk = 0..3);
+    //  * the row indices of those rows the same way;
+    //  * x along the right-hand sides: column tile t is right-hand side 32 (t >> 1) + 2 lm + (t & 1).
+    // Per batch of 16 rows: 2 NA + 8 + 2 loads instead of 4 NA + 16 + 4.
+    const int jb[2] = {min(2 * lm, nr - 1), min(32 + 2 * lm, nr - 1)};
     constexpr int KU = 4;
     // The row indices of batch k+1 are requested together with the operands of batch k: one round
     // trip per batch instead of two (index -> X row). Long trailing parts (K = r - c up to 2000 at
     // the top of the tree) make this loop a pure latency chain.
     long long xr[KU], xn[KU];
+    auto request_rows = [&](int kb) {
 #pragma unroll
-    for (int u = 0; u < KU; u++) xn[u] = rows[min(c + wave * 4 * KU + 4 * u + lk, r - 1)];
+        for (int h = 0; h < 2; h++) {
+            const int q = kb + 8 * h + 2 * lk;
+            const i2u v = *(const i2u *)(rows + min(q, r - 1));
+            xn[2 * h] = v.x;
+            xn[2 * h + 1] = q + 1 < r ? v.y : v.x;          // past the list: any valid row (its product is masked)
+        }
+    };
+    request_rows(c + wave * 4 * KU);
     for (int k0 = c + wave * 4 * KU; k0 < r; k0 += NW * 4 * KU) {
         double av[KU][NA], bv[KU][4];
 #pragma unroll
         for (int u = 0; u < KU; u++) xr[u] = xn[u];
+        request_rows(k0 + NW * 4 * KU);
 #pragma unroll
-        for (int u = 0; u < KU; u++) xn[u] = rows[min(k0 + NW * 4 * KU + 4 * u + lk, r - 1)];
+        for (int h = 0; h < 2; h++) {
+            const int q = k0 + 8 * h + 2 * lk;
+            const double m0 = q < r ? 1.0 : 0.0, m1 = q + 1 < r ? 1.0 : 0.0;
 #pragma unroll
-        for (int u = 0; u < KU; u++) {
-            const int qc = min(k0 + 4 * u + lk, r - 1);
-#pragma unroll
-            for (int a = 0; a < NA; a++) av[u][a] = pa[a][qc];
-#pragma unroll
-            for (int t = 0; t < 4; t++) bv[u][t] = X[xr[u] * ldx + jc[t]];
+            for (int a = 0; a < NA; a++) {
+                const d2u v = *(const d2u *)(pa[a] + min(q, r - 1));
+                av[2 * h][a] = v.x * m0; av[2 * h + 1][a] = v.y * m1;
+            }
         }
 #pragma unroll
-        for (int u = 0; u < KU; u++) {
-            const double mk = (k0 + 4 * u + lk) < r ? 1.0 : 0.0;
+        for (int u = 0; u < KU; u++)
 #pragma unroll
-            for (int a = 0; a < NA; a++) av[u][a] *= mk;
-        }
+            for (int t2 = 0; t2 < 2; t2++) {
+                const d2u y = *(const d2u *)(X + xr[u] * ldx + jb[t2]);
+                bv[u][2 * t2] = y.x; bv[u][2 * t2 + 1] = y.y;
+            }
 #pragma unroll
         for (int u = 0; u < KU; u++)
 #pragma unroll
@@ -963,27 +1009,54 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_gemm_longk(DevSym S, const int 
                 for (int t = 0; t < 4; t++)
                     acc[a][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][a], bv[u][t], acc[a][t], 0, 0, 0);
     }
-    if (NW == 4) splitk_reduce4<NA>(acc, red, wave, lane);
-    else splitk_reduce_nw<NW>(acc[0], red, wave, lane);
-    // X -= acc in two passes (all loads, then all stores: one round trip instead of a chain of 8)
+    if constexpr (NA == 2 && NW == 4) {
+        // wave w owns row tile w >> 1 (own columns i0 + 16 (w >> 1) + lk + 4 rr) x right-hand sides 32 (w & 1) + 2 lm, + 1:
+        // x is read and written 16 bytes per lane (all loads, then all stores)
+        splitk_reduce4_pairs(acc, red, wave, lane);
+        const int a = wave >> 1, hc = wave & 1;
+        const int j = 32 * hc + 2 * lm;
+        d2u xv[4];
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
-        if (t == wave && t < nt) {
-            const int j = t * 16 + lm;
-            const int jcl = min(j, nr - 1);
-            double xv[NA][4];
+        for (int rr = 0; rr < 4; rr++)
+            xv[rr] = *(const d2u *)(Xown + (long long)(first + min(i0 + a * 16 + lk + 4 * rr, c - 1)) * ldx + min(j, nr - 1));
 #pragma unroll
-            for (int a = 0; a < NA; a++)
+        for (int rr = 0; rr < 4; rr++) {
+            const int col = i0 + a * 16 + lk + 4 * rr;
+            if (col < c && j < nr) {
+                double x0 = 0.0, x1 = 0.0;
 #pragma unroll
-                for (int rr = 0; rr < 4; rr++)
-                    xv[a][rr] = Xown[(long long)(first + min(i0 + a * 16 + lk + 4 * rr, c - 1)) * ldx + jcl];
+                for (int aa = 0; aa < 2; aa++)
 #pragma unroll
-            for (int a = 0; a < NA; a++)
+                    for (int h = 0; h < 2; h++)
+                        if (aa == a && h == hc) { x0 = xv[rr].x - acc[aa][2 * h][rr]; x1 = xv[rr].y - acc[aa][2 * h + 1][rr]; }
+                double *dst = Xown + (long long)(first + col) * ldx + j;
+                if (j + 1 < nr) *(d2u *)dst = (d2u){x0, x1};
+                else dst[0] = x0;
+            }
+        }
+    } else {
+        if (NW == 4) splitk_reduce4<NA>(acc, red, wave, lane);
+        else splitk_reduce_nw<NW>(acc[0], red, wave, lane);
+        // X -= acc in two passes (all loads, then all stores: one round trip instead of a chain of 8)
 #pragma unroll
-                for (int rr = 0; rr < 4; rr++) {
-                    const int col = i0 + a * 16 + lk + 4 * rr;
-                    if (col < c && j < nr) Xown[(long long)(first + col) * ldx + j] = xv[a][rr] - acc[a][t][rr];
-                }
+        for (int t = 0; t < 4; t++) {
+            if (t == wave) {
+                const int j = 32 * (t >> 1) + 2 * lm + (t & 1);
+                const int jcl = min(j, nr - 1);
+                double xv[NA][4];
+#pragma unroll
+                for (int a = 0; a < NA; a++)
+#pragma unroll
+                    for (int rr = 0; rr < 4; rr++)
+                        xv[a][rr] = Xown[(long long)(first + min(i0 + a * 16 + lk + 4 * rr, c - 1)) * ldx + jcl];
+#pragma unroll
+                for (int a = 0; a < NA; a++)
+#pragma unroll
+                    for (int rr = 0; rr < 4; rr++) {
+                        const int col = i0 + a * 16 + lk + 4 * rr;
+                        if (col < c && j < nr) Xown[(long long)(first + col) * ldx + j] = xv[a][rr] - acc[a][t][rr];
+                    }
+            }
         }
     }
 }
