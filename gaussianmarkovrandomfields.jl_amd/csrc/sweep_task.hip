@@ -167,8 +167,11 @@ __global__ __launch_bounds__(TASK_THREADS, 1) void k_fwd_task(DevSym S, const Sw
         for (int u = 0; u < 4; u++) xo[u] = tinv_elem(P, m.ld, m.c, kk + lm, 4 * u + lk, true);
 #pragma unroll
         for (int u = 0; u < 4; u++) xt[u] = pa[(long long)min(4 * u + lk, m.c - 1) * m.ld] * ((4 * u + lk) < m.c ? 1.0 : 0.0);
+        {   // the tile's 16 local rows in ONE load (lane l: row i0 + (l & 15)), handed to the lanes that use them
+            const int v = lr[min(i0 + lm, m.r - 1)];
 #pragma unroll
-        for (int rr = 0; rr < 4; rr++) xl[rr] = lr[min(i0 + lk + 4 * rr, m.r - 1)];
+            for (int rr = 0; rr < 4; rr++) xl[rr] = __shfl(v, lk + 4 * rr, 64);
+        }
     };
     request(0, opA_o, opA_t, opA_l);
     auto front = [&](const int f, double (&ao)[4], double (&at)[4], int (&li)[4], double (&no)[4], double (&nt_)[4], int (&nli)[4]) {
@@ -207,8 +210,9 @@ __global__ __launch_bounds__(TASK_THREADS, 1) void k_fwd_task(DevSym S, const Sw
                         for (int u = 0; u < 4; u++) { av[u] = at[u]; l2[u] = li[u]; }
                     } else {
                         const double *pa = P + min(i0 + lm, r - 1);
+                        const int v = lr[min(i0 + lm, r - 1)];
 #pragma unroll
-                        for (int rr = 0; rr < 4; rr++) l2[rr] = lr[min(i0 + lk + 4 * rr, r - 1)];
+                        for (int rr = 0; rr < 4; rr++) l2[rr] = __shfl(v, lk + 4 * rr, 64);
 #pragma unroll
                         for (int u = 0; u < 4; u++) av[u] = pa[(long long)min(4 * u + lk, c - 1) * ld] * ((4 * u + lk) < c ? 1.0 : 0.0);
                     }
@@ -273,8 +277,9 @@ __global__ __launch_bounds__(TASK_THREADS, 1) void k_fwd_task(DevSym S, const Sw
 #pragma unroll
                 for (int u = 0; u < 4; u++) mfma4_lds(acc, at[u], V, o + 4 * u + lk, cl);            // c > 16: rows o .. o+15 exist
             } else {
+                const int v = lr[min(i0 + lm, r - 1)];
 #pragma unroll
-                for (int rr = 0; rr < 4; rr++) l2[rr] = lr[min(i0 + lk + 4 * rr, r - 1)];
+                for (int rr = 0; rr < 4; rr++) l2[rr] = __shfl(v, lk + 4 * rr, 64);
                 double av[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) av[u] = pa[(long long)(4 * u + lk) * ld];
@@ -364,11 +369,19 @@ __global__ __launch_bounds__(TASK_THREADS, 1) void k_bwd_task(DevSym S, const Sw
         const double *P = L + m.pp;
         const int *lr = S.lrow + m.rp;
         const double *pa = P + (long long)min(k0 + lm, m.c - 1) * m.ld;
+        // rows in pairs along k: a lane loads rows q, q + 1 (q = c + 8 h + 2 lk) of its column in one 16-byte load and
+        // feeds k-steps 2 h and 2 h + 1 with them (k-step 2 h + e covers rows c + 8 h + 2 lk + e); the 32 local rows
+        // come in ONE load (lane l: row c + (l & 31)). 5 vector memory instructions instead of 16: the address unit,
+        // ~16 cycles per instruction whatever its lanes do, is what bounds a front here.
+        {
+            const int v = lr[min(m.c + (lane & 31), m.r - 1)];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int qq = min(m.c + 4 * u + lk, m.r - 1);
-            x1[u] = pa[qq];
-            xl[u] = lr[qq];
+            for (int h = 0; h < 4; h++) {
+                const gmrfx_d2u a = *(const gmrfx_d2u *)(pa + min(m.c + 8 * h + 2 * lk, m.r - 1));
+                x1[2 * h] = a.x; x1[2 * h + 1] = a.y;
+                xl[2 * h] = __shfl(v, 8 * h + 2 * lk, 64);
+                xl[2 * h + 1] = __shfl(v, 8 * h + 2 * lk + 1, 64);
+            }
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) xd[u] = tinv_elem(P, m.ld, m.c, k0 + lm, k0 + 4 * u + lk, false);
@@ -387,10 +400,10 @@ __global__ __launch_bounds__(TASK_THREADS, 1) void k_bwd_task(DevSym S, const Sw
             for (int t = 0; t < TPW; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
             if (r > c) {
                 const double *pa = P + (long long)min(k0 + lm, c - 1) * ld;
-                const int kt = (min(r - c, 32) + 3) >> 2;      // k-steps that hold trailing rows (scalar)
 #pragma unroll
-                for (int u = 0; u < 8; u++)
-                    if (u < kt) mfma4_lds(acc, a1[u] * ((c + 4 * u + lk) < r ? 1.0 : 0.0), V, max(l1[u], 0), cl);
+                for (int u = 0; u < 8; u++)         // k-step u = 2 h + e holds rows c + 8 h + 2 lk + e (request())
+                    if (8 * (u >> 1) + (u & 1) < r - c)
+                        mfma4_lds(acc, a1[u] * ((c + 8 * (u >> 1) + 2 * lk + (u & 1)) < r ? 1.0 : 0.0), V, max(l1[u], 0), cl);
 #pragma unroll 1
                 for (int q0 = c + 32; q0 < r; q0 += 16) {      // rare in a task (r - c > 32): one 16-row k-block per pass
                     double av[4];
