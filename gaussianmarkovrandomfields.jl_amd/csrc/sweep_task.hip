@@ -33,7 +33,7 @@ constexpr int TASK_MAXF = 64;        // fronts per task (host enforces)
 constexpr int TASK_THREADS = 1024;   // 16 waves = 4 row-tile slots x 4 column tiles: one wave issues an FP64 MFMA only every ~138 cycles, so
                                      // the MFMAs of a row tile are spread over four waves (on four SIMDs)
 constexpr int TASK_WAVES = TASK_THREADS / 64;
-constexpr int TPW = 1;                           // 16-column tiles of the right-hand sides per wave (measured: 1 beats 2 and 4)
+constexpr int TPW = 1;                           // 16-column tiles of the right-hand sides per wave (measured: 1 at 1024 threads beats 2 at 512 or 1024 and 4 at 256)
 constexpr int TASK_SLOTS = TASK_WAVES * TPW / 4; // row-tile slots
 
 // V is stored row-major with 64 columns; the 16-column tiles of odd rows are swapped pairwise so that the two
