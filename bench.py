@@ -150,6 +150,8 @@ def main():
                     help="multi-process rehearsal on a box with ONE GPU: every rank uses cuda:0 and the "
                          "process group runs on gloo (RCCL refuses two ranks on one device)")
     ap.add_argument("--extras", action="store_true", help="also time selinv-diag and 256-sample rand (cfg 3)")
+    ap.add_argument("--shard-timeout", type=float, default=300.0,
+                    help="N > 1: seconds the sharded strong-scaling run may take before the replica line is printed without it")
     ap.add_argument("--no-shard", action="store_true",
                     help="N > 1: only time the independent replicas (weak scaling); by default the headline of an N > 1 run is "
                          "ONE factorisation sharded over the N GPUs (strong scaling, gmrfx/shard.py) and the replicas are reported beside it")
@@ -239,13 +241,6 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-
-    sharded = None
-    if dist is not None and not args.no_shard:
-        try:
-            sharded = bench_sharded(args, Q, mesh, dist, rank, world, local_rank)
-        except Exception as e:           # the replica line must survive a failure of the sharded path
-            sharded = {"error": repr(e)} if rank == 0 else None
 
     # hyper-parameter loop (docs/.../workspace_factorization_reuse.jl:94-102): new values -> numeric
     # factorisation -> logpdf(z) = -r'Qr/2 + logdet(Q)/2 - n log(2 pi)/2, Q's values and z resident in HBM.
@@ -416,6 +411,32 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(Q, mesh, args.nrhs)
+
+    # ---- N > 1: ONE factorisation sharded over the ranks (the headline of a multi-GPU run), LAST and under a watchdog:
+    # the replica line above is complete by now, and an exchange that never completes (the sharded path has not run on
+    # a multi-GPU node yet) must not take it down. Every rank arms the same timer at the same barrier; when it fires,
+    # rank 0 prints the replica line with the failure recorded and all ranks leave.
+    sharded = None
+    printed = [False]
+    if dist is not None and not args.no_shard:
+        import threading
+        dist.barrier()
+
+        def give_up():
+            if rank == 0 and not printed[0]:
+                out["sharded"] = {"error": f"the sharded run did not finish within {args.shard_timeout} s"}
+                out["replicas"] = {"value": out["value"], "ms_per_step": out["ms_per_step"], "scaling": "weak"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(args.shard_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            sharded = bench_sharded(args, Q, mesh, dist, rank, world, local_rank)
+        except Exception as e:           # the replica line must survive a failure of the sharded path
+            sharded = {"error": repr(e)} if rank == 0 else None
+
+    if rank == 0:
         if world > 1:
             replicas = {"value": out["value"], "ms_per_step": out["ms_per_step"], "scaling": "weak",
                         "note": "one independent workspace per GPU (the reference's WorkspacePool pattern), no data-path collective"}
@@ -429,9 +450,10 @@ def main():
             else:
                 out["sharded"] = sharded
             out["replicas"] = replicas
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+        printed[0] = True
     if dist is not None:
-        dist.barrier()
+        dist.barrier()          # (still under the watchdog: a rank that failed alone would wait here for ever)
         dist.destroy_process_group()
 
 
