@@ -131,6 +131,18 @@ void Device::upload(const Symbolic &S) {
         up(ip, qs); ds_.qsrc = ip;
         up(ip, qd); ds_.qdst = ip;
         up(ip, qc); ds_.qcol = ip;
+        // entries are sorted by column inside a front: one pointer per column of L replaces a search per panel column
+        std::vector<int> qcp((size_t)S.n + 1);
+        for (i32 s = 0; s < ns; s++) {
+            i64 q = S.qptr[s];
+            for (i32 tc = 0; tc < S.ncols(s); tc++) {
+                qcp[(size_t)S.sfirst[s] + tc] = (int)q;
+                while (q < S.qptr[s + 1] && qc[q] == tc) q++;
+            }
+            if (q != S.qptr[s + 1]) throw std::runtime_error("scatter map of a front is not sorted by column");
+        }
+        qcp[(size_t)S.n] = (int)S.qptr[ns];
+        up(ip, qcp); ds_.qcolptr = ip;
         HC(hipStreamSynchronize(stream));
     }
     {
@@ -145,6 +157,7 @@ void Device::upload(const Symbolic &S) {
         for (i32 s = 0; s < ns; s++) wptr[s + 1] = wptr[s] + (S.nrows(s) - S.ncols(s));
         std::vector<EdgeRec> edges(S.children.size());
         std::vector<int> etile;
+        std::vector<int> erow;
         for (i32 p = 0; p < ns; p++) {
             const int cp = S.ncols(p), mp = S.nrows(p) - cp, nT = (mp + 31) / 32;
             for (i64 ch = S.childptr[p]; ch < S.childptr[p + 1]; ch++) {
@@ -152,7 +165,7 @@ void Device::upload(const Symbolic &S) {
                 const int cd = S.ncols(d), md = S.nrows(d) - cd;
                 const i64 reloff = S.rowptr[d] + cd;
                 if (etile.size() + (size_t)nT + 1 >= (size_t)INT_MAX) throw std::runtime_error("edge tile table too large");
-                EdgeRec e{d, md, (int)etile.size(), 0, (long long)reloff, wptr[d], (long long)S.cbptr[d]};
+                EdgeRec e{d, md, (int)etile.size(), 0, (long long)reloff, wptr[d], (long long)S.cbptr[d], (long long)erow.size()};
                 int a = 0;
                 for (int T = 0; T <= nT; T++) {
                     const int key = cp + 32 * T;
@@ -160,12 +173,16 @@ void Device::upload(const Symbolic &S) {
                     etile.push_back(a);
                 }
                 e.nown = etile[e.tptr];
+                erow.resize(erow.size() + (size_t)cp, -1);      // which child row lands in own column tc of the parent
+                for (int a2 = 0; a2 < e.nown; a2++) erow[(size_t)e.eoff + (size_t)S.rel[reloff + a2]] = a2;
                 edges[ch] = e;
             }
         }
         const EdgeRec *ep; up(ep, edges); ds_.edge = ep;
         if (etile.empty()) etile.push_back(0);
         up(ip, etile); ds_.etile = ip;
+        if (erow.empty()) erow.push_back(-1);
+        up(ip, erow); ds_.erow = ip;
         HC(hipStreamSynchronize(stream));
         h_edges_.swap(edges);      // read once more by the tile records of the contribution-block SYRK (init)
         h_etile_.swap(etile);

@@ -19,6 +19,7 @@ struct EdgeRec {
     long long reloff;  // offset of the child's trailing rows in DevSym::rel
     long long woff;    // DevSym::wptr[d]
     long long cboff;   // DevSym::cbptr[d]
+    long long eoff;    // offset of this edge's column table in DevSym::erow
 };
 
 // Pointers to the symbolic structure in HBM; passed to kernels by value.
@@ -39,6 +40,9 @@ struct DevSym {
     const int *qdst;            // destination ROW inside the panel column qcol (entries sorted by column, then row)
     const int *qcol;            // front-local destination column (row / column kept apart: a panel may hold more
                                 // than 2^31 entries -- the 47 000-column root of a 126^3-node 3-D mesh)
+    const int *qcolptr;         // n+1: first entry (index into qsrc / qdst) of every column of L, in elimination order
+    const int *erow;            // per child edge, per own column tc of the parent (EdgeRec::eoff + tc): the child's trailing
+                                // row that maps to that column, or -1 -- the panel assembly looks up, it does not search
     const long long *wptr;      // nsuper+1: prefix sum of trailing rows (r-c)
     const long long *diagoff;   // n
     const int *perm;            // n

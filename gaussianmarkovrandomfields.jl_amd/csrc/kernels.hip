@@ -73,29 +73,24 @@ __global__ __launch_bounds__(256) void k_assemble(DevSym S, const int *__restric
     const int c = S.sfirst[s + 1] - S.sfirst[s];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tl = WIDE ? (int)threadIdx.x : lane;
-    const int tc = WIDE ? (int)blockIdx.x : blockIdx.x * ASM_CW + wave;
+    const int tc = WIDE ? (int)blockIdx.x : blockIdx.x * ASM_CW + __builtin_amdgcn_readfirstlane(wave);
     if (tc >= c) return;
     const int ld = S.ld[s];
     double *Pc = L + S.panelptr[s] + (long long)tc * ld;
     for (int i = 2 * tl; i < ld; i += 2 * NL) *(d2u *)(Pc + i) = (d2u){0.0, 0.0};      // ld is even
     if (WIDE) __syncthreads();
-    {
-        const long long q0 = S.qptr[s];
-        const int nq = (int)(S.qptr[s + 1] - q0);
-        const int *qd = S.qdst + q0;
-        const int *qs = S.qsrc + q0;
-        int lo, hi;
-        wave_lower_bound2(S.qcol + q0, nq, tc, tc + 1, lane, lo, hi);
-        for (int q = lo + tl; q < hi; q += NL) Pc[qd[q]] = nzval[qs[q]];
+    {   // Q's entries of this column: [qcolptr[k], qcolptr[k + 1]) for column k of L (no search)
+        const int gk = S.sfirst[s] + tc;
+        const int lo = S.qcolptr[gk], hi = S.qcolptr[gk + 1];
+        for (int q = lo + tl; q < hi; q += NL) Pc[S.qdst[q]] = nzval[S.qsrc[q]];
     }
     if (WIDE) __syncthreads();
     for (long long ch = S.childptr[s]; ch < S.childptr[s + 1]; ch++) {
         const EdgeRec er = S.edge[ch];
         const int md = er.md;
         const int *reld = S.rel + er.reloff;
-        int j, j1;
-        wave_lower_bound2(reld, er.nown, tc, tc + 1, lane, j, j1);   // only rows mapped into own columns
-        if (j1 == j) continue;                    // this child has no row mapped to column tc (workgroup-uniform)
+        const int j = S.erow[er.eoff + tc];       // the child's row that maps to column tc (table, no search)
+        if (j < 0) continue;                      // none (workgroup-uniform)
         const double *Uc = CB + er.cboff + (long long)j * md;
         // four independent row chunks in flight per lane (rel -> P read-modify-write chain; row pairs per lane as in
         // k_assemble_lds were measured slower here: the scattered read-modify-write of P is the long pole, not the loads)
@@ -1195,28 +1190,23 @@ __global__ __launch_bounds__(256) void k_assemble_lds(DevSym S, const int *__res
     const int s = list[blockIdx.y];
     const int c = S.sfirst[s + 1] - S.sfirst[s];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tc = blockIdx.x * ASM_CW + wave;
+    const int tc = blockIdx.x * ASM_CW + __builtin_amdgcn_readfirstlane(wave);
     if (tc >= c) return;
     const int ld = S.ld[s];
     double *Cw = col_lds + wave * ldmax;
     double *Pc = L + S.panelptr[s] + (long long)tc * ld;
     for (int i = lane; i < ld; i += 64) Cw[i] = 0.0;
-    {
-        const long long q0 = S.qptr[s];
-        const int nq = (int)(S.qptr[s + 1] - q0);
-        const int *qd = S.qdst + q0;
-        const int *qs = S.qsrc + q0;
-        int lo, hi;
-        wave_lower_bound2(S.qcol + q0, nq, tc, tc + 1, lane, lo, hi);
-        for (int q = lo + lane; q < hi; q += 64) Cw[qd[q]] = nzval[qs[q]];
+    {   // Q's entries of this column: [qcolptr[k], qcolptr[k + 1]) for column k of L (no search)
+        const int gk = S.sfirst[s] + tc;
+        const int lo = S.qcolptr[gk], hi = S.qcolptr[gk + 1];
+        for (int q = lo + lane; q < hi; q += 64) Cw[S.qdst[q]] = nzval[S.qsrc[q]];
     }
     for (long long ch = S.childptr[s]; ch < S.childptr[s + 1]; ch++) {
         const EdgeRec er = S.edge[ch];
         const int md = er.md;
         const int *reld = S.rel + er.reloff;
-        int j, j1;
-        wave_lower_bound2(reld, er.nown, tc, tc + 1, lane, j, j1);   // only rows mapped into own columns
-        if (j1 == j) continue;                    // this child has no row mapped to column tc
+        const int j = S.erow[er.eoff + tc];       // the child's row that maps to column tc (table, no search)
+        if (j < 0) continue;                      // none
         const double *Uc = CB + er.cboff + (long long)j * md;
         // Rows in PAIRS per lane (one 16-byte value load + one 8-byte index load cover 128 rows of the column), four
         // chunks in flight, and chunks past the end of the child's column issue nothing: the kernel is bound by the
