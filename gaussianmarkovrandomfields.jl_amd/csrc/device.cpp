@@ -633,7 +633,7 @@ void Device::forward(int nr, int ldx, int lo, int hi) {
             launch_fwd_small(stream, ds_, d_sw_levellist_ + L.first + off, L.ncls[k], kClsRows[k], d_L_, d_X_, d_W_, nr, ldx);
         const int *list = d_sw_levellist_ + L.first + L.nsmall;
         const int nf = L.count - L.nsmall;
-        launch_fwd_assemble(stream, ds_, list, nf, L.max_cols, d_X_, d_W_, nr, ldx, 1);   // own rows only
+        launch_fwd_assemble(stream, ds_, list, nf, L.max_cols, d_X_, d_W_, nr, ldx);   // own rows only
         // y = L11^-1 b as one triangular product per front (dense inverse, inverse.hip), then the
         // trailing update W -= L21 y with K = all columns of the front
         // y of the big fronts stays in X2 (no copy back): the update below and the backward sweep read it there

@@ -647,59 +647,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
 // Triangular sweeps, X row-major (ldx doubles per row), nr <= 64 right-hand sides per pass
 // ------------------------------------------------------------------------------------------
 
-// Forward: add the children's update vectors into this front's own rows of X and into W_s.
+// Forward: add the children's update vectors into this front's OWN rows of X (the trailing rows, W_s, are assembled
+// inside k_fwd_update_longk and written once). A workgroup owns FWD_RB own rows x 64 right-hand sides; which row of a
+// child lands in own row tc comes from the per-edge table DevSym::erow (no search), the rows of X are read once,
+// receive the children one after the other (fixed order) in registers and are written once.
 __global__ __launch_bounds__(256) void k_fwd_assemble(DevSym S, const int *__restrict__ list, double *__restrict__ X,
-                                                      double *__restrict__ W, int nr, int ldx, int own_only) {
+                                                      const double *__restrict__ W, int nr, int ldx) {
     const int s = list[blockIdx.y];
     const int c = S.sfirst[s + 1] - S.sfirst[s];
-    const int r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
     const int i0 = blockIdx.x * FWD_RB;
-    // own_only: the trailing rows (W_s) are assembled inside k_fwd_update_longk, written once
-    const int rlim = own_only ? c : r;
-    if (i0 >= rlim) return;
-    const int i1 = min(i0 + FWD_RB, rlim);
+    if (i0 >= c) return;
+    const long long ch0 = S.childptr[s], ch1 = S.childptr[s + 1];
+    if (ch0 == ch1) return;
     const int first = S.sfirst[s];
-    double *Ws = W + S.wptr[s] * ldx;
-    const int tid = threadIdx.x;
-    if (!own_only) {
-        const int a = max(i0, c);
-        const int cnt = (i1 - a) * nr;
-        for (int idx = tid; idx < cnt; idx += 256) {
-            const int i = a + idx / nr, j = idx % nr;
-            Ws[(long long)(i - c) * ldx + j] = 0.0;
-        }
-    }
-    __syncthreads();
-    for (long long ch = S.childptr[s]; ch < S.childptr[s + 1]; ch++) {
+    const int j = threadIdx.x & 63, g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (j >= nr) return;
+    constexpr int NU = FWD_RB / 4;                       // rows per thread: i0 + g + 4 u
+    double x[NU];
+#pragma unroll
+    for (int u = 0; u < NU; u++) x[u] = X[(long long)(first + min(i0 + g + 4 * u, c - 1)) * ldx + j];
+    for (long long ch = ch0; ch < ch1; ch++) {
         const EdgeRec er = S.edge[ch];
-        const int md = er.md;
-        const int *reld = S.rel + er.reloff;
+        const int *er_row = S.erow + er.eoff;
         const double *Wd = W + er.woff * ldx;
-        int a0, a1;
-        wave_lower_bound2(reld, md, i0, i1, (int)(threadIdx.x & 63), a0, a1);
-        const int cnt = (a1 - a0) * nr;    // <= FWD_RB * 64 = 8 entries per thread, loads batched
-        int tiv[8];
-        double v[8], xv[8];
-        double *dst[8];
+        int jr[NU];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int idx = min(tid + 256 * u, max(cnt - 1, 0));
-            const int a = min(a0 + idx / nr, md - 1), j = idx % nr;
-            tiv[u] = reld[a];
-            v[u] = Wd[(long long)a * ldx + j];
-        }
+        for (int u = 0; u < NU; u++) jr[u] = er_row[min(i0 + g + 4 * u, c - 1)];      // wave-uniform
+        double v[NU];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int idx = min(tid + 256 * u, max(cnt - 1, 0));
-            const int j = idx % nr;
-            dst[u] = tiv[u] < c ? X + (long long)(first + tiv[u]) * ldx + j : Ws + (long long)(tiv[u] - c) * ldx + j;
-            xv[u] = *dst[u];
-        }
+        for (int u = 0; u < NU; u++) v[u] = jr[u] >= 0 ? Wd[(long long)jr[u] * ldx + j] : 0.0;
 #pragma unroll
-        for (int u = 0; u < 8; u++)
-            if (tid + 256 * u < cnt) *dst[u] = xv[u] + v[u];
-        __syncthreads();
+        for (int u = 0; u < NU; u++) x[u] += v[u];
     }
+#pragma unroll
+    for (int u = 0; u < NU; u++)
+        if (i0 + g + 4 * u < c) X[(long long)(first + i0 + g + 4 * u) * ldx + j] = x[u];
 }
 
 // Forward update of a big front after y = L11^-1 b: W_s = (children) - L21 y with K = all c columns.
@@ -1292,10 +1274,10 @@ void launch_gemm_nt(hipStream_t st, const DevSym &S, const int *list, int nactiv
     else
         hipLaunchKernelGGL(k_gemm_nt<2>, dim3(odd(cdiv(maxM, 64)), odd(cdiv(maxN, 64)), nactive), dim3(256), 0, st, S, list, k0, K, c0, c1, L, fa);
 }
-void launch_fwd_assemble(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_rows, double *X,
-                         double *W, int nr, int ldx, int own_only) {
-    if (nfronts <= 0 || max_rows <= 0) return;
-    hipLaunchKernelGGL(k_fwd_assemble, dim3(odd(cdiv(max_rows, FWD_RB)), nfronts), dim3(256), 0, st, S, list, X, W, nr, ldx, own_only);
+void launch_fwd_assemble(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, double *X,
+                         const double *W, int nr, int ldx) {
+    if (nfronts <= 0 || max_cols <= 0) return;
+    hipLaunchKernelGGL(k_fwd_assemble, dim3(odd(cdiv(max_cols, FWD_RB)), nfronts), dim3(256), 0, st, S, list, X, W, nr, ldx);
 }
 void launch_fwd_update(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_trail, const double *L,
                        double *X, double *W, int nr, int ldx) {
