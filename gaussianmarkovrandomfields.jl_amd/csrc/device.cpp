@@ -150,6 +150,7 @@ void Device::upload(const Symbolic &S) {
         for (i32 s = 0; s < ns; s++) wptr[s + 1] = wptr[s] + (S.nrows(s) - S.ncols(s));
         sum_trail_ = wptr[ns];
         up(lp, wptr); ds_.wptr = lp;
+        h_wptr_ = wptr;
         HC(hipStreamSynchronize(stream));
     }
     {
@@ -382,6 +383,49 @@ void Device::upload(const Symbolic &S) {
         if (recs.empty()) recs.push_back(SyrkTile{});
         const SyrkTile *rp; up(rp, recs); d_syrk_recs_ = const_cast<SyrkTile *>(rp);
         HC(hipStreamSynchronize(stream));
+        // forward update: one record per 32-row tile of the trailing rows of every big front of the SWEEP levels, front
+        // by front, cut into 8 runs of equal cost (a front's tiles share its y and its children's update vectors)
+        std::vector<FwdTile> ft;
+        for (i32 l = 0; l < S.nlevels; l++) {
+            LevelInfo &L = swlevels_[l];
+            cost.clear();
+            L.fwd_off = (long long)ft.size();
+            for (int k = L.nsmall; syrk_xcd_ && k < L.count; k++) {
+                const i32 s = S.sw_levellist[L.first + k];
+                const int c = S.ncols(s), r = S.nrows(s), m = r - c;
+                const i64 ch0 = S.childptr[s];
+                const int nch = (int)(S.childptr[s + 1] - ch0);
+                for (int T = 0; T * 32 < m; T++) {
+                    FwdTile t{};
+                    t.pp = (long long)S.panelptr[s]; t.xoff = S.sfirst[s]; t.woff = h_wptr_[s]; t.ch0 = (long long)ch0;
+                    t.c = c; t.r = r; t.ld = (int)S.ld[s]; t.i0 = c + 32 * T; t.nch = nch; t.tile = T;
+                    for (int q = 0; q < std::min(nch, 2); q++) {
+                        const EdgeRec &e = h_edges_[ch0 + q];
+                        t.md[q] = e.md; t.reloff[q] = e.reloff; t.cwoff[q] = e.woff;
+                        t.a0[q] = h_etile_[(size_t)e.tptr + T]; t.a1[q] = h_etile_[(size_t)e.tptr + T + 1];
+                    }
+                    ft.push_back(t);
+                    cost.push_back((double)(c + 64));
+                }
+            }
+            const size_t nt = cost.size();
+            if (nt >= (size_t)INT_MAX / 8) throw std::runtime_error("too many update-vector tiles in one level");
+            double tot = 0, acc = 0;
+            for (size_t t = 0; t < nt; t++) tot += cost[t];
+            int x = 0;
+            L.fwd_split.start[0] = 0;
+            for (size_t t = 0; t < nt; t++) {
+                while (x < 7 && acc >= tot * (x + 1) / 8) L.fwd_split.start[++x] = (int)t;
+                acc += cost[t];
+            }
+            while (x < 8) L.fwd_split.start[++x] = (int)nt;
+            L.fwd_per = 0;
+            for (int q = 0; q < 8; q++) L.fwd_per = std::max(L.fwd_per, L.fwd_split.start[q + 1] - L.fwd_split.start[q]);
+        }
+        if (ft.empty()) ft.push_back(FwdTile{});
+        const FwdTile *fp; up(fp, ft); d_fwd_recs_ = const_cast<FwdTile *>(fp);
+        HC(hipStreamSynchronize(stream));
+        std::vector<long long>().swap(h_wptr_);
         std::vector<EdgeRec>().swap(h_edges_);
         std::vector<int>().swap(h_etile_);
     }
@@ -644,7 +688,11 @@ void Device::forward(int nr, int ldx, int lo, int hi) {
             launch_xmul(stream, ds_, list, na, L.max_cols, 0, d_L_, d_X_, d_X2_, nr, ldx, j, inv_cap_);
             if (j + 1 < nbk) launch_fwd_own_update(stream, ds_, list, L.active[(size_t)(j + 1) * inv_cap_ / NB], L.max_cols, d_L_, d_X2_, d_X_, nr, ldx, j, inv_cap_);
         }
-        launch_fwd_update(stream, ds_, list, nf, level_max_trail(L), d_L_, d_X2_, d_W_, nr, ldx);
+        // levels with many tiles: record-driven, per-XCD runs; the handful-of-fronts levels keep the 16-row latency variant
+        if (syrk_xcd_ && (long long)((level_max_trail(L) + 31) / 32) * nf > 128)
+            launch_fwd_update_recs(stream, ds_, d_fwd_recs_ + L.fwd_off, L.fwd_split, L.fwd_per, d_L_, d_X2_, d_W_, nr, ldx);
+        else
+            launch_fwd_update(stream, ds_, list, nf, level_max_trail(L), d_L_, d_X2_, d_W_, nr, ldx);
     }
 }
 

@@ -84,6 +84,20 @@ struct SyrkTile {
 };
 static_assert(sizeof(SyrkTile) == 128, "SyrkTile is one 128-byte record");
 
+// The same idea for the forward update of a big front (k_fwd_update_rec): one record per 32-row tile of the trailing rows.
+struct FwdTile {
+    long long pp;            // offset of the front's panel in the factor storage
+    long long xoff;          // first own row of the front in X (= sfirst)
+    long long woff;          // first row of the front's update vector in W (= wptr)
+    long long ch0;           // first child edge (children beyond the second go the long way)
+    int c, r, ld, i0;        // columns, rows, leading dimension, first front row of the tile (>= c)
+    int nch, tile;           // number of children, 32-row tile index (for the long way)
+    int md[2], a0[2], a1[2]; // first two children: trailing rows, and the rows [a0, a1) that fall into this tile
+    int pad[4];
+    long long reloff[2], cwoff[2];   // their relative-row lists and update vectors
+};
+static_assert(sizeof(FwdTile) == 128, "FwdTile is one 128-byte record");
+
 struct LevelInfo {
     int first;        // offset into levellist
     int count;        // fronts in level
@@ -96,6 +110,10 @@ struct LevelInfo {
     long long syrk_off = 0;   // offset of the level's tiles in Device::d_syrk_recs_
     SyrkSplit syrk_split{};   // run of XCD x = [start[x], start[x + 1])
     int syrk_per = 0;         // longest run: the grid is 8 * syrk_per workgroups
+    // forward update (sweep levels only): 32-row tiles of the trailing rows, same per-XCD hand-out
+    long long fwd_off = 0;
+    SyrkSplit fwd_split{};
+    int fwd_per = 0;
 };
 
 class Device {
@@ -189,9 +207,11 @@ private:
     const long long *d_zbptr_ = nullptr;   // arena offsets of the trailing inverse blocks (Symbolic::zbptr)
     const int *d_iperm_ = nullptr;   // inverse permutation (original row -> position), used by the RHS transposes
     int *d_levellist_ = nullptr;
+    FwdTile *d_fwd_recs_ = nullptr;     // one record per 32-row tile of every big front's update vector (sweep levels)
     SyrkTile *d_syrk_recs_ = nullptr;   // one record per contribution-block tile, level by level, in hand-out order
     std::vector<EdgeRec> h_edges_;      // host copies of the edge records / tile tables between upload() and init()
     std::vector<int> h_etile_;
+    std::vector<long long> h_wptr_;
     bool syrk_xcd_ = true;          // GMRFX_SYRK_XCD=0: k_syrk_cb on a plain 3-D grid (front, tile row, tile column) instead
     int *d_levellist2_ = nullptr;   // per level: the big fronts re-ordered [even positions..., odd positions...] (two-stream panel chains)
     bool two_chains_ = true;

@@ -27,6 +27,8 @@ void launch_trsm(hipStream_t st, const DevSym &S, const int *list, int nactive, 
                  double *L, double *Yh, const long long *yoff, const FrontArg &fa);
 void launch_gemm_nt(hipStream_t st, const DevSym &S, const int *list, int nactive, int k0, int K, int c0, int c1,
                     int maxM, int maxN, double *L, const FrontArg &fa);
+void launch_fwd_update_recs(hipStream_t st, const DevSym &S, const FwdTile *recs, const SyrkSplit &split, int per_xcd, const double *L,
+                            double *X, double *W, int nr, int ldx);
 void launch_fwd_assemble(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, double *X,
                          const double *W, int nr, int ldx);
 void launch_fwd_update(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_trail, const double *L,

@@ -831,6 +831,126 @@ __global__ __launch_bounds__(256) void k_fwd_update_longk(DevSym S, const int *_
     }
 }
 
+// The same update driven by one 128-byte record per 32-row tile (FwdTile, device.h), handed out in one contiguous run per
+// XCD like the contribution-block tiles: a tile of a mid-level front is a chain of round trips (front -> geometry ->
+// edge records -> tile ranges -> entries -> k-batches), not arithmetic. Here the record arrives in one scalar load, the
+// first k-batch and the first child's entries are requested right behind it. Same sums in the same order as
+// k_fwd_update_longk<2>.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k_fwd_update_rec(DevSym S, const FwdTile *__restrict__ recs, const SyrkSplit split,
+                                                        const double *__restrict__ L, const double *__restrict__ X,
+                                                        double *__restrict__ W, int nr, int ldx) {
+    __shared__ double red[3 * 16 * 64];
+    __shared__ double Tl[32 * 64];   // children's contributions to this tile of W_s
+    const int xcd = blockIdx.x & 7;
+    const int tix = split.start[xcd] + (int)(blockIdx.x >> 3);
+    if (tix >= split.start[xcd + 1]) return;
+    const FwdTile T = recs[tix];
+    const int c = T.c, r = T.r, ld = T.ld, i0 = T.i0;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lm = lane & 15, lk = lane >> 4;
+    const double *P = L + T.pp;
+    const double *Yb = X + T.xoff * ldx;
+    double *Ws = W + T.woff * ldx;
+    // ---- first k-batch of this wave (rows / right-hand sides in pairs, see k_fwd_update_longk)
+    const double *pa = P + min(i0 + 2 * lm, r - 1);
+    const int jb[2] = {min(2 * lm, nr - 1), min(32 + 2 * lm, nr - 1)};
+    constexpr int KU = 4;
+    double av[KU][2], bv[KU][4];
+    auto request = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < KU; u++) {
+            const int kc = min(k0 + 4 * u + lk, c - 1);
+            const d2u x = *(const d2u *)(pa + (long long)kc * ld);
+            av[u][0] = x.x; av[u][1] = x.y;
+#pragma unroll
+            for (int t2 = 0; t2 < 2; t2++) {
+                const d2u y = *(const d2u *)(Yb + (long long)kc * ldx + jb[t2]);
+                bv[u][2 * t2] = y.x; bv[u][2 * t2 + 1] = y.y;
+            }
+        }
+    };
+    const int kfirst = wave * 4 * KU;
+    if (kfirst < c) request(kfirst);
+    // ---- the children's update vectors for these rows, gathered into LDS in child order
+    const int j = lane, g = __builtin_amdgcn_readfirstlane(wave);
+    const int jcl = min(j, nr - 1);
+    const double jm = j < nr ? 1.0 : 0.0;
+    int rt;
+    double wv[8];
+    auto fetch = [&](const int *reld, const double *Wd, int md, int a0, int a1) {
+        rt = reld[min(a0 + j, md - 1)];
+        const int na = a1 - a0 - g;                 // this wave's rows: a0 + g + 4 u < a1  <=>  4 u < na
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (4 * u < na) wv[u] = Wd[(long long)(a0 + g + 4 * u) * ldx + jcl];
+    };
+    auto add = [&](int a0, int a1) {
+        const int na = a1 - a0 - g;
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (4 * u < na) {
+                const int tr = __builtin_amdgcn_readlane(rt, g + 4 * u);
+                if (tr >= i0 && tr < i0 + 32) Tl[(tr - i0) * 64 + j] += wv[u] * jm;
+            }
+    };
+    if (T.nch > 0) fetch(S.rel + T.reloff[0], W + T.cwoff[0] * ldx, T.md[0], T.a0[0], T.a1[0]);
+    for (int i = g; i < 32; i += 4) Tl[i * 64 + j] = 0.0;
+    __syncthreads();
+    if (T.nch > 0) {
+        add(T.a0[0], T.a1[0]);
+        __syncthreads();
+    }
+    if (T.nch > 1) {
+        fetch(S.rel + T.reloff[1], W + T.cwoff[1] * ldx, T.md[1], T.a0[1], T.a1[1]);
+        add(T.a0[1], T.a1[1]);
+        __syncthreads();
+    }
+    for (long long cb = T.ch0 + 2; cb < T.ch0 + T.nch; cb++) {      // further children: the long way
+        const EdgeRec er = S.edge[cb];
+        const int a0 = S.etile[er.tptr + T.tile], a1 = S.etile[er.tptr + T.tile + 1];
+        fetch(S.rel + er.reloff, W + er.woff * ldx, er.md, a0, a1);
+        add(a0, a1);
+        __syncthreads();
+    }
+    d4 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc[a][t] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int k0 = kfirst; k0 < c; k0 += 16 * KU) {
+        if (k0 > kfirst) request(k0);
+#pragma unroll
+        for (int u = 0; u < KU; u++) {
+            const double mk = (k0 + 4 * u + lk) < c ? 1.0 : 0.0;
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    acc[a][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][a] * mk, bv[u][t], acc[a][t], 0, 0, 0);
+        }
+    }
+    // wave w owns row tile w >> 1 (rows i0 + 2 (lk + 4 rr) + (w >> 1)) x right-hand sides 32 (w & 1) + 2 lm, + 1
+    splitk_reduce4_pairs(acc, red, wave, lane);
+    const int a = wave >> 1, hc = wave & 1;
+    const int jj = 32 * hc + 2 * lm;
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {
+        const int i = i0 + 2 * (lk + 4 * rr) + a;
+        if (i < r && jj < nr) {
+            double *dst = Ws + (long long)(i - c) * ldx + jj;
+            const double *tl = Tl + (i - i0) * 64 + jj;
+            double x0 = 0.0, x1 = 0.0;
+#pragma unroll
+            for (int aa = 0; aa < 2; aa++)
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+                    if (aa == a && h == hc) { x0 = tl[0] - acc[aa][2 * h][rr]; x1 = tl[1] - acc[aa][2 * h + 1][rr]; }
+            if (jj + 1 < nr) *(d2u *)dst = (d2u){x0, x1};
+            else dst[0] = x0;
+        }
+    }
+}
+
 // Blocked forward substitution inside a front wider than `cap` columns: after y_blk = X_blk b_blk, the own rows
 // below the block get  b[i] -= sum_{q in block} L[i][q] y[q].  A workgroup owns 32 rows x 64 right-hand sides,
 // its four waves split the K range (the block's columns); the partial tiles are summed through LDS.
@@ -1286,6 +1406,11 @@ void launch_fwd_update(hipStream_t st, const DevSym &S, const int *list, int nfr
         hipLaunchKernelGGL(k_fwd_update_longk<1>, dim3(odd(cdiv(max_trail, 16)), nfronts), dim3(256), 0, st, S, list, L, X, W, nr, ldx);
     else
         hipLaunchKernelGGL(k_fwd_update_longk<2>, dim3(odd(cdiv(max_trail, 32)), nfronts), dim3(256), 0, st, S, list, L, X, W, nr, ldx);
+}
+void launch_fwd_update_recs(hipStream_t st, const DevSym &S, const FwdTile *recs, const SyrkSplit &split, int per_xcd, const double *L,
+                            double *X, double *W, int nr, int ldx) {
+    if (per_xcd <= 0) return;
+    hipLaunchKernelGGL(k_fwd_update_rec, dim3(8 * (unsigned)per_xcd), dim3(256), 0, st, S, recs, split, L, X, W, nr, ldx);
 }
 void launch_bwd_gemm(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, const double *L,
                      const double *X, double *Xown, int nr, int ldx, int blk, int cap) {
