@@ -1417,7 +1417,8 @@ void launch_bwd_gemm(hipStream_t st, const DevSym &S, const int *list, int nfron
     if (nfronts <= 0 || max_cols <= 0) return;
     if (blk >= 0) max_cols = std::min(max_cols - blk * cap, cap);
     if (max_cols <= 0) return;
-    if ((long long)cdiv(max_cols, 32) * nfronts <= 128)
+    // the 8-wave, 16-column variant up to ~3 workgroups per CU (measured: 512-1024 beats 128 and 2048)
+    if ((long long)cdiv(max_cols, 32) * nfronts <= 768)
         hipLaunchKernelGGL((k_bwd_gemm_longk<1, 8>), dim3(odd(cdiv(max_cols, 16)), nfronts), dim3(512), 0, st, S, list, L, X, Xown, nr, ldx, blk, cap);
     else
         hipLaunchKernelGGL((k_bwd_gemm_longk<2, 4>), dim3(odd(cdiv(max_cols, 32)), nfronts), dim3(256), 0, st, S, list, L, X, Xown, nr, ldx, blk, cap);
