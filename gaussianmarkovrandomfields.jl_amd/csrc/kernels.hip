@@ -1177,20 +1177,35 @@ __global__ __launch_bounds__(256) void k_permute(const int *__restrict__ iperm, 
     const int tid = threadIdx.x;
     const int a = tid & 63, b = tid >> 6;
     if (tid < 64) rowL[tid] = (i0 + tid < n) ? (iperm ? iperm[i0 + tid] : i0 + tid) : 0;
+    // all 16 loads of a thread are issued before the first use (clamped addresses, predicated stores): the kernel only
+    // moves bytes, and a load -> LDS store -> load chain leaves 15 of every 16 round trips idle
+    double v[16];
     if (dir == 0) {
-        const int i = i0 + a;
-        for (int j = b; j < nr; j += 4) T[a * 65 + j] = (i < n) ? Bc[i + (long long)j * ldb] : 0.0;
+        const int i = i0 + a, ic = min(i, n - 1);
+#pragma unroll
+        for (int u = 0; u < 16; u++) v[u] = Bc[ic + (long long)min(b + 4 * u, nr - 1) * ldb];
+#pragma unroll
+        for (int u = 0; u < 16; u++) T[a * 65 + b + 4 * u] = v[u];
         __syncthreads();
-        for (int kk = b; kk < 64; kk += 4)
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const int kk = b + 4 * u;
             if (i0 + kk < n && a < nr) X[(long long)rowL[kk] * ldx + a] = T[kk * 65 + a];
+        }
     } else {
         __syncthreads();
-        for (int kk = b; kk < 64; kk += 4)
-            if (i0 + kk < n && a < nr) T[kk * 65 + a] = X[(long long)rowL[kk] * ldx + a];
+        const int ac = min(a, nr - 1);
+#pragma unroll
+        for (int u = 0; u < 16; u++) v[u] = X[(long long)rowL[b + 4 * u] * ldx + ac];
+#pragma unroll
+        for (int u = 0; u < 16; u++) T[(b + 4 * u) * 65 + a] = v[u];
         __syncthreads();
         const int i = i0 + a;
-        if (i < n)
-            for (int j = b; j < nr; j += 4) Bc[i + (long long)j * ldb] = T[a * 65 + j];
+        if (i < n) {
+#pragma unroll
+            for (int u = 0; u < 16; u++)
+                if (b + 4 * u < nr) Bc[i + (long long)(b + 4 * u) * ldb] = T[a * 65 + b + 4 * u];
+        }
     }
 }
 
