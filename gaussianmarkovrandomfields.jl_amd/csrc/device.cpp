@@ -257,6 +257,28 @@ void Device::upload(const Symbolic &S) {
         const int *b; up(b, S.sub_last); d_sub_last_ = const_cast<int *>(b);
         for (int k = 0; k < 3; k++) nsub_cls_[k] = S.nsub_cls[k];
         const int *sl; up(sl, S.sel_levellist); d_sel_levellist_ = const_cast<int *>(sl);
+        // one 32-byte geometry record per position of the level lists (kernels.h, front_view)
+        auto frecs = [&](const std::vector<i32> &lst, FrontView *&dst) {
+            std::vector<FrontView> v(lst.size());
+            for (size_t k = 0; k < lst.size(); k++) {
+                const i32 s = lst[k];
+                v[k] = FrontView{(int)s, S.ncols(s), S.nrows(s), (int)S.ld[s], (int)S.sfirst[s], 0, (long long)S.panelptr[s]};
+            }
+            const FrontView *p; up(p, v); dst = const_cast<FrontView *>(p);
+        };
+        frecs(S.levellist, d_frec_);
+        frecs(S.sel_levellist, d_sel_frec_);
+        {   // ... and of the even / odd re-ordering of the big fronts (two panel chains per level)
+            std::vector<i32> l2(S.levellist.begin(), S.levellist.end());
+            for (i32 l = 0; l < S.nlevels; l++) {
+                const i64 f = S.levelptr[l] + S.level_nsmall[l], e = S.levelptr[l + 1];
+                i64 w = f;
+                for (i64 k = f; k < e; k += 2) l2[w++] = S.levellist[k];
+                for (i64 k = f + 1; k < e; k += 2) l2[w++] = S.levellist[k];
+            }
+            frecs(l2, d_frec2_);
+        }
+        HC(hipStreamSynchronize(stream));
     }
     HC(hipStreamSynchronize(stream));
 
@@ -492,7 +514,7 @@ void Device::factor_levels(int lo, int hi) {
         }
         for (int hf = 0; hf < nhalf; hf++) {
             hipStream_t st = hf == 0 ? stream : stream3;
-            const int *hl = two ? d_levellist2_ + L.first + L.nsmall + (hf == 0 ? 0 : (nf + 1) / 2) : list;
+            const FrontView *hl = two ? d_frec2_ + L.first + L.nsmall + (hf == 0 ? 0 : (nf + 1) / 2) : d_frec_ + L.first + L.nsmall;
             auto act = [&](int b) { const int a = L.active[b]; return two ? (hf == 0 ? (a + 1) / 2 : a / 2) : a; };
             // geometry of the widest front of the (half-)list (fronts are sorted by decreasing width): when it is
             // the only one still active, the panel kernels get it in their arguments (kernels.h, FrontArg)
@@ -955,7 +977,7 @@ void Device::selinv_levels(int hi, int lo) {
         if (snsmall > 0) {
             const int *sl = d_sel_levellist_ + sfirst;
             launch_sel_gather(stream, dsz, sl, snsmall, 128, d_Z_, d_cb_);
-            launch_trsm(stream, dsz, sl, snsmall, 0, 1, 128, d_L_, d_tmp_, d_yoff_, FrontArg{0, 0, 0, 0, 0, 0, 0});
+            launch_trsm(stream, dsz, d_sel_frec_ + sfirst, snsmall, 0, 1, 128, d_L_, d_tmp_, d_yoff_, FrontArg{0, 0, 0, 0, 0, 0, 0});
             launch_sel_symm(stream, dsz, sl, snsmall, 0, 128, d_Z_, d_cb_, d_tmp_, d_yoff_);
             launch_sel_diag(stream, dsz, sl, snsmall, 0, d_L_, d_Z_, d_tmp_, d_yoff_);
         }

@@ -67,6 +67,10 @@ struct SweepTask {
     long long woff;        // DevSym::wptr[root]
 };
 
+// geometry of one front for the panel kernels: in the kernel arguments (FrontArg) or one record per level-list position
+struct FrontArg { int on, s, c, r, ld, first; long long pp; };
+struct FrontView { int s, c, r, ld, first, pad; long long pp; };   // 32 bytes
+
 struct SyrkSplit { int start[9]; };   // tile runs of the 8 XCDs inside a level's tile list
 
 // Everything a workgroup of k_syrk_cb_rec needs for one 64 x 64 contribution-block tile, in ONE 128-byte record (one
@@ -213,6 +217,7 @@ private:
     std::vector<int> h_etile_;
     std::vector<long long> h_wptr_;
     bool syrk_xcd_ = true;          // GMRFX_SYRK_XCD=0: k_syrk_cb on a plain 3-D grid (front, tile row, tile column) instead
+    FrontView *d_frec_ = nullptr, *d_frec2_ = nullptr, *d_sel_frec_ = nullptr;   // geometry records parallel to the level lists
     int *d_levellist2_ = nullptr;   // per level: the big fronts re-ordered [even positions..., odd positions...] (two-stream panel chains)
     bool two_chains_ = true;
     int *d_sub_first_ = nullptr, *d_sub_last_ = nullptr, *d_sel_levellist_ = nullptr;

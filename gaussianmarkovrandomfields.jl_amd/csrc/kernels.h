@@ -10,22 +10,20 @@ constexpr int NB = 64;       // block-column width of the dense partial factoris
 constexpr int ASM_CW = 4;    // front columns owned by one assembly workgroup
 constexpr int FWD_RB = 32;    // front rows owned by one forward-assembly workgroup
 
-// Geometry of one front. Normally read through list[z] -> sfirst / rowptr / ld / panelptr: two
-// dependent round trips at the start of every kernel. The panel chain at the top of the tree
-// (potrf -> trsm -> gemm, ~120 dependent launches on a single front) gets it in the kernel arguments.
+// (FrontArg / FrontView -- the geometry of one front for the panel kernels -- live in device.h. The panel chain at the top
+// of the tree, potrf -> trsm -> gemm, ~120 dependent launches on a single front, gets it in the kernel arguments; everything
+// else reads one record at its position in the level list.)
 // two doubles that are only known to be 8-byte aligned (one 16-byte load; the hardware takes unaligned addresses)
 typedef double gmrfx_d2u __attribute__((ext_vector_type(2), aligned(8)));
 
-struct FrontArg { int on, s, c, r, ld, first; long long pp; };
-struct FrontView { int s, c, r, ld, first; long long pp; };
 void launch_assemble(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, int max_rows,
                      const double *nzval, double *L, double *CB);
 void launch_syrk_cb(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_trail, const double *L, double *CB);
 // The same tiles from self-contained records, one contiguous run per XCD (workgroup id mod 8 = XCD): see k_syrk_cb_rec.
 void launch_syrk_cb_recs(hipStream_t st, const DevSym &S, const SyrkTile *recs, const SyrkSplit &split, int per_xcd, const double *L, double *CB);
-void launch_trsm(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int mode, int max_rows_below,
+void launch_trsm(hipStream_t st, const DevSym &S, const FrontView *frec, int nactive, int kb, int mode, int max_rows_below,
                  double *L, double *Yh, const long long *yoff, const FrontArg &fa);
-void launch_gemm_nt(hipStream_t st, const DevSym &S, const int *list, int nactive, int k0, int K, int c0, int c1,
+void launch_gemm_nt(hipStream_t st, const DevSym &S, const FrontView *frec, int nactive, int k0, int K, int c0, int c1,
                     int maxM, int maxN, double *L, const FrontArg &fa);
 void launch_fwd_update_recs(hipStream_t st, const DevSym &S, const FwdTile *recs, const SyrkSplit &split, int per_xcd, const double *L,
                             double *X, double *W, int nr, int ldx);
@@ -120,18 +118,21 @@ __device__ __forceinline__ void wave_gemm_32x32_strided(gmrfx_d4 (&acc)[2][2], c
     }
 }
 
-__device__ __forceinline__ FrontView front_view(const DevSym &S, const int *__restrict__ list, const int z, const FrontArg &fa) {
+// Geometry of the front a workgroup works on: from the kernel arguments (one active front: the top-of-tree chains) or from
+// ONE 32-byte record at the workgroup's position in the level list (Device::d_frec_*) -- not list -> five index arrays,
+// which is a dependent round trip more on every launch of the panel chains.
+__device__ __forceinline__ FrontView front_view(const FrontView *__restrict__ frec, const int z, const FrontArg &fa) {
     FrontView v;
     if (fa.on) {
-        v.s = fa.s; v.c = fa.c; v.r = fa.r; v.ld = fa.ld; v.first = fa.first; v.pp = fa.pp;
+        v.s = fa.s; v.c = fa.c; v.r = fa.r; v.ld = fa.ld; v.first = fa.first; v.pad = 0; v.pp = fa.pp;
     } else {
-        const int s = list[z];
-        v.s = s;
-        v.first = S.sfirst[s];
-        v.c = S.sfirst[s + 1] - v.first;
-        v.r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
-        v.ld = S.ld[s];
-        v.pp = S.panelptr[s];
+        // two 16-byte loads through a differently typed pointer: written as `v = frec[z]` the compiler merges the two
+        // sources into ONE pointer (kernel arguments or record) and reads the fields with flat vector loads, one
+        // dependent round trip for `c` and another for the rest
+        const int4 *q = reinterpret_cast<const int4 *>(frec + z);
+        const int4 a = q[0], b = q[1];
+        v.s = a.x; v.c = a.y; v.r = a.z; v.ld = a.w; v.first = b.x; v.pad = 0;
+        v.pp = ((long long)b.w << 32) | (unsigned)b.z;
     }
     return v;
 }
@@ -282,7 +283,7 @@ void launch_factor_small(hipStream_t st, const DevSym &S, const int *list, int n
 // phase 0: factor, 1: forward sweep, 2: backward sweep of whole small subtrees (one workgroup per subtree)
 void launch_subtree(hipStream_t st, const DevSym &S, int phase, const int *sub_first, const int *sub_last, int ntasks,
                     int rmax, const double *nzval, double *L, double *CB, int *info, double *X, double *W, int nr, int ldx);
-void launch_potrf64(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, double *L, int *info, const FrontArg &fa);   // potrf64.hip
+void launch_potrf64(hipStream_t st, const DevSym &S, const FrontView *frec, int nactive, int kb, double *L, int *info, const FrontArg &fa);   // potrf64.hip
 void launch_fwd_small(hipStream_t st, const DevSym &S, const int *list, int nfronts, int rmax, const double *L,
                       double *X, double *W, int nr, int ldx);
 void launch_bwd_small(hipStream_t st, const DevSym &S, const int *list, int nfronts, int rmax, const double *L,

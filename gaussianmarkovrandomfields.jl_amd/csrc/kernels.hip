@@ -141,7 +141,7 @@ __device__ __forceinline__ void stage_linv(const double *__restrict__ Dg, int ld
 //   mode 1 (selected inversion): Yh[i, :]  <- L[i, blk] * Linv
 // One wave owns 16 rows (reads all of them before it writes), a workgroup 64 rows.
 template <int MODE, int SPLIT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k_trsm(DevSym S, const int *__restrict__ list, int kb,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k_trsm(DevSym S, const FrontView *__restrict__ frec, int kb,
                                               double *__restrict__ L, double *__restrict__ Yh,
                                               const long long *__restrict__ yoff, FrontArg fa) {
     // SPLIT = 0: a workgroup owns 128 rows, each wave 32 of them (all four 16-column tiles) as 16 row PAIRS: MFMA
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
     // and each wave ONE column tile of them -- many more workgroups, a quarter of the MFMA
     // chain per wave (a single CU sustains only ~0.14 TFLOP/s of FP64 MFMA).
     __shared__ double Ti[NB * NB];
-    const FrontView fv = front_view(S, list, blockIdx.y, fa);
+    const FrontView fv = front_view(frec, blockIdx.y, fa);
     const int s = fv.s, c = fv.c, r = fv.r;
     if (kb >= c) return;
     const int w = min(NB, c - kb);
@@ -253,13 +253,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 // Trailing update inside the panel (see the comment in the kernel); the contribution block is k_syrk_cb.
 // CB -= L21 L21' (K = all c columns).
 template <int TW>   // MFMA tiles per wave and dimension: wave tile 16*TW squared, workgroup tile twice that
-__global__ __launch_bounds__(256) void k_gemm_nt(DevSym S, const int *__restrict__ list, int k0, int K, int c0, int c1,
+__global__ __launch_bounds__(256) void k_gemm_nt(DevSym S, const FrontView *__restrict__ frec, int k0, int K, int c0, int c1,
                                                  double *__restrict__ L, FrontArg fa) {
     // panel columns [c0, min(c1, c)) of the front, rows c0 .. r-1:  C -= A A'  with A = the K
     // (finished) panel columns k0 .. k0+K-1 of those rows. Two-level blocking: K = 64 updates stay
     // inside the current 256-column block, the rest of the panel is updated once per 256 columns
     // with K = 256 (a quarter of the read-modify-write traffic of a flat right-looking sweep).
-    const FrontView fv = front_view(S, list, blockIdx.z, fa);
+    const FrontView fv = front_view(frec, blockIdx.z, fa);
     const int c = fv.c;
     if (c0 >= c) return;
     const int r = fv.r;
@@ -1382,20 +1382,20 @@ void launch_syrk_cb_recs(hipStream_t st, const DevSym &S, const SyrkTile *recs, 
     if (per_xcd <= 0) return;
     hipLaunchKernelGGL(k_syrk_cb_rec, dim3(8 * (unsigned)per_xcd), dim3(256), 0, st, S, recs, split, L, CB);
 }
-void launch_trsm(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int mode, int max_rows_below,
+void launch_trsm(hipStream_t st, const DevSym &S, const FrontView *frec, int nactive, int kb, int mode, int max_rows_below,
                  double *L, double *Yh, const long long *yoff, const FrontArg &fa) {
     if (nactive <= 0 || max_rows_below <= 0) return;
     const bool split = (long long)cdiv(max_rows_below, 64) * nactive <= 128;
     const dim3 grid(odd(cdiv(max_rows_below, split ? 16 : 128)), nactive);
     if (mode == 0) {
-        if (split) hipLaunchKernelGGL((k_trsm<0, 1>), grid, dim3(256), 0, st, S, list, kb, L, Yh, yoff, fa);
-        else hipLaunchKernelGGL((k_trsm<0, 0>), grid, dim3(256), 0, st, S, list, kb, L, Yh, yoff, fa);
+        if (split) hipLaunchKernelGGL((k_trsm<0, 1>), grid, dim3(256), 0, st, S, frec, kb, L, Yh, yoff, fa);
+        else hipLaunchKernelGGL((k_trsm<0, 0>), grid, dim3(256), 0, st, S, frec, kb, L, Yh, yoff, fa);
     } else {
-        if (split) hipLaunchKernelGGL((k_trsm<1, 1>), grid, dim3(256), 0, st, S, list, kb, L, Yh, yoff, fa);
-        else hipLaunchKernelGGL((k_trsm<1, 0>), grid, dim3(256), 0, st, S, list, kb, L, Yh, yoff, fa);
+        if (split) hipLaunchKernelGGL((k_trsm<1, 1>), grid, dim3(256), 0, st, S, frec, kb, L, Yh, yoff, fa);
+        else hipLaunchKernelGGL((k_trsm<1, 0>), grid, dim3(256), 0, st, S, frec, kb, L, Yh, yoff, fa);
     }
 }
-void launch_gemm_nt(hipStream_t st, const DevSym &S, const int *list, int nactive, int k0, int K, int c0, int c1,
+void launch_gemm_nt(hipStream_t st, const DevSym &S, const FrontView *frec, int nactive, int k0, int K, int c0, int c1,
                     int maxM, int maxN, double *L, const FrontArg &fa) {
     if (nactive <= 0 || maxM <= 0 || maxN <= 0) return;
     // 64x64 workgroup tiles, operands straight from L2 at 3-4 waves per SIMD. Measured on MI355X: the
@@ -1405,9 +1405,9 @@ void launch_gemm_nt(hipStream_t st, const DevSym &S, const int *list, int nactiv
     // Levels with a handful of fronts are latency bound: 32x32 workgroup tiles there (four times
     // the workgroups, a quarter of the MFMA chain per wave).
     if ((long long)cdiv(maxM, 64) * cdiv(maxN, 64) * nactive <= 256)
-        hipLaunchKernelGGL(k_gemm_nt<1>, dim3(odd(cdiv(maxM, 32)), odd(cdiv(maxN, 32)), nactive), dim3(256), 0, st, S, list, k0, K, c0, c1, L, fa);
+        hipLaunchKernelGGL(k_gemm_nt<1>, dim3(odd(cdiv(maxM, 32)), odd(cdiv(maxN, 32)), nactive), dim3(256), 0, st, S, frec, k0, K, c0, c1, L, fa);
     else
-        hipLaunchKernelGGL(k_gemm_nt<2>, dim3(odd(cdiv(maxM, 64)), odd(cdiv(maxN, 64)), nactive), dim3(256), 0, st, S, list, k0, K, c0, c1, L, fa);
+        hipLaunchKernelGGL(k_gemm_nt<2>, dim3(odd(cdiv(maxM, 64)), odd(cdiv(maxN, 64)), nactive), dim3(256), 0, st, S, frec, k0, K, c0, c1, L, fa);
 }
 void launch_fwd_assemble(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, double *X,
                          const double *W, int nr, int ldx) {

@@ -47,10 +47,10 @@ __device__ __forceinline__ double rsqrt_nr(double p) {
 
 }  // namespace
 
-__global__ __launch_bounds__(256) void k_potrf64(DevSym S, const int *__restrict__ list, int kb,
+__global__ __launch_bounds__(256) void k_potrf64(DevSym S, const FrontView *__restrict__ frec, int kb,
                                                  double *__restrict__ L, int *__restrict__ info, FrontArg fa) {
     __shared__ __attribute__((aligned(16))) double Sb[2][4 * 64];   // strip [parity][q * 64 + row]
-    const FrontView fv = front_view(S, list, blockIdx.x, fa);
+    const FrontView fv = front_view(frec, blockIdx.x, fa);
     const int c = fv.c;
     if (kb >= c) return;
     const int w = min(NB, c - kb);
@@ -205,10 +205,10 @@ __global__ __launch_bounds__(256) void k_potrf64(DevSym S, const int *__restrict
     }
 }
 
-void launch_potrf64(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, double *L, int *info,
+void launch_potrf64(hipStream_t st, const DevSym &S, const FrontView *frec, int nactive, int kb, double *L, int *info,
                     const FrontArg &fa) {
     if (nactive <= 0) return;
-    hipLaunchKernelGGL(k_potrf64, dim3(nactive), dim3(256), 0, st, S, list, kb, L, info, fa);
+    hipLaunchKernelGGL(k_potrf64, dim3(nactive), dim3(256), 0, st, S, frec, kb, L, info, fa);
 }
 
 }  // namespace gmrfx
