@@ -839,3 +839,47 @@ def test_sweep_tasks_on_and_off_agree(name, monkeypatch):
         assert relerr(on.backend_backward_solve(B), Zo) < 1e-10
         assert relerr(on.backend_backward_solve(B), off.backend_backward_solve(B)) < 1e-11
     assert np.array_equal(on.backend_solve(B), on.backend_solve(B))        # still bit-reproducible
+
+
+@pytest.mark.parametrize("name", ["matern64_coords", "cfg1_alpha3_65x65", "matern3d_10", "rand400"])
+def test_tile_records_and_plain_grid_give_the_same_bits(name, monkeypatch):
+    """The record-driven kernels (contribution-block SYRK and forward update: one self-contained record per tile, handed
+    out in per-XCD runs, csrc/kernels.hip k_syrk_cb_rec / k_fwd_update_rec; the default) against the plain-grid forms
+    they replaced (GMRFX_SYRK_XCD=0): the SAME factor bit for bit (same sums in the same order), the same solve bits,
+    and the factor against the oracle entry by entry."""
+    Q, kw = next((sp.csc_matrix(q), k) for n, q, k in CASES if n == name)
+    n = Q.shape[0]
+    rec = gmrfx.MI355XBackend(Q, **kw)
+    monkeypatch.setenv("GMRFX_SYRK_XCD", "0")
+    grid = gmrfx.MI355XBackend(Q, ordering=rec.ordering_permutation())
+    monkeypatch.delenv("GMRFX_SYRK_XCD")
+    a, b = rec.factor_values(), grid.factor_values()          # before any solve (solves fill the dense inverses in)
+    assert np.array_equal(a, b)
+    F = orc.OracleFactor(Q, rec.ordering_permutation())
+    Lg, Lo = rec.factor_csc(), F.L()
+    assert abs(Lg - Lo).max() <= 1e-10 * abs(Lo).max()
+    B = np.random.default_rng(9).standard_normal((n, 37))     # odd count: the pair loads' last right-hand side is alone
+    Xr, Xg = rec.backend_solve(B), grid.backend_solve(B)
+    assert np.array_equal(Xr, Xg)
+    assert relerr(Xr, F.solve(B)) < 1e-10
+
+
+def test_tile_records_and_plain_grid_give_the_same_bits_on_a_mesh_with_many_tiles(monkeypatch):
+    """The same on a 300 x 300-node mesh (9e4 unknowns): levels with hundreds of big fronts and more than 128 update
+    tiles, so that k_syrk_cb_rec, k_fwd_update_rec and the 8-wave backward variant all run; factor and solves bit for
+    bit equal to the plain-grid forms, residual against Q."""
+    mesh = spde.grid_mesh_2d(300, 300, jitter=0.25, seed=3)
+    Q = sp.csc_matrix(spde.matern_precision(mesh, 0, 0.2))
+    n = Q.shape[0]
+    rec = gmrfx.MI355XBackend(Q, coords=mesh.points)
+    monkeypatch.setenv("GMRFX_SYRK_XCD", "0")
+    grid = gmrfx.MI355XBackend(Q, ordering=rec.ordering_permutation())
+    monkeypatch.delenv("GMRFX_SYRK_XCD")
+    assert np.array_equal(rec.factor_values(), grid.factor_values())
+    assert rec.compute_logdet() == grid.compute_logdet()
+    B = np.random.default_rng(10).standard_normal((n, 64))
+    Xr, Xg = rec.backend_solve(B), grid.backend_solve(B)
+    assert np.array_equal(Xr, Xg)
+    assert np.linalg.norm(Q @ Xr - B) / np.linalg.norm(B) < 1e-10
+    Z = B[:, :7]
+    assert np.array_equal(rec.backend_backward_solve(Z), grid.backend_backward_solve(Z))
