@@ -390,6 +390,9 @@ def main():
                       "frac": sweep_gbs / HBM_PEAK_GBS,
                       "traffic": 0.5 * (pmc["sweep_forward"]["total_bytes"] + pmc["sweep_backward"]["total_bytes"]) if pmc else None,
                       "kernel": "triangular sweep (mean of forward and backward, all launches)", "ms": sweep_ms, "bytes": bytes_sweep}
+        if roof_sweep["traffic"]:
+            # the bytes the sweeps really move (PMC), W / x hand-off between the levels included, against the same peak
+            roof_sweep["frac_of_peak_with_measured_traffic"] = roof_sweep["traffic"] / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         out = {
             "metric": "factor+solve(64 RHS) throughput", "value": world * n / (elapsed / args.steps), "unit": "DoF/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
