@@ -49,6 +49,7 @@ Device::~Device() {
     for (auto &e : ev_) if (e) (void)hipEventDestroy(e);
     for (auto &l : ev_lane_) for (auto &e : l) if (e) (void)hipEventDestroy(e);
     if (ev_ready_) (void)hipEventDestroy(ev_ready_);
+    if (ev_ready2_) (void)hipEventDestroy(ev_ready2_);
     if (ev_done1_) (void)hipEventDestroy(ev_done1_);
     if (stream3) (void)hipStreamDestroy(stream3);
     for (auto &e : ev_syrk_) if (e) (void)hipEventDestroy(e);
@@ -89,6 +90,7 @@ void Device::init(const Symbolic &S, int dev) {
     for (auto &ev : ev_) HC(hipEventCreate(&ev));
     for (auto &l : ev_lane_) for (auto &ev : l) HC(hipEventCreate(&ev));
     HC(hipEventCreateWithFlags(&ev_ready_, hipEventDisableTiming));
+    HC(hipEventCreateWithFlags(&ev_ready2_, hipEventDisableTiming));
     HC(hipEventCreateWithFlags(&ev_done1_, hipEventDisableTiming));
     upload(S);
 }
@@ -252,6 +254,7 @@ void Device::upload(const Symbolic &S) {
             }
             const int *l2p; up(l2p, l2); d_levellist2_ = const_cast<int *>(l2p);
             if (const char *e = std::getenv("GMRFX_TWO_CHAINS")) two_chains_ = std::atoi(e) != 0;
+            if (const char *e = std::getenv("GMRFX_SMALL_ON_SIDE")) small_on_side_ = std::atoi(e) != 0;
         }
         const int *a; up(a, S.sub_first); d_sub_first_ = const_cast<int *>(a);
         const int *b; up(b, S.sub_last); d_sub_last_ = const_cast<int *>(b);
@@ -495,10 +498,19 @@ void Device::factor_levels(int lo, int hi) {
     int nsy = (int)syrk_launches;
     for (int lev = lo; lev < hi; lev++) {
         auto &L = levels_[lev];
-        for (int k = 0, off = 0; k < 4; off += L.ncls[k], k++)
-            launch_factor_small(stream, ds_, d_levellist_ + L.first + off, L.ncls[k], kClsRows[k], nz_src_, d_L_, d_cb_, d_info_);
         const int *list = d_levellist_ + L.first + L.nsmall;
         const int nf = L.count - L.nsmall;
+        // The small fronts of a level (fused one-workgroup kernels) and its big fronts (assembly -> panel chain -> SYRK)
+        // only depend on the levels below, not on each other: when a level has both, the small ones run on the second
+        // stream next to the big-front pipeline, and the level ends when both have.
+        const bool split_small = small_on_side_ && L.nsmall > 0 && nf > 0;
+        hipStream_t st_small = split_small ? stream3 : stream;
+        if (split_small) {
+            HC(hipEventRecord(ev_ready_, stream));
+            HC(hipStreamWaitEvent(stream3, ev_ready_, 0));
+        }
+        for (int k = 0, off = 0; k < 4; off += L.ncls[k], k++)
+            launch_factor_small(st_small, ds_, d_levellist_ + L.first + off, L.ncls[k], kClsRows[k], nz_src_, d_L_, d_cb_, d_info_);
         launch_assemble(stream, ds_, list, nf, L.max_cols, L.max_rows, nz_src_, d_L_, d_cb_);
         const int nblk = level_nblk(L);
         // The panel factorisation of a level is a chain of small dependent launches per 64-column block (potrf64 on ONE
@@ -509,8 +521,8 @@ void Device::factor_levels(int lo, int hi) {
         const bool two = two_chains_ && nf >= 2 && nblk >= 4 && !sharded();
         const int nhalf = two ? 2 : 1;
         if (two) {
-            HC(hipEventRecord(ev_ready_, stream));
-            HC(hipStreamWaitEvent(stream3, ev_ready_, 0));
+            HC(hipEventRecord(ev_ready2_, stream));               // (after the assembly of this level's panels)
+            HC(hipStreamWaitEvent(stream3, ev_ready2_, 0));
         }
         for (int hf = 0; hf < nhalf; hf++) {
             hipStream_t st = hf == 0 ? stream : stream3;
@@ -549,6 +561,10 @@ void Device::factor_levels(int lo, int hi) {
             else launch_syrk_cb(stream, ds_, list, nf, level_max_trail(L), d_L_, d_cb_);
             HC(hipEventRecord(ev_syrk_[2 * nsy + 1], stream));
             nsy++;
+        }
+        if (split_small && !two) {        // (with two chains the join before the SYRK already covered the small fronts)
+            HC(hipEventRecord(ev_done1_, stream3));
+            HC(hipStreamWaitEvent(stream, ev_done1_, 0));
         }
     }
     syrk_launches = nsy;

@@ -220,6 +220,7 @@ private:
     FrontView *d_frec_ = nullptr, *d_frec2_ = nullptr, *d_sel_frec_ = nullptr;   // geometry records parallel to the level lists
     int *d_levellist2_ = nullptr;   // per level: the big fronts re-ordered [even positions..., odd positions...] (two-stream panel chains)
     bool two_chains_ = true;
+    bool small_on_side_ = true;     // GMRFX_SMALL_ON_SIDE=0: a level's small fronts before its big fronts, on one stream
     int *d_sub_first_ = nullptr, *d_sub_last_ = nullptr, *d_sel_levellist_ = nullptr;
     int nsub_cls_[3] = {0, 0, 0};
     double *d_L_ = nullptr, *d_Z_ = nullptr, *d_cb_ = nullptr, *d_nz_ = nullptr;
@@ -253,7 +254,7 @@ private:
     // one pass is launch-latency bound (4.6 ms for 1 column, 5.9 for 64), two interleave on the idle CUs.
     double *d_Xb_ = nullptr, *d_X2b_ = nullptr, *d_Wb_ = nullptr;   // lane 1 (lane 0 = d_X_ / d_X2_ / d_W_ on `stream`)
     hipEvent_t ev_lane_[2][5] = {};
-    hipEvent_t ev_ready_ = nullptr, ev_done1_ = nullptr;
+    hipEvent_t ev_ready_ = nullptr, ev_ready2_ = nullptr, ev_done1_ = nullptr;
     int *d_info_ = nullptr;
     struct RowDiagPlan { long long nseg = 0, cnt = 0, nvals = 0; long long *seg = nullptr, *off = nullptr; int *p = nullptr, *q = nullptr; double *vals = nullptr, *out = nullptr; };
     std::vector<RowDiagPlan> rd_plans_;
