@@ -118,6 +118,107 @@ __device__ __forceinline__ void wave_gemm_32x32_strided(gmrfx_d4 (&acc)[2][2], c
     }
 }
 
+// ---- the same 32 x 32 wave product with the operand rows in PAIRS: MFMA row lm of tile 0 / 1 is row 2 lm / 2 lm + 1 of the
+// wave's 32 (both dimensions), so a 16-byte load feeds two tiles. Output: acc[a][b][rr] = D[m0 + 2 (lk + 4 rr) + a][n0 + 2 lm + b].
+// _pm: generic accessors (masked heads / tails); _rr: both operands with contiguous rows (base + q * stride); _rk: first
+// operand with contiguous rows, second with contiguous k (one row pointer per tile): k in pairs, k-step 2 h + e of a batch
+// holds k = batch + 8 h + 2 lk + e. The three share the row mapping, so pieces of one K range can use different forms.
+template <class FA, class FB>
+__device__ __forceinline__ void wave_gemm_32x32_pm(gmrfx_d4 (&acc)[2][2], int m0, int n0, int qlo, int qhi, FA fa, FB fb,
+                                                   int lm, int lk) {
+    constexpr int KU = 4;
+    for (int q0 = qlo & ~3; q0 < qhi; q0 += 4 * KU) {
+        double av[KU][2], bv[KU][2];
+#pragma unroll
+        for (int u = 0; u < KU; u++) {
+            const int q = q0 + 4 * u + lk;
+            const double mk = (q >= qlo && q < qhi) ? 1.0 : 0.0;
+#pragma unroll
+            for (int a = 0; a < 2; a++) av[u][a] = fa(m0 + 2 * lm + a, q) * mk;
+#pragma unroll
+            for (int b = 0; b < 2; b++) bv[u][b] = fb(q, n0 + 2 * lm + b);
+        }
+#pragma unroll
+        for (int u = 0; u < KU; u++)
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++)
+                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][a], bv[u][b], acc[a][b], 0, 0, 0);
+    }
+}
+// qlo, qhi multiples of 4
+__device__ __forceinline__ void wave_gemm_32x32_rr(gmrfx_d4 (&acc)[2][2], const double *pa2, long long sa, const double *pb2,
+                                                   long long sb, int qlo, int qhi, int lk) {
+    constexpr int KU = 4;
+    int q0 = qlo;
+    for (; q0 + 4 * KU <= qhi; q0 += 4 * KU) {
+        gmrfx_d2u av[KU], bv[KU];
+#pragma unroll
+        for (int u = 0; u < KU; u++) {
+            const long long q = q0 + 4 * u + lk;
+            av[u] = *(const gmrfx_d2u *)(pa2 + q * sa);
+            bv[u] = *(const gmrfx_d2u *)(pb2 + q * sb);
+        }
+#pragma unroll
+        for (int u = 0; u < KU; u++) {
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u].x, bv[u].x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u].x, bv[u].y, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u].y, bv[u].x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u].y, bv[u].y, acc[1][1], 0, 0, 0);
+        }
+    }
+    for (; q0 < qhi; q0 += 4) {
+        const long long q = q0 + lk;
+        const gmrfx_d2u av = *(const gmrfx_d2u *)(pa2 + q * sa), bv = *(const gmrfx_d2u *)(pb2 + q * sb);
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, bv.x, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, bv.y, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, bv.x, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, bv.y, acc[1][1], 0, 0, 0);
+    }
+}
+// batches of 8 k's from qlo while they fit below qhi; returns the first k it did NOT do (the caller finishes with _pm)
+__device__ __forceinline__ int wave_gemm_32x32_rk(gmrfx_d4 (&acc)[2][2], const double *pa2, long long sa, const double *pb_t0,
+                                                  const double *pb_t1, int qlo, int qhi, int lk) {
+    int q0 = qlo;
+    for (; q0 + 16 <= qhi; q0 += 16) {
+        gmrfx_d2u av[4], b0[2], b1[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const long long q = q0 + 8 * h + 2 * lk;
+            b0[h] = *(const gmrfx_d2u *)(pb_t0 + q);
+            b1[h] = *(const gmrfx_d2u *)(pb_t1 + q);
+            av[2 * h] = *(const gmrfx_d2u *)(pa2 + q * sa);
+            av[2 * h + 1] = *(const gmrfx_d2u *)(pa2 + (q + 1) * sa);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2 * h].x, b0[h].x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2 * h].x, b1[h].x, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2 * h].y, b0[h].x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2 * h].y, b1[h].x, acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2 * h + 1].x, b0[h].y, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2 * h + 1].x, b1[h].y, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2 * h + 1].y, b0[h].y, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2 * h + 1].y, b1[h].y, acc[1][1], 0, 0, 0);
+        }
+    }
+    for (; q0 + 8 <= qhi; q0 += 8) {
+        const long long q = q0 + 2 * lk;
+        const gmrfx_d2u b0 = *(const gmrfx_d2u *)(pb_t0 + q), b1 = *(const gmrfx_d2u *)(pb_t1 + q);
+        const gmrfx_d2u a0 = *(const gmrfx_d2u *)(pa2 + q * sa), a1 = *(const gmrfx_d2u *)(pa2 + (q + 1) * sa);
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, b0.x, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, b1.x, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, b0.x, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, b1.x, acc[1][1], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, b0.y, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, b1.y, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, b0.y, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, b1.y, acc[1][1], 0, 0, 0);
+    }
+    return q0;
+}
+
 // Geometry of the front a workgroup works on: from the kernel arguments (one active front: the top-of-tree chains) or from
 // ONE 32-byte record at the workgroup's position in the level list (Device::d_frec_*) -- not list -> five index arrays,
 // which is a dependent round trip more on every launch of the panel chains.

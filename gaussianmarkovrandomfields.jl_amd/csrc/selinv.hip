@@ -233,6 +233,11 @@ __global__ __launch_bounds__(256) void k_sel_dense(DevSym S, const int *__restri
     for (int a = 0; a < 2; a++)
 #pragma unroll
         for (int b = 0; b < 2; b++) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+    // Operand rows in PAIRS throughout (kernels.h, wave_gemm_32x32_pm / _rr / _rk): tile a of the "m" index is
+    // m0 + 2 lm + a on the operand side and m0 + 2 (lk + 4 rr) + a in the accumulators, tile b of the "n" index is
+    // n0 + 2 lm + b -- 16-byte loads and stores, half the vector memory instructions. Lanes past the last row re-read
+    // the last pair; their results are never stored.
+    const int mlast = max(m - 1, 0) & ~1, clast = (c - 1) & ~1;
     if (phase == 0) {
         // m = i (row of L21), n = k
         auto fa = [&](int i, int q) { return P[(c + min(i, m - 1)) + (long long)min(max(q, 0), c - 1) * ld]; };
@@ -240,22 +245,20 @@ __global__ __launch_bounds__(256) void k_sel_dense(DevSym S, const int *__restri
         // q < n0 + 32 touches the diagonal of X for this tile's columns: masked accessors; beyond it every
         // X[q][k] (k < q) is a plain element P[k + q ld]: pointer form (rows / columns clamped at the edges only)
         const int qs = min((n0 + 32 + 3) & ~3, c), qe = c & ~3;
-        wave_gemm_32x32(acc, m0, n0, n0, qs, fa, fb, lm, lk);
-        if (qe > qs) {
-            const double *const pa[2] = {P + c + min(m0 + lm, m - 1), P + c + min(m0 + 16 + lm, m - 1)};
-            const double *const pb[2] = {P + min(n0 + lm, c - 1), P + min(n0 + 16 + lm, c - 1)};
-            wave_gemm_32x32_strided(acc, pa, ld, pb, ld, qs, qe, lk);
-        }
-        if (c > max(qe, qs)) wave_gemm_32x32(acc, m0, n0, max(qe, qs), c, fa, fb, lm, lk);
+        wave_gemm_32x32_pm(acc, m0, n0, n0, qs, fa, fb, lm, lk);
+        if (qe > qs) wave_gemm_32x32_rr(acc, P + c + min(m0 + 2 * lm, mlast), ld, P + min(n0 + 2 * lm, clast), ld, qs, qe, lk);
+        if (c > max(qe, qs)) wave_gemm_32x32_pm(acc, m0, n0, max(qe, qs), c, fa, fb, lm, lk);
 #pragma unroll
         for (int a = 0; a < 2; a++)
 #pragma unroll
-            for (int b = 0; b < 2; b++)
-#pragma unroll
-                for (int rr = 0; rr < 4; rr++) {
-                    const int i = m0 + a * 16 + lk + 4 * rr, k = n0 + b * 16 + lm;
-                    if (i < m && k < c) Y[k + (long long)i * c] = acc[a][b][rr];
+            for (int rr = 0; rr < 4; rr++) {
+                const int i = m0 + 2 * (lk + 4 * rr) + a, k = n0 + 2 * lm;
+                if (i < m && k < c) {
+                    double *dst = Y + k + (long long)i * c;
+                    if (k + 1 < c) *(gmrfx_d2u *)dst = (gmrfx_d2u){acc[a][0][rr], acc[a][1][rr]};
+                    else dst[0] = acc[a][0][rr];
                 }
+            }
     } else if (phase == 1) {
         // m = k, n = i
         auto fa = [&](int k, int q) { return Y[min(k, c - 1) + (long long)min(max(q, 0), m - 1) * c]; };
@@ -264,32 +267,31 @@ __global__ __launch_bounds__(256) void k_sel_dense(DevSym S, const int *__restri
             return ZBs[max(ii, qq) + (long long)min(ii, qq) * m];
         };
         // Z22 is symmetric with only its lower triangle stored: q below the tile's rows i reads ZB[i + q m]
-        // (contiguous along the lanes), q above them ZB[q + i m] (contiguous along q); the 32 q's on the tile's
-        // own diagonal block go through the accessor
-        const int ql = min(n0 & ~3, m), qh = min((n0 + 32 + 3) & ~3, m), qe = m & ~3;
-        const double *const pa[2] = {Y + min(m0 + lm, c - 1), Y + min(m0 + 16 + lm, c - 1)};
-        if (ql > 0) {
-            const double *const pb[2] = {ZBs + min(n0 + lm, m - 1), ZBs + min(n0 + 16 + lm, m - 1)};
-            wave_gemm_32x32_strided(acc, pa, c, pb, m, 0, ql, lk);
-        }
-        wave_gemm_32x32(acc, m0, n0, ql, qh, fa, fb, lm, lk);
-        if (qe > qh) {
-            const double *const pb[2] = {ZBs + (long long)min(n0 + lm, m - 1) * m, ZBs + (long long)min(n0 + 16 + lm, m - 1) * m};
-            wave_gemm_32x32_strided(acc, pa, c, pb, 1, qh, qe, lk);
-        }
-        if (m > max(qe, qh)) wave_gemm_32x32(acc, m0, n0, max(qe, qh), m, fa, fb, lm, lk);
+        // (contiguous along the lanes: row pairs), q above them ZB[q + i m] (contiguous along q: k pairs); the 32 q's
+        // on the tile's own diagonal block go through the accessor
+        const int ql = min(n0 & ~3, m), qh = min((n0 + 32 + 3) & ~3, m);
+        const double *pa2 = Y + min(m0 + 2 * lm, clast);
+        if (ql > 0) wave_gemm_32x32_rr(acc, pa2, c, ZBs + min(n0 + 2 * lm, mlast), m, 0, ql, lk);
+        wave_gemm_32x32_pm(acc, m0, n0, ql, qh, fa, fb, lm, lk);
+        int qd = qh;
+        if (m - qh >= 8)
+            qd = wave_gemm_32x32_rk(acc, pa2, c, ZBs + (long long)min(n0 + 2 * lm, m - 1) * m,
+                                    ZBs + (long long)min(n0 + 2 * lm + 1, m - 1) * m, qh, m, lk);
+        if (m > qd) wave_gemm_32x32_pm(acc, m0, n0, qd, m, fa, fb, lm, lk);
 #pragma unroll
         for (int a = 0; a < 2; a++)
 #pragma unroll
-            for (int b = 0; b < 2; b++)
-#pragma unroll
-                for (int rr = 0; rr < 4; rr++) {
-                    const int k = m0 + a * 16 + lk + 4 * rr, i = n0 + b * 16 + lm;
-                    if (k < c && i < m) {
-                        Zp[(c + i) + (long long)k * ld] = -acc[a][b][rr];
-                        Zt[k + (long long)i * c] = -acc[a][b][rr];
-                    }
+            for (int rr = 0; rr < 4; rr++) {
+                const int k = m0 + 2 * (lk + 4 * rr) + a, i = n0 + 2 * lm;
+                if (k < c && i < m) {
+                    double *dst = Zp + (c + i) + (long long)k * ld;
+                    Zt[k + (long long)i * c] = -acc[a][0][rr];
+                    if (i + 1 < m) {
+                        *(gmrfx_d2u *)dst = (gmrfx_d2u){-acc[a][0][rr], -acc[a][1][rr]};
+                        Zt[k + (long long)(i + 1) * c] = -acc[a][1][rr];
+                    } else dst[0] = -acc[a][0][rr];
                 }
+            }
     } else {
         // m = b, n = a (a >= b)
         auto fa1 = [&](int b, int k) { return xinv_elem(P, ld, c, k, b); };
@@ -297,13 +299,9 @@ __global__ __launch_bounds__(256) void k_sel_dense(DevSym S, const int *__restri
         // a >= b tiles only (n0 >= m0): k < n0 + 32 touches the diagonal of X for the tile's a's; beyond it both
         // X[k][b] and X[k][a] are plain elements of the upper triangle
         const int ks = min((n0 + 32 + 3) & ~3, c), ke = c & ~3;
-        wave_gemm_32x32(acc, m0, n0, n0, ks, fa1, fb1, lm, lk);
-        if (ke > ks) {
-            const double *const pa[2] = {P + min(m0 + lm, c - 1), P + min(m0 + 16 + lm, c - 1)};
-            const double *const pb[2] = {P + min(n0 + lm, c - 1), P + min(n0 + 16 + lm, c - 1)};
-            wave_gemm_32x32_strided(acc, pa, ld, pb, ld, ks, ke, lk);
-        }
-        if (c > max(ke, ks)) wave_gemm_32x32(acc, m0, n0, max(ke, ks), c, fa1, fb1, lm, lk);
+        wave_gemm_32x32_pm(acc, m0, n0, n0, ks, fa1, fb1, lm, lk);
+        if (ke > ks) wave_gemm_32x32_rr(acc, P + min(m0 + 2 * lm, clast), ld, P + min(n0 + 2 * lm, clast), ld, ks, ke, lk);
+        if (c > max(ke, ks)) wave_gemm_32x32_pm(acc, m0, n0, max(ke, ks), c, fa1, fb1, lm, lk);
         if (m > 0) {
             auto fa2 = [&](int b, int q) { return -Zt[min(b, c - 1) + (long long)min(max(q, 0), m - 1) * c]; };
             auto fb2 = [&](int q, int a) { return Y[min(a, c - 1) + (long long)min(max(q, 0), m - 1) * c]; };
@@ -315,24 +313,28 @@ __global__ __launch_bounds__(256) void k_sel_dense(DevSym S, const int *__restri
 #pragma unroll
                 for (int b = 0; b < 2; b++) acc2[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
             const int me = m & ~3;
-            const double *const pa[2] = {Zt + min(m0 + lm, c - 1), Zt + min(m0 + 16 + lm, c - 1)};
-            const double *const pb[2] = {Y + min(n0 + lm, c - 1), Y + min(n0 + 16 + lm, c - 1)};
-            wave_gemm_32x32_strided(acc2, pa, c, pb, c, 0, me, lk);
+            wave_gemm_32x32_rr(acc2, Zt + min(m0 + 2 * lm, clast), c, Y + min(n0 + 2 * lm, clast), c, 0, me, lk);
 #pragma unroll
             for (int a = 0; a < 2; a++)
 #pragma unroll
                 for (int b = 0; b < 2; b++) acc[a][b] -= acc2[a][b];
-            if (m > me) wave_gemm_32x32(acc, m0, n0, me, m, fa2, fb2, lm, lk);
+            if (m > me) wave_gemm_32x32_pm(acc, m0, n0, me, m, fa2, fb2, lm, lk);
         }
 #pragma unroll
         for (int a = 0; a < 2; a++)
 #pragma unroll
-            for (int b = 0; b < 2; b++)
-#pragma unroll
-                for (int rr = 0; rr < 4; rr++) {
-                    const int bb = m0 + a * 16 + lk + 4 * rr, aa = n0 + b * 16 + lm;
-                    if (aa < c && bb < c && aa >= bb) Zp[aa + (long long)bb * ld] = acc[a][b][rr];
+            for (int rr = 0; rr < 4; rr++) {
+                const int bb = m0 + 2 * (lk + 4 * rr) + a, aa = n0 + 2 * lm;
+                if (bb < c) {
+                    double *dst = Zp + aa + (long long)bb * ld;
+                    const bool v0 = aa < c && aa >= bb, v1 = aa + 1 < c && aa + 1 >= bb;
+                    if (v0 && v1) *(gmrfx_d2u *)dst = (gmrfx_d2u){acc[a][0][rr], acc[a][1][rr]};
+                    else {
+                        if (v0) dst[0] = acc[a][0][rr];
+                        if (v1) dst[1] = acc[a][1][rr];
+                    }
                 }
+            }
     }
 }
 
