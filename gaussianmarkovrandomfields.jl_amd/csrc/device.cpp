@@ -117,6 +117,25 @@ void Device::upload(const Symbolic &S) {
     up(ip, S.ld); ds_.ld = ip;
     tmp64 = conv<long long>(S.cbptr); up(lp, tmp64); ds_.cbptr = lp; HC(hipStreamSynchronize(stream));
     tmp64 = conv<long long>(S.zbptr); up(lp, tmp64); d_zbptr_ = lp; HC(hipStreamSynchronize(stream));
+    {   // selected inversion: one gather record per supernode
+        std::vector<SelRec> sr((size_t)ns);
+        for (i32 s = 0; s < ns; s++) {
+            SelRec t{};
+            const i32 p = S.sparent[s];
+            t.p = (int)p;
+            t.rel = (long long)S.rowptr[s] + S.ncols(s);
+            t.m = S.nrows(s) - S.ncols(s);
+            t.out = (long long)S.zbptr[s];
+            if (p >= 0) {
+                t.zp = (long long)S.panelptr[p]; t.zbp = (long long)S.zbptr[p];
+                t.cp = S.ncols(p); t.mp = S.nrows(p) - S.ncols(p); t.ldp = (int)S.ld[p];
+            }
+            t.foreign = (S.shard_world > 1 && p >= 0 && S.owner[p] != S.shard_rank) ? 1 : 0;   // (= DevSym::foreign_parent)
+            sr[(size_t)s] = t;
+        }
+        const SelRec *sp; up(sp, sr); d_selrec_ = sp;
+        HC(hipStreamSynchronize(stream));
+    }
     tmp64 = conv<long long>(S.childptr); up(lp, tmp64); ds_.childptr = lp; HC(hipStreamSynchronize(stream));
     up(ip, S.children); ds_.children = ip;
     up(ip, S.sparent); ds_.sparent = ip;
@@ -985,14 +1004,14 @@ void Device::selinv_levels(int hi, int lo) {
         const int nf = scount - snsmall;
         // big fronts: whole-front step through the dense inverse (selinv.hip, k_sel_dense).
         // Yt lives at d_tmp_ + yoff[s], Z21t right behind it (offset (r-c)*c): pass both bases.
-        launch_sel_gather(stream, dsz, list, nf, level_max_trail(L), d_Z_, d_cb_);
+        launch_sel_gather(stream, d_selrec_, dsz, list, nf, level_max_trail(L), d_Z_, d_cb_);
         for (int phase = 0; phase < 3; phase++)
             launch_sel_dense(stream, dsz, list, nf, phase, L.max_cols, level_max_trail(L), d_L_, d_Z_, d_cb_, d_tmp_,
                              d_tmp_, d_yoff_);
         // small fronts of the level (<= 128 rows, <= 64 columns: one block step)
         if (snsmall > 0) {
             const int *sl = d_sel_levellist_ + sfirst;
-            launch_sel_gather(stream, dsz, sl, snsmall, 128, d_Z_, d_cb_);
+            launch_sel_gather(stream, d_selrec_, dsz, sl, snsmall, 128, d_Z_, d_cb_);
             launch_trsm(stream, dsz, d_sel_frec_ + sfirst, snsmall, 0, 1, 128, d_L_, d_tmp_, d_yoff_, FrontArg{0, 0, 0, 0, 0, 0, 0});
             launch_sel_symm(stream, dsz, sl, snsmall, 0, 128, d_Z_, d_cb_, d_tmp_, d_yoff_);
             launch_sel_diag(stream, dsz, sl, snsmall, 0, d_L_, d_Z_, d_tmp_, d_yoff_);
@@ -1027,7 +1046,7 @@ void Device::selinv_phase(int what, int hi, int lo) {
         DevSym dsz = ds_;
         dsz.cbptr = d_zbptr_;
         const int a = fc_levelptr_[hi], b = fc_levelptr_[hi + 1];
-        launch_sel_gather(stream, dsz, d_fchild_ + a, b - a, fc_maxtrail_[hi], d_Z_, d_cb_);
+        launch_sel_gather(stream, d_selrec_, dsz, d_fchild_ + a, b - a, fc_maxtrail_[hi], d_Z_, d_cb_);
     } else if (what == 2) {
         if (lo < 0 || hi > nl || lo > hi) throw std::invalid_argument("selinv phase: level range out of bounds");
         HC(hipEventRecord(ev_[0], stream));

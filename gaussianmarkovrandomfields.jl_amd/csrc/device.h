@@ -102,6 +102,17 @@ struct FwdTile {
 };
 static_assert(sizeof(FwdTile) == 128, "FwdTile is one 128-byte record");
 
+// What k_sel_gather needs about a front and its parent, in one 64-byte record per supernode (selected inversion).
+struct SelRec {
+    long long rel;           // offset of the front's trailing rows in DevSym::rel
+    long long zp;            // parent's panel in Z
+    long long zbp;           // parent's trailing inverse block in the arena (selected-inversion layout)
+    long long out;           // this front's trailing inverse block
+    int m, cp, mp, ldp;      // trailing rows; parent's columns, trailing rows, leading dimension
+    int p, foreign, pad[2];  // parent (-1: root), 1 = the block arrives over the wire (sharded)
+};
+static_assert(sizeof(SelRec) == 64, "SelRec is 64 bytes");
+
 struct LevelInfo {
     int first;        // offset into levellist
     int count;        // fronts in level
@@ -201,6 +212,7 @@ private:
     std::vector<std::pair<void *, size_t>> allocs_;
 
     const Symbolic *S_ = nullptr;
+    const SelRec *d_selrec_ = nullptr;    // one per supernode
     DevSym ds_{};
     std::vector<LevelInfo> levels_;
     std::vector<LevelInfo> swlevels_;   // the sweeps' level schedule: levels_ without the fronts of the sweep tasks

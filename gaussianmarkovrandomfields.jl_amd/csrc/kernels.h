@@ -395,7 +395,7 @@ void launch_sweep_tasks(hipStream_t st, const DevSym &S, int phase, const SweepT
                         const double *L, double *X, double *W, int nr, int ldx);
 
 // selinv.hip -- Takahashi recursion, top-down over the supernodal tree
-void launch_sel_gather(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_trail,
+void launch_sel_gather(hipStream_t st, const SelRec *recs, const DevSym &S, const int *list, int nfronts, int max_trail,
                        const double *Z, double *ZB);
 void launch_sel_symm(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int max_rows_below,
                      double *Z, const double *ZB, const double *Yh, const long long *yoff);

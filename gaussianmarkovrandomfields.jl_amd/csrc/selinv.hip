@@ -20,26 +20,20 @@ namespace gmrfx {
 typedef gmrfx_d4 d4;
 
 // ZB_s[i,j] = Zf_parent(rel[i], rel[j]) for i >= j.
-__global__ __launch_bounds__(256) void k_sel_gather(DevSym S, const int *__restrict__ list,
+__global__ __launch_bounds__(256) void k_sel_gather(const SelRec *__restrict__ recs, DevSym S, const int *__restrict__ list,
                                                     const double *__restrict__ Z, double *__restrict__ ZB) {
-    const int s = list[blockIdx.y];
-    const int p = S.sparent[s];
-    if (p < 0) return;
-    if (S.foreign_parent && S.foreign_parent[s]) return;     // sharded: the block was gathered by the parent's owner and sent here
-    const int c = S.sfirst[s + 1] - S.sfirst[s];
-    const int r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
-    const int m = r - c;
+    // front -> ONE 64-byte record (its geometry and its parent's) instead of front -> parent -> two sets of index arrays
+    const SelRec R = recs[list[blockIdx.y]];
+    if (R.p < 0 || R.foreign) return;        // root; sharded: the block was gathered by the parent's owner and sent here
+    const int m = R.m;
     const int j0 = blockIdx.x * 16;
     if (j0 >= m) return;
     const int j1 = min(j0 + 16, m);
-    const int *rel = S.rel + S.rowptr[s] + c;
-    const int cp = S.sfirst[p + 1] - S.sfirst[p];
-    const int rp = (int)(S.rowptr[p + 1] - S.rowptr[p]);
-    const int mp = rp - cp;
-    const int ldp = S.ld[p];
-    const double *Zp = Z + S.panelptr[p];
-    const double *ZBp = ZB + S.cbptr[p];
-    double *out = ZB + S.cbptr[s];
+    const int *rel = S.rel + R.rel;
+    const int cp = R.cp, mp = R.mp, ldp = R.ldp;
+    const double *Zp = Z + R.zp;
+    const double *ZBp = ZB + R.zbp;
+    double *out = ZB + R.out;
     // the 16 source columns of this tile (uniform per workgroup), then every thread walks the rows with the 16
     // loads of its row in flight at once (rows above the diagonal of the tile are clamped onto it and not stored)
     const double *src[16];
@@ -340,10 +334,10 @@ __global__ __launch_bounds__(256) void k_sel_dense(DevSym S, const int *__restri
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-void launch_sel_gather(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_trail,
+void launch_sel_gather(hipStream_t st, const SelRec *recs, const DevSym &S, const int *list, int nfronts, int max_trail,
                        const double *Z, double *ZB) {
     if (nfronts <= 0 || max_trail <= 0) return;
-    hipLaunchKernelGGL(k_sel_gather, dim3((unsigned)(cdiv(max_trail, 16) | 1), nfronts), dim3(256), 0, st, S, list, Z, ZB);
+    hipLaunchKernelGGL(k_sel_gather, dim3((unsigned)(cdiv(max_trail, 16) | 1), nfronts), dim3(256), 0, st, recs, S, list, Z, ZB);
 }
 void launch_sel_symm(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int max_rows_below,
                      double *Z, const double *ZB, const double *Yh, const long long *yoff) {
