@@ -51,91 +51,51 @@ __global__ __launch_bounds__(256) void k_inv_stage(DevSym S, const int *__restri
     for (int a = 0; a < 2; a++)
 #pragma unroll
         for (int b = 0; b < 2; b++) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
-    constexpr int KU = 4;
+    // operand rows in pairs (kernels.h, wave_gemm_32x32_pm / _rr / _kr): tile a of the rows is i0 + 2 lm + a on the operand
+    // side and i0 + 2 (lk + 4 rr) + a in the accumulators, tile b of the columns is j0 + 2 lm + b
+    const int nlast = (nC - 1) & ~1;
     if (phase == 1) {
         // D[m][n]: m = i (rows of Bm), n = j.  A_mfma[m=i][q] = Bm[i][q] = P[(o+B+i) + (o+q)*ld]
         //                                      B_mfma[q][n=j] = Ainv[q][j] (q >= j) = X[o+q][o+j]
         const double *Ablk = P + o + (long long)o * ld;   // origin of block A inside the panel
+        auto fa = [&](int i, int q) { return P[(o + B + min(i, nC - 1)) + (long long)(o + min(max(q, 0), B - 1)) * ld]; };
+        auto fb = [&](int q, int j) { return xinv_elem(Ablk, ld, B, q, j); };
         // q >= j0 + 32 is below the diagonal of Ainv for every column j of this wave tile: plain elements
         // Ablk[j + q ld], pointer form; only the first k-steps need the masked accessor
         const int qs = min(j0 + 32, B);
-        if (B > qs) {
-            const double *const pa[2] = {P + (o + B + min(i0 + lm, nC - 1)) + (long long)o * ld,
-                                         P + (o + B + min(i0 + 16 + lm, nC - 1)) + (long long)o * ld};
-            const double *const pb[2] = {Ablk + j0 + lm, Ablk + j0 + 16 + lm};
-            wave_gemm_32x32_strided(acc, pa, ld, pb, ld, qs, B, lk);
-        }
-        for (int q0 = (j0 & ~15); q0 < qs; q0 += 4 * KU) {
-            double av[KU][2], bv[KU][2];
-#pragma unroll
-            for (int u = 0; u < KU; u++) {
-                const int q = q0 + 4 * u + lk;
-#pragma unroll
-                for (int a = 0; a < 2; a++) {
-                    const int i = min(i0 + a * 16 + lm, nC - 1);
-                    av[u][a] = P[(o + B + i) + (long long)(o + min(q, B - 1)) * ld] * (q < B ? 1.0 : 0.0);
-                }
-#pragma unroll
-                for (int b = 0; b < 2; b++) bv[u][b] = xinv_elem(Ablk, ld, B, q, j0 + b * 16 + lm);
-            }
-#pragma unroll
-            for (int u = 0; u < KU; u++)
-#pragma unroll
-                for (int a = 0; a < 2; a++)
-#pragma unroll
-                    for (int b = 0; b < 2; b++)
-                        acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][a], bv[u][b], acc[a][b], 0, 0, 0);
-        }
-        // D[m = i][n = j] -> T'[j + i*B], j on the lanes (contiguous)
+        if (B > qs) wave_gemm_32x32_rr(acc, P + (o + B + min(i0 + 2 * lm, nlast)) + (long long)o * ld, ld, Ablk + j0 + 2 * lm, ld, qs, B, lk);
+        wave_gemm_32x32_pm(acc, i0, j0, j0 & ~15, qs, fa, fb, lm, lk);
+        // D[m = i][n = j] -> T'[j + i*B], j on the lanes (contiguous): 16 bytes per lane
 #pragma unroll
         for (int a = 0; a < 2; a++)
 #pragma unroll
-            for (int b = 0; b < 2; b++)
-#pragma unroll
-                for (int rr = 0; rr < 4; rr++) {
-                    const int i = i0 + a * 16 + lk + 4 * rr, j = j0 + b * 16 + lm;
-                    if (i < nC) Tp[j + (long long)i * B] = acc[a][b][rr];
-                }
+            for (int rr = 0; rr < 4; rr++) {
+                const int i = i0 + 2 * (lk + 4 * rr) + a, j = j0 + 2 * lm;
+                if (i < nC) *(gmrfx_d2u *)(Tp + j + (long long)i * B) = (gmrfx_d2u){acc[a][0][rr], acc[a][1][rr]};
+            }
     } else {
         // D[m][n]: m = i (rows of C), n = j.  A_mfma[m=i][q] = Cinv[i][q] (q <= i) = X[o+B+i][o+B+q]
         //                                      B_mfma[q][n=j] = T[q][j] = T'[j + q*B]
         const double *Cblk = P + (o + B) + (long long)(o + B) * ld;
+        auto fa = [&](int i, int q) { return xinv_elem(Cblk, ld, nC, i, q); };
+        auto fb = [&](int q, int j) { return Tp[j + (long long)min(max(q, 0), nC - 1) * B]; };
         const int qhi = min(nC, i0 + 32);
         // q < i0 is left of the diagonal of Cinv for every row i of this wave tile: plain elements Cblk[q + i ld]
-        const int qb = min(i0, nC) & ~15;
-        if (qb > 0) {
-            const double *const pa[2] = {Cblk + (long long)min(i0 + lm, nC - 1) * ld, Cblk + (long long)min(i0 + 16 + lm, nC - 1) * ld};
-            const double *const pb[2] = {Tp + j0 + lm, Tp + j0 + 16 + lm};
-            wave_gemm_32x32_strided(acc, pa, 1, pb, B, 0, qb, lk);
-        }
-        for (int q0 = qb; q0 < qhi; q0 += 4 * KU) {
-            double av[KU][2], bv[KU][2];
-#pragma unroll
-            for (int u = 0; u < KU; u++) {
-                const int q = q0 + 4 * u + lk;
-#pragma unroll
-                for (int a = 0; a < 2; a++) av[u][a] = xinv_elem(Cblk, ld, nC, i0 + a * 16 + lm, q);
-#pragma unroll
-                for (int b = 0; b < 2; b++) bv[u][b] = Tp[(j0 + b * 16 + lm) + (long long)min(q, nC - 1) * B];
-            }
-#pragma unroll
-            for (int u = 0; u < KU; u++)
-#pragma unroll
-                for (int a = 0; a < 2; a++)
-#pragma unroll
-                    for (int b = 0; b < 2; b++)
-                        acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][a], bv[u][b], acc[a][b], 0, 0, 0);
-        }
+        // (contiguous along q: k pairs); T' rows contiguous along j (row pairs)
+        const int qb = min(i0, nC) & ~7;
+        int qd = 0;
+        if (qb > 0)
+            qd = wave_gemm_32x32_kr(acc, Cblk + (long long)min(i0 + 2 * lm, nC - 1) * ld, Cblk + (long long)min(i0 + 2 * lm + 1, nC - 1) * ld,
+                                    Tp + j0 + 2 * lm, B, 0, qb, lk);
+        wave_gemm_32x32_pm(acc, i0, j0, qd, qhi, fa, fb, lm, lk);
         // X10[i][j] = -acc, stored at upper (row o+j, col o+B+i): j on the lanes (contiguous)
 #pragma unroll
         for (int a = 0; a < 2; a++)
 #pragma unroll
-            for (int b = 0; b < 2; b++)
-#pragma unroll
-                for (int rr = 0; rr < 4; rr++) {
-                    const int i = i0 + a * 16 + lk + 4 * rr, j = j0 + b * 16 + lm;
-                    if (i < nC) P[(o + j) + (long long)(o + B + i) * ld] = -acc[a][b][rr];
-                }
+            for (int rr = 0; rr < 4; rr++) {
+                const int i = i0 + 2 * (lk + 4 * rr) + a, j = j0 + 2 * lm;
+                if (i < nC) *(gmrfx_d2u *)(P + (o + j) + (long long)(o + B + i) * ld) = (gmrfx_d2u){-acc[a][0][rr], -acc[a][1][rr]};
+            }
     }
 }
 

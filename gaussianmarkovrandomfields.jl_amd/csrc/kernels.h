@@ -219,6 +219,48 @@ __device__ __forceinline__ int wave_gemm_32x32_rk(gmrfx_d4 (&acc)[2][2], const d
     return q0;
 }
 
+// the mirror image of _rk: FIRST operand with contiguous k (one row pointer per tile), second with contiguous rows
+__device__ __forceinline__ int wave_gemm_32x32_kr(gmrfx_d4 (&acc)[2][2], const double *pa_t0, const double *pa_t1, const double *pb2,
+                                                  long long sb, int qlo, int qhi, int lk) {
+    int q0 = qlo;
+    for (; q0 + 16 <= qhi; q0 += 16) {
+        gmrfx_d2u bv[4], a0[2], a1[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const long long q = q0 + 8 * h + 2 * lk;
+            a0[h] = *(const gmrfx_d2u *)(pa_t0 + q);
+            a1[h] = *(const gmrfx_d2u *)(pa_t1 + q);
+            bv[2 * h] = *(const gmrfx_d2u *)(pb2 + q * sb);
+            bv[2 * h + 1] = *(const gmrfx_d2u *)(pb2 + (q + 1) * sb);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[h].x, bv[2 * h].x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[h].x, bv[2 * h].y, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[h].x, bv[2 * h].x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[h].x, bv[2 * h].y, acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[h].y, bv[2 * h + 1].x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[h].y, bv[2 * h + 1].y, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[h].y, bv[2 * h + 1].x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[h].y, bv[2 * h + 1].y, acc[1][1], 0, 0, 0);
+        }
+    }
+    for (; q0 + 8 <= qhi; q0 += 8) {
+        const long long q = q0 + 2 * lk;
+        const gmrfx_d2u a0 = *(const gmrfx_d2u *)(pa_t0 + q), a1 = *(const gmrfx_d2u *)(pa_t1 + q);
+        const gmrfx_d2u b0 = *(const gmrfx_d2u *)(pb2 + q * sb), b1 = *(const gmrfx_d2u *)(pb2 + (q + 1) * sb);
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, b0.x, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, b0.y, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, b0.x, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, b0.y, acc[1][1], 0, 0, 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, b1.x, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, b1.y, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, b1.x, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, b1.y, acc[1][1], 0, 0, 0);
+    }
+    return q0;
+}
+
 // Geometry of the front a workgroup works on: from the kernel arguments (one active front: the top-of-tree chains) or from
 // ONE 32-byte record at the workgroup's position in the level list (Device::d_frec_*) -- not list -> five index arrays,
 // which is a dependent round trip more on every launch of the panel chains.
