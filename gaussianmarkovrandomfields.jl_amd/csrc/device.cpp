@@ -522,14 +522,19 @@ void Device::factor_levels(int lo, int hi) {
         // The small fronts of a level (fused one-workgroup kernels) and its big fronts (assembly -> panel chain -> SYRK)
         // only depend on the levels below, not on each other: when a level has both, the small ones run on the second
         // stream next to the big-front pipeline, and the level ends when both have.
-        const bool split_small = small_on_side_ && L.nsmall > 0 && nf > 0;
-        hipStream_t st_small = split_small ? stream3 : stream;
+        // A level with small fronts only still has up to four size classes = four launches with a tail each: the widest
+        // non-empty class stays on the main stream, the others go to the second one.
+        int ncls_used = 0, widest = -1;
+        for (int k = 0; k < 4; k++) if (L.ncls[k] > 0) { ncls_used++; widest = k; }
+        const bool split_small = small_on_side_ && L.nsmall > 0 && (nf > 0 || ncls_used > 1);
         if (split_small) {
             HC(hipEventRecord(ev_ready_, stream));
             HC(hipStreamWaitEvent(stream3, ev_ready_, 0));
         }
-        for (int k = 0, off = 0; k < 4; off += L.ncls[k], k++)
+        for (int k = 0, off = 0; k < 4; off += L.ncls[k], k++) {
+            hipStream_t st_small = !split_small ? stream : (nf > 0 || k != widest) ? stream3 : stream;
             launch_factor_small(st_small, ds_, d_levellist_ + L.first + off, L.ncls[k], kClsRows[k], nz_src_, d_L_, d_cb_, d_info_);
+        }
         launch_assemble(stream, ds_, list, nf, L.max_cols, L.max_rows, nz_src_, d_L_, d_cb_);
         const int nblk = level_nblk(L);
         // The panel factorisation of a level is a chain of small dependent launches per 64-column block (potrf64 on ONE
