@@ -48,6 +48,7 @@ Device::~Device() {
     for (auto &p : allocs_) (void)hipFree(p.first);
     for (auto &e : ev_) if (e) (void)hipEventDestroy(e);
     for (auto &l : ev_lane_) for (auto &e : l) if (e) (void)hipEventDestroy(e);
+    if (h_info_) (void)hipHostFree(h_info_);
     if (ev_ready_) (void)hipEventDestroy(ev_ready_);
     if (ev_ready2_) (void)hipEventDestroy(ev_ready2_);
     if (ev_done1_) (void)hipEventDestroy(ev_done1_);
@@ -89,6 +90,8 @@ void Device::init(const Symbolic &S, int dev) {
     HC(hipEventCreateWithFlags(&ev_inv_, hipEventDisableTiming));
     for (auto &ev : ev_) HC(hipEventCreate(&ev));
     for (auto &l : ev_lane_) for (auto &ev : l) HC(hipEventCreate(&ev));
+    HC(hipHostMalloc((void **)&h_info_, sizeof(int), hipHostMallocDefault));
+    *h_info_ = INT_MAX;
     HC(hipEventCreateWithFlags(&ev_ready_, hipEventDisableTiming));
     HC(hipEventCreateWithFlags(&ev_ready2_, hipEventDisableTiming));
     HC(hipEventCreateWithFlags(&ev_done1_, hipEventDisableTiming));
@@ -600,7 +603,10 @@ void Device::factor_levels(int lo, int hi) {
 // small-front levels at the bottom of the forward sweep.
 void Device::start_inverse_async() {
     if (!inverse_pending) return;
-    HC(hipEventRecord(ev_fact_, stream));
+    // ev_fact_ = "the factor is final": recorded at the end of the factorisation, so that whatever the caller has put on
+    // the main stream since then (the transpose of the right-hand sides) does not hold the inverses back
+    if (!fact_event_valid_) HC(hipEventRecord(ev_fact_, stream));
+    fact_event_valid_ = false;
     HC(hipStreamWaitEvent(stream2, ev_fact_, 0));
     invert_diag_blocks(stream2, NB, inv_cap_);
     HC(hipEventRecord(ev_inv_, stream2));
@@ -635,8 +641,13 @@ void Device::refactorize(const double *nzval, bool on_device) {
     HC(hipEventRecord(ev_[0], stream));
     factor_levels(0, (int)levels_.size());
     HC(hipEventRecord(ev_[1], stream));
+    HC(hipEventRecord(ev_fact_, stream));
+    fact_event_valid_ = true;
     inverse_pending = true;
+    // the pivot report travels with the factorisation (pinned host word): no blocking copy after the synchronisation
+    HC(hipMemcpyAsync(h_info_, d_info_, sizeof(int), hipMemcpyDeviceToHost, stream));
     HC(hipStreamSynchronize(stream));
+    info_cached_ = true;
     HC(hipGetLastError());
     float ms = 0;
     HC(hipEventElapsedTime(&ms, ev_[0], ev_[1]));
@@ -656,6 +667,8 @@ void Device::refactorize_phase(const double *d_nzval, int phase) {
     if (!sharded()) throw std::invalid_argument("gmrfx_refactorize_phase needs a handle created with shard_world > 1");
     const int nl = (int)levels_.size();
     const int split = std::min<int>(S_->shard_level, nl);
+    info_cached_ = false;
+    fact_event_valid_ = false;
     HC(hipEventRecord(ev_[0], stream));
     if (phase == 0) {               // the subtrees this rank owns
         nz_src_ = d_nzval;
@@ -706,7 +719,8 @@ void Device::refactorize_update(const double *h, bool on_device) {
 
 long long Device::fail_col() {
     int v = INT_MAX;
-    HC(hipMemcpy(&v, d_info_, sizeof(int), hipMemcpyDeviceToHost));
+    if (info_cached_) v = *h_info_;
+    else HC(hipMemcpy(&v, d_info_, sizeof(int), hipMemcpyDeviceToHost));
     return v == INT_MAX ? -1 : v;
 }
 
@@ -889,6 +903,7 @@ void Device::solve(const double *B, long long ldb, long long nrhs, double *X, lo
         // full solve: X = P b ; backward-only (F.UP \ z): z is taken in elimination order as is
         launch_permute(stream, mode == 0 ? d_iperm_ : nullptr, (int)n, const_cast<double *>(dB) + j0 * ldin, ldin, d_X_, nr, ldx, 0);
         HC(hipEventRecord(ev[1], stream));
+
         if (mode == 0) forward(nr, ldx, 0, (int)levels_.size());
         HC(hipEventRecord(ev[2], stream));
         backward(nr, ldx, mode == 0, (int)levels_.size(), 0);

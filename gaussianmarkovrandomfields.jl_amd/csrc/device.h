@@ -252,6 +252,9 @@ private:
     // inversion needs the full inverses and runs the remaining stages on demand (B from inv_cap_ up).
     int inv_cap_ = 2048;     // measured: cfg 2 flat between 1024 and 4096 (6.18 vs 6.26 ms), 3-D 100^3 solve 44 vs 54 ms
     bool inverse_full_ = false;
+    bool fact_event_valid_ = false;   // ev_fact_ was recorded at the end of the last factorisation
+    int *h_info_ = nullptr;           // pinned: the pivot report of the last factorisation
+    bool info_cached_ = false;
     void invert_diag_blocks(hipStream_t st, int b_from, int b_to);
     void start_inverse_async();
     void wait_inverse();
