@@ -652,12 +652,7 @@ void Device::refactorize(const double *nzval, bool on_device) {
     float ms = 0;
     HC(hipEventElapsedTime(&ms, ev_[0], ev_[1]));
     ms_factor = ms;
-    ms_syrk = 0;
-    for (long long k = 0; k < syrk_launches; k++) {
-        float t = 0;
-        HC(hipEventElapsedTime(&t, ev_syrk_[2 * k], ev_syrk_[2 * k + 1]));
-        ms_syrk += t;
-    }
+    syrk_times_pending_ = true;      // the per-launch event times are only read when somebody asks for the statistics
     factorized = true;
     selinv_valid = false;
 }
@@ -715,6 +710,20 @@ void Device::refactorize_update(const double *h, bool on_device) {
     }
     launch_newton_update(stream, d_prior_, d_nz_, S_->nnz_in, d_hmap_, dh, hmap_cnt_);
     refactorize(d_nz_, true);
+}
+
+double Device::syrk_ms() {
+    if (syrk_times_pending_) {
+        HC(hipSetDevice(device));
+        ms_syrk = 0;
+        for (long long k = 0; k < syrk_launches; k++) {
+            float t = 0;
+            HC(hipEventElapsedTime(&t, ev_syrk_[2 * k], ev_syrk_[2 * k + 1]));
+            ms_syrk += t;
+        }
+        syrk_times_pending_ = false;
+    }
+    return ms_syrk;
 }
 
 long long Device::fail_col() {

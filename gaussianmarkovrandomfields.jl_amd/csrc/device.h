@@ -191,6 +191,8 @@ public:
     double ms_factor = 0, ms_solve = 0, ms_fwd = 0, ms_bwd = 0, ms_perm = 0, ms_bsolve = 0, ms_logdet = 0, ms_selinv = 0;
     long long last_nrhs = 0;
     double ms_quadform = 0;
+    bool syrk_times_pending_ = false;
+    double syrk_ms();                 // summed HIP-event time of the SYRK launches of the last factorisation (read lazily)
     double ms_syrk = 0, syrk_flops = 0;   // dominant kernel (k_syrk_cb): live HIP-event time per refactorisation, flops
     long long syrk_launches = 0;
     double bytes_total = 0;

@@ -700,7 +700,7 @@ extern "C" int32_t gmrfx_get_stats(const gmrfx_handle *h, gmrfx_stats *out, int3
         st.ms_factor = D.ms_factor; st.ms_solve = D.ms_solve; st.ms_solve_fwd = D.ms_fwd; st.ms_solve_bwd = D.ms_bwd;
         st.ms_solve_perm = D.ms_perm; st.ms_backward_solve = D.ms_bsolve; st.ms_logdet = D.ms_logdet; st.ms_selinv = D.ms_selinv;
         st.last_nrhs = D.last_nrhs;
-        st.ms_syrk = D.ms_syrk; st.syrk_flops = D.syrk_flops; st.syrk_launches = D.syrk_launches;
+        st.ms_syrk = const_cast<gmrfx::Device &>(D).syrk_ms(); st.syrk_flops = D.syrk_flops; st.syrk_launches = D.syrk_launches;
         st.ms_quadform = D.ms_quadform;
         if (D.factorized) st.fail_col = const_cast<Device &>(D).fail_col();
     }
