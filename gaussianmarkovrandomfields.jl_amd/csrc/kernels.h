@@ -78,46 +78,6 @@ __device__ __forceinline__ void wave_gemm_32x32(gmrfx_d4 (&acc)[2][2], int m0, i
     }
 }
 
-// The same product for an INTERIOR k range (no clamps, no masks): both operands are addressed as
-// base[tile] + q * stride with per-lane base pointers, q in [qlo, qhi), qlo and qhi multiples of 4. The generic
-// accessor form above spends more VALU time on index clamps, selects and 64-bit address products per operand
-// element than the MFMAs take; here a k-step is 4 loads and 4 MFMAs.
-__device__ __forceinline__ void wave_gemm_32x32_strided(gmrfx_d4 (&acc)[2][2], const double *const (&pa)[2], long long sa,
-                                                        const double *const (&pb)[2], long long sb, int qlo, int qhi, int lk) {
-    constexpr int KU = 4;
-    int q0 = qlo;
-    for (; q0 + 4 * KU <= qhi; q0 += 4 * KU) {
-        double av[KU][2], bv[KU][2];
-#pragma unroll
-        for (int u = 0; u < KU; u++) {
-            const long long q = q0 + 4 * u + lk;
-#pragma unroll
-            for (int a = 0; a < 2; a++) av[u][a] = pa[a][q * sa];
-#pragma unroll
-            for (int b = 0; b < 2; b++) bv[u][b] = pb[b][q * sb];
-        }
-#pragma unroll
-        for (int u = 0; u < KU; u++)
-#pragma unroll
-            for (int a = 0; a < 2; a++)
-#pragma unroll
-                for (int b = 0; b < 2; b++)
-                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][a], bv[u][b], acc[a][b], 0, 0, 0);
-    }
-    for (; q0 < qhi; q0 += 4) {
-        const long long q = q0 + lk;
-        double av[2], bv[2];
-#pragma unroll
-        for (int a = 0; a < 2; a++) av[a] = pa[a][q * sa];
-#pragma unroll
-        for (int b = 0; b < 2; b++) bv[b] = pb[b][q * sb];
-#pragma unroll
-        for (int a = 0; a < 2; a++)
-#pragma unroll
-            for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
-    }
-}
-
 // ---- the same 32 x 32 wave product with the operand rows in PAIRS: MFMA row lm of tile 0 / 1 is row 2 lm / 2 lm + 1 of the
 // wave's 32 (both dimensions), so a 16-byte load feeds two tiles. Output: acc[a][b][rr] = D[m0 + 2 (lk + 4 rr) + a][n0 + 2 lm + b].
 // _pm: generic accessors (masked heads / tails); _rr: both operands with contiguous rows (base + q * stride); _rk: first
