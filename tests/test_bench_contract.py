@@ -1,0 +1,52 @@
+"""The bench.py contract on a GPU box: ONE JSON line with the headline metric, the roofline of the dominant kernel (live HIP
+events), the secondary roofline objects, the phases and the correctness evidence -- on a reduced grid so that it runs in
+seconds (the driver runs the default 1000 x 1000 configuration). Also the two-rank rehearsal (two processes on this one GPU,
+gloo): the N > 1 line carries the sharded strong-scaling result as the headline and the replicas next to it."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _run(args, timeout=600):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_has_the_contract_fields():
+    d = _run(["--grid", "300", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "roofline_factor", "roofline_sweep", "phases_ms", "check"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["dtype"] == "f64" and d["unit"] == "DoF/s"
+    assert d["vs_baseline"] is None and d["higher_is_better"] is True and "workload" in d["config"]
+    assert abs(d["value"] - d["config"]["n"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 78.6 and r["kernel"] == "k_syrk_cb_rec"
+    assert 0.0 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["launches_per_step"] >= 1 and r["ms_per_step"] > 0.0          # live HIP events around every launch
+    assert d["roofline_sweep"]["bound"] == "hbm" and d["roofline_sweep"]["peak"] == 8000.0 and 0.0 < d["roofline_sweep"]["frac"] < 1.0
+    assert 0.0 < d["roofline_factor"]["frac"] < 1.0
+    assert d["check"]["rel_residual"] < 1e-10 and d["check"]["fail_col"] == -1
+    ph = d["phases_ms"]
+    assert ph["factor"] > 0 and ph["solve"] > 0 and abs(ph["solve"] - (ph["solve_fwd"] + ph["solve_bwd"] + ph["solve_perm"])) < 0.3 * ph["solve"]
+    assert d["logpdf_ms"] > 0 and d["logpdf_relerr_vs_host"] < 1e-12
+
+
+def test_two_rank_rehearsal_line_is_sharded_strong_scaling():
+    d = _run(["--gpus", "2", "--rehearse", "--grid", "200", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-logpdf"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "replicas" in d and d["replicas"]["scaling"] == "weak"
+    sh = d["sharded"]
+    assert "error" not in sh and sh["check"]["info"] == 0 and sh["check"]["rel_residual"] < 1e-10
+    assert abs(sh["check"]["logdet"] - d["check"]["logdet"]) < 1e-11 * abs(d["check"]["logdet"])
+    assert d["value"] == sh["value"] and d["ms_per_step"] == sh["ms_per_step"]
