@@ -17,18 +17,22 @@ void hip_check(hipError_t e, const char *what) {
 }
 #define HC(x) hip_check((x), #x)
 
+static constexpr size_t kPairSlackBytes = 16;
 template <class T> T *Device::dalloc(size_t count) {
     // 16 bytes of slack behind every array: kernels that load rows in pairs (16 bytes per lane) may read one element
     // past the last one; the value is never used, but the address must be mapped
     void *p = nullptr;
-    const size_t bytes = std::max<size_t>(count, 1) * sizeof(T) + 16;
+    const size_t bytes = std::max<size_t>(count, 1) * sizeof(T) + kPairSlackBytes;
     HC(hipMalloc(&p, bytes));
     allocs_.push_back({p, bytes});
     bytes_total += (double)bytes;
     return (T *)p;
 }
 
+// Grows a buffer that may be replaced during the life of the handle: the NEW buffer is allocated first, so that a failed
+// allocation (exception) leaves the old pointer and its capacity valid; callers raise their *_cap_ only after the return.
 template <class T> T *Device::dregrow(T *old, size_t count) {
+    T *fresh = dalloc<T>(count);
     if (old) {
         HC(hipDeviceSynchronize());       // nothing in flight may still read the old buffer
         for (size_t k = 0; k < allocs_.size(); k++)
@@ -39,7 +43,7 @@ template <class T> T *Device::dregrow(T *old, size_t count) {
             }
         (void)hipFree(old);
     }
-    return dalloc<T>(count);
+    return fresh;
 }
 
 Device::~Device() {
@@ -276,6 +280,7 @@ void Device::upload(const Symbolic &S) {
             }
             const int *l2p; up(l2p, l2); d_levellist2_ = const_cast<int *>(l2p);
             if (const char *e = std::getenv("GMRFX_TWO_CHAINS")) two_chains_ = std::atoi(e) != 0;
+            if (const char *e = std::getenv("GMRFX_LEVEL_MARK")) level_mark_ = std::atoi(e) != 0;
             if (const char *e = std::getenv("GMRFX_SMALL_ON_SIDE")) small_on_side_ = std::atoi(e) != 0;
         }
         const int *a; up(a, S.sub_first); d_sub_first_ = const_cast<int *>(a);
@@ -481,13 +486,18 @@ void Device::upload(const Symbolic &S) {
     first_multiblock_level_ = S.nlevels;
     for (i32 l = 0; l < S.nlevels; l++) if (levels_[l].max_cols > NB) { first_multiblock_level_ = l; break; }
 
+    // INVARIANT (pair loads): the kernels that read operand rows in 16-byte pairs (sweep_task.hip, k_syrk_cb_rec, selinv.hip)
+    // may read ONE double past a column's last row; for the last column of the last panel that is element l_size_ of the
+    // buffer. Every buffer that holds panels (d_L_, d_Z_, a clone) is therefore allocated through dalloc (16 bytes of
+    // slack) and zeroed INCLUDING the slack, so the extra element is mapped and finite (it only ever meets a 0.0 mask).
     l_size_ = S.panelptr[ns];
+    static_assert(kPairSlackBytes >= sizeof(double), "pair loads read one element past the end");
     d_L_ = dalloc<double>((size_t)l_size_);
     d_cb_ = dalloc<double>((size_t)S.cb_arena);
     d_nz_ = dalloc<double>((size_t)S.nnz_in);
     d_info_ = dalloc<int>(2);
     d_part_ = dalloc<double>(1024 + 8);
-    HC(hipMemsetAsync(d_L_, 0, (size_t)l_size_ * sizeof(double), stream));
+    HC(hipMemsetAsync(d_L_, 0, (size_t)l_size_ * sizeof(double) + kPairSlackBytes, stream));
     HC(hipStreamSynchronize(stream));
 }
 
@@ -520,6 +530,7 @@ void Device::factor_levels(int lo, int hi) {
     int nsy = (int)syrk_launches;
     for (int lev = lo; lev < hi; lev++) {
         auto &L = levels_[lev];
+        if (level_mark_) launch_level_mark(stream, 3, lev);
         const int *list = d_levellist_ + L.first + L.nsmall;
         const int nf = L.count - L.nsmall;
         // The small fronts of a level (fused one-workgroup kernels) and its big fronts (assembly -> panel chain -> SYRK)
@@ -681,6 +692,7 @@ void Device::refactorize_phase(const double *d_nzval, int phase) {
     float ms = 0;
     HC(hipEventElapsedTime(&ms, ev_[0], ev_[1]));
     ms_factor = phase == 0 ? ms : ms_factor + ms;
+    selinv_begun_ = false;
     if (split + phase >= nl) { factorized = true; selinv_valid = false; inverse_pending = true; }   // last phase done
 }
 
@@ -691,7 +703,8 @@ void Device::set_prior(const double *prior_nzval, const long long *map, long lon
         if (map[k] < 0 || map[k] >= nnz) throw std::invalid_argument("Hessian index map points outside the stored pattern of Q");
     if (!d_prior_) d_prior_ = dalloc<double>((size_t)nnz);
     HC(hipMemcpyAsync(d_prior_, prior_nzval, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice, stream));
-    if (cnt > hmap_cap_ || !d_hmap_) {
+    if (cnt > hmap_cap_ || !d_hmap_ || !d_h_) {
+        hmap_cap_ = 0;      // (if the second allocation throws, the next call regrows both)
         d_hmap_ = dregrow(d_hmap_, (size_t)std::max<long long>(cnt, 1));
         d_h_ = dregrow(d_h_, (size_t)std::max<long long>(cnt, 1));
         hmap_cap_ = cnt;
@@ -750,6 +763,7 @@ void Device::ensure_rhs_capacity(long long nrhs) {
 }
 
 void Device::forward(int nr, int ldx, int lo, int hi) {
+    if (level_mark_ && lo == 0) launch_level_mark(stream, 1, -1);
     if (lo == 0) launch_sweep_tasks(stream, ds_, 1, d_swt_, nswt_, d_L_, d_X_, d_W_, nr, ldx);
     if (lo == 0)
         for (int k = 0, off = 0; k < 3; off += nsub_cls_[k], k++)
@@ -757,6 +771,7 @@ void Device::forward(int nr, int ldx, int lo, int hi) {
                            nullptr, d_X_, d_W_, nr, ldx);
     for (int lev = lo; lev < hi; lev++) {
         auto &L = swlevels_[lev];
+        if (level_mark_) launch_level_mark(stream, 1, lev);
         if (lev == std::max(lo, first_multiblock_level_)) wait_inverse();
         for (int k = 0, off = 0; k < 4; off += L.ncls[k], k++)
             launch_fwd_small(stream, ds_, d_sw_levellist_ + L.first + off, L.ncls[k], kClsRows[k], d_L_, d_X_, d_W_, nr, ldx);
@@ -788,6 +803,7 @@ void Device::backward(int nr, int ldx, bool y_in_x2, int hi, int lo) {
     wait_inverse();   // (a no-op event wait once the forward sweep has passed it)
     for (int l = hi - 1; l >= lo; l--) {
         auto &L = swlevels_[l];
+        if (level_mark_) launch_level_mark(stream, 2, l);
         const int *list = d_sw_levellist_ + L.first + L.nsmall;
         const int nf = L.count - L.nsmall;
         for (int k = 0, off = 0; k < 4; off += L.ncls[k], k++)
@@ -812,6 +828,7 @@ void Device::backward(int nr, int ldx, bool y_in_x2, int hi, int lo) {
             }
         }
     }
+    if (level_mark_ && lo == 0) launch_level_mark(stream, 2, -1);
     if (lo == 0)
         for (int k = 0, off = 0; k < 3; off += nsub_cls_[k], k++)
             launch_subtree(stream, ds_, 2, d_sub_first_ + off, d_sub_last_ + off, nsub_cls_[k], kClsRows[k], nullptr, d_L_, nullptr,
@@ -864,7 +881,7 @@ void Device::solve(const double *B, long long ldb, long long nrhs, double *X, lo
     long long ldin = ldb, ldout = ldx_out;
     if (!on_device) {
         const long long need = n * nrhs;
-        if (need > io_cap_) { io_cap_ = std::max(need, 2 * io_cap_); d_io_ = dregrow(d_io_, (size_t)io_cap_); }
+        if (need > io_cap_) { const long long cap = std::max(need, 2 * io_cap_); d_io_ = dregrow(d_io_, (size_t)cap); io_cap_ = cap; }
         if (ldb == n) HC(hipMemcpyAsync(d_io_, B, (size_t)need * sizeof(double), hipMemcpyHostToDevice, stream));
         else HC(hipMemcpy2DAsync(d_io_, n * sizeof(double), B, ldb * sizeof(double), n * sizeof(double), nrhs, hipMemcpyHostToDevice, stream));
         dB = d_io_; dXo = d_io_; ldin = n; ldout = n;
@@ -977,9 +994,11 @@ void Device::quadform(const double *d_nz, const double *d_X, long long ldx, long
     }
     const int nblk = quadform_blocks((int)S.n);
     if (nvec > qf_cap_) {
-        qf_cap_ = std::max<long long>(nvec, 2 * qf_cap_);     // geometric growth, the old buffers are freed
-        d_qf_part_ = dregrow(d_qf_part_, (size_t)qf_cap_ * nblk);
-        d_qf_out_ = dregrow(d_qf_out_, (size_t)qf_cap_);
+        const long long cap = std::max<long long>(nvec, 2 * qf_cap_);     // geometric growth, the old buffers are freed
+        qf_cap_ = 0;        // (a failed second allocation must not leave the pair with different sizes behind one capacity)
+        d_qf_part_ = dregrow(d_qf_part_, (size_t)cap * nblk);
+        d_qf_out_ = dregrow(d_qf_out_, (size_t)cap);
+        qf_cap_ = cap;
     }
     HC(hipEventRecord(ev_[0], stream));
     launch_quadform(stream, (int)S.n, d_in_colptr_, d_in_row_, d_nz, S.in_use, d_X, ldx, (int)nvec, d_mu, d_qf_part_, d_qf_out_);
@@ -1017,7 +1036,7 @@ void Device::selinv_begin() {
         HC(hipMemcpyAsync(d_yoff_, yoff.data(), yoff.size() * sizeof(long long), hipMemcpyHostToDevice, stream));
         HC(hipStreamSynchronize(stream));
     }
-    HC(hipMemsetAsync(d_Z_, 0, (size_t)l_size_ * sizeof(double), stream));
+    HC(hipMemsetAsync(d_Z_, 0, (size_t)l_size_ * sizeof(double) + kPairSlackBytes, stream));
 }
 
 void Device::selinv_levels(int hi, int lo) {
@@ -1066,9 +1085,13 @@ void Device::selinv_phase(int what, int hi, int lo) {
     HC(hipSetDevice(device));
     if (!sharded()) throw std::invalid_argument("gmrfx_selinv_phase needs a handle created with shard_world > 1");
     const int nl = (int)levels_.size();
+    if (what != 0 && !selinv_begun_)       // (phases 1-3 launch kernels on the workspaces phase 0 allocates)
+        throw std::invalid_argument("selinv phase 1, 2 or 3 before phase 0 (begin) since the last refactorisation");
     if (what == 0) {
+        if (!factorized) throw std::invalid_argument("selinv phase 0 before the factorisation has finished");
         selinv_valid = false;
         selinv_begin();
+        selinv_begun_ = true;
         ms_selinv = 0;
     } else if (what == 1) {
         if (hi < 0 || hi >= nl) throw std::invalid_argument("selinv phase: level out of range");

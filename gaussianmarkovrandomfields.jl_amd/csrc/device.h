@@ -234,6 +234,8 @@ private:
     FrontView *d_frec_ = nullptr, *d_frec2_ = nullptr, *d_sel_frec_ = nullptr;   // geometry records parallel to the level lists
     int *d_levellist2_ = nullptr;   // per level: the big fronts re-ordered [even positions..., odd positions...] (two-stream panel chains)
     bool two_chains_ = true;
+    bool selinv_begun_ = false;   // sharded selected inversion: phase 0 has run since the last refactorisation (gmrfx_selinv_phase)
+    bool level_mark_ = false;     // GMRFX_LEVEL_MARK=1: an empty marker kernel in front of every level (profiling aid, tools/sweep_levels.py)
     bool small_on_side_ = true;     // GMRFX_SMALL_ON_SIDE=0: a level's small fronts before its big fronts, on one stream
     int *d_sub_first_ = nullptr, *d_sub_last_ = nullptr, *d_sel_levellist_ = nullptr;
     int nsub_cls_[3] = {0, 0, 0};

@@ -1444,6 +1444,12 @@ void launch_fwd_own_update(hipStream_t st, const DevSym &S, const int *list, int
     if (nfronts <= 0 || rows_below <= 0) return;
     hipLaunchKernelGGL(k_fwd_own_update, dim3(odd(cdiv(rows_below, 32)), nfronts), dim3(256), 0, st, S, list, L, Y, X, nr, ldx, blk, cap);
 }
+// Profiling aid (GMRFX_LEVEL_MARK=1, tools/sweep_levels.py): an empty kernel whose launch geometry names the phase and tree
+// level that follows it in the stream, so that a kernel trace / counter pass can be cut into levels without guessing.
+__global__ void k_level_mark() {}
+void launch_level_mark(hipStream_t st, int phase, int level) {
+    hipLaunchKernelGGL(k_level_mark, dim3(level + 2), dim3(64 * phase), 0, st);      // level -1 = the sweep tasks / subtrees
+}
 void launch_permute(hipStream_t st, const int *perm, int n, double *Bc, long long ldb, double *X, int nr, int ldx, int dir) {
     hipLaunchKernelGGL(k_permute, dim3(cdiv(n, 64)), dim3(256), 0, st, perm, n, Bc, ldb, X, nr, ldx, dir);
 }

@@ -65,7 +65,8 @@ typedef struct gmrfx_opts {
                                enables geometric nested dissection; NULL otherwise */
     /* Sharding ONE factorisation over shard_world processes (one GPU each): every process creates
      * its handle with the same pattern / options and its own shard_rank. The supernodal tree is cut
-     * into subtrees dealt to the ranks; the fronts above them (the "top") belong to rank 0. See the
+     * into subtrees dealt to the ranks; every front above them (the "top") is owned by ONE rank of the
+     * group whose subtrees it joins (the least loaded owner of its children). See the
      * gmrfx_shard_* entry points. shard_world <= 1: unsharded (default). */
     int32_t shard_rank, shard_world;
 } gmrfx_opts;
