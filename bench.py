@@ -25,6 +25,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "gaussianmarkovrandomfields.jl_amd"))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
+SHARD_TIMEOUT_EXIT = 3     # the sharded (strong-scaling) run hung: replica line printed with the error, every rank exits 3
+SHARD_FAILED_EXIT = 4      # the sharded run raised: replica line printed with the error, every rank exits 4
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 FP64_MFMA_PEAK_TF = 78.6   # datasheet FP64 matrix peak (32 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz)
 FP64_MFMA_MEASURED_TF = 75.7   # sustained v_mfma_f64_16x16x4_f64 with >= 2 issuing waves per SIMD (tools/micro/mix64.hip);
@@ -420,17 +422,28 @@ def main():
     # a multi-GPU node yet) must not take it down. Every rank arms the same timer at the same barrier; when it fires,
     # rank 0 prints the replica line with the failure recorded and all ranks leave.
     sharded = None
+    shard_raised = False
     printed = [False]
+    out_lock = None
+    watchdog = None
     if dist is not None and not args.no_shard:
         import threading
+        out_lock = threading.Lock()
         dist.barrier()
 
         def give_up():
-            if rank == 0 and not printed[0]:
-                out["sharded"] = {"error": f"the sharded run did not finish within {args.shard_timeout} s"}
-                out["replicas"] = {"value": out["value"], "ms_per_step": out["ms_per_step"], "scaling": "weak"}
-                print(json.dumps(out), flush=True)
-            os._exit(0)
+            # The sharded run hangs or an exchange never completes: flush the replica line with the failure recorded, then
+            # leave with a NON-ZERO code on every rank (a process that has touched the GPU and is killed by its watchdog has
+            # failed; the launcher and the driver must see that).
+            with out_lock:
+                if rank == 0 and not printed[0]:
+                    out["sharded"] = {"error": f"the sharded run did not finish within {args.shard_timeout} s"}
+                    out["replicas"] = {"value": out["value"], "ms_per_step": out["ms_per_step"], "scaling": "weak"}
+                    print(json.dumps(out), flush=True)
+                    printed[0] = True
+            if rank != 0:
+                time.sleep(1.0)     # the launcher ends all ranks when the first one fails: rank 0 prints first
+            os._exit(SHARD_TIMEOUT_EXIT)
         watchdog = threading.Timer(args.shard_timeout, give_up)
         watchdog.daemon = True
         watchdog.start()
@@ -438,6 +451,7 @@ def main():
             sharded = bench_sharded(args, Q, mesh, dist, rank, world, local_rank)
         except Exception as e:           # the replica line must survive a failure of the sharded path
             sharded = {"error": repr(e)} if rank == 0 else None
+            shard_raised = True
 
     if rank == 0:
         if world > 1:
@@ -453,11 +467,26 @@ def main():
             else:
                 out["sharded"] = sharded
             out["replicas"] = replicas
-        print(json.dumps(out), flush=True)
-        printed[0] = True
+        if out_lock is not None:
+            with out_lock:
+                if not printed[0]:
+                    print(json.dumps(out), flush=True)
+                    printed[0] = True
+        else:
+            print(json.dumps(out), flush=True)
+    failed = False
     if dist is not None:
+        # did the sharded path fail on rank 0 (exception)? every rank leaves with the same code
+        flag = torch.tensor([1 if (shard_raised or (rank == 0 and not args.no_shard and (sharded is None or "error" in sharded))) else 0],
+                            dtype=torch.int64, device="cpu" if args.rehearse else dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        failed = bool(flag.item())
         dist.barrier()          # (still under the watchdog: a rank that failed alone would wait here for ever)
+        if watchdog is not None:
+            watchdog.cancel()
         dist.destroy_process_group()
+    if failed:
+        raise SystemExit(SHARD_FAILED_EXIT)     # the JSON line (replica headline + the error) is out; the exit code says so too
 
 
 if __name__ == "__main__":

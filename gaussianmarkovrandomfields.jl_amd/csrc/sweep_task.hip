@@ -22,6 +22,8 @@
 // Summation order is fixed (fronts in postorder, one owner per entry): bit-reproducible like the rest of the solver.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace gmrfx {
@@ -30,16 +32,27 @@ typedef gmrfx_d4 d4;
 
 constexpr int TASK_ROWS = 288;       // local-vector rows (Symbolic::swt_rows <= this)
 constexpr int TASK_MAXF = 64;        // fronts per task (host enforces)
-constexpr int TASK_THREADS = 1024;   // 16 waves = 4 row-tile slots x 4 column tiles: one wave issues an FP64 MFMA only every ~138 cycles, so
-                                     // the MFMAs of a row tile are spread over four waves (on four SIMDs)
-constexpr int TASK_WAVES = TASK_THREADS / 64;
-constexpr int TPW = 1;                           // 16-column tiles of the right-hand sides per wave (measured: 1 at 1024 threads beats 2 at 512 or 1024 and 4 at 256)
-constexpr int TASK_SLOTS = TASK_WAVES * TPW / 4; // row-tile slots
+constexpr int TPW = 1;               // 16-column tiles of the right-hand sides per wave (measured: 1 beats 2 and 4)
+constexpr int TASK_SLOTS = 4;        // row-tile slots
+constexpr int TASK_GROUPS = 16;      // row groups of the copy loops (= threads / NC)
+// A workgroup keeps NC columns of the local vector: NC = 64 -> 16 waves (4 row-tile slots x 4 column tiles; one wave issues
+// an FP64 MFMA only every ~138 cycles, so the MFMAs of a row tile are spread over the waves of four SIMDs), 144 KB of LDS,
+// ONE workgroup per CU. NC = 32 -> 8 waves, 72 KB: the two column halves of a task are two workgroups (ids b and b + 8: same
+// XCD, so the second reader of the task's panels finds them in that XCD's L2) and TWO workgroups are resident per CU -- the
+// memory phases of one (panel warm-up, the slice of X in, x out) run under the latency-bound front chain of the other.
 
-// V is stored row-major with 64 columns; the 16-column tiles of odd rows are swapped pairwise so that the two
+// V is stored row-major with NC columns; the 16-column tiles of odd rows are swapped pairwise so that the two
 // k-rows a ds_read_b64 lane group (lanes 0-31 = two k-rows x 16 columns) touches fall into different halves of the
-// 64 LDS banks (row stride = 512 B = 0 mod 256 would otherwise be a 2-way conflict on every operand read).
-__device__ __forceinline__ int vidx(int row, int col) { return row * 64 + (col ^ ((row & 1) << 4)); }
+// 64 LDS banks (row stride = 512 / 256 B = 0 mod 256 would otherwise be a 2-way conflict on every operand read).
+template <int NC> __device__ __forceinline__ int vidx(int row, int col) { return row * NC + (col ^ ((row & 1) << 4)); }
+
+// which (task, column half) a workgroup runs; false: nothing to do
+template <int NC> __device__ __forceinline__ bool task_of_block(int ntasks, int nr, int &t, int &cbase) {
+    const int b = blockIdx.x;
+    if (NC == 64) { t = b; cbase = 0; }
+    else { t = ((b >> 4) << 3) | (b & 7); cbase = ((b >> 3) & 1) * NC; }
+    return t < ntasks && cbase < nr;
+}
 
 
 struct TaskMeta { int c, r, ld, o; long long pp, rp; };   // per front: columns, rows, panel ld, first own local row, panel / row-list offsets
@@ -72,7 +85,8 @@ __device__ __forceinline__ double tinv_elem(const double *__restrict__ P, int ld
 // Loads the geometry of the task's fronts into LDS (one round trip for the whole task instead of one per front) and
 // touches the task's panels and local-row lists, which are contiguous in HBM (postorder), so that the per-front
 // operand loads hit L2.
-__device__ __forceinline__ double task_prologue(const DevSym &S, const SweepTask &T, TaskMeta *meta, const double *__restrict__ L) {
+template <int NC> __device__ __forceinline__ double task_prologue(const DevSym &S, const SweepTask &T, TaskMeta *meta, const double *__restrict__ L) {
+    constexpr int TASK_THREADS = NC * 16;
     const int tid = threadIdx.x;
     const int nf = T.s1 - T.s0 + 1;
     if (tid < nf) {
@@ -97,18 +111,18 @@ __device__ __forceinline__ double task_prologue(const DevSym &S, const SweepTask
 }
 
 // acc[t] += a (this lane's element of a 16 x 4 A operand) x V[row kq][column tile t], t = 0..3
-__device__ __forceinline__ void mfma4_lds(d4 (&acc)[TPW], const double a, const double *V, const int kq, const int cl) {
-    const double *vr = V + kq * 64;
+template <int NC> __device__ __forceinline__ void mfma4_lds(d4 (&acc)[TPW], const double a, const double *V, const int kq, const int cl) {
+    const double *vr = V + kq * NC;
     const int sw = (kq & 1) << 4;
 #pragma unroll
     for (int t = 0; t < TPW; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, vr[(t * 16 + cl) ^ sw], acc[t], 0, 0, 0);
 }
 // V[rows l2[rr]][all four column tiles] -= acc (rows lk + 4 rr of the tile; distinct rows inside a front)
-__device__ __forceinline__ void scatter_sub(double *V, const int (&l2)[4], const d4 (&acc)[TPW], const int nvalid, const int lk, const int cl) {
+template <int NC> __device__ __forceinline__ void scatter_sub(double *V, const int (&l2)[4], const d4 (&acc)[TPW], const int nvalid, const int lk, const int cl) {
 #pragma unroll
     for (int rr = 0; rr < 4; rr++) {
         if (lk + 4 * rr < nvalid) {
-            double *vr = V + l2[rr] * 64;
+            double *vr = V + l2[rr] * NC;
             const int sw = (l2[rr] & 1) << 4;
 #pragma unroll
             for (int t = 0; t < TPW; t++) vr[(t * 16 + cl) ^ sw] -= acc[t][rr];
@@ -119,30 +133,35 @@ __device__ __forceinline__ void scatter_sub(double *V, const int (&l2)[4], const
 // ------------------------------------------------------------------------------------------------------------
 // forward: V <- [b of the subtree ; 0]; per front y = L11^-1 b (own rows, written to X), V[trailing] -= L21 y
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TASK_THREADS, 1) void k_fwd_task(DevSym S, const SweepTask *__restrict__ tasks,
-                                                     const double *__restrict__ L, double *__restrict__ X, double *__restrict__ W,
-                                                     int nr, int ldx) {
-    __shared__ double V[TASK_ROWS * 64];
+template <int NC> __global__ __launch_bounds__(NC * 16) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_fwd_task(DevSym S, const SweepTask *__restrict__ tasks, int ntasks, const double *__restrict__ L, double *__restrict__ X,
+                double *__restrict__ W, int nr_all, int ldx) {
+    __shared__ double V[TASK_ROWS * NC];
     __shared__ TaskMeta meta[TASK_MAXF];
-    const SweepTask T = tasks[blockIdx.x];
+    int tsk, cbase;
+    if (!task_of_block<NC>(ntasks, nr_all, tsk, cbase)) return;
+    X += cbase; W += cbase;                             // this workgroup's NC columns of the right-hand sides
+    const int nr = min(nr_all - cbase, NC);
+    const SweepTask T = tasks[tsk];
     const int col0 = T.col0, NT = T.nt, nf = T.s1 - T.s0 + 1, mroot = T.mroot;
     const int tid = threadIdx.x;
-    const int j = tid & 63, g = tid >> 6;              // g: TASK_WAVES row groups
+    const int j = tid % NC, g = tid / NC;               // g: TASK_GROUPS row groups
     const int jc = min(j, nr - 1);
     const double jm = j < nr ? 1.0 : 0.0;
-    const double sink = task_prologue(S, T, meta, L);
+    const double sink = task_prologue<NC>(S, T, meta, L);
     // the subtree's slice of X: NT contiguous rows, four row loads in flight per thread
-    for (int i0 = g; i0 < NT; i0 += 4 * TASK_WAVES) {
+    for (int i0 = g; i0 < NT; i0 += 4 * TASK_GROUPS) {
         double v[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) v[u] = X[(long long)(col0 + min(i0 + TASK_WAVES * u, NT - 1)) * ldx + jc];
+        for (int u = 0; u < 4; u++) v[u] = X[(long long)(col0 + min(i0 + TASK_GROUPS * u, NT - 1)) * ldx + jc];
 #pragma unroll
-        for (int u = 0; u < 4; u++) if (i0 + TASK_WAVES * u < NT) V[vidx(i0 + TASK_WAVES * u, j)] = v[u] * jm;
+        for (int u = 0; u < 4; u++) if (i0 + TASK_GROUPS * u < NT) V[vidx<NC>(i0 + TASK_GROUPS * u, j)] = v[u] * jm;
     }
-    for (int i = NT + g; i < NT + mroot; i += TASK_WAVES) V[vidx(i, j)] = 0.0;
+    for (int i = NT + g; i < NT + mroot; i += TASK_GROUPS) V[vidx<NC>(i, j)] = 0.0;
     __syncthreads();
+    constexpr int CT = NC / 16;                         // column tiles = waves per row-tile slot
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int w = wv / (4 / TPW), th = wv % (4 / TPW);  // this wave's row-tile slot and its part of the right-hand sides (scalars)
+    const int w = wv / CT, th = wv % CT;                // this wave's row-tile slot and its part of the right-hand sides (scalars)
     const int lane = tid & 63;
     const int lm = lane & 15, lk = lane >> 4;
     const int cl = th * 16 * TPW + lm;                  // column of this lane in the first of its tiles
@@ -192,7 +211,7 @@ __global__ __launch_bounds__(TASK_THREADS, 1) void k_fwd_task(DevSym S, const Sw
                 for (int t = 0; t < TPW; t++) y[t] = (d4){0.0, 0.0, 0.0, 0.0};
                 const int ku = (c + 3) >> 2;          // k-steps that hold columns of the front (scalar)
 #pragma unroll
-                for (int u = 0; u < 4; u++) if (u < ku) mfma4_lds(y, ao[u], V, o + min(4 * u + lk, c - 1), cl);
+                for (int u = 0; u < 4; u++) if (u < ku) mfma4_lds<NC>(y, ao[u], V, o + min(4 * u + lk, c - 1), cl);
                 if (w == 0) {
 #pragma unroll
                     for (int t = 0; t < TPW; t++)
@@ -225,7 +244,7 @@ __global__ __launch_bounds__(TASK_THREADS, 1) void k_fwd_task(DevSym S, const Sw
 #pragma unroll
                             for (int t = 0; t < TPW; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], y[t][u], acc[t], 0, 0, 0);
                         }
-                    scatter_sub(V, l2, acc, r - i0, lk, cl);
+                    scatter_sub<NC>(V, l2, acc, r - i0, lk, cl);
                 }
             }
             __syncthreads();
@@ -238,7 +257,7 @@ __global__ __launch_bounds__(TASK_THREADS, 1) void k_fwd_task(DevSym S, const Sw
 #pragma unroll
             for (int t = 0; t < TPW; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int u = 0; u < 4; u++) mfma4_lds(acc, ao[u], V, o + min(4 * u + lk, c - 1), cl);     // zero beyond column c / above the diagonal
+            for (int u = 0; u < 4; u++) mfma4_lds<NC>(acc, ao[u], V, o + min(4 * u + lk, c - 1), cl);     // zero beyond column c / above the diagonal
             const int qhi = min(c, k0 + 16);
 #pragma unroll 1
             for (int q0 = 16; q0 < qhi; q0 += 16) {
@@ -246,7 +265,7 @@ __global__ __launch_bounds__(TASK_THREADS, 1) void k_fwd_task(DevSym S, const Sw
 #pragma unroll
                 for (int u = 0; u < 4; u++) av[u] = tinv_elem(P, ld, c, k0 + lm, q0 + 4 * u + lk, true);
 #pragma unroll
-                for (int u = 0; u < 4; u++) mfma4_lds(acc, av[u], V, o + min(q0 + 4 * u + lk, c - 1), cl);
+                for (int u = 0; u < 4; u++) mfma4_lds<NC>(acc, av[u], V, o + min(q0 + 4 * u + lk, c - 1), cl);
             }
         }
         __syncthreads();            // every slot has read b before any y is written
@@ -257,7 +276,7 @@ __global__ __launch_bounds__(TASK_THREADS, 1) void k_fwd_task(DevSym S, const Sw
                 for (int rr = 0; rr < 4; rr++) {
                     const int k = k0 + lk + 4 * rr;
                     if (k < c) {
-                        V[vidx(o + k, t * 16 + cl)] = acc[t][rr];
+                        V[vidx<NC>(o + k, t * 16 + cl)] = acc[t][rr];
                         if (t * 16 + cl < nr) Xo[(long long)k * ldx + t * 16 + cl] = acc[t][rr];
                     }
                 }
@@ -275,7 +294,7 @@ __global__ __launch_bounds__(TASK_THREADS, 1) void k_fwd_task(DevSym S, const Sw
 #pragma unroll
                 for (int u = 0; u < 4; u++) l2[u] = li[u];
 #pragma unroll
-                for (int u = 0; u < 4; u++) mfma4_lds(acc, at[u], V, o + 4 * u + lk, cl);            // c > 16: rows o .. o+15 exist
+                for (int u = 0; u < 4; u++) mfma4_lds<NC>(acc, at[u], V, o + 4 * u + lk, cl);            // c > 16: rows o .. o+15 exist
             } else {
                 const int v = lr[min(i0 + lm, r - 1)];
 #pragma unroll
@@ -284,7 +303,7 @@ __global__ __launch_bounds__(TASK_THREADS, 1) void k_fwd_task(DevSym S, const Sw
 #pragma unroll
                 for (int u = 0; u < 4; u++) av[u] = pa[(long long)(4 * u + lk) * ld];
 #pragma unroll
-                for (int u = 0; u < 4; u++) mfma4_lds(acc, av[u], V, o + 4 * u + lk, cl);
+                for (int u = 0; u < 4; u++) mfma4_lds<NC>(acc, av[u], V, o + 4 * u + lk, cl);
             }
 #pragma unroll 1
             for (int q0 = 16; q0 < c; q0 += 16) {
@@ -295,9 +314,9 @@ __global__ __launch_bounds__(TASK_THREADS, 1) void k_fwd_task(DevSym S, const Sw
                     av[u] = pa[(long long)min(q, c - 1) * ld] * (q < c ? 1.0 : 0.0);
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++) mfma4_lds(acc, av[u], V, o + min(q0 + 4 * u + lk, c - 1), cl);
+                for (int u = 0; u < 4; u++) mfma4_lds<NC>(acc, av[u], V, o + min(q0 + 4 * u + lk, c - 1), cl);
             }
-            scatter_sub(V, l2, acc, r - i0, lk, cl);     // distinct rows inside a front, one wave per row tile: no conflicts
+            scatter_sub<NC>(V, l2, acc, r - i0, lk, cl);     // distinct rows inside a front, one wave per row tile: no conflicts
         }
         __syncthreads();
     };
@@ -312,7 +331,7 @@ __global__ __launch_bounds__(TASK_THREADS, 1) void k_fwd_task(DevSym S, const Sw
     // ---- write-out: the root's update vector W (y went to X front by front) -----------------------------------
     if (j < nr) {
         double *Wr = W + T.woff * ldx;
-        for (int i = g; i < mroot; i += TASK_WAVES) Wr[(long long)i * ldx + j] = V[vidx(NT + i, j)];
+        for (int i = g; i < mroot; i += TASK_GROUPS) Wr[(long long)i * ldx + j] = V[vidx<NC>(NT + i, j)];
     }
     if (sink == 1.2345678e-300) X[(long long)col0 * ldx] = sink;      // keeps the warm-up loads alive; never true
 }
@@ -321,40 +340,46 @@ __global__ __launch_bounds__(TASK_THREADS, 1) void k_fwd_task(DevSym S, const Sw
 // backward: V <- [y (or z) of the subtree ; x of the root's trailing rows]; per front, root first:
 // t = y - L21' x[trailing], x = L11^-T t
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TASK_THREADS, 1) void k_bwd_task(DevSym S, const SweepTask *__restrict__ tasks,
-                                                     const double *__restrict__ L, double *__restrict__ X, int nr, int ldx) {
-    __shared__ double V[TASK_ROWS * 64];
+template <int NC> __global__ __launch_bounds__(NC * 16) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_bwd_task(DevSym S, const SweepTask *__restrict__ tasks, int ntasks, const double *__restrict__ L, double *__restrict__ X,
+                int nr_all, int ldx) {
+    __shared__ double V[TASK_ROWS * NC];
     __shared__ TaskMeta meta[TASK_MAXF];
-    const SweepTask T = tasks[blockIdx.x];
+    int tsk, cbase;
+    if (!task_of_block<NC>(ntasks, nr_all, tsk, cbase)) return;
+    X += cbase;
+    const int nr = min(nr_all - cbase, NC);
+    const SweepTask T = tasks[tsk];
     const int col0 = T.col0, NT = T.nt, nf = T.s1 - T.s0 + 1, mroot = T.mroot;
     const int tid = threadIdx.x;
-    const int j = tid & 63, g = tid >> 6;
+    const int j = tid % NC, g = tid / NC;
     const int jc = min(j, nr - 1);
     const double jm = j < nr ? 1.0 : 0.0;
-    const double sink = task_prologue(S, T, meta, L);
-    for (int i0 = g; i0 < NT; i0 += 4 * TASK_WAVES) {
+    const double sink = task_prologue<NC>(S, T, meta, L);
+    for (int i0 = g; i0 < NT; i0 += 4 * TASK_GROUPS) {
         double v[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) v[u] = X[(long long)(col0 + min(i0 + TASK_WAVES * u, NT - 1)) * ldx + jc];
+        for (int u = 0; u < 4; u++) v[u] = X[(long long)(col0 + min(i0 + TASK_GROUPS * u, NT - 1)) * ldx + jc];
 #pragma unroll
-        for (int u = 0; u < 4; u++) if (i0 + TASK_WAVES * u < NT) V[vidx(i0 + TASK_WAVES * u, j)] = v[u] * jm;
+        for (int u = 0; u < 4; u++) if (i0 + TASK_GROUPS * u < NT) V[vidx<NC>(i0 + TASK_GROUPS * u, j)] = v[u] * jm;
     }
     {   // x of the root's trailing rows (ancestors of the subtree: final)
         const int *rows = S.rows + T.rroot;
-        for (int i0 = g; i0 < mroot; i0 += 4 * TASK_WAVES) {
+        for (int i0 = g; i0 < mroot; i0 += 4 * TASK_GROUPS) {
             int ri[4];
             double v[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) ri[u] = rows[min(i0 + TASK_WAVES * u, mroot - 1)];
+            for (int u = 0; u < 4; u++) ri[u] = rows[min(i0 + TASK_GROUPS * u, mroot - 1)];
 #pragma unroll
             for (int u = 0; u < 4; u++) v[u] = X[(long long)ri[u] * ldx + jc];
 #pragma unroll
-            for (int u = 0; u < 4; u++) if (i0 + TASK_WAVES * u < mroot) V[vidx(NT + i0 + TASK_WAVES * u, j)] = v[u] * jm;
+            for (int u = 0; u < 4; u++) if (i0 + TASK_GROUPS * u < mroot) V[vidx<NC>(NT + i0 + TASK_GROUPS * u, j)] = v[u] * jm;
         }
     }
     __syncthreads();
+    constexpr int CT = NC / 16;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int w = wv / (4 / TPW), th = wv % (4 / TPW);
+    const int w = wv / CT, th = wv % CT;
     const int lane = tid & 63;
     const int lm = lane & 15, lk = lane >> 4;
     const int cl = th * 16 * TPW + lm;
@@ -403,7 +428,7 @@ __global__ __launch_bounds__(TASK_THREADS, 1) void k_bwd_task(DevSym S, const Sw
 #pragma unroll
                 for (int u = 0; u < 8; u++)         // k-step u = 2 h + e holds rows c + 8 h + 2 lk + e (request())
                     if (8 * (u >> 1) + (u & 1) < r - c)
-                        mfma4_lds(acc, a1[u] * ((c + 8 * (u >> 1) + 2 * lk + (u & 1)) < r ? 1.0 : 0.0), V, max(l1[u], 0), cl);
+                        mfma4_lds<NC>(acc, a1[u] * ((c + 8 * (u >> 1) + 2 * lk + (u & 1)) < r ? 1.0 : 0.0), V, max(l1[u], 0), cl);
 #pragma unroll 1
                 for (int q0 = c + 32; q0 < r; q0 += 16) {      // rare in a task (r - c > 32): one 16-row k-block per pass
                     double av[4];
@@ -416,7 +441,7 @@ __global__ __launch_bounds__(TASK_THREADS, 1) void k_bwd_task(DevSym S, const Sw
                     }
 #pragma unroll
                     for (int u = 0; u < 4; u++)
-                        mfma4_lds(acc, av[u] * ((q0 + 4 * u + lk) < r ? 1.0 : 0.0), V, l2[u], cl);
+                        mfma4_lds<NC>(acc, av[u] * ((q0 + 4 * u + lk) < r ? 1.0 : 0.0), V, l2[u], cl);
                 }
             }
         }
@@ -432,7 +457,7 @@ __global__ __launch_bounds__(TASK_THREADS, 1) void k_bwd_task(DevSym S, const Sw
                 for (int u = 0; u < 4; u++) {
                     if (u < ku) {
                         const int kq = o + min(4 * u + lk, c - 1);
-                        const double *vr = V + kq * 64;
+                        const double *vr = V + kq * NC;
                         const int sw = (kq & 1) << 4;
 #pragma unroll
                         for (int t = 0; t < TPW; t++)
@@ -443,7 +468,7 @@ __global__ __launch_bounds__(TASK_THREADS, 1) void k_bwd_task(DevSym S, const Sw
                 for (int t = 0; t < TPW; t++)
 #pragma unroll
                     for (int rr = 0; rr < 4; rr++)
-                        if (lk + 4 * rr < c) V[vidx(o + lk + 4 * rr, t * 16 + cl)] = x[t][rr];
+                        if (lk + 4 * rr < c) V[vidx<NC>(o + lk + 4 * rr, t * 16 + cl)] = x[t][rr];
             }
             __syncthreads();
             return;
@@ -454,7 +479,7 @@ __global__ __launch_bounds__(TASK_THREADS, 1) void k_bwd_task(DevSym S, const Sw
 #pragma unroll
                 for (int rr = 0; rr < 4; rr++) {
                     const int k = k0 + lk + 4 * rr;
-                    if (k < c) V[vidx(o + k, t * 16 + cl)] -= acc[t][rr];
+                    if (k < c) V[vidx<NC>(o + k, t * 16 + cl)] -= acc[t][rr];
                 }
         }
         __syncthreads();
@@ -463,14 +488,14 @@ __global__ __launch_bounds__(TASK_THREADS, 1) void k_bwd_task(DevSym S, const Sw
 #pragma unroll
             for (int t = 0; t < TPW; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int u = 0; u < 4; u++) mfma4_lds(acc, ad[u], V, o + min(k0 + 4 * u + lk, c - 1), cl);
+            for (int u = 0; u < 4; u++) mfma4_lds<NC>(acc, ad[u], V, o + min(k0 + 4 * u + lk, c - 1), cl);
 #pragma unroll 1
             for (int q0 = k0 + 16; q0 < c; q0 += 16) {
                 double av[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) av[u] = tinv_elem(P, ld, c, k0 + lm, q0 + 4 * u + lk, false);   // Linv[q][k], q >= k
 #pragma unroll
-                for (int u = 0; u < 4; u++) mfma4_lds(acc, av[u], V, o + min(q0 + 4 * u + lk, c - 1), cl);
+                for (int u = 0; u < 4; u++) mfma4_lds<NC>(acc, av[u], V, o + min(q0 + 4 * u + lk, c - 1), cl);
             }
         }
         __syncthreads();            // every slot has read t before any x is written
@@ -480,7 +505,7 @@ __global__ __launch_bounds__(TASK_THREADS, 1) void k_bwd_task(DevSym S, const Sw
 #pragma unroll
                 for (int rr = 0; rr < 4; rr++) {
                     const int k = k0 + lk + 4 * rr;
-                    if (k < c) V[vidx(o + k, t * 16 + cl)] = acc[t][rr];
+                    if (k < c) V[vidx<NC>(o + k, t * 16 + cl)] = acc[t][rr];
                 }
         }
         __syncthreads();
@@ -494,15 +519,25 @@ __global__ __launch_bounds__(TASK_THREADS, 1) void k_bwd_task(DevSym S, const Sw
         if (f == 0) front(0, opA_1, opA_l, opA_d, opB_1, opB_l, opB_d);
     }
     if (j < nr)
-        for (int i = g; i < NT; i += TASK_WAVES) X[(long long)(col0 + i) * ldx + j] = V[vidx(i, j)];
+        for (int i = g; i < NT; i += TASK_GROUPS) X[(long long)(col0 + i) * ldx + j] = V[vidx<NC>(i, j)];
     if (sink == 1.2345678e-300) X[(long long)col0 * ldx] = sink;
 }
 
+static int task_nc() {      // GMRFX_TASK_NC = 64: one 64-column workgroup per task (one per CU); 32 (default): two column halves, two resident per CU
+    static const int v = [] { const char *e = std::getenv("GMRFX_TASK_NC"); const int x = e ? std::atoi(e) : 32; return x == 64 ? 64 : 32; }();
+    return v;
+}
 void launch_sweep_tasks(hipStream_t st, const DevSym &S, int phase, const SweepTask *tasks, int ntasks,
                         const double *L, double *X, double *W, int nr, int ldx) {
     if (ntasks <= 0) return;
-    if (phase == 1) hipLaunchKernelGGL(k_fwd_task, dim3(ntasks), dim3(TASK_THREADS), 0, st, S, tasks, L, X, W, nr, ldx);
-    else hipLaunchKernelGGL(k_bwd_task, dim3(ntasks), dim3(TASK_THREADS), 0, st, S, tasks, L, X, nr, ldx);
+    if (task_nc() == 64) {
+        if (phase == 1) hipLaunchKernelGGL(k_fwd_task<64>, dim3(ntasks), dim3(1024), 0, st, S, tasks, ntasks, L, X, W, nr, ldx);
+        else hipLaunchKernelGGL(k_bwd_task<64>, dim3(ntasks), dim3(1024), 0, st, S, tasks, ntasks, L, X, nr, ldx);
+    } else {
+        const int grid = ((ntasks + 7) / 8) * 16;       // blocks b and b + 8 (same XCD): the two column halves of one task
+        if (phase == 1) hipLaunchKernelGGL(k_fwd_task<32>, dim3(grid), dim3(512), 0, st, S, tasks, ntasks, L, X, W, nr, ldx);
+        else hipLaunchKernelGGL(k_bwd_task<32>, dim3(grid), dim3(512), 0, st, S, tasks, ntasks, L, X, nr, ldx);
+    }
 }
 int sweep_task_rows_max() { return TASK_ROWS; }
 }  // namespace gmrfx

@@ -13,11 +13,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _run(args, timeout=600):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+def _run(args, timeout=600, expect_rc=0, extra_env=None):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", **(extra_env or {}))
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, capture_output=True,
                        text=True, timeout=timeout)
-    assert p.returncode == 0, p.stderr[-2000:]
+    assert p.returncode == expect_rc, (p.returncode, p.stderr[-2000:])
     lines = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
     return json.loads(lines[0])
@@ -50,3 +50,12 @@ def test_two_rank_rehearsal_line_is_sharded_strong_scaling():
     assert "error" not in sh and sh["check"]["info"] == 0 and sh["check"]["rel_residual"] < 1e-10
     assert abs(sh["check"]["logdet"] - d["check"]["logdet"]) < 1e-11 * abs(d["check"]["logdet"])
     assert d["value"] == sh["value"] and d["ms_per_step"] == sh["ms_per_step"]
+
+
+def test_sharded_run_that_hangs_exits_non_zero_with_the_replica_line():
+    """rc == 0 only when the sharded run finished: a watchdog that fires prints the replica line ONCE with the error recorded
+    and every rank (so the launcher too) leaves with a non-zero code."""
+    d = _run(["--gpus", "2", "--rehearse", "--grid", "200", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-logpdf",
+              "--shard-timeout", "0.001"], expect_rc=1)      # torch.distributed.run maps any failed rank to exit code 1
+    assert d["scaling"] == "weak" and "error" in d["sharded"] and "did not finish" in d["sharded"]["error"]
+    assert d["replicas"]["value"] == d["value"]

@@ -7,6 +7,6 @@ for v in "$@"; do
   python - <<PY
 import json
 d=json.load(open("gpurun_out/ab_$v.json"))
-print("$var=$v","step",round(d["ms_per_step"],3),"factor",round(d["phases_ms"]["factor"],3),"solve",round(d["phases_ms"]["solve"],3),"syrk",round(d["roofline"]["ms_per_step"],3),"TF",round(d["roofline"]["achieved"],2),"resid",d["check"]["rel_residual"],"logdet",d["check"]["logdet"])
+print("$var=$v","step",round(d["ms_per_step"],3),"factor",round(d["phases_ms"]["factor"],3),"solve",round(d["phases_ms"]["solve"],3),"fwd",round(d["phases_ms"]["solve_fwd"],3),"bwd",round(d["phases_ms"]["solve_bwd"],3),"syrk",round(d["roofline"]["ms_per_step"],3),"TF",round(d["roofline"]["achieved"],2),"resid",d["check"]["rel_residual"],"logdet",d["check"]["logdet"])
 PY
 done
