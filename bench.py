@@ -52,7 +52,10 @@ def cholmod_reference(Q, perm, Bn, workdir):
         Q.data.astype(np.float64).tofile(os.path.join(workdir, "nzval.bin"))
         (np.asarray(perm, dtype=np.int64) + 1).tofile(os.path.join(workdir, "perm.bin"))
         np.asfortranarray(Bn).T.copy().tofile(os.path.join(workdir, "B.bin"))       # column-major n x nrhs
-        r = subprocess.run([jl, "-t", "auto", os.path.join(ROOT, "bench", "cholmod_baseline.jl"), workdir],
+        # second argument: the script also writes the parity vectors (logdet, F \ B, F.UP \ z, ...; tests/test_cholmod_parity.py);
+        # under gpurun_out/ they travel back from a GPU box
+        r = subprocess.run([jl, "-t", "auto", os.path.join(ROOT, "bench", "cholmod_baseline.jl"), workdir,
+                            os.path.join(ROOT, "gpurun_out", "cholmod_out")],
                            capture_output=True, text=True, timeout=900)
         if r.returncode != 0:
             return {"status": "julia found but the CHOLMOD script failed", "stderr": r.stderr[-400:]}
