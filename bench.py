@@ -146,15 +146,15 @@ def bench_sharded(args, Q, mesh, dist, rank, world, local_rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--grid", type=int, default=1000, help="nodes per side of the 2-D mesh (cfg 2: 1000)")
     ap.add_argument("--nrhs", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-process rehearsal on a box with ONE GPU: every rank uses cuda:0 and the "
                          "process group runs on gloo (RCCL refuses two ranks on one device)")
-    ap.add_argument("--extras", action="store_true", help="also time selinv-diag and 256-sample rand (cfg 3)")
+    ap.add_argument("--extras", action="store_true", help="also time predictor variances diag(A Sigma A') and the Newton iterate (f1, f4)")
     ap.add_argument("--shard-timeout", type=float, default=300.0,
                     help="N > 1: seconds the sharded strong-scaling run may take before the replica line is printed without it")
     ap.add_argument("--no-shard", action="store_true",
@@ -163,6 +163,8 @@ def main():
     ap.add_argument("--no-logpdf", action="store_true",
                     help="skip the (untimed) logpdf loop after the timed steps: keeps kernel traces / PMC passes to whole "
                          "refactorise+solve steps (tools/prof_summary.py, tools/pmc_traffic.py)")
+    ap.add_argument("--no-cfg3", action="store_true",
+                    help="skip the (untimed) cfg-3 block after the timed steps: selected inverse + 256 samples on the same factor")
     ap.add_argument("--pool", type=int, default=0,
                     help="extra: throughput of P independent workspaces driven concurrently on this GPU "
                          "(the reference's WorkspacePool pattern; reported separately, never as `value`)")
@@ -279,14 +281,28 @@ def main():
         logpdf_relerr = abs(lp - lp_host) / abs(lp_host)
 
     extras = {}
-    if args.extras and rank == 0:
-        be.selinv_compute_dev()
-        extras["ms_selinv"] = be.stats()["ms_selinv"]
+    cfg3 = None
+    if not args.no_cfg3 and rank == 0:
+        # BASELINE cfg 3 on the same factor (untimed by `value`; median of 3 each): Takahashi selected inverse on pattern(L)
+        # (compute_selinv!, backend.jl:226-257) and 256 samples P' L^-T z (backend_backward_solve, backend.jl:281-284)
+        t_sel, t_rand = [], []
         d_Z = torch.randn((256, n), generator=torch.Generator(device="cpu").manual_seed(2), dtype=torch.float64).to(dev)
         d_S = torch.empty_like(d_Z)
         torch.cuda.synchronize()
-        be.backward_solve_dev(d_Z.data_ptr(), n, 256, d_S.data_ptr(), n)
-        extras["ms_rand256"] = be.stats()["ms_backward_solve"]
+        for _ in range(3):
+            be.refactorize_dev(d_nz.data_ptr())          # (a refactorisation drops the selected-inverse cache)
+            be.selinv_compute_dev()
+            t_sel.append(be.stats()["ms_selinv"])
+            be.backward_solve_dev(d_Z.data_ptr(), n, 256, d_S.data_ptr(), n)
+            t_rand.append(be.stats()["ms_backward_solve"])
+        extras["ms_selinv"] = float(np.median(t_sel))
+        extras["ms_rand256"] = float(np.median(t_rand))
+        sy = be.symbolic()
+        cc = np.diff(sy.super_first).astype(np.float64)
+        mm = np.diff(sy.row_ptr).astype(np.float64) - cc
+        # per front: Y = L21 X (2 c^2 m), Z21 = -Z22 Y (2 c m^2), Z11 = X'X - Y'Z21 (c^3 / 3 + 2 c^2 m), X = L11^-1 (c^3 / 3)
+        sel_flops = float((2.0 * cc * mm * mm + 4.0 * cc * cc * mm + 2.0 * cc ** 3 / 3.0).sum())
+        cfg3 = {"sel_flops": sel_flops}
 
     if args.extras and rank == 0:
         # predictor marginal variances: diag(A Sigma A') for a P1 evaluation matrix with one random
@@ -398,6 +414,23 @@ def main():
         if roof_sweep["traffic"]:
             # the bytes the sweeps really move (PMC), W / x hand-off between the levels included, against the same peak
             roof_sweep["frac_of_peak_with_measured_traffic"] = roof_sweep["traffic"] / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        roof_cfg3 = {}
+        if cfg3 is not None:
+            sel_tf = cfg3["sel_flops"] / (extras["ms_selinv"] * 1e-3) / 1e12
+            roof_cfg3["roofline_selinv"] = {
+                "bound": "mfma", "achieved": sel_tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": sel_tf / FP64_MFMA_PEAK_TF,
+                "traffic": None, "kernel": "selected inversion on pattern(L) (all launches; dominant: k_sel_dense, Z21 = -Z22 Y of the big fronts)",
+                "ms": extras["ms_selinv"], "flops": cfg3["sel_flops"], "flops_over_factor_flops": cfg3["sel_flops"] / st["factor_flops"],
+                "bytes_min": 16.0 * nnzl, "gbs_on_bytes_min": 16.0 * nnzl / (extras["ms_selinv"] * 1e-3) / 1e9,
+                "note": "cfg 3: flops = sum_s 2 c m^2 + 4 c^2 m + 2 c^3 / 3 (Takahashi recursion through the dense inverse of L11); "
+                        "bytes_min = L read + Z written once"}
+            # 256 samples = 4 passes of 64 columns, each one backward sweep + the transposes of its columns (SURVEY 8d:
+            # bytes_backward_solve = bytes_sweep + 8 n nrhs)
+            rb = 4.0 * (8.0 * nnzl + 4.0 * st["sum_rows"] + 16.0 * n * 64 + 8.0 * n * 64)
+            roof_cfg3["roofline_rand256"] = {
+                "bound": "hbm", "achieved": rb / (extras["ms_rand256"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": rb / (extras["ms_rand256"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "256 samples P' L^-T z: 4 backward sweeps of 64 columns on two lanes", "ms": extras["ms_rand256"], "bytes": rb}
         out = {
             "metric": "factor+solve(64 RHS) throughput", "value": world * n / (elapsed / args.steps), "unit": "DoF/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
@@ -408,7 +441,7 @@ def main():
                        "nrhs": args.nrhs, "parallelism": "1 workspace per GPU (replicas)" if world > 1 else "1 GPU",
                        "ordering": "own geometric nested dissection"},
             "roofline": roof_kernel,
-            "roofline_factor": roof_factor, "roofline_sweep": roof_sweep,
+            "roofline_factor": roof_factor, "roofline_sweep": roof_sweep, **roof_cfg3,
             "phases_ms": {"factor": mf, "solve": ms_, "solve_fwd": mfw, "solve_bwd": mbw, "solve_perm": med(t_perm),
                           "symbolic_host": st0["ms_symbolic"], **extras},
             "logpdf_per_s": (1e3 / logpdf_ms) if logpdf_ms else None, "logpdf_ms": logpdf_ms, "ms_quadform": ms_quadform,

@@ -44,7 +44,7 @@ def test_single_gpu_line_has_the_contract_fields():
 
 
 def test_two_rank_rehearsal_line_is_sharded_strong_scaling():
-    d = _run(["--gpus", "2", "--rehearse", "--grid", "200", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-logpdf"])
+    d = _run(["--gpus", "2", "--rehearse", "--grid", "200", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-logpdf", "--no-cfg3"])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "replicas" in d and d["replicas"]["scaling"] == "weak"
     sh = d["sharded"]
     assert "error" not in sh and sh["check"]["info"] == 0 and sh["check"]["rel_residual"] < 1e-10
@@ -55,7 +55,7 @@ def test_two_rank_rehearsal_line_is_sharded_strong_scaling():
 def test_sharded_run_that_hangs_exits_non_zero_with_the_replica_line():
     """rc == 0 only when the sharded run finished: a watchdog that fires prints the replica line ONCE with the error recorded
     and every rank (so the launcher too) leaves with a non-zero code."""
-    d = _run(["--gpus", "2", "--rehearse", "--grid", "200", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-logpdf",
+    d = _run(["--gpus", "2", "--rehearse", "--grid", "200", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-logpdf", "--no-cfg3",
               "--shard-timeout", "0.001"], expect_rc=1)      # torch.distributed.run maps any failed rank to exit code 1
     assert d["scaling"] == "weak" and "error" in d["sharded"] and "did not finish" in d["sharded"]["error"]
     assert d["replicas"]["value"] == d["value"]

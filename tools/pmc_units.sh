@@ -5,8 +5,8 @@
 # MFMA busy / (4 x CU busy), cycles of TA time per vector memory instruction).
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 rm -rf gpurun_out/pu1 gpurun_out/pu2
-rocprofv3 --pmc TA_TA_BUSY_sum SQ_BUSY_CU_CYCLES -d gpurun_out/pu1 --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-logpdf > /dev/null 2> gpurun_out/pu1.err || { tail -3 gpurun_out/pu1.err; exit 1; }
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS -d gpurun_out/pu2 --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-logpdf > /dev/null 2> gpurun_out/pu2.err || { tail -3 gpurun_out/pu2.err; exit 1; }
+rocprofv3 --pmc TA_TA_BUSY_sum SQ_BUSY_CU_CYCLES -d gpurun_out/pu1 --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-logpdf --no-cfg3 > /dev/null 2> gpurun_out/pu1.err || { tail -3 gpurun_out/pu1.err; exit 1; }
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS -d gpurun_out/pu2 --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-logpdf --no-cfg3 > /dev/null 2> gpurun_out/pu2.err || { tail -3 gpurun_out/pu2.err; exit 1; }
 python3 - <<'PY' > gpurun_out/pmc_units.txt
 import csv, glob, os
 def load(d):
