@@ -266,6 +266,25 @@ void Device::upload(const Symbolic &S) {
             T.woff = wp[r];
         }
         const SweepTask *tp; up(tp, tk); d_swt_ = const_cast<SweepTask *>(tp);
+        // wave tasks (sweep_wave.hip): the tasks by LDS class -- rows of the local vector <= kWaveRows[k] -- heaviest first inside
+        // a class (the list is already sorted by work); the big class is launched first
+        {
+            if (const char *e = std::getenv("GMRFX_TASK_MODE")) {       // A/B knob: "wg" / "wave" force one form for every width
+                const std::string m(e);
+                wave_max_nr_ = m == "wg" ? 0 : m == "wave" ? 64 : wave_max_nr_;
+            }
+            std::vector<int> ord;
+            for (int k = 0; k < kWaveClasses; k++) {
+                wave_first_[k] = (int)ord.size();
+                for (int t = 0; t < nswt_; t++) {
+                    const int rows = tk[t].nt + tk[t].mroot;
+                    if (rows <= kWaveRows[k] && (k == 0 || rows > kWaveRows[k - 1])) ord.push_back(t);
+                }
+                wave_count_[k] = (int)ord.size() - wave_first_[k];
+            }
+            if ((int)ord.size() != nswt_) throw std::runtime_error("internal: a sweep task exceeds the largest wave-task class");
+            const int *op; up(op, ord); d_wave_order_ = op;
+        }
         HC(hipStreamSynchronize(stream));
     }
     {
@@ -649,6 +668,7 @@ void Device::refactorize(const double *nzval, bool on_device) {
     // this call only returns once they have finished): no private copy
     nz_src_ = src;
     if (sharded()) throw std::invalid_argument("sharded handle: use gmrfx_refactorize_phase (two phases with an exchange in between)");
+    factor_serial_++;
     HC(hipEventRecord(ev_[0], stream));
     factor_levels(0, (int)levels_.size());
     HC(hipEventRecord(ev_[1], stream));
@@ -675,6 +695,7 @@ void Device::refactorize_phase(const double *d_nzval, int phase) {
     const int split = std::min<int>(S_->shard_level, nl);
     info_cached_ = false;
     fact_event_valid_ = false;
+    factor_serial_++;
     HC(hipEventRecord(ev_[0], stream));
     if (phase == 0) {               // the subtrees this rank owns
         nz_src_ = d_nzval;
@@ -762,9 +783,32 @@ void Device::ensure_rhs_capacity(long long nrhs) {
     }
 }
 
+// The bottom subtrees. Up to wave_max_nr_ (32) right-hand sides: one wave per (task, 16 columns), sweep_wave.hip, biggest LDS
+// class first -- measured at cfg 2 (tools/nrhs_sweep.py): 1 RHS 3.10 vs 3.97 ms per solve, 16: 3.23 vs 4.22, 32: 3.93 vs 4.39;
+// wider passes: the workgroup tasks of sweep_task.hip (64 RHS: 4.90 vs 5.58 ms -- the general op pipeline of the wave form
+// issues ~2.5x the instructions per front). GMRFX_TASK_MODE = wg / wave forces one form.
+void Device::sweep_tasks(int phase, int nr, int ldx) {
+    if (nr > wave_max_nr_) { launch_sweep_tasks(stream, ds_, phase, d_swt_, nswt_, d_L_, d_X_, phase == 1 ? d_W_ : nullptr, nr, ldx); return; }
+    ensure_rdiag();
+    for (int k = kWaveClasses - 1; k >= 0; k--)
+        launch_wave_tasks(stream, ds_, phase, d_swt_, d_wave_order_ + wave_first_[k], wave_count_[k], kWaveRows[k], d_L_, d_rdiag_,
+                          d_rdiag_ + S_->n, d_X_, d_W_, nr, ldx);
+}
+
+// 1 / L_jj (+ the zero word masked operand elements are read from), once per factorisation, on the current `stream`:
+// solve() calls this BEFORE its lanes fork, so that a second lane never reads it half-written
+void Device::ensure_rdiag() {
+    if (wave_max_nr_ <= 0 || nswt_ <= 0) return;
+    if (!d_rdiag_) { d_rdiag_ = dalloc<double>((size_t)S_->n + 2); rdiag_for_ = 0; }
+    if (rdiag_for_ == factor_serial_) return;
+    launch_rdiag(stream, d_L_, ds_.diagoff, (int)S_->n, d_rdiag_);
+    HC(hipMemsetAsync(d_rdiag_ + S_->n, 0, 2 * sizeof(double), stream));
+    rdiag_for_ = factor_serial_;
+}
+
 void Device::forward(int nr, int ldx, int lo, int hi) {
     if (level_mark_ && lo == 0) launch_level_mark(stream, 1, -1);
-    if (lo == 0) launch_sweep_tasks(stream, ds_, 1, d_swt_, nswt_, d_L_, d_X_, d_W_, nr, ldx);
+    if (lo == 0) sweep_tasks(1, nr, ldx);
     if (lo == 0)
         for (int k = 0, off = 0; k < 3; off += nsub_cls_[k], k++)
             launch_subtree(stream, ds_, 1, d_sub_first_ + off, d_sub_last_ + off, nsub_cls_[k], kClsRows[k], nullptr, d_L_, nullptr,
@@ -833,7 +877,7 @@ void Device::backward(int nr, int ldx, bool y_in_x2, int hi, int lo) {
         for (int k = 0, off = 0; k < 3; off += nsub_cls_[k], k++)
             launch_subtree(stream, ds_, 2, d_sub_first_ + off, d_sub_last_ + off, nsub_cls_[k], kClsRows[k], nullptr, d_L_, nullptr,
                            nullptr, d_X_, nullptr, nr, ldx);
-    if (lo == 0) launch_sweep_tasks(stream, ds_, 2, d_swt_, nswt_, d_L_, d_X_, nullptr, nr, ldx);
+    if (lo == 0) sweep_tasks(2, nr, ldx);
 }
 
 void Device::solve_phase(const double *d_B, long long ldb, long long nrhs, double *d_Xout, long long ldx_out, int phase) {
@@ -876,6 +920,7 @@ void Device::solve(const double *B, long long ldb, long long nrhs, double *X, lo
     const long long n = S_->n;
     ensure_rhs_capacity(nrhs);
     start_inverse_async();
+    ensure_rdiag();
     const double *dB = B;
     double *dXo = X;
     long long ldin = ldb, ldout = ldx_out;

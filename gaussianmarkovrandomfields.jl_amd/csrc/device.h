@@ -234,6 +234,16 @@ private:
     FrontView *d_frec_ = nullptr, *d_frec2_ = nullptr, *d_sel_frec_ = nullptr;   // geometry records parallel to the level lists
     int *d_levellist2_ = nullptr;   // per level: the big fronts re-ordered [even positions..., odd positions...] (two-stream panel chains)
     bool two_chains_ = true;
+    // wave tasks (sweep_wave.hip): task ids by LDS class
+    static constexpr int kWaveClasses = 2;
+    static constexpr int kWaveRows[kWaveClasses] = {160, 288};
+    int wave_max_nr_ = 32;        // passes of up to this many right-hand sides use the wave tasks (0: never)
+    const int *d_wave_order_ = nullptr;
+    int wave_first_[kWaveClasses] = {0, 0}, wave_count_[kWaveClasses] = {0, 0};
+    void sweep_tasks(int phase, int nr, int ldx);
+    void ensure_rdiag();
+    double *d_rdiag_ = nullptr;                   // n reciprocals of L's diagonal (+ a zero word): operands of the wave tasks
+    unsigned long long factor_serial_ = 1, rdiag_for_ = 0;    // d_rdiag_ belongs to factorisation number rdiag_for_
     bool selinv_begun_ = false;   // sharded selected inversion: phase 0 has run since the last refactorisation (gmrfx_selinv_phase)
     bool level_mark_ = false;     // GMRFX_LEVEL_MARK=1: an empty marker kernel in front of every level (profiling aid, tools/sweep_levels.py)
     bool small_on_side_ = true;     // GMRFX_SMALL_ON_SIDE=0: a level's small fronts before its big fronts, on one stream

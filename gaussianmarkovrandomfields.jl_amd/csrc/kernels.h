@@ -397,6 +397,11 @@ void launch_bwd_small(hipStream_t st, const DevSym &S, const int *list, int nfro
 void launch_sweep_tasks(hipStream_t st, const DevSym &S, int phase, const SweepTask *tasks, int ntasks,
                         const double *L, double *X, double *W, int nr, int ldx);
 
+// sweep_wave.hip -- the same tasks, one wave per (task, 16 right-hand sides); order = task ids of one LDS class
+void launch_wave_tasks(hipStream_t st, const DevSym &S, int phase, const SweepTask *tasks, const int *order, int ntasks, int rows_cap,
+                       const double *L, const double *rdiag, const double *zero, double *X, double *W, int nr, int ldx);
+void launch_rdiag(hipStream_t st, const double *L, const long long *diagoff, int n, double *out);
+
 // selinv.hip -- Takahashi recursion, top-down over the supernodal tree
 void launch_sel_gather(hipStream_t st, const SelRec *recs, const DevSym &S, const int *list, int nfronts, int max_trail,
                        const double *Z, double *ZB);

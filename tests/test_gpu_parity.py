@@ -883,3 +883,27 @@ def test_tile_records_and_plain_grid_give_the_same_bits_on_a_mesh_with_many_tile
     assert np.linalg.norm(Q @ Xr - B) / np.linalg.norm(B) < 1e-10
     Z = B[:, :7]
     assert np.array_equal(rec.backend_backward_solve(Z), grid.backend_backward_solve(Z))
+
+
+@pytest.mark.parametrize("mode", ["wg", "wave"])
+@pytest.mark.parametrize("nrhs", [1, 17, 33, 64])
+def test_sweep_task_forms_match_the_oracle(mode, nrhs, monkeypatch):
+    """The two forms of the bottom-subtree sweep tasks -- 16-wave workgroups on a 32-column local vector (sweep_task.hip)
+    and one wave per (task, 16 columns) with an op pipeline (sweep_wave.hip; the default up to 32 right-hand sides) --
+    forced for every width through GMRFX_TASK_MODE: full solves and backward solves against the oracle on the same
+    permutation, on a mesh whose tasks include wide fronts (17 .. 64 columns), partial column tiles and both LDS classes."""
+    mesh = spde.grid_mesh_2d(150, 150, jitter=0.25, seed=11)
+    Q = sp.csc_matrix(spde.matern_precision(mesh, 0, 0.2))
+    n = Q.shape[0]
+    monkeypatch.setenv("GMRFX_TASK_MODE", mode)
+    be = gmrfx.MI355XBackend(Q, coords=mesh.points)
+    monkeypatch.delenv("GMRFX_TASK_MODE")
+    cap, first, last, _ = be.sweep_tasks()
+    assert len(first) > 50 and cap == 288
+    F = orc.OracleFactor(Q, be.ordering_permutation())
+    B = np.random.default_rng(100 + nrhs).standard_normal((n, nrhs))
+    assert relerr(be.backend_solve(B), F.solve(B)) < 1e-10
+    Z = B[:, : min(nrhs, 5)]
+    assert relerr(be.backend_backward_solve(Z), F.backward_solve(Z)) < 1e-10
+    # bit-reproducible: the same call twice gives the same bits
+    assert np.array_equal(be.backend_solve(B), be.backend_solve(B))
