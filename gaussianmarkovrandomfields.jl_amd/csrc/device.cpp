@@ -300,6 +300,7 @@ void Device::upload(const Symbolic &S) {
             const int *l2p; up(l2p, l2); d_levellist2_ = const_cast<int *>(l2p);
             if (const char *e = std::getenv("GMRFX_TWO_CHAINS")) two_chains_ = std::atoi(e) != 0;
             if (const char *e = std::getenv("GMRFX_LEVEL_MARK")) level_mark_ = std::atoi(e) != 0;
+            if (const char *e = std::getenv("GMRFX_LOOKAHEAD")) lookahead_ = std::atoi(e) != 0;
             if (const char *e = std::getenv("GMRFX_SMALL_ON_SIDE")) small_on_side_ = std::atoi(e) != 0;
         }
         const int *a; up(a, S.sub_first); d_sub_first_ = const_cast<int *>(a);
@@ -575,13 +576,61 @@ void Device::factor_levels(int lo, int hi) {
         // wide fronts run TWO independent chains -- the fronts at even / odd positions of the width-sorted list -- on two
         // streams, so one half's trsm / gemm fills the chip while the other half sits in potrf64. Same arithmetic per
         // front: bit-identical factor.
-        const bool two = two_chains_ && nf >= 2 && nblk >= 4 && !sharded();
+        const bool la = lookahead_ && nf >= 1 && nblk >= 2;
+        const bool two = !la && two_chains_ && nf >= 2 && nblk >= 4 && !sharded();
         const int nhalf = two ? 2 : 1;
+        if (la) {
+            // LOOK-AHEAD chain (potrf64.hip): the diagonal chain P(b) on the main stream keeps its own band up to date; the
+            // bulk -- G(b-1), the trailing update inside the 256-column outer block without the band tiles, then T(b), the
+            // rows below the band -- follows one step behind on the second stream:
+            //   main:  P(b) waits for T(b-2)                     bulk:  G(b-1), T(b) wait for P(b)
+            // and the main stream picks the bulk up again at the end of every outer block (the K = 256 update of the rest of
+            // the panel reads all of it) and of the panel (the SYRK does).
+            const FrontView *hl = d_frec_ + L.first + L.nsmall;
+            FrontArg f1{0, 0, 0, 0, 0, 0, 0}, f0{0, 0, 0, 0, 0, 0, 0};
+            {
+                const i32 s1 = S_->levellist[L.first + L.nsmall];
+                f1 = FrontArg{1, (int)s1, S_->ncols(s1), S_->nrows(s1), (int)S_->ld[s1], (int)S_->sfirst[s1], (long long)S_->panelptr[s1]};
+            }
+            while ((int)ev_la_p_.size() < nblk) {
+                hipEvent_t a, b;
+                HC(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+                HC(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+                ev_la_p_.push_back(a); ev_la_t_.push_back(b);
+            }
+            for (int b = 0; b < nblk; b++) {
+                const int kb = b * NB, na = L.active[b];
+                if (na <= 0) break;
+                const FrontArg &fa = na == 1 ? f1 : f0;
+                const int J0 = (b / OBK) * OBK, J1 = J0 + OBK;
+                const bool first_in_outer = b == J0;
+                const bool last_of_panel = b + 1 >= nblk || L.active[b + 1] <= 0;
+                const bool next_in_outer = !last_of_panel && b + 1 < J1;
+                if (first_in_outer) launch_potrf64(stream, ds_, hl, na, kb, d_L_, d_info_, fa);
+                else {
+                    if (b - 2 >= J0) HC(hipStreamWaitEvent(stream, ev_la_t_[b - 2], 0));
+                    launch_potrf64_la(stream, ds_, hl, na, kb, J0 * NB, d_L_, d_info_, fa);
+                }
+                HC(hipEventRecord(ev_la_p_[b], stream));
+                HC(hipStreamWaitEvent(stream3, ev_la_p_[b], 0));
+                if (!first_in_outer)        // G(b-1): columns b .. J1-1 of the outer block -= L[:, b-1] L[., b-1]', band tiles left out
+                    launch_gemm_nt(stream3, ds_, hl, na, kb - NB, NB, kb, J1 * NB, L.max_rows - kb, std::min(J1 * NB, L.max_cols) - kb,
+                                   d_L_, fa, 1);
+                launch_trsm(stream3, ds_, hl, na, kb, 0, L.max_rows - kb - 1, d_L_, nullptr, nullptr, fa, next_in_outer ? 1 : 0);
+                HC(hipEventRecord(ev_la_t_[b], stream3));
+                if (!next_in_outer) {       // end of the outer block (or of the panel): the main stream needs all of it
+                    HC(hipStreamWaitEvent(stream, ev_la_t_[b], 0));
+                    if (!last_of_panel && J1 < nblk)
+                        launch_gemm_nt(stream, ds_, hl, L.active[J1], J0 * NB, OBK * NB, J1 * NB, INT_MAX, L.max_rows - J1 * NB,
+                                       L.max_cols - J1 * NB, d_L_, L.active[J1] == 1 ? f1 : f0);
+                }
+            }
+        }
         if (two) {
             HC(hipEventRecord(ev_ready2_, stream));               // (after the assembly of this level's panels)
             HC(hipStreamWaitEvent(stream3, ev_ready2_, 0));
         }
-        for (int hf = 0; hf < nhalf; hf++) {
+        for (int hf = 0; hf < nhalf && !la; hf++) {
             hipStream_t st = hf == 0 ? stream : stream3;
             const FrontView *hl = two ? d_frec2_ + L.first + L.nsmall + (hf == 0 ? 0 : (nf + 1) / 2) : d_frec_ + L.first + L.nsmall;
             auto act = [&](int b) { const int a = L.active[b]; return two ? (hf == 0 ? (a + 1) / 2 : a / 2) : a; };

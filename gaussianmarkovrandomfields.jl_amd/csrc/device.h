@@ -234,6 +234,12 @@ private:
     FrontView *d_frec_ = nullptr, *d_frec2_ = nullptr, *d_sel_frec_ = nullptr;   // geometry records parallel to the level lists
     int *d_levellist2_ = nullptr;   // per level: the big fronts re-ordered [even positions..., odd positions...] (two-stream panel chains)
     bool two_chains_ = true;
+    bool lookahead_ = false;      // GMRFX_LOOKAHEAD=1: look-ahead panel chain (potrf64.hip k_potrf64_la). OFF by default: measured at cfg 2
+                                  // (round 3) the left-looking band prologue costs 12 us + 6 us per earlier block of the outer block
+                                  // on top of the 15 us factorisation, more than the trsm + gemm launches (5 + 5 us) it takes off
+                                  // the critical path: factorisation 11.06 -> 12.99 ms. Kept (and parity-tested) as the base for a
+                                  // cheaper prologue.
+    std::vector<hipEvent_t> ev_la_p_, ev_la_t_;     // per 64-column block: diagonal chain done / bulk trsm done
     // wave tasks (sweep_wave.hip): task ids by LDS class
     static constexpr int kWaveClasses = 2;
     static constexpr int kWaveRows[kWaveClasses] = {160, 288};

@@ -22,9 +22,9 @@ void launch_syrk_cb(hipStream_t st, const DevSym &S, const int *list, int nfront
 // The same tiles from self-contained records, one contiguous run per XCD (workgroup id mod 8 = XCD): see k_syrk_cb_rec.
 void launch_syrk_cb_recs(hipStream_t st, const DevSym &S, const SyrkTile *recs, const SyrkSplit &split, int per_xcd, const double *L, double *CB);
 void launch_trsm(hipStream_t st, const DevSym &S, const FrontView *frec, int nactive, int kb, int mode, int max_rows_below,
-                 double *L, double *Yh, const long long *yoff, const FrontArg &fa);
+                 double *L, double *Yh, const long long *yoff, const FrontArg &fa, int la = 0);
 void launch_gemm_nt(hipStream_t st, const DevSym &S, const FrontView *frec, int nactive, int k0, int K, int c0, int c1,
-                    int maxM, int maxN, double *L, const FrontArg &fa);
+                    int maxM, int maxN, double *L, const FrontArg &fa, int band = 0);
 void launch_fwd_update_recs(hipStream_t st, const DevSym &S, const FwdTile *recs, const SyrkSplit &split, int per_xcd, const double *L,
                             double *X, double *W, int nr, int ldx);
 void launch_fwd_assemble(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, double *X,
@@ -221,6 +221,31 @@ __device__ __forceinline__ int wave_gemm_32x32_kr(gmrfx_d4 (&acc)[2][2], const d
     return q0;
 }
 
+// Stage the inverse of the diagonal block into LDS as a full w x w lower-triangular matrix
+// Ti[k*NB + q] = Linv[k][q] (zero above the diagonal, reciprocal on it).
+__device__ __forceinline__ void stage_linv(const double *__restrict__ Dg, int ld, int w, double *Ti, int tid) {
+    // 16 independent clamped loads per thread. Every use of the loaded value is unconditional
+    // arithmetic (mask multiply / reciprocal), so the compiler cannot sink a load under a
+    // branch and the 16 loads issue back to back.
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+        const int idx = tid + 256 * u;
+        const int q = idx % NB, k = idx / NB;   // element Linv[k][q], stored at (q, k) for q < k
+        const int qq = min(q, w - 1), kk = min(k, w - 1);
+        v[u] = Dg[min(qq, kk) + (long long)max(qq, kk) * ld];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+        const int idx = tid + 256 * u;
+        const int q = idx % NB, k = idx / NB;
+        const double mk = (k < w && q < k) ? 1.0 : 0.0;
+        double x = v[u] * mk;
+        if (q == k && k < w) x = fast_rcp(v[u]);
+        Ti[k * NB + q] = x;
+    }
+}
+
 // Geometry of the front a workgroup works on: from the kernel arguments (one active front: the top-of-tree chains) or from
 // ONE 32-byte record at the workgroup's position in the level list (Device::d_frec_*) -- not list -> five index arrays,
 // which is a dependent round trip more on every launch of the panel chains.
@@ -387,7 +412,10 @@ void launch_factor_small(hipStream_t st, const DevSym &S, const int *list, int n
 // phase 0: factor, 1: forward sweep, 2: backward sweep of whole small subtrees (one workgroup per subtree)
 void launch_subtree(hipStream_t st, const DevSym &S, int phase, const int *sub_first, const int *sub_last, int ntasks,
                     int rmax, const double *nzval, double *L, double *CB, int *info, double *X, double *W, int nr, int ldx);
-void launch_potrf64(hipStream_t st, const DevSym &S, const FrontView *frec, int nactive, int kb, double *L, int *info, const FrontArg &fa);   // potrf64.hip
+void launch_potrf64(hipStream_t st, const DevSym &S, const FrontView *frec, int nactive, int kb, double *L, int *info, const FrontArg &fa);
+// look-ahead form: brings the band tiles (b, b-1), (b, b) up to date left-looking over columns kb0 .. kb-1, then factors (potrf64.hip)
+void launch_potrf64_la(hipStream_t st, const DevSym &S, const FrontView *frec, int nactive, int kb, int kb0, double *L, int *info,
+                       const FrontArg &fa);   // potrf64.hip
 void launch_fwd_small(hipStream_t st, const DevSym &S, const int *list, int nfronts, int rmax, const double *L,
                       double *X, double *W, int nr, int ldx);
 void launch_bwd_small(hipStream_t st, const DevSym &S, const int *list, int nfronts, int rmax, const double *L,

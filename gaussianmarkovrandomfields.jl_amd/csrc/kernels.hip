@@ -111,31 +111,6 @@ __global__ __launch_bounds__(256) void k_assemble(DevSym S, const int *__restric
     }
 }
 
-// Stage the inverse of the diagonal block into LDS as a full w x w lower-triangular matrix
-// Ti[k*NB + q] = Linv[k][q] (zero above the diagonal, reciprocal on it).
-__device__ __forceinline__ void stage_linv(const double *__restrict__ Dg, int ld, int w, double *Ti, int tid) {
-    // 16 independent clamped loads per thread. Every use of the loaded value is unconditional
-    // arithmetic (mask multiply / reciprocal), so the compiler cannot sink a load under a
-    // branch and the 16 loads issue back to back.
-    double v[16];
-#pragma unroll
-    for (int u = 0; u < 16; u++) {
-        const int idx = tid + 256 * u;
-        const int q = idx % NB, k = idx / NB;   // element Linv[k][q], stored at (q, k) for q < k
-        const int qq = min(q, w - 1), kk = min(k, w - 1);
-        v[u] = Dg[min(qq, kk) + (long long)max(qq, kk) * ld];
-    }
-#pragma unroll
-    for (int u = 0; u < 16; u++) {
-        const int idx = tid + 256 * u;
-        const int q = idx % NB, k = idx / NB;
-        const double mk = (k < w && q < k) ? 1.0 : 0.0;
-        double x = v[u] * mk;
-        if (q == k && k < w) x = fast_rcp(v[u]);
-        Ti[k * NB + q] = x;
-    }
-}
-
 // Panel rows below the diagonal block as a GEMM with the inverted block (FP64 MFMA):
 //   mode 0 (factorisation):      A[i, blk] <- A[i, blk] * Linv'      (in place, = L21 rows)
 //   mode 1 (selected inversion): Yh[i, :]  <- L[i, blk] * Linv
@@ -143,7 +118,7 @@ __device__ __forceinline__ void stage_linv(const double *__restrict__ Dg, int ld
 template <int MODE, int SPLIT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k_trsm(DevSym S, const FrontView *__restrict__ frec, int kb,
                                               double *__restrict__ L, double *__restrict__ Yh,
-                                              const long long *__restrict__ yoff, FrontArg fa) {
+                                              const long long *__restrict__ yoff, FrontArg fa, int la) {
     // SPLIT = 0: a workgroup owns 128 rows, each wave 32 of them (all four 16-column tiles) as 16 row PAIRS: MFMA
     // row lm of tile 0 / 1 is row 2 lm / 2 lm + 1 of the wave's 32, so one 16-byte load per lane and k-step feeds both
     // tiles and the results leave 16 bytes at a time (half the vector memory instructions, half the LDS reads and half
@@ -156,7 +131,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
     const int s = fv.s, c = fv.c, r = fv.r;
     if (kb >= c) return;
     const int w = min(NB, c - kb);
-    const int row0 = kb + w + blockIdx.x * (SPLIT ? 16 : 128);
+    // la (look-ahead panel chain, potrf64.hip): the rows of the NEXT 64-column block (the sub-diagonal tile) are solved by
+    // the diagonal chain itself (k_potrf64_la) -- this launch starts below them
+    const int skip = (MODE == 0 && la) ? min(NB, max(0, c - kb - w)) : 0;
+    const int row0 = kb + w + skip + blockIdx.x * (SPLIT ? 16 : 128);
     if (row0 >= r) return;
     const int ld = fv.ld;
     double *Pp = L + fv.pp;
@@ -254,7 +232,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 // CB -= L21 L21' (K = all c columns).
 template <int TW>   // MFMA tiles per wave and dimension: wave tile 16*TW squared, workgroup tile twice that
 __global__ __launch_bounds__(256) void k_gemm_nt(DevSym S, const FrontView *__restrict__ frec, int k0, int K, int c0, int c1,
-                                                 double *__restrict__ L, FrontArg fa) {
+                                                 double *__restrict__ L, FrontArg fa, int band) {
     // panel columns [c0, min(c1, c)) of the front, rows c0 .. r-1:  C -= A A'  with A = the K
     // (finished) panel columns k0 .. k0+K-1 of those rows. Two-level blocking: K = 64 updates stay
     // inside the current 256-column block, the rest of the panel is updated once per 256 columns
@@ -271,6 +249,14 @@ __global__ __launch_bounds__(256) void k_gemm_nt(DevSym S, const FrontView *__re
     const int bi = blockIdx.x, bj = blockIdx.y;
     constexpr int WT = 16 * TW, GT = 2 * WT;
     if (bj > bi || bi * GT >= M || bj * GT >= N) return;
+    // band (look-ahead panel chain): the diagonal and sub-diagonal 64 x 64 tiles of every target block column -- rows of
+    // the front's own columns, i.e. < c -- are kept up to date by the diagonal chain (k_potrf64_la); skipped here. c0 is
+    // a multiple of 64 and GT divides 64, so a tile lies in ONE 64-block per dimension.
+    // (the sub-diagonal tile of the LAST block column of the outer block lies in the next outer block -- rows >= c1 --, whose
+    //  first diagonal step has no left-looking prologue: it is updated here like any other tile)
+    const bool in_band = band && ((bi * GT) >> 6) - ((bj * GT) >> 6) < 2 && c0 + (((bi * GT) >> 6) << 6) < c1;
+    const int band_rows = in_band ? c - c0 : 0;         // rows (relative to c0) below this are not stored
+    if (in_band && bi * GT + GT <= band_rows) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i0 = bi * GT + (wave & 1) * WT, j0 = bj * GT + (wave >> 1) * WT;
     if (i0 >= M || j0 >= N || j0 > i0 + WT - 1) return;
@@ -359,7 +345,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(DevSym S, const FrontView *__re
 #pragma unroll
             for (int rr = 0; rr < 4; rr++) {
                 const int i = i0 + 2 * lm, j = j0 + 2 * (lk + 4 * rr) + b;
-                const bool v0 = i < M && j < N && i >= j, v1 = i + 1 < M && j < N && i + 1 >= j;
+                const bool v0 = i < M && j < N && i >= j && i >= band_rows, v1 = i + 1 < M && j < N && i + 1 >= j && i + 1 >= band_rows;
                 double *dst = C + i + (long long)j * ldc;
                 const double x0 = cv[b][rr].x - acc[0][b][rr], x1 = cv[b][rr].y - acc[1][b][rr];
                 if (v0 && v1) *(d2u *)dst = (d2u){x0, x1};
@@ -388,7 +374,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(DevSym S, const FrontView *__re
                 for (int rr = 0; rr < 4; rr++) {
                     const int i = i0 + a * 16 + lm;
                     const int j = j0 + b * 16 + lk + 4 * rr;
-                    if (i < M && j < N && i >= j) C[i + (long long)j * ldc] = cv[a][b][rr] - acc[a][b][rr];
+                    if (i < M && j < N && i >= j && i >= band_rows) C[i + (long long)j * ldc] = cv[a][b][rr] - acc[a][b][rr];
                 }
     }
 }
@@ -1383,20 +1369,20 @@ void launch_syrk_cb_recs(hipStream_t st, const DevSym &S, const SyrkTile *recs, 
     hipLaunchKernelGGL(k_syrk_cb_rec, dim3(8 * (unsigned)per_xcd), dim3(256), 0, st, S, recs, split, L, CB);
 }
 void launch_trsm(hipStream_t st, const DevSym &S, const FrontView *frec, int nactive, int kb, int mode, int max_rows_below,
-                 double *L, double *Yh, const long long *yoff, const FrontArg &fa) {
+                 double *L, double *Yh, const long long *yoff, const FrontArg &fa, int la) {
     if (nactive <= 0 || max_rows_below <= 0) return;
     const bool split = (long long)cdiv(max_rows_below, 64) * nactive <= 128;
     const dim3 grid(odd(cdiv(max_rows_below, split ? 16 : 128)), nactive);
     if (mode == 0) {
-        if (split) hipLaunchKernelGGL((k_trsm<0, 1>), grid, dim3(256), 0, st, S, frec, kb, L, Yh, yoff, fa);
-        else hipLaunchKernelGGL((k_trsm<0, 0>), grid, dim3(256), 0, st, S, frec, kb, L, Yh, yoff, fa);
+        if (split) hipLaunchKernelGGL((k_trsm<0, 1>), grid, dim3(256), 0, st, S, frec, kb, L, Yh, yoff, fa, la);
+        else hipLaunchKernelGGL((k_trsm<0, 0>), grid, dim3(256), 0, st, S, frec, kb, L, Yh, yoff, fa, la);
     } else {
-        if (split) hipLaunchKernelGGL((k_trsm<1, 1>), grid, dim3(256), 0, st, S, frec, kb, L, Yh, yoff, fa);
-        else hipLaunchKernelGGL((k_trsm<1, 0>), grid, dim3(256), 0, st, S, frec, kb, L, Yh, yoff, fa);
+        if (split) hipLaunchKernelGGL((k_trsm<1, 1>), grid, dim3(256), 0, st, S, frec, kb, L, Yh, yoff, fa, la);
+        else hipLaunchKernelGGL((k_trsm<1, 0>), grid, dim3(256), 0, st, S, frec, kb, L, Yh, yoff, fa, la);
     }
 }
 void launch_gemm_nt(hipStream_t st, const DevSym &S, const FrontView *frec, int nactive, int k0, int K, int c0, int c1,
-                    int maxM, int maxN, double *L, const FrontArg &fa) {
+                    int maxM, int maxN, double *L, const FrontArg &fa, int band) {
     if (nactive <= 0 || maxM <= 0 || maxN <= 0) return;
     // 64x64 workgroup tiles, operands straight from L2 at 3-4 waves per SIMD. Measured on MI355X: the
     // sustained v_mfma_f64_16x16x4_f64 rate is 36.3 TFLOP/s (tools/micro/mfma64.hip), this kernel reaches
@@ -1405,9 +1391,9 @@ void launch_gemm_nt(hipStream_t st, const DevSym &S, const FrontView *frec, int 
     // Levels with a handful of fronts are latency bound: 32x32 workgroup tiles there (four times
     // the workgroups, a quarter of the MFMA chain per wave).
     if ((long long)cdiv(maxM, 64) * cdiv(maxN, 64) * nactive <= 256)
-        hipLaunchKernelGGL(k_gemm_nt<1>, dim3(odd(cdiv(maxM, 32)), odd(cdiv(maxN, 32)), nactive), dim3(256), 0, st, S, frec, k0, K, c0, c1, L, fa);
+        hipLaunchKernelGGL(k_gemm_nt<1>, dim3(odd(cdiv(maxM, 32)), odd(cdiv(maxN, 32)), nactive), dim3(256), 0, st, S, frec, k0, K, c0, c1, L, fa, band);
     else
-        hipLaunchKernelGGL(k_gemm_nt<2>, dim3(odd(cdiv(maxM, 64)), odd(cdiv(maxN, 64)), nactive), dim3(256), 0, st, S, frec, k0, K, c0, c1, L, fa);
+        hipLaunchKernelGGL(k_gemm_nt<2>, dim3(odd(cdiv(maxM, 64)), odd(cdiv(maxN, 64)), nactive), dim3(256), 0, st, S, frec, k0, K, c0, c1, L, fa, band);
 }
 void launch_fwd_assemble(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, double *X,
                          const double *W, int nr, int ldx) {

@@ -25,6 +25,8 @@
 
 namespace gmrfx {
 
+typedef gmrfx_d4 d4;
+
 namespace {
 
 // phase-cycle instrumentation for tools/micro/potrf_prof.hip (compiled out of the library)
@@ -47,16 +49,11 @@ __device__ __forceinline__ double rsqrt_nr(double p) {
 
 }  // namespace
 
-__global__ __launch_bounds__(256) void k_potrf64(DevSym S, const FrontView *__restrict__ frec, int kb,
-                                                 double *__restrict__ L, int *__restrict__ info, FrontArg fa) {
-    __shared__ __attribute__((aligned(16))) double Sb[2][4 * 64];   // strip [parity][q * 64 + row]
-    const FrontView fv = front_view(frec, blockIdx.x, fa);
-    const int c = fv.c;
-    if (kb >= c) return;
-    const int w = min(NB, c - kb);
-    const int ld = fv.ld;
-    double *P = L + fv.pp + kb + (long long)kb * ld;
-    const int tid = threadIdx.x;
+// The 256 threads (tid 0..255) of a workgroup factor the w x w block whose current values are src[i + j * sld] (the panel
+// itself, or the block a look-ahead prologue left in LDS) and write L / (L^-1)' to the panel block P (leading dimension ld).
+// Sb: 2 x 4 x 64 doubles of LDS.
+__device__ __forceinline__ void potrf64_body(const double *src, const int sld, double *__restrict__ P, const int ld, const int w,
+                                             double (*Sb)[4 * 64], int *__restrict__ info, const int first_col, const int tid) {
     const int ty = tid & 15, tx = tid >> 4;     // lanes walk rows: coalesced panel loads / stores
     const int i0 = 4 * ty, j0 = 4 * tx;
 
@@ -67,7 +64,7 @@ __global__ __launch_bounds__(256) void k_potrf64(DevSym S, const FrontView *__re
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int i = i0 + r, j = j0 + cc;
-            const double v = P[min(i, w - 1) + (long long)min(j, w - 1) * ld];
+            const double v = src[min(i, w - 1) + min(j, w - 1) * sld];
             const double mk = (i < w && j < w && i >= j) ? 1.0 : 0.0;
             a[r][cc] = v * mk + ((i == j && i >= w) ? 1.0 : 0.0);
         }
@@ -188,7 +185,7 @@ __global__ __launch_bounds__(256) void k_potrf64(DevSym S, const FrontView *__re
         __syncthreads();
         C64_MARK(5);
     }
-    if (badcol != 0x7fffffff) atomicMin(info, fv.first + kb + badcol);
+    if (badcol != 0x7fffffff) atomicMin(info, first_col + badcol);
     double *Pt = P + i0 + (long long)j0 * ld;
     if (w == NB) {
         // full block (all but the last block column of a front): no per-element predicates
@@ -205,10 +202,146 @@ __global__ __launch_bounds__(256) void k_potrf64(DevSym S, const FrontView *__re
     }
 }
 
+__global__ __launch_bounds__(256) void k_potrf64(DevSym S, const FrontView *__restrict__ frec, int kb,
+                                                 double *__restrict__ L, int *__restrict__ info, FrontArg fa) {
+    __shared__ __attribute__((aligned(16))) double Sb[2][4 * 64];   // strip [parity][q * 64 + row]
+    const FrontView fv = front_view(frec, blockIdx.x, fa);
+    const int c = fv.c;
+    if (kb >= c) return;
+    const int w = min(NB, c - kb);
+    const int ld = fv.ld;
+    double *P = L + fv.pp + kb + (long long)kb * ld;
+    potrf64_body(P, ld, P, ld, w, Sb, info, fv.first + kb, threadIdx.x);
+}
+
+// ---- LOOK-AHEAD form (round 3) ------------------------------------------------------------------------------------------
+// The panel chain of a big front was potrf64 -> trsm -> gemm per 64-column block: three dependent launches, two of which
+// only exist on the critical path because the NEXT diagonal block needs their results in two 64 x 64 tiles. Here the
+// diagonal chain serves itself: before it factors block b (b > first block of its 256-column outer block), the workgroup
+// brings the BAND -- the sub-diagonal tile (b, b-1) and the diagonal tile (b, b) -- up to date left-looking,
+//     S    = A[b, b-1] - sum_{j < b-1} L[b, j] L[b-1, j]'        (j runs over the earlier blocks of the outer block)
+//     Lsub = S Linv[b-1]'                                        -> written to L[b, b-1]
+//     D    = A[b, b]   - sum_{j < b-1} L[b, j] L[b, j]' - Lsub Lsub'
+// on the MFMA with sixteen waves (<= 2 us), and factors D from LDS. The bulk kernels (trsm of the rows below the band,
+// trailing update of everything but the band tiles) run one step behind on a second stream and never touch these tiles
+// (k_trsm `la`, k_gemm_nt `band`): the critical path per block is this one kernel.
+__global__ __launch_bounds__(512) void k_potrf64_la(DevSym S, const FrontView *__restrict__ frec, int kb, int kb0,
+                                                    double *__restrict__ L, int *__restrict__ info, FrontArg fa) {
+    // 8 waves (the factorisation below needs ~150 registers per thread: 16 waves would spill it): wave v owns the 16 x 16
+    // tiles (ti, tj) and (ti, tj + 1), ti = v & 3, tj = 2 (v >> 2) -- they share the A operand
+    __shared__ __attribute__((aligned(16))) double Sb[2][4 * 64];
+    __shared__ double Sm[NB * NB];      // S (column-major), later D
+    __shared__ double Ls[NB * NB];      // Lsub (column-major)
+    __shared__ double Ti[NB * NB];      // Linv of block b-1: Ti[k * NB + q] = Linv[k][q]
+    const FrontView fv = front_view(frec, blockIdx.x, fa);
+    const int c = fv.c;
+    if (kb >= c) return;
+    const int w = min(NB, c - kb);
+    const int ld = fv.ld;
+    double *Pf = L + fv.pp;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, lm = lane & 15, lk = lane >> 4;
+    const int ti = wave & 3, tj0 = 2 * (wave >> 2);
+    const int kp = kb - NB;                             // first column of block b-1 (a full block: one follows it)
+    // ---- phase A: the sums over the earlier blocks of the outer block (columns kb0 .. kp-1), S and D tiles at once -----
+    const int ia = min(16 * ti + lm, w - 1);            // row of block b (A operand), clamped
+    const double *Ab = Pf + kb + (long long)kb0 * ld;   // row block b, from column kb0
+    const double *Ap = Pf + kp + (long long)kb0 * ld;   // row block b-1
+    d4 accS[2], accD[2];
+#pragma unroll
+    for (int e = 0; e < 2; e++) { accS[e] = (d4){0.0, 0.0, 0.0, 0.0}; accD[e] = (d4){0.0, 0.0, 0.0, 0.0}; }
+    const int Kprev = kp - kb0;                         // multiple of 64
+    for (int k0 = 0; k0 < Kprev; k0 += 16) {
+        double av[4], bp[2][4], bb[2][4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const long long off = (long long)(k0 + 4 * u + lk) * ld;
+            av[u] = Ab[ia + off];
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                bp[e][u] = Ap[16 * (tj0 + e) + lm + off];
+                bb[e][u] = Ab[min(16 * (tj0 + e) + lm, w - 1) + off];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                accS[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bp[e][u], accS[e], 0, 0, 0);
+                accD[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bb[e][u], accD[e], 0, 0, 0);
+            }
+    }
+    // tile element D[i = 4 rr + lk][j = lm]; the panel's own values of the tiles
+    {
+        double so[2][4], d0[2][4];
+#pragma unroll
+        for (int e = 0; e < 2; e++)
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                const int i = min(16 * ti + 4 * rr + lk, w - 1), j = 16 * (tj0 + e) + lm;
+                so[e][rr] = Pf[kb + i + (long long)(kp + j) * ld];
+                d0[e][rr] = Pf[kb + i + (long long)(kb + min(j, w - 1)) * ld];
+            }
+#pragma unroll
+        for (int e = 0; e < 2; e++)
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                const int i = 16 * ti + 4 * rr + lk, j = 16 * (tj0 + e) + lm;
+                Sm[j * NB + i] = so[e][rr] - accS[e][rr];
+                accD[e][rr] = d0[e][rr] - accD[e][rr];          // kept in registers until phase C
+            }
+    }
+    stage_linv(Pf + kp + (long long)kp * ld, ld, NB, Ti, tid & 255);      // (two copies of the same values: harmless)
+    __syncthreads();
+    // ---- phase B: Lsub = S Linv[b-1]' (Linv lower: k <= q) ------------------------------------------------------------
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        const int tj = tj0 + e;
+        d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+        const int ku = 4 * (tj + 1);        // wave-uniform
+#pragma unroll 4
+        for (int u = 0; u < ku; u++) {
+            const int k = 4 * u + lk;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Sm[k * NB + 16 * ti + lm], Ti[(16 * tj + lm) * NB + k], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+            const int i = 16 * ti + 4 * rr + lk, q = 16 * tj + lm;
+            Ls[q * NB + i] = acc[rr];
+            if (i < w) Pf[kb + i + (long long)(kp + q) * ld] = acc[rr];
+        }
+    }
+    __syncthreads();
+    // ---- phase C: D -= Lsub Lsub' (lower tiles only), D -> LDS (every wave has read S before the barrier above: its
+    //      buffer becomes D) -------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        const int tj = tj0 + e;
+        if (ti >= tj) {
+            d4 accC = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const int q = 4 * u + lk;
+                accC = __builtin_amdgcn_mfma_f64_16x16x4f64(Ls[q * NB + 16 * ti + lm], Ls[q * NB + 16 * tj + lm], accC, 0, 0, 0);
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) Sm[(16 * tj + lm) * NB + 16 * ti + 4 * rr + lk] = accD[e][rr] - accC[rr];
+        }
+    }
+    __syncthreads();
+    if (tid >= 256) return;             // (a finished wave no longer counts at the barriers of the factorisation below)
+    potrf64_body(Sm, NB, Pf + kb + (long long)kb * ld, ld, w, Sb, info, fv.first + kb, tid);
+}
+
 void launch_potrf64(hipStream_t st, const DevSym &S, const FrontView *frec, int nactive, int kb, double *L, int *info,
                     const FrontArg &fa) {
     if (nactive <= 0) return;
     hipLaunchKernelGGL(k_potrf64, dim3(nactive), dim3(256), 0, st, S, frec, kb, L, info, fa);
+}
+void launch_potrf64_la(hipStream_t st, const DevSym &S, const FrontView *frec, int nactive, int kb, int kb0, double *L, int *info,
+                       const FrontArg &fa) {
+    if (nactive <= 0) return;
+    hipLaunchKernelGGL(k_potrf64_la, dim3(nactive), dim3(512), 0, st, S, frec, kb, kb0, L, info, fa);
 }
 
 }  // namespace gmrfx

@@ -907,3 +907,24 @@ def test_sweep_task_forms_match_the_oracle(mode, nrhs, monkeypatch):
     assert relerr(be.backend_backward_solve(Z), F.backward_solve(Z)) < 1e-10
     # bit-reproducible: the same call twice gives the same bits
     assert np.array_equal(be.backend_solve(B), be.backend_solve(B))
+
+
+def test_lookahead_panel_chain_matches_the_oracle(monkeypatch):
+    """GMRFX_LOOKAHEAD=1 (off by default, slower at cfg 2): the diagonal chain keeps its band tiles up to date left-looking
+    (k_potrf64_la) while trsm / gemm follow one step behind on a second stream without touching them. Same factor as the
+    oracle entry by entry on fronts with several 64-column blocks, partial last blocks and more than one 256-column outer
+    block; solve and log-determinant as well."""
+    rng = np.random.default_rng(21)
+    n = 700
+    A = sp.random(n, n, density=0.25, random_state=5, format="csc")
+    Q = sp.csc_matrix(A @ A.T + n * sp.identity(n))
+    monkeypatch.setenv("GMRFX_LOOKAHEAD", "1")
+    be = gmrfx.MI355XBackend(Q)
+    monkeypatch.delenv("GMRFX_LOOKAHEAD")
+    assert be.stats()["max_cols"] > 320           # a front with more than one outer block
+    F = orc.OracleFactor(Q, be.ordering_permutation())
+    Lg, Lo = be.factor_csc(), F.L()
+    assert abs(Lg - Lo).max() <= 1e-10 * abs(Lo).max()
+    B = rng.standard_normal((n, 3))
+    assert relerr(be.backend_solve(B), F.solve(B)) < 1e-10
+    assert abs(be.compute_logdet() - F.logdet()) < 1e-11 * abs(F.logdet())
