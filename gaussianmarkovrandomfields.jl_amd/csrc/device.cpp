@@ -174,16 +174,14 @@ void Device::upload(const Symbolic &S) {
         HC(hipStreamSynchronize(stream));
     }
     {
-        std::vector<long long> wptr(ns + 1, 0);
-        for (i32 s = 0; s < ns; s++) wptr[s + 1] = wptr[s] + (S.nrows(s) - S.ncols(s));
+        const std::vector<long long> wptr = conv<long long>(S.wptr);     // (Symbolic::wptr: per-rank layout on sharded handles)
         sum_trail_ = wptr[ns];
         up(lp, wptr); ds_.wptr = lp;
         h_wptr_ = wptr;
         HC(hipStreamSynchronize(stream));
     }
     {
-        std::vector<long long> wptr(ns + 1, 0);
-        for (i32 s = 0; s < ns; s++) wptr[s + 1] = wptr[s] + (S.nrows(s) - S.ncols(s));
+        const std::vector<long long> wptr = conv<long long>(S.wptr);
         std::vector<EdgeRec> edges(S.children.size());
         std::vector<int> etile;
         std::vector<int> erow;
@@ -252,8 +250,7 @@ void Device::upload(const Symbolic &S) {
     {
         const int *a; up(a, S.sw_levellist); d_sw_levellist_ = const_cast<int *>(a);
         nswt_ = (int)S.swt_first.size();
-        std::vector<long long> wp(ns + 1, 0);
-        for (i32 s = 0; s < ns; s++) wp[s + 1] = wp[s] + (S.nrows(s) - S.ncols(s));
+        const std::vector<long long> wp = conv<long long>(S.wptr);
         std::vector<SweepTask> tk((size_t)nswt_);
         for (int t = 0; t < nswt_; t++) {
             const i32 f = S.swt_first[t], r = S.swt_last[t];

@@ -207,8 +207,7 @@ extern "C" int32_t gmrfx_shard_edges(const gmrfx_handle *h, int64_t *child, int6
                                      int64_t *child_level) {
     if (!h || !child || !src || !dst || !level || !cb_offset || !cb_count || !w_row0 || !w_nrows) return GMRFX_ERR_INVALID_ARG;
     const Symbolic &S = h->S;
-    std::vector<int64_t> wptr(S.nsuper + 1, 0);
-    for (i32 s = 0; s < S.nsuper; s++) wptr[s + 1] = wptr[s] + (S.nrows(s) - S.ncols(s));
+    const std::vector<i64> &wptr = S.wptr;      // cross-edge children come first, identically on every rank
     for (size_t k = 0; k < S.shard_edges.size(); k++) {
         const i32 d = S.shard_edges[k], p = S.sparent[d];
         const int64_t m = S.nrows(d) - S.ncols(d);
@@ -359,7 +358,8 @@ static void build_zpattern(gmrfx_handle *h) {
             const i32 b = S.perm[S.sfirst[s] + j];
             for (i32 i = j; i < r; i++) {
                 const i32 a = S.perm[rows[i]];
-                const i64 off = S.panelptr[s] + (i64)j * S.ld[s] + i;
+                // a sharded handle holds the panels of its own fronts only: every other entry reads the zeroed slack word
+                const i64 off = (S.shard_world <= 1 || S.owner[s] == S.shard_rank) ? S.panelptr[s] + (i64)j * S.ld[s] + i : S.panelptr[S.nsuper];
                 ent[w[b]++] = {a, off};
                 if (i != j) ent[w[a]++] = {b, off};
             }
@@ -429,7 +429,9 @@ static inline long long z_offset(const Symbolic &S, i64 i, i64 j) {
     const i32 *rows = S.rows.data() + S.rowptr[s];
     const i32 r = S.nrows(s);
     const i32 *it = std::lower_bound(rows, rows + r, a);
-    return (it != rows + r && *it == a) ? (long long)(S.panelptr[s] + (i64)(b - S.sfirst[s]) * S.ld[s] + (it - rows)) : -1;
+    if (it == rows + r || *it != a) return -1;
+    if (S.shard_world > 1 && S.owner[s] != S.shard_rank) return (long long)S.panelptr[S.nsuper];      // another rank's panel: the zeroed slack word
+    return (long long)(S.panelptr[s] + (i64)(b - S.sfirst[s]) * S.ld[s] + (it - rows));
 }
 
 extern "C" int32_t gmrfx_selinv_extract(gmrfx_handle *h, int64_t ncol, const int64_t *colptr, const int64_t *rowval,
@@ -731,7 +733,15 @@ extern "C" int32_t gmrfx_symbolic_get(const gmrfx_handle *h, int64_t *super_firs
     if (panel_ld) for (i32 s = 0; s < ns; s++) panel_ld[s] = S.ld[s];
     if (level) for (i32 s = 0; s < ns; s++) level[s] = S.level[s];
     if (q_src) for (size_t k = 0; k < S.qsrc.size(); k++) q_src[k] = S.qsrc[k];
-    if (q_dst) for (size_t k = 0; k < S.qdst.size(); k++) q_dst[k] = S.qdst[k];
+    if (q_dst) {
+        for (size_t k = 0; k < S.qdst.size(); k++) q_dst[k] = S.qdst[k];
+        // a sharded handle stores the panels of its own fronts only: the entries of Q that go into another rank's panel
+        // have no destination here (-1)
+        if (S.shard_world > 1)
+            for (i32 s = 0; s < ns; s++)
+                if (S.owner[s] != S.shard_rank)
+                    for (i64 k = S.qptr[s]; k < S.qptr[s + 1]; k++) q_dst[k] = -1;
+    }
     return GMRFX_OK;
 }
 

@@ -480,8 +480,40 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
         for (i32 s = 0; s < ns; s++) S.nlevels = std::max(S.nlevels, S.level[s] + 1);
         S.nlevels = std::max(S.nlevels, S.shard_level);
     }
-    // does this rank execute front s?  (top fronts: rank 0)
+    // does this rank execute front s?
     auto mine = [&](i32 s) { return S.shard_world == 1 || S.owner[s] == S.shard_rank; };
+
+    // ---- per-rank storage of a sharded factorisation (round 3) ---------------------------------------------------------
+    // A rank only holds what it works on: the PANELS of its own fronts (panels never cross ranks; every other front gets a
+    // zero-length panel, and whoever reads an entry of one -- the selected-inverse getters -- is sent to the zeroed slack
+    // word behind the buffer, panelptr[nsuper]); update vectors W and contribution blocks of its own fronts plus those of
+    // the CROSS-EDGE children (the children of an owner-crossing tree edge, sent child's owner -> parent's owner). The
+    // cross-edge children come first in both layouts, in front order, identically on every rank: a transfer still goes
+    // into the SAME offset on both ends, and no rank needs to know another rank's private layout.
+    S.cross_child.assign(ns, 0);
+    for (i32 d : S.shard_edges) S.cross_child[d] = 1;
+    if (S.shard_world > 1) {
+        i64 off = 0;
+        for (i32 s = 0; s < ns; s++) {
+            S.panelptr[s] = off;
+            if (mine(s)) { off += (i64)S.ld[s] * S.ncols(s); off = (off + 15) & ~i64(15); }
+        }
+        S.panelptr[ns] = off;
+        for (i32 s = 0; s < ns; s++)
+            for (i32 j = 0; j < S.ncols(s); j++)
+                S.diagoff[S.sfirst[s] + j] = mine(s) ? S.panelptr[s] + (i64)j * S.ld[s] + j : off;
+    }
+    S.wptr.assign(ns + 1, 0);
+    {
+        i64 w = 0;
+        if (S.shard_world > 1) {
+            for (i32 s = 0; s < ns; s++) if (S.cross_child[s]) { S.wptr[s] = w; w += S.nrows(s) - S.ncols(s); }
+            for (i32 s = 0; s < ns; s++) if (!S.cross_child[s] && mine(s)) { S.wptr[s] = w; w += S.nrows(s) - S.ncols(s); }
+        } else {
+            for (i32 s = 0; s < ns; s++) { S.wptr[s] = w; w += S.nrows(s) - S.ncols(s); }
+        }
+        S.wptr[ns] = w;
+    }
     // small fronts (fused LDS kernels, small.hip): r <= 96 or r <= 128 rows and <= 64 columns
     S.small_rows = opt.small_front_rows >= 0 ? opt.small_front_rows : 96;    // measured on cfg 2: 96 beats 128 and 64 (tools/sweep notes in DESIGN.md)
     S.is_small.resize(ns);
@@ -682,23 +714,34 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
             }
         };
         auto bsz = [&](i32 s) { const i64 m = S.nrows(s) - S.ncols(s); return ((m * m) + 15) & ~i64(15); };
+        // sharded: the blocks of the cross-edge children sit in an exchange region at the start of the arena (same offsets
+        // on every rank, no reuse: a handful of blocks); behind it this rank's own fronts share slots by lifetime
+        i64 xtop = 0;
+        auto in_arena = [&](i32 s) { return S.shard_world == 1 || (mine(s) && !S.cross_child[s]); };
+        if (S.shard_world > 1)
+            for (i32 s = 0; s < ns; s++) {
+                S.cbptr[s] = S.zbptr[s] = 0;
+                if (S.cross_child[s]) { S.cbptr[s] = S.zbptr[s] = xtop; xtop += bsz(s); }
+            }
         std::vector<std::vector<i32>> bylevel(S.nlevels);
-        for (i32 s = 0; s < ns; s++) bylevel[S.level[s]].push_back(s);
-        i64 peak = 0;
+        for (i32 s = 0; s < ns; s++) if (in_arena(s)) bylevel[S.level[s]].push_back(s);
+        i64 peak = xtop;
         {   // factorisation: bottom-up
             Arena A;
+            A.top = xtop;
             for (i32 l = 0; l < S.nlevels; l++) {
                 for (i32 s : bylevel[l]) if (bsz(s) > 0) S.cbptr[s] = A.alloc(bsz(s));
                 peak = std::max(peak, A.top);
                 for (i32 s : bylevel[l])
                     for (i64 q = S.childptr[s]; q < S.childptr[s + 1]; q++) {
                         const i32 d = S.children[q];
-                        if (bsz(d) > 0) A.release(S.cbptr[d], bsz(d));
+                        if (bsz(d) > 0 && in_arena(d)) A.release(S.cbptr[d], bsz(d));
                     }
             }
         }
         {   // selected inversion: top-down
             Arena A;
+            A.top = xtop;
             std::vector<i32> minchild(ns, -1);
             for (i32 s = 0; s < ns; s++) {
                 i32 mc = S.level[s];                                   // no children: released after its own level
@@ -706,7 +749,7 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
                 minchild[s] = mc;
             }
             std::vector<std::vector<i32>> dies(S.nlevels);
-            for (i32 s = 0; s < ns; s++) dies[minchild[s]].push_back(s);
+            for (i32 s = 0; s < ns; s++) if (in_arena(s)) dies[minchild[s]].push_back(s);
             for (i32 l = S.nlevels - 1; l >= 0; l--) {
                 for (i32 s : bylevel[l]) if (bsz(s) > 0) S.zbptr[s] = A.alloc(bsz(s));
                 peak = std::max(peak, A.top);

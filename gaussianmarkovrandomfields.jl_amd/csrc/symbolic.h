@@ -53,6 +53,10 @@ struct Symbolic {
     std::vector<i64> zbptr;       // nsuper, the same arena as the selected inversion uses it (trailing inverse blocks:
                                   // a block lives from its front's level DOWN to its lowest child's level)
     i64 cb_arena = 0;             // doubles
+    std::vector<i64> wptr;        // nsuper+1: first row of front s in the update-vector buffer W ([nsuper] = total rows). Unsharded:
+                                  // prefix sum of the trailing rows; sharded: cross-edge children first (same on every rank), then
+                                  // this rank's own fronts, nothing for the others
+    std::vector<uint8_t> cross_child;   // nsuper: child of an owner-crossing tree edge (sharded handles)
     // supernodal tree
     std::vector<i64> childptr;    // nsuper+1
     std::vector<i32> children;    // children lists (ascending)

@@ -13,7 +13,8 @@ class HostSim:
         self.c = np.diff(sy.super_first)
         self.r = np.diff(sy.row_ptr)
         self.L = np.zeros(int(sy.panel_ptr[-1]))
-        self.L[sy.q_dst] = nzval[sy.q_src]
+        here = sy.q_dst >= 0            # (-1: the entry belongs to a panel another rank of a sharded factorisation stores)
+        self.L[sy.q_dst[here]] = nzval[sy.q_src[here]]
         self.children = [[] for _ in range(ns)]
         for s in range(ns):
             if sy.super_parent[s] >= 0:

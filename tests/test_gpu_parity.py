@@ -564,13 +564,14 @@ def _shard_gpu_worker(rank, world, port, q):
         # compare the panels this rank factored with an unsharded handle, bit for bit
         ref = g.MI355XBackend(Q, coords=m.points, device=0)
         rv = ref.factor_values()
+        rsy = ref.symbolic()            # a sharded handle only stores its own panels: its panel offsets are its own
         same = True
         why = []
         for s in np.nonzero(mine)[0]:
-            a, b = int(sy.panel_ptr[s]), int(sy.panel_ptr[s + 1])
+            a, ar = int(sy.panel_ptr[s]), int(rsy.panel_ptr[s])
             c, r, ldp = int(sy.super_first[s + 1] - sy.super_first[s]), int(sy.row_ptr[s + 1] - sy.row_ptr[s]), int(sy.panel_ld[s])
             Pa = vals[a:a + ldp * c].reshape(c, ldp).T[:r]
-            Pb = rv[a:a + ldp * c].reshape(c, ldp).T[:r]
+            Pb = rv[ar:ar + ldp * c].reshape(c, ldp).T[:r]
             if not np.array_equal(np.tril(Pa), np.tril(Pb)):
                 same = False
                 why.append(f"panel {s} (c={c}, r={r}) differs by {np.abs(np.tril(Pa) - np.tril(Pb)).max():.3e}")
@@ -595,6 +596,8 @@ def _shard_gpu_worker(rank, world, port, q):
             same = False
             why.append(f"sharded selinv diagonal differs from the unsharded one by {np.abs(dsh - dref).max():.3e} (rel {np.abs(dsh / dref - 1).max():.3e})")
         info = dict(sf.be.shard_info()); info["why"] = why[:5]
+        st, rst = sf.be.stats(), ref.stats()
+        info["mem"] = {k: (float(st[k]), float(rst[k])) for k in ("bytes_factor", "bytes_cb_arena", "bytes_device_total")}
         q.put((rank, ld, ref.compute_logdet(), bool(same), int(mine.sum()), info))
         dist.barrier()
         sf.close(); ref.close()
@@ -627,6 +630,16 @@ def test_sharded_factorisation_rehearsal_on_one_gpu(world):
         assert same and nmine > 0, f"rank {rank}: {info.get('why')}"
         assert abs(ld - ld_ref) <= 1e-12 * abs(ld_ref)
         assert info["n_top_fronts"] >= 1
+    # per-rank memory: a rank stores the panels of its own fronts only -- every panel exactly once over the ranks -- and
+    # its arena holds its own contribution blocks plus the exchange region of the cross-edge children
+    fac = [info["mem"]["bytes_factor"][0] for *_, info in got]
+    ref_fac = got[0][5]["mem"]["bytes_factor"][1]
+    assert abs(sum(fac) - ref_fac) <= 0.01 * ref_fac + 128 * 8 * 50000
+    assert max(fac) <= (0.70 if world == 2 else 0.45) * ref_fac, (fac, ref_fac)
+    for *_, info in got:
+        assert info["mem"]["bytes_cb_arena"][0] <= 1.05 * info["mem"]["bytes_cb_arena"][1]
+        # (bytes_device_total also holds the right-hand-side panels, n x 64 doubles twice, and the symbolic tables, which
+        #  every rank keeps whole: on this 14 400-node mesh they outweigh the factor)
 
 
 def test_randomised_pattern_sweep():
