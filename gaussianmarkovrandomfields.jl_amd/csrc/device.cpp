@@ -61,7 +61,17 @@ Device::~Device() {
     if (ev_fact_) (void)hipEventDestroy(ev_fact_);
     if (ev_inv_) (void)hipEventDestroy(ev_inv_);
     if (stream2) (void)hipStreamDestroy(stream2);
-    if (stream) (void)hipStreamDestroy(stream);
+    if (own_stream_) (void)hipStreamDestroy(own_stream_);
+}
+
+// The caller's stream becomes the main stream (sharded drivers: torch's current stream, so that the library's kernels,
+// torch's copies and the RCCL operations torch enqueues are ordered by the stream itself and no host-side synchronisation
+// is needed between a phase and the exchange behind it); async: the phase entry points return after enqueueing.
+void Device::set_external_stream(hipStream_t s, bool use, bool async) {
+    HC(hipSetDevice(device));
+    HC(hipStreamSynchronize(stream));
+    stream = use ? s : own_stream_;
+    async_phases_ = use && async;
 }
 
 template <class T, class U> static std::vector<T> conv(const std::vector<U> &v) { return std::vector<T>(v.begin(), v.end()); }
@@ -82,6 +92,7 @@ void Device::init(const Symbolic &S, int dev) {
         const char *e = std::getenv("GMRFX_STREAM_PRIO");
         const bool prio = !e || std::atoi(e) != 0;
         HC(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, prio ? hi : 0));
+        own_stream_ = stream;
         HC(hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, prio ? lo : 0));
         HC(hipStreamCreateWithPriority(&stream3, hipStreamNonBlocking, prio ? hi : 0));
         if (const char *c = std::getenv("GMRFX_INV_CAP")) {      // testing knob: power of two >= 64
@@ -754,11 +765,13 @@ void Device::refactorize_phase(const double *d_nzval, int phase) {
         factor_levels(lev, lev + 1);
     }
     HC(hipEventRecord(ev_[1], stream));
-    HC(hipStreamSynchronize(stream));
-    HC(hipGetLastError());
-    float ms = 0;
-    HC(hipEventElapsedTime(&ms, ev_[0], ev_[1]));
-    ms_factor = phase == 0 ? ms : ms_factor + ms;
+    if (!async_phases_) {
+        HC(hipStreamSynchronize(stream));
+        HC(hipGetLastError());
+        float ms = 0;
+        HC(hipEventElapsedTime(&ms, ev_[0], ev_[1]));
+        ms_factor = phase == 0 ? ms : ms_factor + ms;
+    }
     selinv_begun_ = false;
     if (split + phase >= nl) { factorized = true; selinv_valid = false; inverse_pending = true; }   // last phase done
 }
@@ -809,7 +822,10 @@ double Device::syrk_ms() {
 long long Device::fail_col() {
     int v = INT_MAX;
     if (info_cached_) v = *h_info_;
-    else HC(hipMemcpy(&v, d_info_, sizeof(int), hipMemcpyDeviceToHost));
+    else {
+        HC(hipStreamSynchronize(stream));       // (asynchronous phases / an external main stream: the factorisation may still run)
+        HC(hipMemcpy(&v, d_info_, sizeof(int), hipMemcpyDeviceToHost));
+    }
     return v == INT_MAX ? -1 : v;
 }
 
@@ -937,6 +953,7 @@ void Device::solve_phase(const double *d_B, long long ldb, long long nrhs, doubl
     if (phase == 0) {                                     // transpose in + forward over the own subtrees
         ensure_rhs_capacity(nrhs);
         start_inverse_async();
+        ensure_rdiag();
         launch_permute(stream, d_iperm_, (int)n, const_cast<double *>(d_B), ldb, d_X_, nr, ldx, 0);
         forward(nr, ldx, 0, split);
     } else if (phase >= 100 && phase < 100 + (nl - split)) {       // forward, top level split + (phase - 100)
@@ -947,15 +964,27 @@ void Device::solve_phase(const double *d_B, long long ldb, long long nrhs, doubl
         backward(nr, ldx, true, lev + 1, lev);
     } else if (phase == 2) {                              // backward over the own subtrees
         backward(nr, ldx, true, split, 0);
+    } else if (phase == 10) {                             // F.UP \ z: z is taken in elimination order as is, no forward sweep
+        ensure_rhs_capacity(nrhs);
+        start_inverse_async();
+        ensure_rdiag();
+        launch_permute(stream, nullptr, (int)n, const_cast<double *>(d_B), ldb, d_X_, nr, ldx, 0);
+    } else if (phase >= 300 && phase < 300 + (nl - split)) {       // backward-only solve, top level split + (phase - 300)
+        const int lev = split + phase - 300;
+        backward(nr, ldx, false, lev + 1, lev);
+    } else if (phase == 12) {                             // backward-only solve over the own subtrees
+        backward(nr, ldx, false, split, 0);
     } else if (phase == 3) {                              // transpose out (rank 0, after the gather)
         launch_permute(stream, d_iperm_, (int)n, d_Xout, ldx_out, d_X_, nr, ldx, 1);
-    } else throw std::invalid_argument("solve phase must be 0, 2, 3, 100 + k or 200 + k (k = top level)");
+    } else throw std::invalid_argument("solve phase must be 0, 2, 3, 10, 12, 100 + k, 200 + k or 300 + k (k = top level)");
     HC(hipEventRecord(ev_[1], stream));
-    HC(hipStreamSynchronize(stream));
-    HC(hipGetLastError());
-    float ms = 0;
-    HC(hipEventElapsedTime(&ms, ev_[0], ev_[1]));
-    ms_solve = phase == 0 ? ms : ms_solve + ms;
+    if (!async_phases_) {
+        HC(hipStreamSynchronize(stream));
+        HC(hipGetLastError());
+        float ms = 0;
+        HC(hipEventElapsedTime(&ms, ev_[0], ev_[1]));
+        ms_solve = (phase == 0 || phase == 10) ? ms : ms_solve + ms;
+    }
     last_nrhs = nrhs;
 }
 
@@ -1195,12 +1224,14 @@ void Device::selinv_phase(int what, int hi, int lo) {
         HC(hipEventRecord(ev_[0], stream));
         selinv_levels(hi, lo);
         HC(hipEventRecord(ev_[1], stream));
-        HC(hipStreamSynchronize(stream));
-        float ms; HC(hipEventElapsedTime(&ms, ev_[0], ev_[1])); ms_selinv += ms;
+        if (!async_phases_) {
+            HC(hipStreamSynchronize(stream));
+            float ms; HC(hipEventElapsedTime(&ms, ev_[0], ev_[1])); ms_selinv += ms;
+        }
     } else if (what == 3) {
         selinv_valid = true;
     } else throw std::invalid_argument("selinv phase must be 0 (begin), 1 (gather for other ranks), 2 (own levels) or 3 (end)");
-    HC(hipStreamSynchronize(stream));
+    if (!async_phases_) HC(hipStreamSynchronize(stream));
     HC(hipGetLastError());
 }
 

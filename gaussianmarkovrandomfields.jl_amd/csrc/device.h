@@ -198,6 +198,8 @@ public:
     double bytes_total = 0;
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t own_stream_ = nullptr;   // the main stream this handle created (`stream` may be the caller's: set_external_stream)
+    bool async_phases_ = false;          // sharded phase entry points return after enqueueing (no host synchronisation, no timings)
     hipStream_t stream2 = nullptr;  // side stream: dense-inverse stages overlap the leaf levels of the forward sweep
     hipStream_t stream3 = nullptr;  // second sweep lane (solves with more than 64 right-hand sides)
     hipEvent_t ev_fact_ = nullptr, ev_inv_ = nullptr;
@@ -247,6 +249,9 @@ private:
     const int *d_wave_order_ = nullptr;
     int wave_first_[kWaveClasses] = {0, 0}, wave_count_[kWaveClasses] = {0, 0};
     void sweep_tasks(int phase, int nr, int ldx);
+public:
+    void set_external_stream(hipStream_t s, bool use, bool async);
+private:
     void ensure_rdiag();
     double *d_rdiag_ = nullptr;                   // n reciprocals of L's diagonal (+ a zero word): operands of the wave tasks
     unsigned long long factor_serial_ = 1, rdiag_for_ = 0;    // d_rdiag_ belongs to factorisation number rdiag_for_

@@ -191,6 +191,13 @@ extern "C" int32_t gmrfx_refactorize_phase(gmrfx_handle *h, const double *d_nzva
         return GMRFX_OK;
     });
 }
+extern "C" int32_t gmrfx_set_stream(gmrfx_handle *h, void *hip_stream, int32_t use_external, int32_t async_phases) {
+    return guarded(h, [&]() -> int32_t {
+        if (int32_t e = need_device(h, false)) return e;
+        h->D->set_external_stream((hipStream_t)hip_stream, use_external != 0, async_phases != 0);
+        return GMRFX_OK;
+    });
+}
 extern "C" int32_t gmrfx_shard_info(const gmrfx_handle *h, int64_t *n_edges, int64_t *n_top_fronts, int64_t *shard_level) {
     if (!h) return GMRFX_ERR_INVALID_ARG;
     const Symbolic &S = h->S;

@@ -410,6 +410,10 @@ class MI355XBackend:
             check(lib().gmrfx_shard_rows(self._h, kind, C.byref(k), ptr(owner), ptr(r0), ptr(nr), ptr(lv)), self._h)
         return owner, r0, nr, lv
 
+    def set_stream(self, hip_stream: int, use_external: bool = True, async_phases: bool = False) -> None:
+        """The caller's HIP stream becomes the handle's main stream (sharded drivers: torch's current stream)."""
+        check(lib().gmrfx_set_stream(self._h, C.c_void_p(int(hip_stream)), int(use_external), int(async_phases)), self._h)
+
     def device_ptr(self, which: int) -> int:
         return int(lib().gmrfx_device_ptr(self._h, which) or 0)
 

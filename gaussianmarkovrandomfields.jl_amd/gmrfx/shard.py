@@ -11,7 +11,14 @@ as ONE batch (batch_isend_irecv). This is the exchange the reference's CPU solve
 src/workspace/backend.jl:165-189) never needs: it has one address space.
 
 Device buffers are handed to torch.distributed without copies: the library's arena / X / W buffers are wrapped as torch
-tensors through __cuda_array_interface__ (RCCL on MI355X nodes); the gloo rehearsal stages through host tensors."""
+tensors through __cuda_array_interface__ (RCCL on MI355X nodes); the gloo rehearsal stages through host tensors.
+
+Ordering (round 3): the handle runs on TORCH'S CURRENT STREAM (gmrfx_set_stream) with asynchronous phases, so a phase, the
+transfers behind it and the next phase are ordered by the stream itself -- torch.distributed makes its communication stream
+wait for the current stream when an operation is enqueued and the current stream wait for the operation in `wait()` --
+and the host never blocks between them (round 2: a stream synchronisation inside every phase call plus a device-wide
+synchronisation after every exchange, 2K + 2 host round trips per step). The per-level views / transfer lists are built
+once. Every rank keeps only its own part of the factor (panels, arena, update vectors: csrc/symbolic.cpp)."""
 from __future__ import annotations
 
 import numpy as np
@@ -41,6 +48,20 @@ class ShardedFactor:
         self.sub_rows = self.be.shard_rows(3)
         self.host_staging = dist.get_backend() == "gloo"      # rehearsal: gloo moves host tensors only
         self.last_info = 0
+        # one stream orders everything: the library's kernels, torch's copies, the transfers torch.distributed enqueues
+        self.be.set_stream(torch.cuda.current_stream(self.dev).cuda_stream, True, True)
+        # per top level: the cross-edge transfers of the factorisation (contribution blocks) and of the forward sweep
+        # (update vectors, per right-hand side), built once
+        e = self.edges
+        self._cb_items, self._w_items = [], []
+        for k in range(self.K):
+            idx = np.flatnonzero(e["level"] == self.L0 + k)
+            self._cb_items.append([(int(e["src"][i]), int(e["dst"][i]), 0, int(e["cb_offset"][i]), int(e["cb_count"][i])) for i in idx])
+            self._w_items.append([(int(e["src"][i]), int(e["dst"][i]), int(e["w_row0"][i]), int(e["w_nrows"][i])) for i in idx])
+        owner, r0, nr, lv = self.top_rows
+        self._top_blocks = [[(int(owner[i]), int(r0[i]), int(nr[i])) for i in np.flatnonzero(lv == self.L0 + k)] for k in range(self.K)]
+        so, sr0, snr, _ = self.sub_rows
+        self._sub_blocks = [(int(so[i]), int(sr0[i]), int(snr[i])) for i in range(len(so))]
 
     # ---- transfers ----------------------------------------------------------------------------------
     def _view(self, which: int, off: int, cnt: int):
@@ -66,10 +87,9 @@ class ShardedFactor:
                 ops.append(dist.P2POp(dist.irecv, v, src, tag=tag))
         if ops:
             for r in dist.batch_isend_irecv(ops):
-                r.wait()
+                r.wait()                # (RCCL: the current STREAM waits; gloo: the host does)
         for v, buf in post:
-            v.copy_(buf)
-        t.cuda.synchronize(self.dev)
+            v.copy_(buf)                # host -> device on the current stream: ordered before the next phase
 
     def _bcast_rows(self, blocks, nrhs: int):
         """blocks: (owner, first row, rows) of X row blocks; every owner broadcasts its blocks (one fused buffer per
@@ -89,7 +109,6 @@ class ShardedFactor:
                 for v in views:
                     v.copy_(buf[o:o + v.numel()])
                     o += v.numel()
-        t.cuda.synchronize(self.dev)
 
     def _edges_of_level(self, lev: int):
         e = self.edges
@@ -97,11 +116,10 @@ class ShardedFactor:
 
     # ---- factorisation ------------------------------------------------------------------------------
     def refactorize_dev(self, d_nzval_ptr: int) -> int:
-        be, e = self.be, self.edges
+        be = self.be
         be.refactorize_phase_dev(d_nzval_ptr, 0)
         for k in range(self.K):
-            idx = self._edges_of_level(self.L0 + k)
-            self._p2p([(int(e["src"][i]), int(e["dst"][i]), 0, int(e["cb_offset"][i]), int(e["cb_count"][i])) for i in idx])
+            self._p2p(self._cb_items[k])
             be.refactorize_phase_dev(d_nzval_ptr, 1 + k)
         # first non-positive pivot over all ranks (0 = none), like the `info` of gmrfx_refactorize
         t = self.torch
@@ -114,24 +132,32 @@ class ShardedFactor:
     # ---- solve --------------------------------------------------------------------------------------
     def solve_dev(self, d_B: int, ldb: int, nrhs: int, d_X: int, ldx: int) -> None:
         """Q X = B with the factor sharded over the ranks; B (full, column-major n x nrhs) on every rank,
-        X (full) is produced on rank 0. 1..64 right-hand sides per call."""
-        be, e = self.be, self.edges
-        be.solve_phase_dev(d_B, ldb, nrhs, d_X, ldx, 0)                      # transpose in + own forward
-        for k in range(self.K):
-            idx = self._edges_of_level(self.L0 + k)
-            self._p2p([(int(e["src"][i]), int(e["dst"][i]), 3, int(e["w_row0"][i]) * nrhs, int(e["w_nrows"][i]) * nrhs) for i in idx])
-            be.solve_phase_dev(d_B, ldb, nrhs, d_X, ldx, 100 + k)            # forward, top level k
-        owner, r0, nr, lv = self.top_rows
+        X (full) is produced on rank 0. Any number of right-hand sides: passes of up to 64 columns."""
+        for j0 in range(0, int(nrhs), 64):
+            self._solve_pass(d_B + 8 * j0 * ldb, ldb, min(64, nrhs - j0), d_X + 8 * j0 * ldx, ldx, backward_only=False)
+
+    def backward_solve_dev(self, d_Z: int, ldz: int, nrhs: int, d_X: int, ldx: int) -> None:
+        """X = P' L^-T Z (`F.UP \\ z`, src/workspace/backend.jl:281-284: the sampling path) with the factor sharded over the
+        ranks; Z (full, column-major n x nrhs, in ELIMINATION order as CHOLMOD takes it) on every rank, X on rank 0."""
+        for j0 in range(0, int(nrhs), 64):
+            self._solve_pass(d_Z + 8 * j0 * ldz, ldz, min(64, nrhs - j0), d_X + 8 * j0 * ldx, ldx, backward_only=True)
+
+    def _solve_pass(self, d_B: int, ldb: int, nrhs: int, d_X: int, ldx: int, backward_only: bool) -> None:
+        be = self.be
+        if backward_only:
+            be.solve_phase_dev(d_B, ldb, nrhs, d_X, ldx, 10)                     # z as is
+        else:
+            be.solve_phase_dev(d_B, ldb, nrhs, d_X, ldx, 0)                      # transpose in + own forward
+            for k in range(self.K):
+                self._p2p([(src, dst, 3, r0 * nrhs, nr * nrhs) for src, dst, r0, nr in self._w_items[k]])
+                be.solve_phase_dev(d_B, ldb, nrhs, d_X, ldx, 100 + k)            # forward, top level k
         for k in range(self.K - 1, -1, -1):
-            be.solve_phase_dev(d_B, ldb, nrhs, d_X, ldx, 200 + k)            # backward, top level k
-            sel = np.flatnonzero(lv == self.L0 + k)
-            self._bcast_rows([(owner[i], r0[i], nr[i]) for i in sel], nrhs)  # x of that level's fronts -> everybody
-        be.solve_phase_dev(d_B, ldb, nrhs, d_X, ldx, 2)                      # own backward
-        so, sr0, snr, _ = self.sub_rows
-        items = [(int(so[i]), 0, 2, int(sr0[i]) * nrhs, int(snr[i]) * nrhs) for i in range(len(so))]
-        self._p2p(items)                                                     # x of the owned subtrees -> rank 0
+            be.solve_phase_dev(d_B, ldb, nrhs, d_X, ldx, (300 if backward_only else 200) + k)    # backward, top level k
+            self._bcast_rows(self._top_blocks[k], nrhs)                          # x of that level's fronts -> everybody
+        be.solve_phase_dev(d_B, ldb, nrhs, d_X, ldx, 12 if backward_only else 2)  # own backward
+        self._p2p([(o, 0, 2, r0 * nrhs, nr * nrhs) for o, r0, nr in self._sub_blocks])     # x of the owned subtrees -> rank 0
         if self.rank == 0:
-            be.solve_phase_dev(d_B, ldb, nrhs, d_X, ldx, 3)                  # transpose out
+            be.solve_phase_dev(d_B, ldb, nrhs, d_X, ldx, 3)                      # transpose out
 
     # ---- selected inversion -------------------------------------------------------------------------
     def selinv_compute(self) -> None:

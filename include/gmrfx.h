@@ -161,6 +161,16 @@ int32_t gmrfx_selinv_phase(gmrfx_handle *h, int32_t what, int32_t level_hi, int3
 int32_t gmrfx_shard_owner(const gmrfx_handle *h, int64_t *owner /* nsuper, >= 0 */, int64_t *is_top /* nsuper, nullable */);
 void   *gmrfx_device_ptr(gmrfx_handle *h, int32_t which /* 0: contribution-block arena, 1: factor panels, 2: X, 3: W */);
 int32_t gmrfx_solve_phase(gmrfx_handle *h, const double *d_B, int64_t ldb, int64_t nrhs, double *d_X, int64_t ldx, int32_t phase);
+/* Backward-only sharded solve, X = P' L^-T Z (`F.UP \ z`, src/workspace/backend.jl:281-284), through the same entry point:
+ * phase 10 = take Z (full, on every rank) in elimination order; 300 + k = backward over top level k [then broadcast that
+ * level's x rows, as after 200 + k]; 12 = backward over the own subtrees; [gather on rank 0]; 3 = transpose out.
+ *
+ * gmrfx_set_stream: the caller's HIP stream becomes the handle's main stream (use_external = 1; 0 restores the handle's
+ * own). A sharded driver passes the stream its communication library orders its operations on (torch's current stream for
+ * torch.distributed / RCCL): kernels, copies and transfers are then ordered by the stream, and with async_phases = 1 the
+ * phase entry points (gmrfx_refactorize_phase / _solve_phase / _selinv_phase) return after enqueueing -- no host-side
+ * synchronisation between a phase and the exchange behind it (their HIP-event timings are not collected then). */
+int32_t gmrfx_set_stream(gmrfx_handle *h, void *hip_stream, int32_t use_external, int32_t async_phases);
 int32_t gmrfx_shard_rows(const gmrfx_handle *h, int32_t kind, int64_t *nblocks, int64_t *owner, int64_t *row0, int64_t *nrows,
                          int64_t *level);
 int32_t gmrfx_logdet_partial(gmrfx_handle *h, double *out);

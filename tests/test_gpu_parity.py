@@ -588,6 +588,27 @@ def _shard_gpu_worker(rank, world, port, q):
             if not resid < 1e-10:
                 same = False
                 why.append(f"residual {resid:.3e}")
+        # backward-only solve (F.UP \\ z, the sampling path) and more than 64 columns (two passes), sharded: same bits as unsharded
+        nb = 70 if world == 2 else 5
+        Zh = torch.randn((nb, Q.shape[0]), generator=torch.Generator().manual_seed(4), dtype=torch.float64)
+        d_Z = Zh.to(dev); d_S = torch.zeros_like(d_Z)
+        torch.cuda.synchronize()
+        sf.backward_solve_dev(d_Z.data_ptr(), Q.shape[0], nb, d_S.data_ptr(), Q.shape[0])
+        d_W = torch.zeros_like(d_Z)
+        sf.solve_dev(d_Z.data_ptr(), Q.shape[0], nb, d_W.data_ptr(), Q.shape[0])
+        torch.cuda.synchronize()
+        if rank == 0:
+            d_Sr = torch.zeros_like(d_Z); d_Wr = torch.zeros_like(d_Z)
+            torch.cuda.synchronize()
+            ref.backward_solve_dev(d_Z.data_ptr(), Q.shape[0], nb, d_Sr.data_ptr(), Q.shape[0])
+            ref.solve_dev(d_Z.data_ptr(), Q.shape[0], nb, d_Wr.data_ptr(), Q.shape[0])
+            torch.cuda.synchronize()
+            if not torch.equal(d_S, d_Sr):
+                same = False
+                why.append(f"sharded backward solve ({nb} columns) differs from the unsharded one by {float((d_S - d_Sr).abs().max()):.3e}")
+            if not torch.equal(d_W, d_Wr):
+                same = False
+                why.append(f"sharded {nb}-column solve differs from the unsharded one by {float((d_W - d_Wr).abs().max()):.3e}")
         # sharded selected inversion: the all-reduced diagonal equals the unsharded one bit for bit
         sf.selinv_compute()
         dsh = sf.selinv_diag()
