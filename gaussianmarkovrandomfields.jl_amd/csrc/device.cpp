@@ -51,6 +51,9 @@ Device::~Device() {
     if (stream) { (void)hipStreamSynchronize(stream); }
     for (auto &p : allocs_) (void)hipFree(p.first);
     for (auto &e : ev_) if (e) (void)hipEventDestroy(e);
+    for (auto &v : ev_level_) for (auto &e : v) (void)hipEventDestroy(e);
+    for (auto &e : ev_la_p_) (void)hipEventDestroy(e);
+    for (auto &e : ev_la_t_) (void)hipEventDestroy(e);
     for (auto &l : ev_lane_) for (auto &e : l) if (e) (void)hipEventDestroy(e);
     if (h_info_) (void)hipHostFree(h_info_);
     if (ev_ready_) (void)hipEventDestroy(ev_ready_);
@@ -558,7 +561,7 @@ void Device::factor_levels(int lo, int hi) {
     int nsy = (int)syrk_launches;
     for (int lev = lo; lev < hi; lev++) {
         auto &L = levels_[lev];
-        if (level_mark_) launch_level_mark(stream, 3, lev);
+        if (level_mark_) { launch_level_mark(stream, 3, lev); level_event(0, lev); }
         const int *list = d_levellist_ + L.first + L.nsmall;
         const int nf = L.count - L.nsmall;
         // The small fronts of a level (fused one-workgroup kernels) and its big fronts (assembly -> panel chain -> SYRK)
@@ -682,6 +685,7 @@ void Device::factor_levels(int lo, int hi) {
         }
     }
     syrk_launches = nsy;
+    if (level_mark_) level_event(0, hi);
 }
 
 // The dense inverses are only needed by the sweeps and the selected inversion of the big
@@ -869,7 +873,7 @@ void Device::ensure_rdiag() {
 }
 
 void Device::forward(int nr, int ldx, int lo, int hi) {
-    if (level_mark_ && lo == 0) launch_level_mark(stream, 1, -1);
+    if (level_mark_ && lo == 0) { launch_level_mark(stream, 1, -1); level_event(1, 0); }
     if (lo == 0) sweep_tasks(1, nr, ldx);
     if (lo == 0)
         for (int k = 0, off = 0; k < 3; off += nsub_cls_[k], k++)
@@ -877,7 +881,7 @@ void Device::forward(int nr, int ldx, int lo, int hi) {
                            nullptr, d_X_, d_W_, nr, ldx);
     for (int lev = lo; lev < hi; lev++) {
         auto &L = swlevels_[lev];
-        if (level_mark_) launch_level_mark(stream, 1, lev);
+        if (level_mark_) { launch_level_mark(stream, 1, lev); level_event(1, 1 + lev); }
         if (lev == std::max(lo, first_multiblock_level_)) wait_inverse();
         for (int k = 0, off = 0; k < 4; off += L.ncls[k], k++)
             launch_fwd_small(stream, ds_, d_sw_levellist_ + L.first + off, L.ncls[k], kClsRows[k], d_L_, d_X_, d_W_, nr, ldx);
@@ -900,6 +904,7 @@ void Device::forward(int nr, int ldx, int lo, int hi) {
         else
             launch_fwd_update(stream, ds_, list, nf, level_max_trail(L), d_L_, d_X2_, d_W_, nr, ldx);
     }
+    if (level_mark_) level_event(1, 1 + hi);
 }
 
 // y_in_x2: the forward sweep left y of the big fronts in X2 (full solve). The backward sweep then turns it
@@ -909,7 +914,7 @@ void Device::backward(int nr, int ldx, bool y_in_x2, int hi, int lo) {
     wait_inverse();   // (a no-op event wait once the forward sweep has passed it)
     for (int l = hi - 1; l >= lo; l--) {
         auto &L = swlevels_[l];
-        if (level_mark_) launch_level_mark(stream, 2, l);
+        if (level_mark_) { launch_level_mark(stream, 2, l); level_event(2, (int)levels_.size() - 1 - l); }
         const int *list = d_sw_levellist_ + L.first + L.nsmall;
         const int nf = L.count - L.nsmall;
         for (int k = 0, off = 0; k < 4; off += L.ncls[k], k++)
@@ -934,12 +939,37 @@ void Device::backward(int nr, int ldx, bool y_in_x2, int hi, int lo) {
             }
         }
     }
-    if (level_mark_ && lo == 0) launch_level_mark(stream, 2, -1);
+    if (level_mark_ && lo == 0) { launch_level_mark(stream, 2, -1); level_event(2, (int)levels_.size()); }
     if (lo == 0)
         for (int k = 0, off = 0; k < 3; off += nsub_cls_[k], k++)
             launch_subtree(stream, ds_, 2, d_sub_first_ + off, d_sub_last_ + off, nsub_cls_[k], kClsRows[k], nullptr, d_L_, nullptr,
                            nullptr, d_X_, nullptr, nr, ldx);
     if (lo == 0) sweep_tasks(2, nr, ldx);
+    if (level_mark_ && lo == 0) level_event(2, (int)levels_.size() + 1);
+}
+
+// GMRFX_LEVEL_MARK=1: HIP events at the level boundaries of the most recent factorisation / forward / backward sweep
+// (slot numbering in level_times()); a profiling aid behind gmrfx_level_times, never on in production runs
+void Device::level_event(int phase, int slot) {
+    auto &v = ev_level_[phase];
+    while ((int)v.size() <= slot) { hipEvent_t e; HC(hipEventCreate(&e)); v.push_back(e); }
+    HC(hipEventRecord(v[slot], stream));
+    level_slots_[phase] = std::max(level_slots_[phase], slot + 1);
+}
+// out[0] = the sweep tasks (0 for the factorisation), out[1 + l] = tree level l, milliseconds; returns the count
+int Device::level_times(int phase, double *out, int cap) {
+    HC(hipSetDevice(device));
+    const int nl = (int)levels_.size();
+    if (!level_mark_ || phase < 0 || phase > 2 || level_slots_[phase] < (phase == 0 ? nl + 1 : nl + 2)) return 0;
+    HC(hipDeviceSynchronize());
+    auto &v = ev_level_[phase];
+    auto dt = [&](int a, int b) { float ms = 0; HC(hipEventElapsedTime(&ms, v[a], v[b])); return (double)ms; };
+    for (int k = 0; k <= nl && k < cap; k++) {
+        if (phase == 0) out[k] = k == 0 ? 0.0 : dt(k - 1, k);                       // slots: start of level l = l, end = nl
+        else if (phase == 1) out[k] = dt(k, k + 1);                                  // slot 0 = start, 1 + l = start of level l, 1 + nl = end
+        else out[k] = k == 0 ? dt(nl, nl + 1) : dt(nl - k, nl - k + 1);              // processing order: level nl-1 .. 0, tasks
+    }
+    return std::min(nl + 1, cap);
 }
 
 void Device::solve_phase(const double *d_B, long long ldb, long long nrhs, double *d_Xout, long long ldx_out, int phase) {

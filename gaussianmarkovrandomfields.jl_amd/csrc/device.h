@@ -251,11 +251,15 @@ private:
     void sweep_tasks(int phase, int nr, int ldx);
 public:
     void set_external_stream(hipStream_t s, bool use, bool async);
+    int level_times(int phase, double *out, int cap);
 private:
     void ensure_rdiag();
     double *d_rdiag_ = nullptr;                   // n reciprocals of L's diagonal (+ a zero word): operands of the wave tasks
     unsigned long long factor_serial_ = 1, rdiag_for_ = 0;    // d_rdiag_ belongs to factorisation number rdiag_for_
     bool selinv_begun_ = false;   // sharded selected inversion: phase 0 has run since the last refactorisation (gmrfx_selinv_phase)
+    std::vector<hipEvent_t> ev_level_[3];
+    int level_slots_[3] = {0, 0, 0};
+    void level_event(int phase, int slot);
     bool level_mark_ = false;     // GMRFX_LEVEL_MARK=1: an empty marker kernel in front of every level (profiling aid, tools/sweep_levels.py)
     bool small_on_side_ = true;     // GMRFX_SMALL_ON_SIDE=0: a level's small fronts before its big fronts, on one stream
     int *d_sub_first_ = nullptr, *d_sub_last_ = nullptr, *d_sel_levellist_ = nullptr;

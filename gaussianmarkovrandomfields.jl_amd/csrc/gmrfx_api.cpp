@@ -191,6 +191,16 @@ extern "C" int32_t gmrfx_refactorize_phase(gmrfx_handle *h, const double *d_nzva
         return GMRFX_OK;
     });
 }
+// Profiling aid (handles created with GMRFX_LEVEL_MARK=1): HIP-event time of every tree level of the most recent
+// factorisation (which = 0), forward (1) or backward (2) sweep. ms[0] = the sweep tasks, ms[1 + l] = level l.
+extern "C" int32_t gmrfx_level_times(gmrfx_handle *h, int32_t which, double *ms, int64_t cap, int64_t *count) {
+    return guarded(h, [&]() -> int32_t {
+        if (int32_t e = need_device(h, false)) return e;
+        if (!ms || !count) throw std::invalid_argument("null output");
+        *count = h->D->level_times(which, ms, (int)cap);
+        return GMRFX_OK;
+    });
+}
 extern "C" int32_t gmrfx_set_stream(gmrfx_handle *h, void *hip_stream, int32_t use_external, int32_t async_phases) {
     return guarded(h, [&]() -> int32_t {
         if (int32_t e = need_device(h, false)) return e;

@@ -414,6 +414,14 @@ class MI355XBackend:
         """The caller's HIP stream becomes the handle's main stream (sharded drivers: torch's current stream)."""
         check(lib().gmrfx_set_stream(self._h, C.c_void_p(int(hip_stream)), int(use_external), int(async_phases)), self._h)
 
+    def level_times(self, which: int) -> np.ndarray:
+        """ms per tree level of the last factorisation (0) / forward (1) / backward (2) sweep ([0] = the sweep tasks); empty
+        unless the handle was created under GMRFX_LEVEL_MARK=1."""
+        out = np.zeros(int(self.stats()["nlevels"]) + 1)
+        cnt = C.c_int64(0)
+        check(lib().gmrfx_level_times(self._h, which, ptr(out), out.size, C.byref(cnt)), self._h)
+        return out[:cnt.value]
+
     def device_ptr(self, which: int) -> int:
         return int(lib().gmrfx_device_ptr(self._h, which) or 0)
 

@@ -201,9 +201,20 @@ class ShardedFactor:
         self.be.close()
 
 
-def plan_summary(be) -> dict:
-    """Who owns how much, and the flop-count bound on the speed-up (host-side, works on symbolic_only handles):
-    time ~ max_r (flops of rank r's subtrees) + sum over top levels of the heaviest rank's flops in that level."""
+def plan_summary(be, level_ms=None) -> dict:
+    """Who owns how much, and bounds on the speed-up of the sharded factorisation (host-side, works on symbolic_only handles).
+
+    flop_bound_speedup: time ~ max_r (flops of rank r's subtrees) + sum over top levels of the heaviest rank's flops in that
+    level -- what the plan could reach if every front ran at one common flop rate.
+
+    level_ms (optional): measured HIP-event time of every tree level of the UNSHARDED run (MI355XBackend.level_times under
+    GMRFX_LEVEL_MARK=1; [0] = the sweep tasks, [1 + l] = level l of the unsharded schedule), for the factorisation alone or
+    summed with the sweeps. It turns the plan into TIME bounds: a rank's subtree fronts cost their flop share of their level's
+    measured time (those levels hold thousands of fronts: throughput-bound, the share is fair); the top fronts are the
+    latency-bound chains at the top of the tree (potrf64 -> trsm -> gemm per 64 columns) that sharding does not shorten:
+      time_bound_speedup_latency : every level that holds a top front still costs its full measured time;
+      time_bound_speedup_share   : the top fronts too only cost the heaviest rank's flop share of their level.
+    The truth lies between the two; the exchanges are not in either."""
     owner, top = be.shard_owner(with_top=True)
     sy = be.symbolic()
     c = np.diff(sy.super_first).astype(np.float64)
@@ -217,5 +228,31 @@ def plan_summary(be) -> dict:
         sel = top & (sy.level == lv)
         t_top += max(float(fl[sel & (owner == k)].sum()) for k in range(W))
     total = float(fl.sum())
-    return {"world": W, "top_fronts": int(top.sum()), "top_flops": float(fl[top].sum()), "local_flops": local,
-            "top_critical_flops": t_top, "flop_bound_speedup": total / (max(local) + t_top)}
+    out = {"world": W, "top_fronts": int(top.sum()), "top_flops": float(fl[top].sum()), "local_flops": local,
+           "top_critical_flops": t_top, "flop_bound_speedup": total / (max(local) + t_top)}
+    if level_ms is not None:
+        # levels of the UNSHARDED schedule: height above the leaves (a sharded handle re-levels its top fronts)
+        ns = len(c)
+        par = np.asarray(sy.super_parent)
+        h = np.zeros(ns, np.int64)
+        for s in range(ns):                         # children have smaller ids than their parents (postorder)
+            if par[s] >= 0:
+                h[par[s]] = max(h[par[s]], h[s] + 1)
+        lm = np.asarray(level_ms, dtype=np.float64)
+        nl = int(h.max()) + 1
+        if lm.size < nl + 1:
+            raise ValueError(f"level_ms has {lm.size} entries, the tree has {nl} levels (+ 1 for the sweep tasks)")
+        t_level = lm[1:nl + 1].copy()
+        t_level[0] += lm[0]                         # the sweep tasks are bottom subtrees: count them with level 0
+        F = np.array([fl[h == l].sum() for l in range(nl)])
+        per_front = t_level[h] * fl / np.maximum(F[h], 1e-300)
+        t_local = max(float(per_front[(owner == k) & ~top].sum()) for k in range(W))
+        top_levels = np.unique(h[top])
+        t_latency = float(sum(t_level[l] for l in top_levels))
+        t_share = float(sum(max(per_front[top & (h == l) & (owner == k)].sum() for k in range(W)) for l in top_levels))
+        # (the non-top fronts of a level that also holds top fronts are already in t_local with their share)
+        t1 = float(t_level.sum())
+        out.update({"measured_ms_one_gpu": t1, "time_bound_ms_latency": t_local + t_latency, "time_bound_ms_share": t_local + t_share,
+                    "time_bound_speedup_latency": t1 / (t_local + t_latency), "time_bound_speedup_share": t1 / (t_local + t_share),
+                    "top_levels": [int(l) for l in top_levels], "top_levels_ms": [float(t_level[l]) for l in top_levels]})
+    return out

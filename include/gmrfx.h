@@ -171,6 +171,10 @@ int32_t gmrfx_solve_phase(gmrfx_handle *h, const double *d_B, int64_t ldb, int64
  * phase entry points (gmrfx_refactorize_phase / _solve_phase / _selinv_phase) return after enqueueing -- no host-side
  * synchronisation between a phase and the exchange behind it (their HIP-event timings are not collected then). */
 int32_t gmrfx_set_stream(gmrfx_handle *h, void *hip_stream, int32_t use_external, int32_t async_phases);
+/* Profiling aid (handles created under GMRFX_LEVEL_MARK=1): HIP-event time of every tree level of the most recent
+ * factorisation (which = 0), forward (1) or backward (2) sweep: ms[0] = the sweep tasks, ms[1 + l] = level l; *count = entries
+ * written (0 when the marks are off). gmrfx/shard.py turns them into the TIME bound of a sharding plan (plan_summary). */
+int32_t gmrfx_level_times(gmrfx_handle *h, int32_t which, double *ms, int64_t cap, int64_t *count);
 int32_t gmrfx_shard_rows(const gmrfx_handle *h, int32_t kind, int64_t *nblocks, int64_t *owner, int64_t *row0, int64_t *nrows,
                          int64_t *level);
 int32_t gmrfx_logdet_partial(gmrfx_handle *h, double *out);

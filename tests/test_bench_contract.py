@@ -44,12 +44,23 @@ def test_single_gpu_line_has_the_contract_fields():
 
 
 def test_two_rank_rehearsal_line_is_sharded_strong_scaling():
-    d = _run(["--gpus", "2", "--rehearse", "--grid", "200", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-logpdf", "--no-cfg3"])
+    d = _run(["--gpus", "2", "--rehearse", "--grid", "200", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-logpdf", "--no-cfg3",
+              "--cfg4-grid", "14"])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "replicas" in d and d["replicas"]["scaling"] == "weak"
     sh = d["sharded"]
     assert "error" not in sh and sh["check"]["info"] == 0 and sh["check"]["rel_residual"] < 1e-10
     assert abs(sh["check"]["logdet"] - d["check"]["logdet"]) < 1e-11 * abs(d["check"]["logdet"])
     assert d["value"] == sh["value"] and d["ms_per_step"] == sh["ms_per_step"]
+    # the plan carries the flop bound AND the time bounds built from one unsharded step's per-level event times
+    pl = sh["plan"]
+    assert 1.0 <= pl["time_bound_speedup_latency"] <= pl["time_bound_speedup_share"] <= 2.0 + 1e-9 and pl["flop_bound_speedup"] <= 2.0 + 1e-9
+    assert pl["measured_ms_one_gpu"] > 0 and len(pl["top_levels"]) == len(pl["top_levels_ms"]) >= 1
+    # every panel is stored on exactly one rank
+    mem = sh["per_rank_hbm_bytes"]
+    assert mem["max_factor_panels"] < 0.75 * mem["sum_factor_panels"]
+    # the additional cfg-4 line (3-D mesh, here 14^3 nodes), sharded the same way
+    c4 = d["cfg4_sharded"]
+    assert "error" not in c4 and c4["n"] == 14 ** 3 and c4["check"]["rel_residual"] < 1e-10 and c4["check"]["info"] == 0 and c4["value"] > 0
 
 
 def test_sharded_run_that_hangs_exits_non_zero_with_the_replica_line():

@@ -185,3 +185,33 @@ def test_sharded_factor_plan_and_logdet_gloo(world):
     assert abs(sharded - ref) <= 1e-10 * abs(ref)
     assert abs(sharded - dense) <= 1e-9 * abs(dense)
     assert info["n_top_fronts"] >= 1 and all(c > 0 for c in counts[1:])      # every rank owns something
+
+
+def test_plan_summary_time_bounds_from_level_times():
+    """gmrfx/shard.py plan_summary with measured per-level times (here: a synthetic profile): both time bounds lie between 1
+    and the world size, the latency form (top levels not shortened) below the share form, and with times proportional to the
+    flops of a level the share form cannot beat the flop count of the heaviest rank."""
+    import gmrfx
+    from gmrfx import shard, spde
+    mesh = spde.grid_mesh_2d(90, 90, jitter=0.25, seed=4)
+    Q = spde.matern_precision(mesh, 0, 0.2)
+    for W in (2, 4):
+        be = gmrfx.MI355XBackend(Q, coords=mesh.points, symbolic_only=True, shard_rank=0, shard_world=W)
+        sy = be.symbolic()
+        c = np.diff(sy.super_first).astype(float); m = np.diff(sy.row_ptr).astype(float) - c
+        fl = c ** 3 / 3 + c * c * m + c * m * m
+        par = np.asarray(sy.super_parent); h = np.zeros(len(c), int)
+        for s in range(len(c)):
+            if par[s] >= 0:
+                h[par[s]] = max(h[par[s]], h[s] + 1)
+        level_ms = np.concatenate([[0.0], [fl[h == l].sum() * 1e-9 for l in range(h.max() + 1)]])
+        p = shard.plan_summary(be, level_ms)
+        assert abs(p["measured_ms_one_gpu"] - level_ms.sum()) < 1e-9 * level_ms.sum()
+        assert 1.0 <= p["time_bound_speedup_latency"] <= p["time_bound_speedup_share"] <= W + 1e-9
+        owner, top = be.shard_owner(with_top=True)
+        heaviest = max(fl[owner == k].sum() for k in range(W))
+        assert p["time_bound_speedup_share"] <= fl.sum() / heaviest + 1e-9
+        assert p["top_levels"] and len(p["top_levels"]) == len(p["top_levels_ms"])
+        with pytest.raises(ValueError):
+            shard.plan_summary(be, level_ms[:3])
+        be.close()

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Flop and TIME bounds of the sharding plan at 2 / 4 / 8 ranks for cfg 2 and cfg 4, from the per-level times measured on one
+GPU (tools/level_times.py -> profiles/r03_level_ms_<cfg>.json). Host only (symbolic-only handles).
+
+    python3 tools/shard_bounds.py [cfg2|cfg4] ...   -> prints a table and one JSON object per configuration"""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "gaussianmarkovrandomfields.jl_amd"))
+import numpy as np
+import gmrfx
+from gmrfx import spde, shard
+
+
+def run(cfg):
+    if cfg == "cfg4":
+        mesh = spde.grid_mesh_3d(126, 126, 126); Q = spde.matern_precision(mesh, 0, 0.4); name = "cfg4_126cubed"
+    else:
+        mesh = spde.grid_mesh_2d(1000, 1000, jitter=0.25, seed=0); Q = spde.matern_precision(mesh, 0, 0.2); name = "cfg2_1000"
+    lv = json.load(open(os.path.join(ROOT, "profiles", f"r03_level_ms_{name}.json")))
+    res = {"workload": name, "one_gpu_ms": {"factor": sum(lv["factor"]), "fwd": sum(lv["fwd"]), "bwd": sum(lv["bwd"])}, "ranks": {}}
+    step = np.asarray(lv["factor"]) + np.asarray(lv["fwd"]) + np.asarray(lv["bwd"])
+    print(f"== {name}: one GPU factor {sum(lv['factor']):.2f} ms + sweeps {sum(lv['fwd']) + sum(lv['bwd']):.2f} ms")
+    print(" ranks  top fronts  flop bound   factor: time bound (latency .. share)   step: time bound (latency .. share)")
+    for W in (2, 4, 8):
+        be = gmrfx.MI355XBackend(Q, coords=mesh.points, symbolic_only=True, shard_rank=0, shard_world=W)
+        pf = shard.plan_summary(be, lv["factor"])
+        ps = shard.plan_summary(be, step)
+        be.close()
+        res["ranks"][W] = {"top_fronts": pf["top_fronts"], "flop_bound_speedup": pf["flop_bound_speedup"],
+                           "factor": {k: pf[k] for k in ("time_bound_speedup_latency", "time_bound_speedup_share", "time_bound_ms_latency", "time_bound_ms_share")},
+                           "step": {k: ps[k] for k in ("time_bound_speedup_latency", "time_bound_speedup_share", "time_bound_ms_latency", "time_bound_ms_share")},
+                           "top_levels": pf["top_levels"], "top_levels_ms_factor": pf["top_levels_ms"]}
+        print(f" {W:5d} {pf['top_fronts']:11d} {pf['flop_bound_speedup']:11.2f}   {pf['time_bound_speedup_latency']:8.2f} .. {pf['time_bound_speedup_share']:5.2f}"
+              f"                       {ps['time_bound_speedup_latency']:8.2f} .. {ps['time_bound_speedup_share']:5.2f}")
+    print(json.dumps(res))
+
+
+for c in (sys.argv[1:] or ["cfg2"]):
+    run(c)
