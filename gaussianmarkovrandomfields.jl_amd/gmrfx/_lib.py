@@ -73,6 +73,14 @@ def lib():
         if not os.path.exists(_LIBPATH):
             raise ImportError(f"{_LIBPATH} not found: build it with `make -C {os.path.dirname(_HERE)}` "
                               "(or __graft_entry__.build()); there is no non-HIP fallback")
+        # One HIP runtime per process: torch ships its own libamdhip64; if libgmrfx.so pulls in the system one FIRST, a later
+        # `import torch` (the *_dev entry points take torch tensors' pointers) finds no GPU. Loading torch first makes
+        # libgmrfx.so resolve against the runtime already in the process. GMRFX_NO_TORCH=1 skips this (hosts without torch).
+        if not os.environ.get("GMRFX_NO_TORCH"):
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         L = C.CDLL(_LIBPATH)
         vp, i64, i32, dbl = C.c_void_p, C.c_int64, C.c_int32, C.c_double
         L.gmrfx_last_create_error.restype = C.c_char_p

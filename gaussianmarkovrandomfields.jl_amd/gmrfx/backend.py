@@ -62,6 +62,7 @@ class MI355XBackend:
         opts.struct_size = C.sizeof(GmrfxOpts)
         opts.uplo = 0 if uplo.upper().startswith("U") else 1
         opts.device = device
+        self.device = device            # HIP device ordinal the handle was asked for (-1: the current device)
         opts.symbolic_only = int(symbolic_only)
         opts.check_posdef = int(check_posdef)
         opts.nd_leaf = nd_leaf

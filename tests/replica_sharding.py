@@ -1,4 +1,4 @@
-"""Multi-GPU driver logic (one process per GPU, torch.distributed). The GMRF path shards over
+"""TEST HELPER (moved out of the package in round 3: the product drives replicas from bench.py itself). Replica sharding over
 INDEPENDENT units -- hyper-parameter points / posterior workspaces, the reference's
 `WorkspacePool` pattern (src/workspace/workspace_pool.jl:42-119) -- so ranks exchange no data
 on the data path; the only collectives are the barrier / MAX-reduce of the timing and an

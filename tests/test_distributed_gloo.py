@@ -24,7 +24,7 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import gmrfx
     from gmrfx import spde
-    from gmrfx.parallel import run_sharded, shard_units
+    from replica_sharding import run_sharded, shard_units
     from mf_hostsim import HostSim
     mesh = spde.grid_mesh_2d(12, 12, jitter=0.2)
     Q0 = spde.matern_precision(mesh, 0, 0.4)
@@ -64,7 +64,7 @@ def test_two_rank_sharded_replicas():
 
 def test_shard_units_partition_properties():
     sys.path.insert(0, os.path.join(ROOT, "gaussianmarkovrandomfields.jl_amd"))
-    from gmrfx.parallel import shard_units
+    from replica_sharding import shard_units
     for n in (0, 1, 7, 8, 9, 64):
         for w in (1, 2, 3, 8):
             parts = [list(shard_units(n, r, w)) for r in range(w)]

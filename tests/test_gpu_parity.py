@@ -820,6 +820,32 @@ def test_kronecker_workspace_matches_dense_kron():
         kw.solve(np.zeros(n + 1))
 
 
+@pytest.mark.parametrize("dense_max", [4096, 0])
+def test_kronecker_workspace_device_path_matches_dense_kron(dense_max):
+    """KroneckerWorkspace.solve_dev / backward_solve_dev: the flat device vector is the column-major n2 x n1 panel of the
+    sweep over factor 2; the small factor is applied as a dense operator (default) or swept too (DENSE_MAX = 0: the
+    transposing fallback for two large factors). Against the dense kron, and bit-compatible with the host-panel path."""
+    import torch
+    Qt = sp.csc_matrix(spde.ar1_precision(9, 0.9))
+    Qs = sp.csc_matrix(spde.matern_precision(spde.grid_mesh_2d(11, 10, jitter=0.2, seed=1), 0, 0.5))
+    kw = gmrfx.KroneckerWorkspace(Qt, Qs)
+    kw.DENSE_MAX = dense_max
+    Q = sp.kron(Qt, Qs).toarray()
+    n = Q.shape[0]
+    rng = np.random.default_rng(3)
+    b = rng.standard_normal(n)
+    xb = kw.solve_dev(torch.from_numpy(b).cuda()).cpu().numpy()
+    assert relerr(xb, np.linalg.solve(Q, b)) < 1e-10
+    assert relerr(xb, kw.solve(b)) < 1e-12
+    z = rng.standard_normal(n)
+    assert relerr(kw.backward_solve_dev(torch.from_numpy(z).cuda()).cpu().numpy(), kw.backward_solve(z)) < 1e-12
+    Z = torch.from_numpy(np.eye(n)).cuda()
+    A = np.stack([kw.backward_solve_dev(Z[k].contiguous()).cpu().numpy() for k in range(n)], axis=1)
+    assert relerr(A @ A.T, np.linalg.inv(Q)) < 1e-9
+    with pytest.raises(ValueError):
+        kw.solve_dev(torch.zeros(n + 1, dtype=torch.float64).cuda())
+
+
 @pytest.mark.parametrize("cap", ["64", "128", "256"])
 def test_blocked_substitution_in_wide_fronts(cap, monkeypatch):
     """Fronts wider than the inverse cap (2048 columns by default; GMRFX_INV_CAP lowers it here) only hold the

@@ -24,6 +24,14 @@ print(f"logdet(Q_t (x) Q_s) = {ld:.6e}: {1e3*(t1-t0):.1f} ms", flush=True)
 z = np.random.default_rng(0).standard_normal(N)
 t0 = time.perf_counter(); x = kw.backward_solve(z); t1 = time.perf_counter()
 print(f"one sample of all {N:.3e} unknowns (host arrays in and out): {t1-t0:.2f} s; "
-      f"GPU time of the spatial sweep ({T} RHS): {kw.ws2.backend.stats()['ms_backward_solve']:.1f} ms", flush=True)
+      f"GPU time of the spatial sweep ({T} RHS): {kw.ws2.stats()['ms_backward_solve']:.1f} ms", flush=True)
+import torch
+zd = torch.from_numpy(z).cuda()
+xd = kw.backward_solve_dev(zd); torch.cuda.synchronize()           # first call: the dense operator of the small factor
+t0 = time.perf_counter(); xd = kw.backward_solve_dev(zd); torch.cuda.synchronize(); t1 = time.perf_counter()
+print(f"one sample, z and x resident in HBM (backward_solve_dev): {1e3*(t1-t0):.1f} ms wall; "
+      f"max |x_dev - x_host| / max |x| = {float((xd.cpu() - torch.from_numpy(x)).abs().max() / np.abs(x).max()):.1e}", flush=True)
+t0 = time.perf_counter(); sd = kw.solve_dev(zd); torch.cuda.synchronize(); t1 = time.perf_counter()
+print(f"one solve of all unknowns, resident (solve_dev): {1e3*(t1-t0):.1f} ms wall", flush=True)
 t0 = time.perf_counter(); v = kw.selinv_diag(); t1 = time.perf_counter()
 print(f"marginal variances: {t1-t0:.2f} s (min {v.min():.3e}, max {v.max():.3e}); sample variance / mean marginal variance = {x.var()/v.mean():.3f}")
