@@ -343,6 +343,14 @@ void Device::upload(const Symbolic &S) {
     }
     HC(hipStreamSynchronize(stream));
 
+    sel_max_cols_.assign(S.nlevels, 0);
+    sel_max_trail_.assign(S.nlevels, 0);
+    for (i32 l = 0; l < S.nlevels; l++)
+        for (i64 k = S.sel_levelptr[l] + S.sel_level_nsmall[l]; k < S.sel_levelptr[l + 1]; k++) {
+            const i32 s = S.sel_levellist[k];
+            sel_max_cols_[l] = std::max(sel_max_cols_[l], (int)S.ncols(s));
+            sel_max_trail_[l] = std::max(sel_max_trail_[l], (int)(S.nrows(s) - S.ncols(s)));
+        }
     auto build_levels = [&](std::vector<LevelInfo> &LV, const std::vector<i64> &lptr, const std::vector<i32> &llist,
                             const std::vector<i32> &lnsmall, const std::vector<i32> &lncls, bool count_flops) {
         LV.clear();
@@ -515,7 +523,9 @@ void Device::upload(const Symbolic &S) {
     ev_syrk_.resize(2 * (size_t)S.nlevels);
     for (auto &e : ev_syrk_) HC(hipEventCreate(&e));
     first_multiblock_level_ = S.nlevels;
-    for (i32 l = 0; l < S.nlevels; l++) if (levels_[l].max_cols > NB) { first_multiblock_level_ = l; break; }
+    // (over the SWEEP lists: the forward sweep waits there for the dense inverses, and a sharded handle's factor lists leave
+    //  out the distributed root, which its owner still sweeps)
+    for (i32 l = 0; l < S.nlevels; l++) if (swlevels_[l].max_cols > NB) { first_multiblock_level_ = l; break; }
 
     // INVARIANT (pair loads): the kernels that read operand rows in 16-byte pairs (sweep_task.hip, k_syrk_cb_rec, selinv.hip)
     // may read ONE double past a column's last row; for the last column of the last panel that is element l_size_ of the
@@ -778,6 +788,49 @@ void Device::refactorize_phase(const double *d_nzval, int phase) {
     }
     selinv_begun_ = false;
     if (split + phase >= nl) { factorized = true; selinv_valid = false; inverse_pending = true; }   // last phase done
+}
+
+// Distributed root (symbolic.h): block phases of the root front's factorisation, driven by gmrfx/shard.py between the
+// broadcasts. Blocks of 256 columns, block b on rank b mod world; the same kernels and the same sums in the same order as
+// the level loop uses for a front of its own (potrf64 -> trsm -> K = 64 update inside the block; K = 256 update of the
+// later blocks), so the factor equals the unsharded one bit for bit.
+void Device::dist_root_phase(const double *d_nzval, int what, int block) {
+    HC(hipSetDevice(device));
+    const i32 R = S_->dist_root;
+    if (R < 0) throw std::invalid_argument("this handle has no distributed root");
+    const int c = S_->ncols(R), r = S_->nrows(R), W = S_->shard_world, me = S_->shard_rank;
+    const int nob = (c + 255) / 256;
+    const FrontArg fa{1, (int)R, c, r, (int)S_->ld[R], (int)S_->sfirst[R], (long long)S_->panelptr[R]};
+    if (what == 0) {
+        if (!d_nzval) throw std::invalid_argument("d_nzval is null");
+        if (!d_dist_list_) {
+            d_dist_list_ = dalloc<int>(1);
+            const int v = R;
+            HC(hipMemcpyAsync(d_dist_list_, &v, sizeof(int), hipMemcpyHostToDevice, stream));
+        }
+        launch_assemble_cyclic(stream, ds_, d_dist_list_, c, d_nzval, d_L_, d_cb_, W, me);
+    } else if (what == 1) {
+        if (block < 0 || block >= nob) throw std::invalid_argument("distributed root: block out of range");
+        if (block % W != me) return;
+        const int b0 = block * OBK, b1 = std::min(b0 + OBK, (c + NB - 1) / NB);
+        for (int b = b0; b < b1; b++) {
+            const int kb = b * NB;
+            launch_potrf64(stream, ds_, nullptr, 1, kb, d_L_, d_info_, fa);
+            launch_trsm(stream, ds_, nullptr, 1, kb, 0, r - kb - 1, d_L_, nullptr, nullptr, fa);
+            if (b + 1 < b1)
+                launch_gemm_nt(stream, ds_, nullptr, 1, kb, NB, kb + NB, b1 * NB, r - kb - NB, std::min(b1 * NB, c) - kb - NB, d_L_, fa);
+        }
+    } else if (what == 2) {
+        if (block < 0 || block >= nob) throw std::invalid_argument("distributed root: block out of range");
+        const int k0 = block * 256, K = std::min(256, c - k0);
+        for (int j = block + 1; j < nob; j++) {
+            if (j % W != me) continue;
+            const int c0 = j * 256;
+            launch_gemm_nt(stream, ds_, nullptr, 1, k0, K, c0, c0 + 256, r - c0, std::min(256, c - c0), d_L_, fa);
+        }
+    } else throw std::invalid_argument("distributed root phase must be 0 (assemble), 1 (factor block) or 2 (apply block)");
+    if (!async_phases_) HC(hipStreamSynchronize(stream));
+    HC(hipGetLastError());
 }
 
 void Device::set_prior(const double *prior_nzval, const long long *map, long long cnt) {
@@ -1202,9 +1255,12 @@ void Device::selinv_levels(int hi, int lo) {
         const int nf = scount - snsmall;
         // big fronts: whole-front step through the dense inverse (selinv.hip, k_sel_dense).
         // Yt lives at d_tmp_ + yoff[s], Z21t right behind it (offset (r-c)*c): pass both bases.
-        launch_sel_gather(stream, d_selrec_, dsz, list, nf, level_max_trail(L), d_Z_, d_cb_);
+        // (geometry over the level's fronts of the SELECTED-INVERSION list: the factor's level list of a sharded handle
+        //  leaves out the distributed root, which the owner still inverts)
+        (void)L;
+        launch_sel_gather(stream, d_selrec_, dsz, list, nf, sel_max_trail_[l], d_Z_, d_cb_);
         for (int phase = 0; phase < 3; phase++)
-            launch_sel_dense(stream, dsz, list, nf, phase, L.max_cols, level_max_trail(L), d_L_, d_Z_, d_cb_, d_tmp_,
+            launch_sel_dense(stream, dsz, list, nf, phase, sel_max_cols_[l], sel_max_trail_[l], d_L_, d_Z_, d_cb_, d_tmp_,
                              d_tmp_, d_yoff_);
         // small fronts of the level (<= 128 rows, <= 64 columns: one block step)
         if (snsmall > 0) {

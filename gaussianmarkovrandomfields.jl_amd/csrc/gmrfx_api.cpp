@@ -90,6 +90,7 @@ extern "C" int32_t gmrfx_create(int64_t n, const int64_t *colptr, const int64_t 
             if (h->opts.shard_rank < 0 || h->opts.shard_rank >= h->opts.shard_world) throw std::invalid_argument("shard_rank out of range");
             so.shard_rank = h->opts.shard_rank;
             so.shard_world = h->opts.shard_world;
+            if (const char *e = std::getenv("GMRFX_DIST_ROOT_MIN")) so.dist_root_min_cols = std::atoi(e);   // columns from which the root is factored by all ranks (0: never)
             so.subtree_max = 0;     // subtree tasks are not shard-aware
         }
         analyze(n, colptr, rowval, index_base, perm, so, h->S);
@@ -235,6 +236,34 @@ extern "C" int32_t gmrfx_shard_edges(const gmrfx_handle *h, int64_t *child, int6
         if (child_level) child_level[k] = S.level[d];
     }
     return GMRFX_OK;
+}
+// Distributed root (symbolic.h: Symbolic::dist_root). info[0] = root supernode or -1, [1] = its columns, [2] = outer blocks of
+// 256 columns, [3] = world, [4] = offset of its panel in gmrfx_device_ptr(h, 1), [5] = leading dimension of the panel,
+// [6] = number of (child, block) column ranges. child / block / offset / count (nullable): the ranges -- `count` doubles at
+// `offset` of the arena (gmrfx_device_ptr(h, 0)) travel from owner[child] to rank block % world before the root is assembled.
+extern "C" int32_t gmrfx_shard_dist_root(const gmrfx_handle *h, int64_t *info, int64_t *child, int64_t *block, int64_t *offset, int64_t *count) {
+    if (!h || !info) return GMRFX_ERR_INVALID_ARG;
+    const Symbolic &S = h->S;
+    const i32 R = S.dist_root;
+    info[0] = R; info[1] = R >= 0 ? S.ncols(R) : 0; info[2] = R >= 0 ? (S.ncols(R) + 255) / 256 : 0; info[3] = S.shard_world;
+    info[4] = R >= 0 ? S.panelptr[R] : 0; info[5] = R >= 0 ? S.ld[R] : 0; info[6] = (int64_t)S.dist_cols_child.size();
+    for (size_t k = 0; k < S.dist_cols_child.size(); k++) {
+        if (child) child[k] = S.dist_cols_child[k];
+        if (block) block[k] = S.dist_cols_block[k];
+        if (offset) offset[k] = S.dist_cols_off[k];
+        if (count) count[k] = S.dist_cols_cnt[k];
+    }
+    return GMRFX_OK;
+}
+// what = 0: assemble this rank's blocks of the root panel (Q's entries + the children's column ranges received);
+// 1: factor outer block `block` (its owner only; the others return at once); 2: apply block `block` (complete on every
+// rank after its broadcast) to this rank's later blocks. Asynchronous on the handle's main stream when async phases are on.
+extern "C" int32_t gmrfx_dist_root_phase(gmrfx_handle *h, const double *d_nzval, int32_t what, int32_t block) {
+    return guarded(h, [&]() -> int32_t {
+        if (int32_t e = need_device(h, false)) return e;
+        h->D->dist_root_phase(d_nzval, what, block);
+        return GMRFX_OK;
+    });
 }
 extern "C" int32_t gmrfx_shard_owner(const gmrfx_handle *h, int64_t *owner, int64_t *is_top) {
     if (!h || !owner) return GMRFX_ERR_INVALID_ARG;

@@ -390,6 +390,8 @@ void launch_bwd_gemm(hipStream_t st, const DevSym &S, const int *list, int nfron
 void launch_fwd_own_update(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, const double *L,
                            const double *Y, double *X, int nr, int ldx, int blk, int cap);
 // iperm: position of original row i in the elimination order (nullptr: identity)
+void launch_assemble_cyclic(hipStream_t st, const DevSym &S, const int *list, int ncols, const double *nzval, double *L, double *CB,
+                            int cyc_w, int cyc_r);
 void launch_level_mark(hipStream_t st, int phase, int level);   // phase 1 = forward sweep, 2 = backward sweep, 3 = factorisation
 void launch_permute(hipStream_t st, const int *iperm, int n, double *Bc, long long ldb, double *X, int nr, int ldx, int dir);
 void launch_newton_update(hipStream_t st, const double *prior, double *nz, long long nnz, const long long *map, const double *h,

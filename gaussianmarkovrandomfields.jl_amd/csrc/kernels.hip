@@ -62,7 +62,7 @@ __device__ __forceinline__ void wave_lower_bound2(const int *__restrict__ a, con
 template <int WIDE>   // 0: one WAVE per column; 1: one WORKGROUP per column (levels with a few tall fronts)
 __global__ __launch_bounds__(256) void k_assemble(DevSym S, const int *__restrict__ list,
                                                   const double *__restrict__ nzval, double *__restrict__ L,
-                                                  double *__restrict__ CB) {
+                                                  double *__restrict__ CB, int cyc_w, int cyc_r) {
     // PANEL part of the front only (front-local columns < c). The contribution-block part is
     // assembled inside k_syrk_cb (children gathered into an LDS tile, CB written exactly once).
     // WIDE: a column of a top-of-tree front has thousands of rows and the level only has a handful
@@ -75,6 +75,8 @@ __global__ __launch_bounds__(256) void k_assemble(DevSym S, const int *__restric
     const int tl = WIDE ? (int)threadIdx.x : lane;
     const int tc = WIDE ? (int)blockIdx.x : blockIdx.x * ASM_CW + __builtin_amdgcn_readfirstlane(wave);
     if (tc >= c) return;
+    // distributed root (cyc_w > 0): this rank assembles the 256-column blocks it owns, block b on rank b mod cyc_w
+    if (cyc_w > 0 && (tc >> 8) % cyc_w != cyc_r) return;
     const int ld = S.ld[s];
     double *Pc = L + S.panelptr[s] + (long long)tc * ld;
     for (int i = 2 * tl; i < ld; i += 2 * NL) *(d2u *)(Pc + i) = (d2u){0.0, 0.0};      // ld is even
@@ -1356,9 +1358,14 @@ void launch_assemble(hipStream_t st, const DevSym &S, const int *list, int nfron
         return;
     }
     if ((long long)cdiv(max_cols, ASM_CW) * nfronts <= 2200)
-        hipLaunchKernelGGL(k_assemble<1>, dim3(odd(max_cols), nfronts), dim3(256), 0, st, S, list, nzval, L, CB);
+        hipLaunchKernelGGL(k_assemble<1>, dim3(odd(max_cols), nfronts), dim3(256), 0, st, S, list, nzval, L, CB, 0, 0);
     else
-        hipLaunchKernelGGL(k_assemble<0>, dim3(odd(cdiv(max_cols, ASM_CW)), nfronts), dim3(256), 0, st, S, list, nzval, L, CB);
+        hipLaunchKernelGGL(k_assemble<0>, dim3(odd(cdiv(max_cols, ASM_CW)), nfronts), dim3(256), 0, st, S, list, nzval, L, CB, 0, 0);
+}
+// the distributed root: one front, only the 256-column blocks b with b mod cyc_w == cyc_r (one workgroup per column)
+void launch_assemble_cyclic(hipStream_t st, const DevSym &S, const int *list, int ncols, const double *nzval, double *L, double *CB,
+                            int cyc_w, int cyc_r) {
+    hipLaunchKernelGGL(k_assemble<1>, dim3(odd(ncols), 1), dim3(256), 0, st, S, list, nzval, L, CB, cyc_w, cyc_r);
 }
 void launch_syrk_cb(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_trail, const double *L, double *CB) {
     if (nfronts <= 0 || max_trail <= 0) return;

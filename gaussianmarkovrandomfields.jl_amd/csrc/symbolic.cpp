@@ -480,7 +480,17 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
         for (i32 s = 0; s < ns; s++) S.nlevels = std::max(S.nlevels, S.level[s] + 1);
         S.nlevels = std::max(S.nlevels, S.shard_level);
     }
-    // does this rank execute front s?
+    // distributed root (symbolic.h): the tree's root, alone on the last level, wide enough, without trailing rows
+    S.dist_root = -1;
+    if (S.shard_world > 1) {
+        const int min_cols = opt.dist_root_min_cols >= 0 ? opt.dist_root_min_cols : 4096;
+        i32 nroots = 0, root = -1;
+        for (i32 s = 0; s < ns; s++) if (S.sparent[s] == -1) { nroots++; root = s; }
+        if (min_cols > 0 && nroots == 1 && S.is_top[root] && S.ncols(root) >= min_cols && S.nrows(root) == S.ncols(root) &&
+            S.level[root] == S.nlevels - 1 && !(opt.subtree_max > 0))
+            S.dist_root = root;
+    }
+    // does this rank execute front s?  (the distributed root: owner[root] runs its sweeps / selected inversion)
     auto mine = [&](i32 s) { return S.shard_world == 1 || S.owner[s] == S.shard_rank; };
 
     // ---- per-rank storage of a sharded factorisation (round 3) ---------------------------------------------------------
@@ -492,16 +502,18 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
     // into the SAME offset on both ends, and no rank needs to know another rank's private layout.
     S.cross_child.assign(ns, 0);
     for (i32 d : S.shard_edges) S.cross_child[d] = 1;
+    if (S.dist_root >= 0)       // every rank assembles its own blocks of the root from (column ranges of) every child's block
+        for (i64 q = S.childptr[S.dist_root]; q < S.childptr[S.dist_root + 1]; q++) S.cross_child[S.children[q]] = 1;
     if (S.shard_world > 1) {
         i64 off = 0;
         for (i32 s = 0; s < ns; s++) {
             S.panelptr[s] = off;
-            if (mine(s)) { off += (i64)S.ld[s] * S.ncols(s); off = (off + 15) & ~i64(15); }
+            if (mine(s) || s == S.dist_root) { off += (i64)S.ld[s] * S.ncols(s); off = (off + 15) & ~i64(15); }
         }
         S.panelptr[ns] = off;
         for (i32 s = 0; s < ns; s++)
             for (i32 j = 0; j < S.ncols(s); j++)
-                S.diagoff[S.sfirst[s] + j] = mine(s) ? S.panelptr[s] + (i64)j * S.ld[s] + j : off;
+                S.diagoff[S.sfirst[s] + j] = mine(s) ? S.panelptr[s] + (i64)j * S.ld[s] + j : off;      // (the root's diagonal counts on owner[root])
     }
     S.wptr.assign(ns + 1, 0);
     {
@@ -557,11 +569,12 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
         }
     }
     S.levelptr.assign(S.nlevels + 1, 0);
-    for (i32 s = 0; s < ns; s++) if (!S.in_subtree[s] && mine(s)) S.levelptr[S.level[s] + 1]++;
+    // (the distributed root is factored by the block phases of Device::dist_root_phase, not by the level loop)
+    for (i32 s = 0; s < ns; s++) if (!S.in_subtree[s] && mine(s) && s != S.dist_root) S.levelptr[S.level[s] + 1]++;
     for (i32 l = 0; l < S.nlevels; l++) S.levelptr[l + 1] += S.levelptr[l];
     S.levellist.resize(S.levelptr[S.nlevels]);
     { std::vector<i64> w(S.levelptr.begin(), S.levelptr.end() - 1);
-      for (i32 s = 0; s < ns; s++) if (!S.in_subtree[s] && mine(s)) S.levellist[w[S.level[s]]++] = s; }
+      for (i32 s = 0; s < ns; s++) if (!S.in_subtree[s] && mine(s) && s != S.dist_root) S.levellist[w[S.level[s]]++] = s; }
     S.level_nsmall.assign(S.nlevels, 0);
     S.level_ncls.assign((size_t)S.nlevels * 4, 0);
     for (i32 l = 0; l < S.nlevels; l++) {
@@ -757,6 +770,26 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
             }
         }
         S.cb_arena = std::max<i64>(peak, 16);
+    }
+
+    // ---- distributed root: which columns of which child's contribution block go to which outer block ----------------
+    S.dist_cols_child.clear(); S.dist_cols_block.clear(); S.dist_cols_off.clear(); S.dist_cols_cnt.clear();
+    if (S.dist_root >= 0) {
+        const i32 R = S.dist_root;
+        for (i64 q = S.childptr[R]; q < S.childptr[R + 1]; q++) {
+            const i32 d = S.children[q];
+            const i32 cd = S.ncols(d), md = S.nrows(d) - cd;
+            const i32 *rel = S.rel.data() + S.rowptr[d] + cd;        // position of the child's trailing rows in the root = root column
+            i32 k = 0;
+            while (k < md) {
+                const i32 b = rel[k] / 256;
+                i32 k1 = k;
+                while (k1 < md && rel[k1] / 256 == b) k1++;
+                S.dist_cols_child.push_back(d); S.dist_cols_block.push_back(b);
+                S.dist_cols_off.push_back(S.cbptr[d] + (i64)k * md); S.dist_cols_cnt.push_back((i64)(k1 - k) * md);
+                k = k1;
+            }
+        }
     }
 
     // ---- Q scatter map -------------------------------------------------------------------

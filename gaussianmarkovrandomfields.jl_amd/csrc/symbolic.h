@@ -25,6 +25,8 @@ struct SymOptions {
     int sweep_task_rows = -1;  // LDS rows of a sweep task's local vector (Symbolic::swt_*); -1 = default, 0 = no sweep tasks
     // multi-GPU sharding of ONE factorisation along the supernodal tree (see Symbolic::owner)
     int shard_rank = 0, shard_world = 1;
+    int dist_root_min_cols = -1;   // sharded handles: the ROOT front is factored by all ranks together when it has at least this many
+                                   // columns (Symbolic::dist_root); -1 = default (4096), 0 = never
 };
 
 // Symmetric adjacency structure without self loops.
@@ -104,6 +106,17 @@ struct Symbolic {
     std::vector<uint8_t> is_top;  // nsuper
     i32 shard_rank = 0, shard_world = 1, shard_level = 0;   // shard_level = nlevels when world == 1
     std::vector<i32> shard_edges; // children d with owner[d] != owner[parent(d)], ordered by (level of the parent, d)
+    // DISTRIBUTED ROOT (round 3): the root front of a 3-D problem holds a fifth of all flops (cfg 4: 47 628 columns, 18 % of
+    // 2e14) and sat on one rank. When dist_root >= 0 its panel is factored by ALL ranks: 256-column outer blocks are dealt
+    // cyclically (block b belongs to rank b mod world), the owner of a block factors its block column (the usual potrf64 /
+    // trsm / gemm chain inside the block), broadcasts it, and every rank applies it to its OWN later blocks (K = 256 update).
+    // Every rank stores the whole root panel (replicated storage, distributed flops); the children's contribution blocks
+    // reach the ranks by COLUMN RANGES (dist_cols_*: the columns of child d that fall into root block b go to the owner of
+    // b, into the same arena offset on both ends). Sweeps and selected inversion of the root stay on owner[root], which
+    // holds the complete factor after the last broadcast. Driver: gmrfx/shard.py.
+    i32 dist_root = -1;
+    std::vector<i32> dist_cols_child, dist_cols_block;     // one entry per (child of the root, outer block) with columns
+    std::vector<i64> dist_cols_off, dist_cols_cnt;         // offset (doubles, in the arena) / count of that column range
     std::vector<i32> shard_sub_root, shard_sub_col0;   // ALL assigned subtrees: root supernode, first column (columns [col0, sfirst[root+1]) are theirs)
     // the caller's pattern (0-based) and which stored triangle defines Q: kept for the quadratic form
     // x'Qx (sqmahal / logpdf), which runs on the caller's CSC values, not on the factor

@@ -411,6 +411,21 @@ class MI355XBackend:
             check(lib().gmrfx_shard_rows(self._h, kind, C.byref(k), ptr(owner), ptr(r0), ptr(nr), ptr(lv)), self._h)
         return owner, r0, nr, lv
 
+    def shard_dist_root(self) -> dict:
+        """The distributed root of a sharded handle (csrc/symbolic.h: Symbolic::dist_root): root supernode (-1: none), its
+        columns / 256-column blocks, the panel's place in device_ptr(1), and the (child, block) column ranges of the children's
+        contribution blocks (offset / count in device_ptr(0)) that travel owner[child] -> rank block % world."""
+        info = np.zeros(8, np.int64)
+        check(lib().gmrfx_shard_dist_root(self._h, ptr(info), None, None, None, None))
+        k = int(info[6])
+        a = {nm: np.empty(k, np.int64) for nm in ("child", "block", "offset", "count")}
+        check(lib().gmrfx_shard_dist_root(self._h, ptr(info), *[ptr(a[nm]) for nm in ("child", "block", "offset", "count")]))
+        return {"root": int(info[0]), "cols": int(info[1]), "blocks": int(info[2]), "world": int(info[3]), "panel_offset": int(info[4]),
+                "panel_ld": int(info[5]), **a}
+
+    def dist_root_phase(self, d_nzval_ptr: int, what: int, block: int = 0) -> None:
+        check(lib().gmrfx_dist_root_phase(self._h, d_nzval_ptr, what, block), self._h)
+
     def set_stream(self, hip_stream: int, use_external: bool = True, async_phases: bool = False) -> None:
         """The caller's HIP stream becomes the handle's main stream (sharded drivers: torch's current stream)."""
         check(lib().gmrfx_set_stream(self._h, C.c_void_p(int(hip_stream)), int(use_external), int(async_phases)), self._h)

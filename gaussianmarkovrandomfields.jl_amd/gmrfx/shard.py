@@ -62,6 +62,17 @@ class ShardedFactor:
         self._top_blocks = [[(int(owner[i]), int(r0[i]), int(nr[i])) for i in np.flatnonzero(lv == self.L0 + k)] for k in range(self.K)]
         so, sr0, snr, _ = self.sub_rows
         self._sub_blocks = [(int(so[i]), int(sr0[i]), int(snr[i])) for i in range(len(so))]
+        # distributed root (csrc/symbolic.h): the last top level holds the root alone and is factored by all ranks together
+        self.dr = self.be.shard_dist_root()
+        if self.dr["root"] >= 0:
+            owner = self.be.shard_owner()
+            dr, W = self.dr, self.world
+            root_kids = set(int(d) for d in dr["child"])
+            # whole contribution blocks into the root are replaced by their column ranges (each range to the owner of its block)
+            self._cb_items[self.K - 1] = [it for it, i in zip(self._cb_items[self.K - 1], np.flatnonzero(e["level"] == self.L0 + self.K - 1))
+                                          if int(e["child"][i]) not in root_kids]
+            self._dr_items = [(int(owner[dr["child"][k]]), int(dr["block"][k]) % W, 0, int(dr["offset"][k]), int(dr["count"][k]))
+                              for k in range(len(dr["child"]))]
 
     # ---- transfers ----------------------------------------------------------------------------------
     def _view(self, which: int, off: int, cnt: int):
@@ -120,6 +131,8 @@ class ShardedFactor:
         be.refactorize_phase_dev(d_nzval_ptr, 0)
         for k in range(self.K):
             self._p2p(self._cb_items[k])
+            if k == self.K - 1 and self.dr["root"] >= 0:
+                self._factor_distributed_root(d_nzval_ptr)
             be.refactorize_phase_dev(d_nzval_ptr, 1 + k)
         # first non-positive pivot over all ranks (0 = none), like the `info` of gmrfx_refactorize
         t = self.torch
@@ -128,6 +141,28 @@ class ShardedFactor:
         self.dist.all_reduce(v, op=self.dist.ReduceOp.MIN)
         self.last_info = 0 if int(v.item()) >= 2 ** 62 else int(v.item()) + 1
         return self.last_info
+
+    def _factor_distributed_root(self, d_nzval_ptr: int) -> None:
+        """The root front, factored by all ranks: 256-column blocks dealt cyclically; per block: its owner factors the block
+        column, broadcasts it (whole columns, one contiguous piece of the panel every rank stores), everybody updates its own
+        later blocks. The children's contribution blocks arrive as column ranges at the owners of the blocks they fall into."""
+        be, dr, W = self.be, self.dr, self.world
+        self._p2p(self._dr_items)
+        be.dist_root_phase(d_nzval_ptr, 0)                          # assemble my blocks
+        ld, c = dr["panel_ld"], dr["cols"]
+        for b in range(dr["blocks"]):
+            be.dist_root_phase(d_nzval_ptr, 1, b)                   # its owner factors block b
+            w = min(256, c - 256 * b)
+            v = self._view(1, dr["panel_offset"] + 256 * b * ld, w * ld)
+            if self.host_staging:
+                buf = v.cpu()
+                self.dist.broadcast(buf, src=b % W)
+                if self.rank != b % W:
+                    v.copy_(buf)
+            else:
+                self.dist.broadcast(v, src=b % W)
+            if b + 1 < dr["blocks"]:
+                be.dist_root_phase(d_nzval_ptr, 2, b)               # apply it to my later blocks
 
     # ---- solve --------------------------------------------------------------------------------------
     def solve_dev(self, d_B: int, ldb: int, nrhs: int, d_X: int, ldx: int) -> None:
