@@ -785,7 +785,7 @@ extern "C" int32_t gmrfx_symbolic_get(const gmrfx_handle *h, int64_t *super_firs
         // have no destination here (-1)
         if (S.shard_world > 1)
             for (i32 s = 0; s < ns; s++)
-                if (S.owner[s] != S.shard_rank)
+                if (S.owner[s] != S.shard_rank && s != S.dist_root)      // (every rank stores the distributed root's panel)
                     for (i64 k = S.qptr[s]; k < S.qptr[s + 1]; k++) q_dst[k] = -1;
     }
     return GMRFX_OK;

@@ -249,7 +249,12 @@ def plan_summary(be, level_ms=None) -> dict:
     latency-bound chains at the top of the tree (potrf64 -> trsm -> gemm per 64 columns) that sharding does not shorten:
       time_bound_speedup_latency : every level that holds a top front still costs its full measured time;
       time_bound_speedup_share   : the top fronts too only cost the heaviest rank's flop share of their level.
-    The truth lies between the two; the exchanges are not in either."""
+    The truth lies between the two; the exchanges are not in either.
+
+    A DISTRIBUTED ROOT (Symbolic::dist_root: factored by all ranks, 256-column blocks dealt cyclically) enters with its flops
+    divided by the world size; its time additionally keeps what does not shrink: the diagonal chain (CHAIN_MS_PER_64 per
+    64-column step, measured at cfg 2) and the block-column broadcasts (the whole lower triangle once per rank at
+    BCAST_GBS, a conservative per-link xGMI figure)."""
     owner, top = be.shard_owner(with_top=True)
     sy = be.symbolic()
     c = np.diff(sy.super_first).astype(np.float64)
@@ -263,8 +268,13 @@ def plan_summary(be, level_ms=None) -> dict:
         sel = top & (sy.level == lv)
         t_top += max(float(fl[sel & (owner == k)].sum()) for k in range(W))
     total = float(fl.sum())
+    dr = be.shard_dist_root()
+    R = dr["root"]
+    if R >= 0:                                      # the root's level holds the root alone: its flops are shared by all ranks
+        t_top -= float(fl[R]) * (1.0 - 1.0 / W)
     out = {"world": W, "top_fronts": int(top.sum()), "top_flops": float(fl[top].sum()), "local_flops": local,
-           "top_critical_flops": t_top, "flop_bound_speedup": total / (max(local) + t_top)}
+           "top_critical_flops": t_top, "flop_bound_speedup": total / (max(local) + t_top),
+           "distributed_root": None if R < 0 else {"supernode": R, "cols": dr["cols"], "blocks": dr["blocks"], "flops": float(fl[R])}}
     if level_ms is not None:
         # levels of the UNSHARDED schedule: height above the leaves (a sharded handle re-levels its top fronts)
         ns = len(c)
@@ -285,6 +295,12 @@ def plan_summary(be, level_ms=None) -> dict:
         top_levels = np.unique(h[top])
         t_latency = float(sum(t_level[l] for l in top_levels))
         t_share = float(sum(max(per_front[top & (h == l) & (owner == k)].sum() for k in range(W)) for l in top_levels))
+        if R >= 0:
+            CHAIN_MS_PER_64, BCAST_GBS = 0.03, 100.0
+            t_root = float(per_front[R])
+            fixed = CHAIN_MS_PER_64 * dr["cols"] / 64.0 + 8.0 * dr["cols"] ** 2 / 2.0 / (BCAST_GBS * 1e6)
+            t_latency += -t_root + min(t_root, t_root / W + fixed)
+            t_share += -t_root + t_root / W
         # (the non-top fronts of a level that also holds top fronts are already in t_local with their share)
         t1 = float(t_level.sum())
         out.update({"measured_ms_one_gpu": t1, "time_bound_ms_latency": t_local + t_latency, "time_bound_ms_share": t_local + t_share,

@@ -215,3 +215,139 @@ def test_plan_summary_time_bounds_from_level_times():
         with pytest.raises(ValueError):
             shard.plan_summary(be, level_ms[:3])
         be.close()
+
+
+def _dist_root_worker(rank, world, port, q):
+    """Host walk (numpy) of the DISTRIBUTED ROOT protocol on the structures the library exports (gmrfx_shard_dist_root):
+    column ranges of the children's contribution blocks to the owners of the 256-column blocks, assembly of the own blocks,
+    per block: owner factors its block column, broadcast, everybody updates its own later blocks."""
+    for p in (os.path.join(ROOT, "gaussianmarkovrandomfields.jl_amd"), os.path.join(ROOT, "oracle"), HERE):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["GMRFX_DIST_ROOT_MIN"] = "512"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import scipy.sparse as sp
+    import gmrfx
+    from mf_hostsim import HostSim
+    # two independent 9 x 9 grid Laplacians, both coupled to one dense 700-column block ordered last (natural ordering):
+    # the dense block is the root front (3 outer blocks of 256 columns), the two grids are its two child subtrees
+    g = 9
+    A1 = sp.diags([-np.ones(g - 1), 2.0 * np.ones(g), -np.ones(g - 1)], [-1, 0, 1])
+    G = sp.kron(sp.identity(g), A1) + sp.kron(A1, sp.identity(g)) + 0.5 * sp.identity(g * g)
+    nd = 700
+    rng = np.random.default_rng(11)
+    Dm = rng.standard_normal((nd, nd)); Dm = Dm @ Dm.T / nd + 5.0 * np.eye(nd)
+    H1 = sp.random(g * g, nd, density=0.05, random_state=1) * 0.1
+    H2 = sp.random(g * g, nd, density=0.05, random_state=2) * 0.1
+    Q = sp.bmat([[G, None, H1], [None, G, H2], [H1.T, H2.T, sp.csr_matrix(Dm)]], format="csc")
+    Q.sort_indices()
+    n = Q.shape[0]
+    be = gmrfx.MI355XBackend(Q, ordering=np.arange(n), symbolic_only=True, shard_rank=rank, shard_world=world)
+    sy = be.symbolic()
+    owner, is_top = be.shard_owner(with_top=True)
+    info, E, dr = be.shard_info(), be.shard_edges(), be.shard_dist_root()
+    L0, K = info["shard_level"], info["n_top_levels"]
+    R = dr["root"]
+    assert R >= 0 and dr["cols"] >= nd and dr["blocks"] == (dr["cols"] + 255) // 256 >= 3 and dr["world"] == world   # (amalgamation may add grid columns)
+    sim = HostSim(sy, n, np.asarray(Q.data))
+    ns = sim.ns
+    assert sy.super_parent[R] == -1 and sy.level[R] == L0 + K - 1 and (sy.level == sy.level[R]).sum() == 1
+    mine = lambda s: owner[s] == rank
+    cb = {}
+
+    def factor_front(s):
+        c, r = sim.c[s], sim.r[s]
+        F = np.zeros((r, r)); P = sim.panel(sim.L, s); F[:, :c] = P
+        for d in sim.children[s]:
+            rel = sim.rel(d)
+            F[np.ix_(rel, rel)] += cb.pop(d)
+        F = np.tril(F); F = F + np.tril(F, -1).T
+        L11 = np.linalg.cholesky(F[:c, :c]); L21 = np.linalg.solve(L11, F[c:, :c].T).T
+        P[:c, :] = np.tril(L11); P[c:, :] = L21
+        cb[s] = F[c:, c:] - L21 @ L21.T
+
+    root_kids = set(int(d) for d in dr["child"])
+    assert root_kids == set(sim.children[R])
+    for lev in range(int(sy.level.max()) + 1):
+        for i in np.flatnonzero(E["level"] == lev):                     # whole blocks along the other cross edges
+            d, src, dst = int(E["child"][i]), int(E["src"][i]), int(E["dst"][i])
+            if d in root_kids:
+                continue
+            m = int(sim.r[d] - sim.c[d])
+            if rank == src:
+                dist.send(torch.from_numpy(np.ascontiguousarray(cb.pop(d))), dst=dst, tag=i)
+            elif rank == dst:
+                buf = torch.empty((m, m), dtype=torch.float64); dist.recv(buf, src=src, tag=i); cb[d] = buf.numpy()
+        for s in sim.order:
+            if sy.level[s] == lev and mine(s) and s != R:
+                factor_front(s)
+    # ---- the distributed root ---------------------------------------------------------------------------------
+    c = int(sim.c[R]); P = sim.panel(sim.L, R)
+    assert P.shape == (c, c)
+    parts = {}                      # (child, block) -> (k0, columns of the child's block)
+    seen = {d: 0 for d in root_kids}
+    for k in range(len(dr["child"])):
+        d, b, cnt = int(dr["child"][k]), int(dr["block"][k]), int(dr["count"][k])
+        md = int(sim.r[d] - sim.c[d]); k0 = seen[d]; w = cnt // md
+        assert cnt == w * md and (sim.rel(d)[k0:k0 + w] // 256 == b).all()
+        seen[d] += w
+        src, dst = int(owner[d]), b % world
+        if src == dst:
+            if rank == src:
+                parts[(d, b)] = (k0, cb[d][:, k0:k0 + w].copy())
+        elif rank == src:
+            dist.send(torch.from_numpy(np.ascontiguousarray(cb[d][:, k0:k0 + w])), dst=dst, tag=5000 + k)
+        elif rank == dst:
+            buf = torch.empty((md, w), dtype=torch.float64); dist.recv(buf, src=src, tag=5000 + k)
+            parts[(d, b)] = (k0, buf.numpy())
+    for d in root_kids:
+        assert seen[d] == sim.r[d] - sim.c[d]                             # every column of every child exactly once
+    for (d, b), (k0, cols) in parts.items():                              # assemble my blocks (lower triangle)
+        rel = sim.rel(d)
+        for jj in range(cols.shape[1]):
+            kk = k0 + jj
+            P[rel[kk:], rel[kk]] += cols[kk:, jj]
+    nb = dr["blocks"]
+    for b in range(nb):
+        lo, hi = 256 * b, min(256 * b + 256, c)
+        if b % world == rank:
+            A = np.tril(P[lo:hi, lo:hi]); A = A + np.tril(A, -1).T
+            Lbb = np.linalg.cholesky(A)
+            P[lo:hi, lo:hi] = Lbb
+            P[hi:, lo:hi] = np.linalg.solve(Lbb, P[hi:, lo:hi].T).T
+        buf = torch.from_numpy(np.ascontiguousarray(P[:, lo:hi]))
+        dist.broadcast(buf, src=b % world)
+        P[:, lo:hi] = buf.numpy()
+        for j in range(b + 1, nb):
+            if j % world == rank:
+                jl, jh = 256 * j, min(256 * j + 256, c)
+                P[jl:, jl:jh] -= P[jl:, lo:hi] @ P[jl:jh, lo:hi].T
+    # every rank now holds the whole root factor: against dense LAPACK on the permuted matrix
+    perm = be.ordering_permutation()
+    Lref = np.linalg.cholesky(Q.toarray()[np.ix_(perm, perm)])
+    first = int(sy.super_first[R])
+    err = float(np.abs(np.tril(P) - Lref[first:first + c, first:first + c]).max())
+    part = 2.0 * sum(np.log(np.diag(sim.panel(sim.L, s)[:sim.c[s]])).sum() for s in range(ns) if mine(s))
+    t = torch.tensor([part], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    q.put((rank, err, float(t.item()), float(2.0 * np.log(np.diag(Lref)).sum()), int(owner[R])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_distributed_root_front_host_walk_gloo(world):
+    """the distributed dense root front on the host walk (numpy blocks, gloo) against dense LAPACK --
+    the column-range lists and block ownership the library exports drive the exchange; every rank ends with the whole root
+    factor, equal to the dense Cholesky factor's block, and the all-reduced log-determinant is the dense one."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dist_root_worker, args=(r, world, 29850 + world, q)) for r in range(world)]
+    [p.start() for p in procs]
+    got = [q.get(timeout=240) for _ in range(world)]
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    for rank, err, ld, ld_ref, root_owner in got:
+        assert err < 1e-10, (rank, err)
+        assert abs(ld - ld_ref) < 1e-10 * abs(ld_ref)
