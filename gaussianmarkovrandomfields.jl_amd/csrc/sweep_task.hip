@@ -85,7 +85,7 @@ __device__ __forceinline__ double tinv_elem(const double *__restrict__ P, int ld
 // Loads the geometry of the task's fronts into LDS (one round trip for the whole task instead of one per front) and
 // touches the task's panels and local-row lists, which are contiguous in HBM (postorder), so that the per-front
 // operand loads hit L2.
-template <int NC> __device__ __forceinline__ double task_prologue(const DevSym &S, const SweepTask &T, TaskMeta *meta, const double *__restrict__ L, int dbg) {
+template <int NC> __device__ __forceinline__ double task_prologue(const DevSym &S, const SweepTask &T, TaskMeta *meta, const double *__restrict__ L) {
     constexpr int TASK_THREADS = NC * 16;
     const int tid = threadIdx.x;
     const int nf = T.s1 - T.s0 + 1;
@@ -104,7 +104,6 @@ template <int NC> __device__ __forceinline__ double task_prologue(const DevSym &
     // L2 warm-up: one load per 128-byte line, summed into a value that is never used for arithmetic (returned and
     // stored only under a condition that cannot hold)
     double sink = 0.0;
-    if (dbg & 2) return sink;          // (timing experiment: no warm-up pass)
     for (long long q = T.p0 + (long long)tid * 16; q < T.p1; q += TASK_THREADS * 16) sink += L[q];
     int isink = 0;
     for (long long q = T.rp0 + (long long)tid * 32; q < T.rp1; q += TASK_THREADS * 32) isink += S.lrow[q];
@@ -136,7 +135,7 @@ template <int NC> __device__ __forceinline__ void scatter_sub(double *V, const i
 // ------------------------------------------------------------------------------------------------------------
 template <int NC> __global__ __launch_bounds__(NC * 16) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_fwd_task(DevSym S, const SweepTask *__restrict__ tasks, int ntasks, const double *__restrict__ L, double *__restrict__ X,
-                double *__restrict__ W, int nr_all, int ldx, int dbg) {
+                double *__restrict__ W, int nr_all, int ldx) {
     __shared__ double V[TASK_ROWS * NC];
     __shared__ TaskMeta meta[TASK_MAXF];
     int tsk, cbase;
@@ -149,7 +148,7 @@ void k_fwd_task(DevSym S, const SweepTask *__restrict__ tasks, int ntasks, const
     const int j = tid % NC, g = tid / NC;               // g: TASK_GROUPS row groups
     const int jc = min(j, nr - 1);
     const double jm = j < nr ? 1.0 : 0.0;
-    const double sink = task_prologue<NC>(S, T, meta, L, dbg);
+    const double sink = task_prologue<NC>(S, T, meta, L);
     // the subtree's slice of X: NT contiguous rows, four row loads in flight per thread
     for (int i0 = g; i0 < NT; i0 += 4 * TASK_GROUPS) {
         double v[4];
@@ -178,11 +177,6 @@ void k_fwd_task(DevSym S, const SweepTask *__restrict__ tasks, int ntasks, const
         const int ntile = (m.r - m.c + 15) >> 4;
         const bool narrow = m.c <= 16;
         if (!(w == 0 || w < ntile || (!narrow && w * 16 < m.c))) return;      // this slot has no work in front f (scalar branch)
-        if (dbg & 4) {       // (timing experiment: no operand loads)
-#pragma unroll
-            for (int u = 0; u < 4; u++) { xo[u] = 0.001 * lm; xt[u] = 0.002 * lk; xl[u] = lk + 4 * u; }
-            return;
-        }
         const double *P = L + m.pp;
         const int *lr = S.lrow + m.rp;
         const int i0 = m.c + w * 16;
@@ -326,7 +320,7 @@ void k_fwd_task(DevSym S, const SweepTask *__restrict__ tasks, int ntasks, const
         }
         __syncthreads();
     };
-    if (!(dbg & 1)) {
+    {
         int f = 0;
         for (; f + 1 < nf; f += 2) {
             front(f, opA_o, opA_t, opA_l, opB_o, opB_t, opB_l);
@@ -348,7 +342,7 @@ void k_fwd_task(DevSym S, const SweepTask *__restrict__ tasks, int ntasks, const
 // ------------------------------------------------------------------------------------------------------------
 template <int NC> __global__ __launch_bounds__(NC * 16) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_bwd_task(DevSym S, const SweepTask *__restrict__ tasks, int ntasks, const double *__restrict__ L, double *__restrict__ X,
-                int nr_all, int ldx, int dbg) {
+                int nr_all, int ldx) {
     __shared__ double V[TASK_ROWS * NC];
     __shared__ TaskMeta meta[TASK_MAXF];
     int tsk, cbase;
@@ -361,7 +355,7 @@ void k_bwd_task(DevSym S, const SweepTask *__restrict__ tasks, int ntasks, const
     const int j = tid % NC, g = tid / NC;
     const int jc = min(j, nr - 1);
     const double jm = j < nr ? 1.0 : 0.0;
-    const double sink = task_prologue<NC>(S, T, meta, L, dbg);
+    const double sink = task_prologue<NC>(S, T, meta, L);
     for (int i0 = g; i0 < NT; i0 += 4 * TASK_GROUPS) {
         double v[4];
 #pragma unroll
@@ -397,13 +391,6 @@ void k_bwd_task(DevSym S, const SweepTask *__restrict__ tasks, int ntasks, const
     auto request = [&](int f, double (&x1)[8], int (&xl)[8], double (&xd)[4]) {
         const TaskMeta m = uniform_meta(meta, f);
         if (k0 >= m.c) return;                                             // this slot has no work in front f (scalar branch)
-        if (dbg & 4) {       // (timing experiment: no operand loads)
-#pragma unroll
-            for (int u = 0; u < 8; u++) { x1[u] = 0.001 * lm; xl[u] = u; }
-#pragma unroll
-            for (int u = 0; u < 4; u++) xd[u] = 0.002 * lk;
-            return;
-        }
         const double *P = L + m.pp;
         const int *lr = S.lrow + m.rp;
         const double *pa = P + (long long)min(k0 + lm, m.c - 1) * m.ld;
@@ -523,7 +510,7 @@ void k_bwd_task(DevSym S, const SweepTask *__restrict__ tasks, int ntasks, const
         }
         __syncthreads();
     };
-    if (!(dbg & 1)) {
+    {
         int f = nf - 1;
         for (; f >= 1; f -= 2) {
             front(f, opA_1, opA_l, opA_d, opB_1, opB_l, opB_d);
@@ -536,10 +523,6 @@ void k_bwd_task(DevSym S, const SweepTask *__restrict__ tasks, int ntasks, const
     if (sink == 1.2345678e-300) X[(long long)col0 * ldx] = sink;
 }
 
-static int task_dbg() {     // GMRFX_TASK_DBG (timing experiments only, WRONG results): 1 = no front loop, 2 = no L2 warm-up pass
-    static const int v = [] { const char *e = std::getenv("GMRFX_TASK_DBG"); return e ? std::atoi(e) : 0; }();
-    return v;
-}
 static int task_nc() {      // GMRFX_TASK_NC = 64: one 64-column workgroup per task (one per CU); 32 (default): two column halves, two resident per CU
     static const int v = [] { const char *e = std::getenv("GMRFX_TASK_NC"); const int x = e ? std::atoi(e) : 32; return x == 64 ? 64 : 32; }();
     return v;
@@ -548,12 +531,12 @@ void launch_sweep_tasks(hipStream_t st, const DevSym &S, int phase, const SweepT
                         const double *L, double *X, double *W, int nr, int ldx) {
     if (ntasks <= 0) return;
     if (task_nc() == 64) {
-        if (phase == 1) hipLaunchKernelGGL(k_fwd_task<64>, dim3(ntasks), dim3(1024), 0, st, S, tasks, ntasks, L, X, W, nr, ldx, task_dbg());
-        else hipLaunchKernelGGL(k_bwd_task<64>, dim3(ntasks), dim3(1024), 0, st, S, tasks, ntasks, L, X, nr, ldx, task_dbg());
+        if (phase == 1) hipLaunchKernelGGL(k_fwd_task<64>, dim3(ntasks), dim3(1024), 0, st, S, tasks, ntasks, L, X, W, nr, ldx);
+        else hipLaunchKernelGGL(k_bwd_task<64>, dim3(ntasks), dim3(1024), 0, st, S, tasks, ntasks, L, X, nr, ldx);
     } else {
         const int grid = ((ntasks + 7) / 8) * 16;       // blocks b and b + 8 (same XCD): the two column halves of one task
-        if (phase == 1) hipLaunchKernelGGL(k_fwd_task<32>, dim3(grid), dim3(512), 0, st, S, tasks, ntasks, L, X, W, nr, ldx, task_dbg());
-        else hipLaunchKernelGGL(k_bwd_task<32>, dim3(grid), dim3(512), 0, st, S, tasks, ntasks, L, X, nr, ldx, task_dbg());
+        if (phase == 1) hipLaunchKernelGGL(k_fwd_task<32>, dim3(grid), dim3(512), 0, st, S, tasks, ntasks, L, X, W, nr, ldx);
+        else hipLaunchKernelGGL(k_bwd_task<32>, dim3(grid), dim3(512), 0, st, S, tasks, ntasks, L, X, nr, ldx);
     }
 }
 int sweep_task_rows_max() { return TASK_ROWS; }
