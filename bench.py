@@ -475,7 +475,7 @@ def main():
         # runs, gfx950 FETCH_SIZE x2 correction): only valid for the workload they were collected on
         pmc = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as fh:
                 pj = json.load(fh)
             if pj["workload"] == {"grid": args.grid, "nrhs": args.nrhs}:
                 pmc = pj
@@ -497,7 +497,7 @@ def main():
                        "kernel": "k_syrk_cb_rec", "launches_per_step": n_launch, "avg_launch_ms": ms_syrk / n_launch,
                        "flops_per_launch": st["syrk_flops"] / n_launch, "ms_per_step": ms_syrk,
                        "note": "achieved = algorithmic flops of the launches of one step / their summed HIP-event time; "
-                               "traffic = PMC HBM bytes per launch (profiles/r02_pmc_traffic.json)"}
+                               "traffic = PMC HBM bytes per launch (profiles/r03_pmc_traffic.json)"}
         roof_factor = {"bound": "mfma", "achieved": factor_tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                        "frac": factor_tf / FP64_MFMA_PEAK_TF, "traffic": pmc["factor"]["total_bytes"] if pmc else None,
                        "peak_measured": FP64_MFMA_MEASURED_TF, "frac_of_measured_peak": factor_tf / FP64_MFMA_MEASURED_TF,
