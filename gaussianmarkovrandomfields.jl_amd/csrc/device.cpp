@@ -790,28 +790,30 @@ void Device::refactorize_phase(const double *d_nzval, int phase) {
     if (split + phase >= nl) { factorized = true; selinv_valid = false; inverse_pending = true; }   // last phase done
 }
 
-// Distributed root (symbolic.h): block phases of the root front's factorisation, driven by gmrfx/shard.py between the
-// broadcasts. Blocks of 256 columns, block b on rank b mod world; the same kernels and the same sums in the same order as
-// the level loop uses for a front of its own (potrf64 -> trsm -> K = 64 update inside the block; K = 256 update of the
-// later blocks), so the factor equals the unsharded one bit for bit.
-void Device::dist_root_phase(const double *d_nzval, int what, int block) {
+// Distributed top fronts (symbolic.h): block phases of one front's factorisation, driven by gmrfx/shard.py between the
+// broadcasts. 256-column blocks dealt cyclically over the front's group; the same kernels and the same sums in the same order
+// as the level loop uses for a front of its own (potrf64 -> trsm -> K = 64 update inside the block; K = 256 update of the later
+// blocks; children gathered + L21 L21' per 64 x 64 tile of the contribution block), so the factor equals the unsharded one.
+void Device::dist_front_phase(const double *d_nzval, int front, int what, int block) {
     HC(hipSetDevice(device));
-    const i32 R = S_->dist_root;
-    if (R < 0) throw std::invalid_argument("this handle has no distributed root");
-    const int c = S_->ncols(R), r = S_->nrows(R), W = S_->shard_world, me = S_->shard_rank;
-    const int nob = (c + 255) / 256;
+    if (front < 0 || front >= S_->nsuper || !S_->is_dist(front)) throw std::invalid_argument("not a distributed front of this handle");
+    const i32 R = front;
+    const int g = S_->group_size(R), me = S_->group_pos(R, S_->shard_rank);
+    if (me < 0) return;
+    const int c = S_->ncols(R), r = S_->nrows(R);
+    const int nob = S_->panel_blocks(R);
     const FrontArg fa{1, (int)R, c, r, (int)S_->ld[R], (int)S_->sfirst[R], (long long)S_->panelptr[R]};
+    if (!d_dist_list_) {
+        d_dist_list_ = dalloc<int>(S_->dist_fronts.size());
+        HC(hipMemcpyAsync(d_dist_list_, S_->dist_fronts.data(), S_->dist_fronts.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+    }
+    const int *list = d_dist_list_ + S_->dist_index[R];
     if (what == 0) {
         if (!d_nzval) throw std::invalid_argument("d_nzval is null");
-        if (!d_dist_list_) {
-            d_dist_list_ = dalloc<int>(1);
-            const int v = R;
-            HC(hipMemcpyAsync(d_dist_list_, &v, sizeof(int), hipMemcpyHostToDevice, stream));
-        }
-        launch_assemble_cyclic(stream, ds_, d_dist_list_, c, d_nzval, d_L_, d_cb_, W, me);
+        launch_assemble_cyclic(stream, ds_, list, c, d_nzval, d_L_, d_cb_, g, me);
     } else if (what == 1) {
-        if (block < 0 || block >= nob) throw std::invalid_argument("distributed root: block out of range");
-        if (block % W != me) return;
+        if (block < 0 || block >= nob) throw std::invalid_argument("distributed front: block out of range");
+        if (block % g != me) return;
         const int b0 = block * OBK, b1 = std::min(b0 + OBK, (c + NB - 1) / NB);
         for (int b = b0; b < b1; b++) {
             const int kb = b * NB;
@@ -821,14 +823,16 @@ void Device::dist_root_phase(const double *d_nzval, int what, int block) {
                 launch_gemm_nt(stream, ds_, nullptr, 1, kb, NB, kb + NB, b1 * NB, r - kb - NB, std::min(b1 * NB, c) - kb - NB, d_L_, fa);
         }
     } else if (what == 2) {
-        if (block < 0 || block >= nob) throw std::invalid_argument("distributed root: block out of range");
+        if (block < 0 || block >= nob) throw std::invalid_argument("distributed front: block out of range");
         const int k0 = block * 256, K = std::min(256, c - k0);
         for (int j = block + 1; j < nob; j++) {
-            if (j % W != me) continue;
+            if (j % g != me) continue;
             const int c0 = j * 256;
             launch_gemm_nt(stream, ds_, nullptr, 1, k0, K, c0, c0 + 256, r - c0, std::min(256, c - c0), d_L_, fa);
         }
-    } else throw std::invalid_argument("distributed root phase must be 0 (assemble), 1 (factor block) or 2 (apply block)");
+    } else if (what == 3) {
+        if (r > c) launch_syrk_cb_cyclic(stream, ds_, list, r - c, d_L_, d_cb_, g, me, nob);
+    } else throw std::invalid_argument("distributed front phase must be 0 (assemble), 1 (factor block), 2 (apply block) or 3 (contribution block)");
     if (!async_phases_) HC(hipStreamSynchronize(stream));
     HC(hipGetLastError());
 }

@@ -252,13 +252,13 @@ private:
 public:
     void set_external_stream(hipStream_t s, bool use, bool async);
     int level_times(int phase, double *out, int cap);
-    void dist_root_phase(const double *d_nzval, int what, int block);
+    void dist_front_phase(const double *d_nzval, int front, int what, int block);
 private:
     void ensure_rdiag();
     double *d_rdiag_ = nullptr;                   // n reciprocals of L's diagonal (+ a zero word): operands of the wave tasks
     unsigned long long factor_serial_ = 1, rdiag_for_ = 0;    // d_rdiag_ belongs to factorisation number rdiag_for_
     std::vector<int> sel_max_cols_, sel_max_trail_;   // per level, over the big fronts of the selected-inversion list
-    int *d_dist_list_ = nullptr;  // one-entry front list (the distributed root) for the assembly kernel
+    int *d_dist_list_ = nullptr;  // the distributed fronts (Symbolic::dist_fronts) as a device list for the assembly / SYRK kernels
     bool selinv_begun_ = false;   // sharded selected inversion: phase 0 has run since the last refactorisation (gmrfx_selinv_phase)
     std::vector<hipEvent_t> ev_level_[3];
     int level_slots_[3] = {0, 0, 0};

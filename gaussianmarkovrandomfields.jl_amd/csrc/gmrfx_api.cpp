@@ -90,7 +90,7 @@ extern "C" int32_t gmrfx_create(int64_t n, const int64_t *colptr, const int64_t 
             if (h->opts.shard_rank < 0 || h->opts.shard_rank >= h->opts.shard_world) throw std::invalid_argument("shard_rank out of range");
             so.shard_rank = h->opts.shard_rank;
             so.shard_world = h->opts.shard_world;
-            if (const char *e = std::getenv("GMRFX_DIST_ROOT_MIN")) so.dist_root_min_cols = std::atoi(e);   // columns from which the root is factored by all ranks (0: never)
+            if (const char *e = std::getenv("GMRFX_DIST_MIN")) so.dist_min_cols = std::atoi(e);   // columns from which a top front is factored by its whole group (0: never)
             so.subtree_max = 0;     // subtree tasks are not shard-aware
         }
         analyze(n, colptr, rowval, index_base, perm, so, h->S);
@@ -237,31 +237,57 @@ extern "C" int32_t gmrfx_shard_edges(const gmrfx_handle *h, int64_t *child, int6
     }
     return GMRFX_OK;
 }
-// Distributed root (symbolic.h: Symbolic::dist_root). info[0] = root supernode or -1, [1] = its columns, [2] = outer blocks of
-// 256 columns, [3] = world, [4] = offset of its panel in gmrfx_device_ptr(h, 1), [5] = leading dimension of the panel,
-// [6] = number of (child, block) column ranges. child / block / offset / count (nullable): the ranges -- `count` doubles at
-// `offset` of the arena (gmrfx_device_ptr(h, 0)) travel from owner[child] to rank block % world before the root is assembled.
-extern "C" int32_t gmrfx_shard_dist_root(const gmrfx_handle *h, int64_t *info, int64_t *child, int64_t *block, int64_t *offset, int64_t *count) {
-    if (!h || !info) return GMRFX_ERR_INVALID_ARG;
+// Distributed top fronts (symbolic.h: Symbolic::dist_fronts). counts[0] = number of distributed fronts, [1] = entries of all
+// groups, [2] = contribution-block transfers of the factorisation, [3] = world. Per front (nullable arrays of counts[0]):
+// supernode, columns, rows, offset of its panel in gmrfx_device_ptr(h, 1), leading dimension of the panel, tree level; gptr
+// (counts[0] + 1) / grank (counts[1]): the ranks of its group. Panel block b (256 columns) is factored by grank[gptr[k] + b mod g].
+extern "C" int32_t gmrfx_shard_dist_fronts(const gmrfx_handle *h, int64_t *counts, int64_t *front, int64_t *cols, int64_t *rows,
+                                           int64_t *panel_offset, int64_t *panel_ld, int64_t *level, int64_t *gptr, int64_t *grank) {
+    if (!h || !counts) return GMRFX_ERR_INVALID_ARG;
     const Symbolic &S = h->S;
-    const i32 R = S.dist_root;
-    info[0] = R; info[1] = R >= 0 ? S.ncols(R) : 0; info[2] = R >= 0 ? (S.ncols(R) + 255) / 256 : 0; info[3] = S.shard_world;
-    info[4] = R >= 0 ? S.panelptr[R] : 0; info[5] = R >= 0 ? S.ld[R] : 0; info[6] = (int64_t)S.dist_cols_child.size();
-    for (size_t k = 0; k < S.dist_cols_child.size(); k++) {
-        if (child) child[k] = S.dist_cols_child[k];
-        if (block) block[k] = S.dist_cols_block[k];
-        if (offset) offset[k] = S.dist_cols_off[k];
-        if (count) count[k] = S.dist_cols_cnt[k];
+    const size_t nf = S.dist_fronts.size();
+    counts[0] = (int64_t)nf; counts[1] = (int64_t)S.dist_grank.size(); counts[2] = (int64_t)S.xf_child.size(); counts[3] = S.shard_world;
+    for (size_t k = 0; k < nf; k++) {
+        const i32 s = S.dist_fronts[k];
+        if (front) front[k] = s;
+        if (cols) cols[k] = S.ncols(s);
+        if (rows) rows[k] = S.nrows(s);
+        if (panel_offset) panel_offset[k] = S.panelptr[s];
+        if (panel_ld) panel_ld[k] = S.ld[s];
+        if (level) level[k] = S.level[s];
+    }
+    if (gptr) for (size_t k = 0; k < S.dist_gptr.size(); k++) gptr[k] = S.dist_gptr[k];
+    if (grank) for (size_t k = 0; k < S.dist_grank.size(); k++) grank[k] = S.dist_grank[k];
+    return GMRFX_OK;
+}
+// Every contribution-block transfer of the sharded factorisation (symbolic.h: xf_*), ordered by the level of the parent:
+// `count` doubles at `offset` of the arena (gmrfx_device_ptr(h, 0)) -- whole columns of `child`'s block -- go src -> dst before
+// the fronts of `level` are assembled; col0 = the first of these columns. (Edges between fronts of one owner, neither
+// distributed, have no entry.)
+extern "C" int32_t gmrfx_shard_transfers(const gmrfx_handle *h, int64_t *child, int64_t *src, int64_t *dst, int64_t *level,
+                                         int64_t *offset, int64_t *count, int64_t *col0) {
+    if (!h) return GMRFX_ERR_INVALID_ARG;
+    const Symbolic &S = h->S;
+    for (size_t k = 0; k < S.xf_child.size(); k++) {
+        if (child) child[k] = S.xf_child[k];
+        if (src) src[k] = S.xf_src[k];
+        if (dst) dst[k] = S.xf_dst[k];
+        if (level) level[k] = S.xf_level[k];
+        if (offset) offset[k] = S.xf_off[k];
+        if (count) count[k] = S.xf_cnt[k];
+        if (col0) col0[k] = S.xf_col0[k];
     }
     return GMRFX_OK;
 }
-// what = 0: assemble this rank's blocks of the root panel (Q's entries + the children's column ranges received);
-// 1: factor outer block `block` (its owner only; the others return at once); 2: apply block `block` (complete on every
-// rank after its broadcast) to this rank's later blocks. Asynchronous on the handle's main stream when async phases are on.
-extern "C" int32_t gmrfx_dist_root_phase(gmrfx_handle *h, const double *d_nzval, int32_t what, int32_t block) {
+// Block phases of distributed front `front` (a supernode of gmrfx_shard_dist_fronts; a no-op on ranks outside its group).
+// what = 0: assemble this rank's panel blocks (Q's entries + the children's columns received); 1: factor panel block `block`
+// (its owner only); 2: apply panel block `block` (complete on every member after its broadcast) to this rank's later panel
+// blocks; 3: this rank's column blocks of the contribution block (children's columns received - L21 L21'). Asynchronous on the
+// handle's main stream when async phases are on.
+extern "C" int32_t gmrfx_dist_front_phase(gmrfx_handle *h, const double *d_nzval, int32_t front, int32_t what, int32_t block) {
     return guarded(h, [&]() -> int32_t {
         if (int32_t e = need_device(h, false)) return e;
-        h->D->dist_root_phase(d_nzval, what, block);
+        h->D->dist_front_phase(d_nzval, front, what, block);
         return GMRFX_OK;
     });
 }
@@ -785,7 +811,7 @@ extern "C" int32_t gmrfx_symbolic_get(const gmrfx_handle *h, int64_t *super_firs
         // have no destination here (-1)
         if (S.shard_world > 1)
             for (i32 s = 0; s < ns; s++)
-                if (S.owner[s] != S.shard_rank && s != S.dist_root)      // (every rank stores the distributed root's panel)
+                if (!S.stored_here(s))      // (every member of its group stores the panel of a distributed front)
                     for (i64 k = S.qptr[s]; k < S.qptr[s + 1]; k++) q_dst[k] = -1;
     }
     return GMRFX_OK;

@@ -388,13 +388,16 @@ __global__ __launch_bounds__(256) void k_gemm_nt(DevSym S, const FrontView *__re
 // (Reference form on a plain 3-D grid, front x tile row x tile column: GMRFX_SYRK_XCD=0. The product path is
 // k_syrk_cb_rec below -- same arithmetic, tiles handed out per XCD from self-contained records.)
 __global__ __launch_bounds__(256) void k_syrk_cb(DevSym S, const int *__restrict__ list, const double *__restrict__ L,
-                                                 double *__restrict__ CB) {
+                                                 double *__restrict__ CB, int cyc_w, int cyc_r, int cyc_b0) {
     __shared__ double Tl[64 * 65];
     const int s = list[blockIdx.z], bi = blockIdx.x, bj = blockIdx.y;
     const int c = S.sfirst[s + 1] - S.sfirst[s];
     const int r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
     const int m = r - c;
     if (bj > bi || bi * 64 >= m) return;
+    // distributed front (cyc_w > 0): this rank computes the 256-column blocks of the contribution block it owns -- block q on
+    // position (cyc_b0 + q) mod cyc_w of the group, cyc_b0 = the panel's blocks (the dealing continues behind the panel)
+    if (cyc_w > 0 && (cyc_b0 + (bj >> 2)) % cyc_w != cyc_r) return;
     const int ld = S.ld[s];
     const double *A = L + S.panelptr[s] + c;
     double *C = CB + S.cbptr[s];
@@ -1369,7 +1372,11 @@ void launch_assemble_cyclic(hipStream_t st, const DevSym &S, const int *list, in
 }
 void launch_syrk_cb(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_trail, const double *L, double *CB) {
     if (nfronts <= 0 || max_trail <= 0) return;
-    hipLaunchKernelGGL(k_syrk_cb, dim3(odd(cdiv(max_trail, 64)), odd(cdiv(max_trail, 64)), nfronts), dim3(256), 0, st, S, list, L, CB);
+    hipLaunchKernelGGL(k_syrk_cb, dim3(odd(cdiv(max_trail, 64)), odd(cdiv(max_trail, 64)), nfronts), dim3(256), 0, st, S, list, L, CB, 0, 0, 0);
+}
+void launch_syrk_cb_cyclic(hipStream_t st, const DevSym &S, const int *list, int trail, const double *L, double *CB, int cyc_w, int cyc_r, int cyc_b0) {
+    if (trail <= 0) return;
+    hipLaunchKernelGGL(k_syrk_cb, dim3(odd(cdiv(trail, 64)), odd(cdiv(trail, 64)), 1), dim3(256), 0, st, S, list, L, CB, cyc_w, cyc_r, cyc_b0);
 }
 void launch_syrk_cb_recs(hipStream_t st, const DevSym &S, const SyrkTile *recs, const SyrkSplit &split, int per_xcd, const double *L, double *CB) {
     if (per_xcd <= 0) return;

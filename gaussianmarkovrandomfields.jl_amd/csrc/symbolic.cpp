@@ -5,6 +5,7 @@
 #include "symbolic.h"
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <map>
@@ -480,17 +481,31 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
         for (i32 s = 0; s < ns; s++) S.nlevels = std::max(S.nlevels, S.level[s] + 1);
         S.nlevels = std::max(S.nlevels, S.shard_level);
     }
-    // distributed root (symbolic.h): the tree's root, alone on the last level, wide enough, without trailing rows
-    S.dist_root = -1;
+    // distributed top fronts (symbolic.h): wide top fronts whose group has more than one rank
+    S.dist_fronts.clear(); S.dist_index.assign(ns, -1); S.dist_gptr.assign(1, 0); S.dist_grank.clear();
     if (S.shard_world > 1) {
-        const int min_cols = opt.dist_root_min_cols >= 0 ? opt.dist_root_min_cols : 4096;
-        i32 nroots = 0, root = -1;
-        for (i32 s = 0; s < ns; s++) if (S.sparent[s] == -1) { nroots++; root = s; }
-        if (min_cols > 0 && nroots == 1 && S.is_top[root] && S.ncols(root) >= min_cols && S.nrows(root) == S.ncols(root) &&
-            S.level[root] == S.nlevels - 1 && !(opt.subtree_max > 0))
-            S.dist_root = root;
+        const int min_cols = opt.dist_min_cols >= 0 ? opt.dist_min_cols : 4096;
+        std::vector<std::vector<i32>> grp(ns);          // ranks below (and at) every top front
+        for (i32 s = 0; s < ns; s++) {
+            if (!S.is_top[s]) continue;
+            std::vector<i32> g;
+            for (i64 q = S.childptr[s]; q < S.childptr[s + 1]; q++) {
+                const i32 d = S.children[q];
+                if (S.is_top[d]) g.insert(g.end(), grp[d].begin(), grp[d].end());
+                else g.push_back(S.owner[d]);
+            }
+            std::sort(g.begin(), g.end());
+            g.erase(std::unique(g.begin(), g.end()), g.end());
+            grp[s] = g;
+            if (min_cols > 0 && !(opt.subtree_max > 0) && S.ncols(s) >= min_cols && g.size() >= 2) {
+                S.dist_index[s] = (i32)S.dist_fronts.size();
+                S.dist_fronts.push_back(s);
+                S.dist_grank.insert(S.dist_grank.end(), g.begin(), g.end());
+                S.dist_gptr.push_back((i32)S.dist_grank.size());
+            }
+        }
     }
-    // does this rank execute front s?  (the distributed root: owner[root] runs its sweeps / selected inversion)
+    // does this rank execute front s?  (a distributed front: owner[s] runs its sweeps / selected inversion)
     auto mine = [&](i32 s) { return S.shard_world == 1 || S.owner[s] == S.shard_rank; };
 
     // ---- per-rank storage of a sharded factorisation (round 3) ---------------------------------------------------------
@@ -502,13 +517,15 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
     // into the SAME offset on both ends, and no rank needs to know another rank's private layout.
     S.cross_child.assign(ns, 0);
     for (i32 d : S.shard_edges) S.cross_child[d] = 1;
-    if (S.dist_root >= 0)       // every rank assembles its own blocks of the root from (column ranges of) every child's block
-        for (i64 q = S.childptr[S.dist_root]; q < S.childptr[S.dist_root + 1]; q++) S.cross_child[S.children[q]] = 1;
+    for (i32 s : S.dist_fronts) {       // the block of a distributed front is written by several ranks, the blocks of its children
+        S.cross_child[s] = 1;           // are read by several: all of them live in the exchange region
+        for (i64 q = S.childptr[s]; q < S.childptr[s + 1]; q++) S.cross_child[S.children[q]] = 1;
+    }
     if (S.shard_world > 1) {
         i64 off = 0;
         for (i32 s = 0; s < ns; s++) {
             S.panelptr[s] = off;
-            if (mine(s) || s == S.dist_root) { off += (i64)S.ld[s] * S.ncols(s); off = (off + 15) & ~i64(15); }
+            if (S.stored_here(s)) { off += (i64)S.ld[s] * S.ncols(s); off = (off + 15) & ~i64(15); }
         }
         S.panelptr[ns] = off;
         for (i32 s = 0; s < ns; s++)
@@ -569,12 +586,12 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
         }
     }
     S.levelptr.assign(S.nlevels + 1, 0);
-    // (the distributed root is factored by the block phases of Device::dist_root_phase, not by the level loop)
-    for (i32 s = 0; s < ns; s++) if (!S.in_subtree[s] && mine(s) && s != S.dist_root) S.levelptr[S.level[s] + 1]++;
+    // (distributed fronts are factored by the block phases of Device::dist_phase, not by the level loop)
+    for (i32 s = 0; s < ns; s++) if (!S.in_subtree[s] && mine(s) && !S.is_dist(s)) S.levelptr[S.level[s] + 1]++;
     for (i32 l = 0; l < S.nlevels; l++) S.levelptr[l + 1] += S.levelptr[l];
     S.levellist.resize(S.levelptr[S.nlevels]);
     { std::vector<i64> w(S.levelptr.begin(), S.levelptr.end() - 1);
-      for (i32 s = 0; s < ns; s++) if (!S.in_subtree[s] && mine(s) && s != S.dist_root) S.levellist[w[S.level[s]]++] = s; }
+      for (i32 s = 0; s < ns; s++) if (!S.in_subtree[s] && mine(s) && !S.is_dist(s)) S.levellist[w[S.level[s]]++] = s; }
     S.level_nsmall.assign(S.nlevels, 0);
     S.level_ncls.assign((size_t)S.nlevels * 4, 0);
     for (i32 l = 0; l < S.nlevels; l++) {
@@ -772,23 +789,32 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
         S.cb_arena = std::max<i64>(peak, 16);
     }
 
-    // ---- distributed root: which columns of which child's contribution block go to which outer block ----------------
-    S.dist_cols_child.clear(); S.dist_cols_block.clear(); S.dist_cols_off.clear(); S.dist_cols_cnt.clear();
-    if (S.dist_root >= 0) {
-        const i32 R = S.dist_root;
-        for (i64 q = S.childptr[R]; q < S.childptr[R + 1]; q++) {
-            const i32 d = S.children[q];
-            const i32 cd = S.ncols(d), md = S.nrows(d) - cd;
-            const i32 *rel = S.rel.data() + S.rowptr[d] + cd;        // position of the child's trailing rows in the root = root column
+    // ---- contribution-block transfers of the factorisation, by column ranges ---------------------------------------------
+    // column k of child d (its k-th trailing row) lands in row/column rel[k] of the parent p: a panel column (< c_p) or a column
+    // of p's own contribution block. It is HELD by cb_owner(d, k / 256) and NEEDED by the owner of that parent block.
+    S.xf_child.clear(); S.xf_src.clear(); S.xf_dst.clear(); S.xf_level.clear(); S.xf_col0.clear(); S.xf_off.clear(); S.xf_cnt.clear();
+    if (S.shard_world > 1) {
+        std::vector<std::array<i64, 7>> xf;
+        for (i32 d = 0; d < ns; d++) {
+            const i32 p = S.sparent[d];
+            if (p == -1) continue;
+            if (!S.is_dist(d) && !S.is_dist(p) && S.owner[d] == S.owner[p]) continue;
+            const i32 cd = S.ncols(d), md = S.nrows(d) - cd, cp = S.ncols(p);
+            const i32 *rel = S.rel.data() + S.rowptr[d] + cd;
+            auto need = [&](i32 k) { return rel[k] < cp ? S.panel_owner(p, rel[k] / 256) : S.cb_owner(p, (rel[k] - cp) / 256); };
             i32 k = 0;
             while (k < md) {
-                const i32 b = rel[k] / 256;
-                i32 k1 = k;
-                while (k1 < md && rel[k1] / 256 == b) k1++;
-                S.dist_cols_child.push_back(d); S.dist_cols_block.push_back(b);
-                S.dist_cols_off.push_back(S.cbptr[d] + (i64)k * md); S.dist_cols_cnt.push_back((i64)(k1 - k) * md);
+                const i32 src = S.cb_owner(d, k / 256), dst = need(k);
+                i32 k1 = k + 1;
+                while (k1 < md && S.cb_owner(d, k1 / 256) == src && need(k1) == dst) k1++;
+                if (src != dst) xf.push_back({(i64)S.level[p], (i64)d, (i64)src, (i64)dst, S.cbptr[d] + (i64)k * md, (i64)(k1 - k) * md, (i64)k});
                 k = k1;
             }
+        }
+        std::stable_sort(xf.begin(), xf.end(), [](const std::array<i64, 7> &a, const std::array<i64, 7> &b) { return a[0] < b[0]; });
+        for (auto &e : xf) {
+            S.xf_level.push_back((i32)e[0]); S.xf_child.push_back((i32)e[1]); S.xf_src.push_back((i32)e[2]); S.xf_dst.push_back((i32)e[3]);
+            S.xf_off.push_back(e[4]); S.xf_cnt.push_back(e[5]); S.xf_col0.push_back((i32)e[6]);
         }
     }
 

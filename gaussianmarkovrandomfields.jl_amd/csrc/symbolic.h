@@ -25,8 +25,8 @@ struct SymOptions {
     int sweep_task_rows = -1;  // LDS rows of a sweep task's local vector (Symbolic::swt_*); -1 = default, 0 = no sweep tasks
     // multi-GPU sharding of ONE factorisation along the supernodal tree (see Symbolic::owner)
     int shard_rank = 0, shard_world = 1;
-    int dist_root_min_cols = -1;   // sharded handles: the ROOT front is factored by all ranks together when it has at least this many
-                                   // columns (Symbolic::dist_root); -1 = default (4096), 0 = never
+    int dist_min_cols = -1;        // sharded handles: a top front is factored by its whole group when it has at least this many columns
+                                   // (Symbolic::dist_fronts); -1 = default (4096), 0 = never
 };
 
 // Symmetric adjacency structure without self loops.
@@ -106,17 +106,38 @@ struct Symbolic {
     std::vector<uint8_t> is_top;  // nsuper
     i32 shard_rank = 0, shard_world = 1, shard_level = 0;   // shard_level = nlevels when world == 1
     std::vector<i32> shard_edges; // children d with owner[d] != owner[parent(d)], ordered by (level of the parent, d)
-    // DISTRIBUTED ROOT (round 3): the root front of a 3-D problem holds a fifth of all flops (cfg 4: 47 628 columns, 18 % of
-    // 2e14) and sat on one rank. When dist_root >= 0 its panel is factored by ALL ranks: 256-column outer blocks are dealt
-    // cyclically (block b belongs to rank b mod world), the owner of a block factors its block column (the usual potrf64 /
-    // trsm / gemm chain inside the block), broadcasts it, and every rank applies it to its OWN later blocks (K = 256 update).
-    // Every rank stores the whole root panel (replicated storage, distributed flops); the children's contribution blocks
-    // reach the ranks by COLUMN RANGES (dist_cols_*: the columns of child d that fall into root block b go to the owner of
-    // b, into the same arena offset on both ends). Sweeps and selected inversion of the root stay on owner[root], which
-    // holds the complete factor after the last broadcast. Driver: gmrfx/shard.py.
-    i32 dist_root = -1;
-    std::vector<i32> dist_cols_child, dist_cols_block;     // one entry per (child of the root, outer block) with columns
-    std::vector<i64> dist_cols_off, dist_cols_cnt;         // offset (doubles, in the arena) / count of that column range
+    // DISTRIBUTED TOP FRONTS (round 3). The dense fronts at the top of a 3-D problem hold most of the flops (cfg 4: the top
+    // three levels are 2.7 of 5.3 s; the root alone 47 628 columns) and each sat on ONE rank. A top front with at least
+    // dist_min_cols columns whose GROUP -- the ranks owning the subtrees below it -- has more than one rank is factored by
+    // the whole group: its panel columns and the columns of its contribution block are cut into 256-column blocks dealt
+    // cyclically over the group (panel block b -> group[b mod g], contribution-block block q -> group[(nbp + q) mod g],
+    // nbp = panel blocks). Per panel block: its owner factors the block column (the usual potrf64 / trsm / gemm chain inside
+    // the block) and broadcasts it inside the group; every member applies it to its OWN later panel blocks (K = 256 update);
+    // when the panel is complete every member computes its OWN blocks of the contribution block. Contribution blocks travel
+    // child -> parent by COLUMN RANGES (xf_*): the columns of a child that fall into a block of the parent go from the rank
+    // that holds them to the rank that owns the block, into the same arena offset on both ends. Every member stores the whole
+    // panel (replicated storage, distributed flops); sweeps and selected inversion of a distributed front stay on owner[s],
+    // which holds the complete panel after the last broadcast. Driver: gmrfx/shard.py.
+    std::vector<i32> dist_fronts;          // the distributed fronts, ascending (children before parents)
+    std::vector<i32> dist_index;           // nsuper: index into dist_fronts or -1
+    std::vector<i32> dist_gptr, dist_grank; // ranks of the group of dist_fronts[k]: dist_grank[dist_gptr[k] .. dist_gptr[k+1]) (sorted)
+    // every contribution-block transfer of the factorisation, ordered by the level of the parent: columns of child xf_child
+    // starting at arena offset xf_off (xf_cnt doubles) go xf_src -> xf_dst
+    std::vector<i32> xf_child, xf_src, xf_dst, xf_level, xf_col0;   // (xf_col0: first column of the range in the child's block)
+    std::vector<i64> xf_off, xf_cnt;
+    bool is_dist(i32 s) const { return !dist_index.empty() && dist_index[s] >= 0; }
+    i32 group_size(i32 s) const { const i32 k = dist_index[s]; return dist_gptr[k + 1] - dist_gptr[k]; }
+    i32 group_rank(i32 s, i32 idx) const { return dist_grank[dist_gptr[dist_index[s]] + idx]; }
+    i32 group_pos(i32 s, i32 rank) const {        // position of `rank` in the group of s, or -1
+        const i32 k = dist_index[s];
+        for (i32 q = dist_gptr[k]; q < dist_gptr[k + 1]; q++) if (dist_grank[q] == rank) return q - dist_gptr[k];
+        return -1;
+    }
+    i32 panel_blocks(i32 s) const { return (ncols(s) + 255) / 256; }
+    // rank holding panel block b / contribution-block column block q of front s
+    i32 panel_owner(i32 s, i32 b) const { return is_dist(s) ? group_rank(s, b % group_size(s)) : owner[s]; }
+    i32 cb_owner(i32 s, i32 q) const { return is_dist(s) ? group_rank(s, (panel_blocks(s) + q) % group_size(s)) : owner[s]; }
+    bool stored_here(i32 s) const { return shard_world == 1 || owner[s] == shard_rank || (is_dist(s) && group_pos(s, shard_rank) >= 0); }
     std::vector<i32> shard_sub_root, shard_sub_col0;   // ALL assigned subtrees: root supernode, first column (columns [col0, sfirst[root+1]) are theirs)
     // the caller's pattern (0-based) and which stored triangle defines Q: kept for the quadratic form
     // x'Qx (sqmahal / logpdf), which runs on the caller's CSC values, not on the factor

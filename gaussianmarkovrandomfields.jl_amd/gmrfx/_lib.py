@@ -58,7 +58,8 @@ EXPORTS = [
     "gmrfx_backward_solve_dev", "gmrfx_logdet", "gmrfx_selinv_compute", "gmrfx_selinv_diag", "gmrfx_selinv_nnz",
     "gmrfx_selinv_csc", "gmrfx_selinv_extract", "gmrfx_get_perm", "gmrfx_get_stats", "gmrfx_symbolic_sizes",
     "gmrfx_symbolic_get", "gmrfx_get_factor_values", "gmrfx_refactorize_phase", "gmrfx_shard_info",
-    "gmrfx_shard_edges", "gmrfx_shard_owner", "gmrfx_device_ptr", "gmrfx_set_stream", "gmrfx_level_times", "gmrfx_shard_dist_root", "gmrfx_dist_root_phase", "gmrfx_logdet_partial", "gmrfx_solve_phase",
+    "gmrfx_shard_edges", "gmrfx_shard_owner", "gmrfx_device_ptr", "gmrfx_set_stream", "gmrfx_level_times", "gmrfx_shard_dist_fronts", "gmrfx_shard_transfers",
+    "gmrfx_dist_front_phase", "gmrfx_logdet_partial", "gmrfx_solve_phase",
     "gmrfx_shard_rows", "gmrfx_set_prior", "gmrfx_refactorize_update", "gmrfx_refactorize_update_dev",
     "gmrfx_quadform", "gmrfx_quadform_dev", "gmrfx_selinv_dot", "gmrfx_selinv_row_diag", "gmrfx_kl_cholesky",
     "gmrfx_selinv_row_diag_plan", "gmrfx_selinv_row_diag_apply", "gmrfx_selinv_row_diag_free",
@@ -115,8 +116,9 @@ def lib():
         L.gmrfx_device_ptr.restype = C.c_void_p
         L.gmrfx_set_stream.argtypes = [vp, vp, i32, i32]
         L.gmrfx_level_times.argtypes = [vp, i32, vp, i64, C.POINTER(i64)]
-        L.gmrfx_shard_dist_root.argtypes = [vp, vp, vp, vp, vp, vp]
-        L.gmrfx_dist_root_phase.argtypes = [vp, vp, i32, i32]
+        L.gmrfx_shard_dist_fronts.argtypes = [vp] + [vp] * 9
+        L.gmrfx_shard_transfers.argtypes = [vp] + [vp] * 7
+        L.gmrfx_dist_front_phase.argtypes = [vp, vp, i32, i32, i32]
         L.gmrfx_logdet_partial.argtypes = [vp, C.POINTER(dbl)]
         L.gmrfx_solve_phase.argtypes = [vp, vp, i64, i64, vp, i64, i32]
         L.gmrfx_shard_rows.argtypes = [vp, i32, C.POINTER(i64), vp, vp, vp, vp]

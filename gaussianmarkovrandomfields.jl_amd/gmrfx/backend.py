@@ -411,20 +411,34 @@ class MI355XBackend:
             check(lib().gmrfx_shard_rows(self._h, kind, C.byref(k), ptr(owner), ptr(r0), ptr(nr), ptr(lv)), self._h)
         return owner, r0, nr, lv
 
-    def shard_dist_root(self) -> dict:
-        """The distributed root of a sharded handle (csrc/symbolic.h: Symbolic::dist_root): root supernode (-1: none), its
-        columns / 256-column blocks, the panel's place in device_ptr(1), and the (child, block) column ranges of the children's
-        contribution blocks (offset / count in device_ptr(0)) that travel owner[child] -> rank block % world."""
-        info = np.zeros(8, np.int64)
-        check(lib().gmrfx_shard_dist_root(self._h, ptr(info), None, None, None, None))
-        k = int(info[6])
-        a = {nm: np.empty(k, np.int64) for nm in ("child", "block", "offset", "count")}
-        check(lib().gmrfx_shard_dist_root(self._h, ptr(info), *[ptr(a[nm]) for nm in ("child", "block", "offset", "count")]))
-        return {"root": int(info[0]), "cols": int(info[1]), "blocks": int(info[2]), "world": int(info[3]), "panel_offset": int(info[4]),
-                "panel_ld": int(info[5]), **a}
+    def shard_dist_fronts(self) -> dict:
+        """The distributed top fronts of a sharded handle (csrc/symbolic.h: Symbolic::dist_fronts): per front its supernode,
+        columns, rows, the panel's place in device_ptr(1), tree level and GROUP (the ranks that factor it together: panel block b
+        of 256 columns on group[b % g], contribution-block block q on group[(panel blocks + q) % g])."""
+        cnt = np.zeros(4, np.int64)
+        check(lib().gmrfx_shard_dist_fronts(self._h, ptr(cnt), *([None] * 8)))
+        nf, ng = int(cnt[0]), int(cnt[1])
+        a = {nm: np.empty(nf, np.int64) for nm in ("front", "cols", "rows", "panel_offset", "panel_ld", "level")}
+        gptr, grank = np.zeros(nf + 1, np.int64), np.empty(ng, np.int64)
+        check(lib().gmrfx_shard_dist_fronts(self._h, ptr(cnt), *[ptr(a[nm]) for nm in ("front", "cols", "rows", "panel_offset", "panel_ld", "level")],
+                                            ptr(gptr), ptr(grank)))
+        a["group"] = [[int(r) for r in grank[gptr[k]:gptr[k + 1]]] for k in range(nf)]
+        a["world"] = int(cnt[3])
+        return a
 
-    def dist_root_phase(self, d_nzval_ptr: int, what: int, block: int = 0) -> None:
-        check(lib().gmrfx_dist_root_phase(self._h, d_nzval_ptr, what, block), self._h)
+    def shard_transfers(self) -> dict:
+        """Every contribution-block transfer of the sharded factorisation (whole columns of `child`'s block: `count` doubles at
+        `offset` of device_ptr(0), src -> dst, before the fronts of `level` are assembled), ordered by level."""
+        cnt = np.zeros(4, np.int64)
+        check(lib().gmrfx_shard_dist_fronts(self._h, ptr(cnt), *([None] * 8)))
+        k = int(cnt[2])
+        names = ("child", "src", "dst", "level", "offset", "count", "col0")
+        a = {nm: np.empty(k, np.int64) for nm in names}
+        check(lib().gmrfx_shard_transfers(self._h, *[ptr(a[nm]) for nm in names]))
+        return a
+
+    def dist_front_phase(self, d_nzval_ptr: int, front: int, what: int, block: int = 0) -> None:
+        check(lib().gmrfx_dist_front_phase(self._h, d_nzval_ptr, front, what, block), self._h)
 
     def set_stream(self, hip_stream: int, use_external: bool = True, async_phases: bool = False) -> None:
         """The caller's HIP stream becomes the handle's main stream (sharded drivers: torch's current stream)."""

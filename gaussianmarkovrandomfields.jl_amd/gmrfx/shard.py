@@ -62,17 +62,19 @@ class ShardedFactor:
         self._top_blocks = [[(int(owner[i]), int(r0[i]), int(nr[i])) for i in np.flatnonzero(lv == self.L0 + k)] for k in range(self.K)]
         so, sr0, snr, _ = self.sub_rows
         self._sub_blocks = [(int(so[i]), int(sr0[i]), int(snr[i])) for i in range(len(so))]
-        # distributed root (csrc/symbolic.h): the last top level holds the root alone and is factored by all ranks together
-        self.dr = self.be.shard_dist_root()
-        if self.dr["root"] >= 0:
-            owner = self.be.shard_owner()
-            dr, W = self.dr, self.world
-            root_kids = set(int(d) for d in dr["child"])
-            # whole contribution blocks into the root are replaced by their column ranges (each range to the owner of its block)
-            self._cb_items[self.K - 1] = [it for it, i in zip(self._cb_items[self.K - 1], np.flatnonzero(e["level"] == self.L0 + self.K - 1))
-                                          if int(e["child"][i]) not in root_kids]
-            self._dr_items = [(int(owner[dr["child"][k]]), int(dr["block"][k]) % W, 0, int(dr["offset"][k]), int(dr["count"][k]))
-                              for k in range(len(dr["child"]))]
+        # contribution-block transfers of the factorisation (column ranges; csrc/symbolic.h xf_*), per top level
+        x = self.be.shard_transfers()
+        self._cb_items = [[(int(x["src"][i]), int(x["dst"][i]), 0, int(x["offset"][i]), int(x["count"][i]))
+                           for i in np.flatnonzero(x["level"] == self.L0 + k)] for k in range(self.K)]
+        # distributed top fronts (csrc/symbolic.h): factored by their whole group, 256-column blocks dealt cyclically; one
+        # process group per distinct group of ranks (created collectively, same order everywhere)
+        self.df = self.be.shard_dist_fronts()
+        self._dist_of_level = [[i for i in range(len(self.df["front"])) if int(self.df["level"][i]) == self.L0 + k] for k in range(self.K)]
+        self._pg = {}
+        for g in self.df["group"]:
+            key = tuple(g)
+            if key not in self._pg:
+                self._pg[key] = None if len(g) == self.world else dist.new_group(ranks=list(g))
 
     # ---- transfers ----------------------------------------------------------------------------------
     def _view(self, which: int, off: int, cnt: int):
@@ -131,8 +133,9 @@ class ShardedFactor:
         be.refactorize_phase_dev(d_nzval_ptr, 0)
         for k in range(self.K):
             self._p2p(self._cb_items[k])
-            if k == self.K - 1 and self.dr["root"] >= 0:
-                self._factor_distributed_root(d_nzval_ptr)
+            for i in self._dist_of_level[k]:
+                if self.rank in self.df["group"][i]:
+                    self._factor_distributed_front(d_nzval_ptr, i)
             be.refactorize_phase_dev(d_nzval_ptr, 1 + k)
         # first non-positive pivot over all ranks (0 = none), like the `info` of gmrfx_refactorize
         t = self.torch
@@ -142,27 +145,30 @@ class ShardedFactor:
         self.last_info = 0 if int(v.item()) >= 2 ** 62 else int(v.item()) + 1
         return self.last_info
 
-    def _factor_distributed_root(self, d_nzval_ptr: int) -> None:
-        """The root front, factored by all ranks: 256-column blocks dealt cyclically; per block: its owner factors the block
-        column, broadcasts it (whole columns, one contiguous piece of the panel every rank stores), everybody updates its own
-        later blocks. The children's contribution blocks arrive as column ranges at the owners of the blocks they fall into."""
-        be, dr, W = self.be, self.dr, self.world
-        self._p2p(self._dr_items)
-        be.dist_root_phase(d_nzval_ptr, 0)                          # assemble my blocks
-        ld, c = dr["panel_ld"], dr["cols"]
-        for b in range(dr["blocks"]):
-            be.dist_root_phase(d_nzval_ptr, 1, b)                   # its owner factors block b
-            w = min(256, c - 256 * b)
-            v = self._view(1, dr["panel_offset"] + 256 * b * ld, w * ld)
+    def _factor_distributed_front(self, d_nzval_ptr: int, i: int) -> None:
+        """A top front factored by its group: per 256-column panel block its owner factors the block column and broadcasts it
+        inside the group (whole columns, one contiguous piece of the panel every member stores), every member updates its own
+        later blocks; then every member computes its own column blocks of the contribution block. The children's blocks have
+        arrived as column ranges at the owners of the blocks they fall into (the level's transfers)."""
+        be, df = self.be, self.df
+        s, c, ld, G = int(df["front"][i]), int(df["cols"][i]), int(df["panel_ld"][i]), df["group"][i]
+        pg = self._pg[tuple(G)]
+        nb = (c + 255) // 256
+        be.dist_front_phase(d_nzval_ptr, s, 0)                      # assemble my panel blocks
+        for b in range(nb):
+            be.dist_front_phase(d_nzval_ptr, s, 1, b)               # its owner factors block b
+            src = G[b % len(G)]
+            v = self._view(1, int(df["panel_offset"][i]) + 256 * b * ld, min(256, c - 256 * b) * ld)
             if self.host_staging:
                 buf = v.cpu()
-                self.dist.broadcast(buf, src=b % W)
-                if self.rank != b % W:
+                self.dist.broadcast(buf, src=src, group=pg)
+                if self.rank != src:
                     v.copy_(buf)
             else:
-                self.dist.broadcast(v, src=b % W)
-            if b + 1 < dr["blocks"]:
-                be.dist_root_phase(d_nzval_ptr, 2, b)               # apply it to my later blocks
+                self.dist.broadcast(v, src=src, group=pg)
+            if b + 1 < nb:
+                be.dist_front_phase(d_nzval_ptr, s, 2, b)           # apply it to my later panel blocks
+        be.dist_front_phase(d_nzval_ptr, s, 3)                      # my blocks of the contribution block
 
     # ---- solve --------------------------------------------------------------------------------------
     def solve_dev(self, d_B: int, ldb: int, nrhs: int, d_X: int, ldx: int) -> None:
@@ -247,14 +253,14 @@ def plan_summary(be, level_ms=None) -> dict:
     summed with the sweeps. It turns the plan into TIME bounds: a rank's subtree fronts cost their flop share of their level's
     measured time (those levels hold thousands of fronts: throughput-bound, the share is fair); the top fronts are the
     latency-bound chains at the top of the tree (potrf64 -> trsm -> gemm per 64 columns) that sharding does not shorten:
-      time_bound_speedup_latency : every level that holds a top front still costs its full measured time;
+      time_bound_speedup_latency : the top fronts of a level still cost their full measured time, one after the other;
       time_bound_speedup_share   : the top fronts too only cost the heaviest rank's flop share of their level.
     The truth lies between the two; the exchanges are not in either.
 
-    A DISTRIBUTED ROOT (Symbolic::dist_root: factored by all ranks, 256-column blocks dealt cyclically) enters with its flops
-    divided by the world size; its time additionally keeps what does not shrink: the diagonal chain (CHAIN_MS_PER_64 per
-    64-column step, measured at cfg 2) and the block-column broadcasts (the whole lower triangle once per rank at
-    BCAST_GBS, a conservative per-link xGMI figure)."""
+    DISTRIBUTED TOP FRONTS (Symbolic::dist_fronts: factored by their whole group, 256-column blocks dealt cyclically) enter with
+    their flops divided by the size of the group on every member; their time additionally keeps what does not shrink: the
+    diagonal chain (CHAIN_MS_PER_64 per 64-column step, measured at cfg 2) and the block-column broadcasts (the panel once per
+    member at BCAST_GBS, a conservative per-link xGMI figure)."""
     owner, top = be.shard_owner(with_top=True)
     sy = be.symbolic()
     c = np.diff(sy.super_first).astype(np.float64)
@@ -263,18 +269,28 @@ def plan_summary(be, level_ms=None) -> dict:
     fl = c ** 3 / 3 + c * c * m + c * m * m
     W = int(owner.max()) + 1
     local = [float(fl[(owner == k) & ~top].sum()) for k in range(W)]
-    t_top = 0.0
-    for lv in np.unique(sy.level[top]):
-        sel = top & (sy.level == lv)
-        t_top += max(float(fl[sel & (owner == k)].sum()) for k in range(W))
+    df = be.shard_dist_fronts()
+    dset = {int(s_): i for i, s_ in enumerate(df["front"])}
+    isd = np.zeros(len(c), bool)
+    isd[list(dset)] = True
+    gsz = {s_: len(df["group"][i]) for s_, i in dset.items()}
+
+    def heaviest(level_of, lv, cost, dcost):
+        """max over ranks of (own undistributed top fronts of level lv at `cost`) + (distributed fronts of its groups at `dcost`)"""
+        sel = top & (level_of == lv)
+        best = 0.0
+        for k in range(W):
+            t = float(cost[sel & ~isd & (owner == k)].sum())
+            t += sum(dcost(s_) for s_, i in dset.items() if level_of[s_] == lv and k in df["group"][i])
+            best = max(best, t)
+        return best
+
+    t_top = sum(heaviest(sy.level, lv, fl, lambda s_: float(fl[s_]) / gsz[s_]) for lv in np.unique(sy.level[top]))
     total = float(fl.sum())
-    dr = be.shard_dist_root()
-    R = dr["root"]
-    if R >= 0:                                      # the root's level holds the root alone: its flops are shared by all ranks
-        t_top -= float(fl[R]) * (1.0 - 1.0 / W)
     out = {"world": W, "top_fronts": int(top.sum()), "top_flops": float(fl[top].sum()), "local_flops": local,
            "top_critical_flops": t_top, "flop_bound_speedup": total / (max(local) + t_top),
-           "distributed_root": None if R < 0 else {"supernode": R, "cols": dr["cols"], "blocks": dr["blocks"], "flops": float(fl[R])}}
+           "distributed_fronts": [{"supernode": s_, "cols": int(c[s_]), "rows": int(r[s_]), "group": gsz[s_], "flops": float(fl[s_])}
+                                  for s_ in sorted(dset)]}
     if level_ms is not None:
         # levels of the UNSHARDED schedule: height above the leaves (a sharded handle re-levels its top fronts)
         ns = len(c)
@@ -293,14 +309,13 @@ def plan_summary(be, level_ms=None) -> dict:
         per_front = t_level[h] * fl / np.maximum(F[h], 1e-300)
         t_local = max(float(per_front[(owner == k) & ~top].sum()) for k in range(W))
         top_levels = np.unique(h[top])
-        t_latency = float(sum(t_level[l] for l in top_levels))
-        t_share = float(sum(max(per_front[top & (h == l) & (owner == k)].sum() for k in range(W)) for l in top_levels))
-        if R >= 0:
-            CHAIN_MS_PER_64, BCAST_GBS = 0.03, 100.0
-            t_root = float(per_front[R])
-            fixed = CHAIN_MS_PER_64 * dr["cols"] / 64.0 + 8.0 * dr["cols"] ** 2 / 2.0 / (BCAST_GBS * 1e6)
-            t_latency += -t_root + min(t_root, t_root / W + fixed)
-            t_share += -t_root + t_root / W
+        CHAIN_MS_PER_64, BCAST_GBS = 0.03, 100.0
+        fixed = lambda s_: CHAIN_MS_PER_64 * c[s_] / 64.0 + 8.0 * (r[s_] * c[s_] - c[s_] ** 2 / 2.0) / (BCAST_GBS * 1e6)
+        d_lat = lambda s_: min(float(per_front[s_]), float(per_front[s_]) / gsz[s_] + fixed(s_))
+        # latency form: the undistributed top fronts of a level cost their full time one after the other (no concurrency between
+        # the groups assumed), its distributed fronts the heaviest member's part
+        t_latency = float(sum(per_front[top & ~isd & (h == l)].sum() + heaviest(h, l, 0.0 * per_front, d_lat) for l in top_levels))
+        t_share = float(sum(heaviest(h, l, per_front, lambda s_: float(per_front[s_]) / gsz[s_]) for l in top_levels))
         # (the non-top fronts of a level that also holds top fronts are already in t_local with their share)
         t1 = float(t_level.sum())
         out.update({"measured_ms_one_gpu": t1, "time_bound_ms_latency": t_local + t_latency, "time_bound_ms_share": t_local + t_share,

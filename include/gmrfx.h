@@ -171,21 +171,27 @@ int32_t gmrfx_solve_phase(gmrfx_handle *h, const double *d_B, int64_t ldb, int64
  * phase entry points (gmrfx_refactorize_phase / _solve_phase / _selinv_phase) return after enqueueing -- no host-side
  * synchronisation between a phase and the exchange behind it (their HIP-event timings are not collected then). */
 int32_t gmrfx_set_stream(gmrfx_handle *h, void *hip_stream, int32_t use_external, int32_t async_phases);
-/* DISTRIBUTED ROOT (sharded handles; csrc/symbolic.h Symbolic::dist_root): when the root front has at least 4096 columns
- * (GMRFX_DIST_ROOT_MIN overrides; 0 = never) it is factored by ALL ranks -- the dense top front of a 3-D problem is a fifth of
- * all flops (cfg 4: 47 628 columns) and the single-address-space call it replaces, `cholesky!(F, S; check = false)`
- * (src/workspace/backend.jl:165-189), has no notion of it. 256-column blocks are dealt cyclically (block b on rank b mod
- * world); every rank stores the whole root panel.
- *   gmrfx_shard_dist_root: info[0] root supernode or -1, [1] columns, [2] blocks, [3] world, [4] panel offset in
- *     gmrfx_device_ptr(h, 1), [5] panel leading dimension, [6] number of column ranges; child / block / offset / count
- *     (nullable): `count` doubles at `offset` of gmrfx_device_ptr(h, 0) -- the columns of `child`'s contribution block that fall
- *     into root block `block` -- travel owner[child] -> rank block % world before the assembly.
- *   gmrfx_dist_root_phase(h, d_nzval, what, block): 0 = assemble this rank's blocks; 1 = factor block `block` (its owner; a
- *     no-op elsewhere) [then broadcast whole columns 256 block .. of the panel from rank block % world]; 2 = apply block
- *     `block` to this rank's later blocks. After the last block gmrfx_refactorize_phase of the last level closes the
- *     factorisation. Same kernels, same sums in the same order as an unsharded handle: bit-identical factor. */
-int32_t gmrfx_shard_dist_root(const gmrfx_handle *h, int64_t *info /* 8 */, int64_t *child, int64_t *block, int64_t *offset, int64_t *count);
-int32_t gmrfx_dist_root_phase(gmrfx_handle *h, const double *d_nzval, int32_t what, int32_t block);
+/* DISTRIBUTED TOP FRONTS (sharded handles; csrc/symbolic.h Symbolic::dist_fronts): a top front with at least 4096 columns
+ * (GMRFX_DIST_MIN overrides; 0 = never) whose group -- the ranks owning the subtrees below it -- has more than one rank is
+ * factored by the WHOLE GROUP: the dense top fronts of a 3-D problem hold most of the flops (cfg 4: the root alone has 47 628
+ * columns) and the single-address-space call this replaces, `cholesky!(F, S; check = false)` (src/workspace/backend.jl:165-189),
+ * has no notion of it. Panel columns and contribution-block columns are cut into 256-column blocks dealt cyclically over the
+ * group (panel block b -> group[b mod g], contribution-block block q -> group[(panel blocks + q) mod g]); every member stores
+ * the whole panel; sweeps and selected inversion of the front stay on its owner.
+ *   gmrfx_shard_dist_fronts: counts[0] fronts, [1] group entries, [2] transfers, [3] world; per front (nullable): supernode,
+ *     columns, rows, panel offset in gmrfx_device_ptr(h, 1), panel leading dimension, tree level; gptr / grank: its group.
+ *   gmrfx_shard_transfers: every contribution-block transfer of the factorisation, ordered by the parent's level: `count`
+ *     doubles (whole columns of `child`'s block) at `offset` of gmrfx_device_ptr(h, 0) go src -> dst before level `level` is
+ *     assembled (col0: the first of these columns). Replaces the cb_offset / cb_count columns of gmrfx_shard_edges for the factorisation.
+ *   gmrfx_dist_front_phase(h, d_nzval, front, what, block): 0 = assemble this rank's panel blocks; 1 = factor panel block
+ *     `block` (its owner; a no-op elsewhere) [then broadcast columns 256 block .. of the panel inside the group]; 2 = apply
+ *     block `block` to this rank's later panel blocks; 3 = this rank's blocks of the contribution block. A no-op on ranks
+ *     outside the group. Same kernels, same sums in the same order as an unsharded handle: bit-identical factor. */
+int32_t gmrfx_shard_dist_fronts(const gmrfx_handle *h, int64_t *counts /* 4 */, int64_t *front, int64_t *cols, int64_t *rows,
+                                int64_t *panel_offset, int64_t *panel_ld, int64_t *level, int64_t *gptr, int64_t *grank);
+int32_t gmrfx_shard_transfers(const gmrfx_handle *h, int64_t *child, int64_t *src, int64_t *dst, int64_t *level,
+                              int64_t *offset, int64_t *count, int64_t *col0);
+int32_t gmrfx_dist_front_phase(gmrfx_handle *h, const double *d_nzval, int32_t front, int32_t what, int32_t block);
 /* Profiling aid (handles created under GMRFX_LEVEL_MARK=1): HIP-event time of every tree level of the most recent
  * factorisation (which = 0), forward (1) or backward (2) sweep: ms[0] = the sweep tasks, ms[1 + l] = level l; *count = entries
  * written (0 when the marks are off). gmrfx/shard.py turns them into the TIME bound of a sharding plan (plan_summary). */

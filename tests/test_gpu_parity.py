@@ -543,8 +543,8 @@ def _shard_gpu_worker(rank, world, port, q, case="2d"):
         dist.init_process_group("gloo", rank=rank, world_size=world)
         import gmrfx as g
         from gmrfx import spde as sp_, shard
-        if case == "3d_dist_root":      # 28^3-node 3-D mesh, root front (~800 columns) factored by all ranks together
-            os.environ["GMRFX_DIST_ROOT_MIN"] = "256"
+        if case == "3d_dist":      # 28^3-node 3-D mesh: the root front (~800 columns) is factored by all ranks together, at world 4 the
+            os.environ["GMRFX_DIST_MIN"] = "256"        # separators below it (~400 columns, with contribution blocks) by two ranks each
             m = sp_.grid_mesh_3d(28, 28, 28)
             Q = sp_.matern_precision(m, 0, 0.4)
         else:
@@ -562,8 +562,8 @@ def _shard_gpu_worker(rank, world, port, q, case="2d"):
                 return bool(torch.equal(a, b))
             return float((a - b).abs().max()) <= 1e-11 * float(b.abs().max())
 
-        if case == "3d_dist_root":
-            assert sf.dr["root"] >= 0 and sf.dr["blocks"] >= 3, sf.dr
+        if case == "3d_dist":
+            assert len(sf.df["front"]) >= 1 and max(sf.df["cols"]) >= 513 and sf.df["group"][-1] == list(range(world)), sf.df
         for _ in range(2):                               # twice: the second run reuses every buffer
             assert sf.refactorize_dev(d_nz.data_ptr()) == 0
         ld = sf.logdet()
@@ -584,8 +584,9 @@ def _shard_gpu_worker(rank, world, port, q, case="2d"):
         same = True
         why = []
         check = set(np.nonzero(mine)[0].tolist())
-        if sf.dr["root"] >= 0:
-            check.add(sf.dr["root"])        # after the last broadcast EVERY rank holds the whole root panel
+        for i, s_ in enumerate(sf.df["front"]):     # after its last broadcast EVERY member of the group holds a distributed front's panel
+            if rank in sf.df["group"][i]:
+                check.add(int(s_))
         for s in sorted(check):
             a, ar = int(sy.panel_ptr[s]), int(rsy.panel_ptr[s])
             c, r, ldp = int(sy.super_first[s + 1] - sy.super_first[s]), int(sy.row_ptr[s + 1] - sy.row_ptr[s]), int(sy.panel_ld[s])
@@ -635,7 +636,8 @@ def _shard_gpu_worker(rank, world, port, q, case="2d"):
         if not (np.array_equal(dsh, dref) if case == "2d" else np.abs(dsh - dref).max() <= 1e-11 * np.abs(dref).max()):
             same = False
             why.append(f"sharded selinv diagonal differs from the unsharded one by {np.abs(dsh - dref).max():.3e} (rel {np.abs(dsh / dref - 1).max():.3e})")
-        info = dict(sf.be.shard_info()); info["why"] = why[:5]; info["dist_root"] = sf.dr["root"]
+        info = dict(sf.be.shard_info()); info["why"] = why[:5]; info["n_dist"] = len(sf.df["front"])
+        info["n_dist_cb"] = int(sum(1 for i in range(len(sf.df["front"])) if sf.df["rows"][i] > sf.df["cols"][i] and len(sf.df["group"][i]) > 1))
         st, rst = sf.be.stats(), ref.stats()
         info["mem"] = {k: (float(st[k]), float(rst[k])) for k in ("bytes_factor", "bytes_cb_arena", "bytes_device_total")}
         q.put((rank, ld, ref.compute_logdet(), bool(same), int(mine.sum()), info))
@@ -687,15 +689,17 @@ def _check_shard_memory(got, world):
 
 
 @pytest.mark.parametrize("world", [2, 4])
-def test_distributed_root_front_rehearsal_on_one_gpu(world):
-    """The root front factored by ALL ranks (256-column blocks dealt cyclically, block-column broadcasts, K = 256 updates of
-    the own later blocks; Symbolic::dist_root, Device::dist_root_phase, shard.py _factor_distributed_root) on a 28^3-node 3-D
-    mesh: every rank's panels -- and the whole root panel on every rank -- equal the unsharded factor bit for bit, and so do
-    the solves, the log-determinant and the selected-inverse diagonal."""
+def test_distributed_top_fronts_rehearsal_on_one_gpu(world):
+    """Top fronts factored by their whole GROUP (256-column blocks dealt cyclically, block-column broadcasts inside the group,
+    K = 256 updates of the own later blocks, own column blocks of the contribution block, children's blocks by column ranges;
+    Symbolic::dist_fronts, Device::dist_front_phase, shard.py _factor_distributed_front) on a 28^3-node 3-D mesh: the root by
+    all ranks, at world 4 the separators below it by two ranks each. Every rank's panels -- and a distributed front's whole
+    panel on every member of its group -- equal the unsharded factor bit for bit, and so do the log-determinant, and to
+    rounding the solves and the selected-inverse diagonal."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_shard_gpu_worker, args=(r, world, 29750 + world, q, "3d_dist_root")) for r in range(world)]
+    procs = [ctx.Process(target=_shard_gpu_worker, args=(r, world, 29750 + world, q, "3d_dist")) for r in range(world)]
     [p.start() for p in procs]
     got = []
     for _ in range(world):
@@ -705,7 +709,9 @@ def test_distributed_root_front_rehearsal_on_one_gpu(world):
     [p.join(timeout=120) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     for rank, ld, ld_ref, same, nmine, info in got:
-        assert same and nmine > 0 and info["dist_root"] >= 0, f"rank {rank}: {info.get('why')}"
+        assert same and nmine > 0 and info["n_dist"] >= 1, f"rank {rank}: {info.get('why')}"
+        if world == 4:
+            assert info["n_dist_cb"] >= 1, info        # a distributed front WITH a contribution block was exercised
         assert abs(ld - ld_ref) <= 1e-12 * abs(ld_ref)
 
 
