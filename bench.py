@@ -243,6 +243,8 @@ def main():
     ap.add_argument("--grid", type=int, default=1000, help="nodes per side of the 2-D mesh (cfg 2: 1000)")
     ap.add_argument("--nrhs", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--separate-calls", action="store_true",
+                    help="time gmrfx_refactorize_dev + gmrfx_solve_dev per step instead of the one pipelined call gmrfx_refactorize_solve_dev")
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-process rehearsal on a box with ONE GPU: every rank uses cuda:0 and the "
                          "process group runs on gloo (RCCL refuses two ranks on one device)")
@@ -315,10 +317,16 @@ def main():
     d_X = torch.empty_like(d_B)
     torch.cuda.synchronize()
 
-    def step():
+    def step_separate():
         be.refactorize_dev(d_nz.data_ptr())
         be.solve_dev(d_B.data_ptr(), n, args.nrhs, d_X.data_ptr(), n)
 
+    def step_pipelined():
+        # workspace_solve on a workspace with new values (gmrf_workspace.jl:170-178 + 207-215) as ONE call: the forward sweep
+        # follows the factorisation up the tree on a second stream; same bits as the two calls
+        be.refactorize_solve_dev(d_nz.data_ptr(), d_B.data_ptr(), n, args.nrhs, d_X.data_ptr(), n)
+
+    step = step_separate if args.separate_calls else step_pipelined
     for _ in range(args.warmup):
         step()
 
@@ -343,6 +351,27 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # The phases one after the other (the two separate calls), untimed by `value`: in the pipelined step the forward sweep runs
+    # beside the factorisation, so the per-phase device times that the factor / sweep rooflines need only exist here. Same
+    # kernels, same launches, same results.
+    pipelined_phases = None
+    ms_step_separate = None
+    if not args.separate_calls:
+        pipelined_phases = {"factor": float(np.median(t_factor)), "behind_factor": float(np.median(t_solve)),
+                            "forward_left_behind_factor": float(np.median(t_fwd)), "backward": float(np.median(t_bwd)),
+                            "syrk_launches": float(np.median(t_syrk))}
+        t_factor, t_solve, t_fwd, t_bwd, t_perm, t_syrk_sep = [], [], [], [], [], []
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step_separate()
+            s = be.stats()
+            t_factor.append(s["ms_factor"]); t_solve.append(s["ms_solve"])
+            t_fwd.append(s["ms_solve_fwd"]); t_bwd.append(s["ms_solve_bwd"]); t_perm.append(s["ms_solve_perm"])
+            t_syrk_sep.append(s["ms_syrk"])
+        torch.cuda.synchronize()
+        ms_step_separate = 1e3 * (time.perf_counter() - t1) / args.steps
+        pipelined_phases["syrk_launches_separate"] = float(np.median(t_syrk_sep))
 
     # hyper-parameter loop (docs/.../workspace_factorization_reuse.jl:94-102): new values -> numeric
     # factorisation -> logpdf(z) = -r'Qr/2 + logdet(Q)/2 - n log(2 pi)/2, Q's values and z resident in HBM.
@@ -496,8 +525,13 @@ def main():
                        "peak_measured": FP64_MFMA_MEASURED_TF, "frac_of_measured_peak": syrk_tf / FP64_MFMA_MEASURED_TF,
                        "kernel": "k_syrk_cb_rec", "launches_per_step": n_launch, "avg_launch_ms": ms_syrk / n_launch,
                        "flops_per_launch": st["syrk_flops"] / n_launch, "ms_per_step": ms_syrk,
-                       "note": "achieved = algorithmic flops of the launches of one step / their summed HIP-event time; "
+                       "note": "achieved = algorithmic flops of the launches of one step / their summed HIP-event time over the "
+                               "timed (pipelined) steps -- the forward sweep of the same step runs beside some of them; "
                                "traffic = PMC HBM bytes per launch (profiles/r03_pmc_traffic.json)"}
+        if pipelined_phases is not None:
+            alone = pipelined_phases["syrk_launches_separate"]
+            roof_kernel.update({"ms_per_step_alone": alone, "achieved_alone": st["syrk_flops"] / (alone * 1e-3) / 1e12,
+                                "frac_alone": st["syrk_flops"] / (alone * 1e-3) / 1e12 / FP64_MFMA_PEAK_TF})
         roof_factor = {"bound": "mfma", "achieved": factor_tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                        "frac": factor_tf / FP64_MFMA_PEAK_TF, "traffic": pmc["factor"]["total_bytes"] if pmc else None,
                        "peak_measured": FP64_MFMA_MEASURED_TF, "frac_of_measured_peak": factor_tf / FP64_MFMA_MEASURED_TF,
@@ -537,6 +571,9 @@ def main():
                        "ordering": "own geometric nested dissection"},
             "roofline": roof_kernel,
             "roofline_factor": roof_factor, "roofline_sweep": roof_sweep, **roof_cfg3,
+            "step_call": "gmrfx_refactorize_dev + gmrfx_solve_dev" if args.separate_calls else
+                         "gmrfx_refactorize_solve_dev (one pipelined call; include/gmrfx.h)",
+            "ms_per_step_separate_calls": ms_step_separate, "pipelined_phases_ms": pipelined_phases,
             "phases_ms": {"factor": mf, "solve": ms_, "solve_fwd": mfw, "solve_bwd": mbw, "solve_perm": med(t_perm),
                           "symbolic_host": st0["ms_symbolic"], **extras},
             "logpdf_per_s": (1e3 / logpdf_ms) if logpdf_ms else None, "logpdf_ms": logpdf_ms, "ms_quadform": ms_quadform,

@@ -52,6 +52,7 @@ Device::~Device() {
     for (auto &p : allocs_) (void)hipFree(p.first);
     for (auto &e : ev_) if (e) (void)hipEventDestroy(e);
     for (auto &v : ev_level_) for (auto &e : v) (void)hipEventDestroy(e);
+    for (auto &e : ev_flevel_) (void)hipEventDestroy(e);
     for (auto &e : ev_la_p_) (void)hipEventDestroy(e);
     for (auto &e : ev_la_t_) (void)hipEventDestroy(e);
     for (auto &l : ev_lane_) for (auto &e : l) if (e) (void)hipEventDestroy(e);
@@ -415,6 +416,51 @@ void Device::upload(const Symbolic &S) {
         }
         d_invT_ = dalloc<double>((size_t)std::max<long long>(tmax, 1));
         HC(hipStreamSynchronize(stream));
+        // the same stages level by level (pipelined factor + solve: the inverses of a level are built right behind its
+        // factorisation; the levels follow each other on one stream, so they share the workspace)
+        std::vector<int> cat;
+        inv_lvl_first_.assign(S.nlevels + 1, 0); inv_lvl_maxc_.assign(S.nlevels, 0); inv_lvl_nact_.assign(S.nlevels, {});
+        std::vector<std::vector<int>> per(S.nlevels);
+        for (int s : il) per[S.level[s]].push_back(s);      // (il is sorted by decreasing width: so is every level's list)
+        for (i32 l = 0; l < S.nlevels; l++) {
+            inv_lvl_first_[l] = (int)cat.size();
+            inv_lvl_maxc_[l] = per[l].empty() ? 0 : S.ncols(per[l][0]);
+            cat.insert(cat.end(), per[l].begin(), per[l].end());
+        }
+        inv_lvl_first_[S.nlevels] = (int)cat.size();
+        if (!cat.empty()) {
+            const int *cp; up(cp, cat); d_inv_lvl_list_ = const_cast<int *>(cp);
+            for (int B = NB; B < inv_maxc_; B *= 2) {
+                std::vector<long long> off(cat.size(), 0);
+                for (i32 l = 0; l < S.nlevels; l++) {
+                    long long acc = 0;
+                    int na = 0;
+                    for (int s : per[l]) {
+                        if (S.ncols(s) <= B) break;
+                        off[(size_t)inv_lvl_first_[l] + na] = acc;
+                        acc += (long long)((S.ncols(s) + 2 * B - 1) / (2 * B)) * B * B;
+                        na++;
+                    }
+                    inv_lvl_nact_[l].push_back(na);
+                }
+                const long long *lq; up(lq, off); d_inv_lvl_toff_.push_back(const_cast<long long *>(lq));
+            }
+            HC(hipStreamSynchronize(stream));
+        }
+    }
+    {   // the highest level a sweep task or a one-workgroup subtree reaches: the bottom of the forward sweep starts behind it
+        bottom_top_level_ = 0;
+        for (size_t t = 0; t < S.swt_last.size(); t++) bottom_top_level_ = std::max<int>(bottom_top_level_, S.level[S.swt_last[t]]);
+        for (i32 s = 0; s < ns; s++) if (S.in_subtree[s]) bottom_top_level_ = std::max<int>(bottom_top_level_, S.level[s]);
+        bottom_top_level_ = std::min<int>(bottom_top_level_, std::max<int>(S.nlevels - 1, 0));
+        // The bottom of the forward sweep is throughput work whose workgroups hold a CU's LDS for their whole life; started
+        // while the factorisation still is throughput work itself (the wide middle of the tree) it only takes the chip away
+        // from it. It is held back until the factorisation reaches its latency-bound top: the first level from which on every
+        // level has at most 32 fronts (GMRFX_FUSED_GATE: levels below the root, overrides).
+        int gate = S.nlevels - 1;
+        while (gate > 0 && levels_[gate - 1].count <= 32) gate--;
+        if (const char *e = std::getenv("GMRFX_FUSED_GATE")) gate = S.nlevels - 1 - std::atoi(e);
+        fused_gate_level_ = std::min<int>(std::max(gate, bottom_top_level_), std::max<int>(S.nlevels - 1, 0));
     }
 
     // Contribution-block tiles of every level in hand-out order: front by front (the level list's order), inside a
@@ -693,6 +739,7 @@ void Device::factor_levels(int lo, int hi) {
             HC(hipEventRecord(ev_done1_, stream3));
             HC(hipStreamWaitEvent(stream, ev_done1_, 0));
         }
+        if (fused_) HC(hipEventRecord(ev_flevel_[lev], stream));      // the panels of this level are final: its sweep may start
     }
     syrk_launches = nsy;
     if (level_mark_) level_event(0, hi);
@@ -725,6 +772,123 @@ void Device::invert_diag_blocks(hipStream_t stream, int b_from, int b_to) {
         launch_inv_stage(stream, ds_, d_invlist_, na, B, inv_maxc_, 1, d_L_, d_invT_, d_inv_toff_[stage]);
         launch_inv_stage(stream, ds_, d_invlist_, na, B, inv_maxc_, 2, d_L_, d_invT_, d_inv_toff_[stage]);
     }
+}
+
+void Device::invert_level(hipStream_t st, int lev) {
+    if (inv_lvl_first_.empty() || inv_lvl_maxc_[lev] <= NB) return;
+    int stage = 0;
+    for (int B = NB; B < std::min(inv_lvl_maxc_[lev], inv_cap_); B *= 2, stage++) {
+        const int na = inv_lvl_nact_[lev][stage];
+        if (na <= 0) break;
+        launch_inv_stage(st, ds_, d_inv_lvl_list_ + inv_lvl_first_[lev], na, B, inv_lvl_maxc_[lev], 1, d_L_, d_invT_, d_inv_lvl_toff_[stage] + inv_lvl_first_[lev]);
+        launch_inv_stage(st, ds_, d_inv_lvl_list_ + inv_lvl_first_[lev], na, B, inv_lvl_maxc_[lev], 2, d_L_, d_invT_, d_inv_lvl_toff_[stage] + inv_lvl_first_[lev]);
+    }
+}
+
+// Numeric factorisation + solve in ONE call, pipelined (gmrfx_refactorize_solve; the reference does both inside one call as
+// well: workspace_solve = ensure_numeric! -> refactorize!, then backend_solve, src/workspace/gmrf_workspace.jl:170-178, 207-215).
+// The top of the factorisation is a chain of small dependent launches that leaves most of the chip idle, the bottom of the
+// forward sweep is throughput work that only needs the BOTTOM of the factor: the forward sweep (transpose in, sweep tasks,
+// then level by level: dense-inverse stages of the level, assembly, triangular product, update) runs on the low-priority
+// side stream and follows the factorisation up the tree -- level l starts when the event "level l is factored" has passed.
+// When the root has been factored only the root's own forward step is left; the backward sweep follows on the main stream.
+// Same kernels, same operands, same order per front as refactorize() + solve(): bit-identical results.
+void Device::refactorize_solve(const double *nzval, bool nz_on_device, const double *B, long long ldb, long long nrhs, double *X, long long ldx_out,
+                               bool b_on_device) {
+    HC(hipSetDevice(device));
+    if (sharded()) throw std::invalid_argument("sharded handle: use the phase entry points (gmrfx/shard.py)");
+    if (nrhs <= 0 || level_mark_ || stream != own_stream_) {      // nothing to pipeline / profiling marks / caller's stream: the plain sequence
+        refactorize(nzval, nz_on_device);
+        if (nrhs > 0) solve(B, ldb, nrhs, X, ldx_out, b_on_device, 0);
+        return;
+    }
+    const long long n = S_->n;
+    const int nl = (int)levels_.size();
+    const double *src = nzval;
+    if (!nz_on_device) {
+        HC(hipMemcpyAsync(d_nz_, nzval, (size_t)S_->nnz_in * sizeof(double), hipMemcpyHostToDevice, stream));
+        src = d_nz_;
+    }
+    nz_held_ = (src == d_nz_);
+    nz_src_ = src;
+    ensure_rhs_capacity(nrhs);
+    const double *dB = B;
+    double *dXo = X;
+    long long ldin = ldb, ldout = ldx_out;
+    if (!b_on_device) {
+        const long long need = n * nrhs;
+        if (need > io_cap_) { const long long cap = std::max(need, 2 * io_cap_); d_io_ = dregrow(d_io_, (size_t)cap); io_cap_ = cap; }
+        if (ldb == n) HC(hipMemcpyAsync(d_io_, B, (size_t)need * sizeof(double), hipMemcpyHostToDevice, stream));
+        else HC(hipMemcpy2DAsync(d_io_, n * sizeof(double), B, ldb * sizeof(double), n * sizeof(double), nrhs, hipMemcpyHostToDevice, stream));
+        dB = d_io_; dXo = d_io_; ldin = n; ldout = n;
+    }
+    while ((int)ev_flevel_.size() < nl + 1) { hipEvent_t e; HC(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ev_flevel_.push_back(e); }
+    factor_serial_++;
+    HC(hipEventRecord(ev_[0], stream));
+    HC(hipEventRecord(ev_ready_, stream));                 // the side stream starts behind the uploads / whatever precedes this call
+    struct Flag { bool &f; ~Flag() { f = false; } } f1{fused_}, f2{fused_fwd_};
+    fused_ = true;
+    factor_levels(0, nl);
+    fused_ = false;
+    HC(hipEventRecord(ev_[1], stream));
+    HC(hipEventRecord(ev_fact_, stream));
+    fact_event_valid_ = true;
+    HC(hipMemcpyAsync(h_info_, d_info_, sizeof(int), hipMemcpyDeviceToHost, stream));
+    factorized = true;
+    selinv_valid = false;
+    // ---- first pass of up to 64 columns: forward sweep on the side stream, behind the level events
+    const int nr = (int)std::min<long long>(64, nrhs), ldx = nr;
+    hipEvent_t *ev = ev_lane_[0];
+    {
+        const hipStream_t main_stream = stream;
+        struct Restore { Device &D; hipStream_t st; ~Restore() { D.stream = st; } } restore{*this, main_stream};
+        stream = stream2;
+        HC(hipStreamWaitEvent(stream, ev_ready_, 0));
+        HC(hipEventRecord(ev[0], stream));
+        launch_permute(stream, d_iperm_, (int)n, const_cast<double *>(dB), ldin, d_X_, nr, ldx, 0);
+        HC(hipEventRecord(ev[1], stream));
+        fused_fwd_ = true;
+        forward(nr, ldx, 0, nl);
+        fused_fwd_ = false;
+        HC(hipEventRecord(ev_inv_, stream));             // every level's inverses exist: later solves pass wait_inverse() at once
+        HC(hipEventRecord(ev[2], stream));
+    }
+    inverse_pending = false;
+    inverse_full_ = inv_maxc_ <= inv_cap_;
+    HC(hipStreamWaitEvent(stream, ev[2], 0));
+    backward(nr, ldx, true, nl, 0);
+    HC(hipEventRecord(ev[3], stream));
+    launch_permute(stream, d_iperm_, (int)n, dXo, ldout, d_X_, nr, ldx, 1);
+    HC(hipEventRecord(ev[4], stream));
+    // ---- further passes: the factor is complete, plain sweeps on the main stream
+    for (long long j0 = 64; j0 < nrhs; j0 += 64) {
+        const int nr2 = (int)std::min<long long>(64, nrhs - j0);
+        launch_permute(stream, d_iperm_, (int)n, const_cast<double *>(dB) + j0 * ldin, ldin, d_X_, nr2, nr2, 0);
+        forward(nr2, nr2, 0, nl);
+        backward(nr2, nr2, true, nl, 0);
+        launch_permute(stream, d_iperm_, (int)n, dXo + j0 * ldout, ldout, d_X_, nr2, nr2, 1);
+    }
+    HC(hipEventRecord(ev_lane_[1][0], stream));
+    if (!b_on_device) {
+        const long long need = n * nrhs;
+        if (ldx_out == n) HC(hipMemcpyAsync(X, d_io_, (size_t)need * sizeof(double), hipMemcpyDeviceToHost, stream));
+        else HC(hipMemcpy2DAsync(X, ldx_out * sizeof(double), d_io_, n * sizeof(double), n * sizeof(double), nrhs, hipMemcpyDeviceToHost, stream));
+    }
+    HC(hipStreamSynchronize(stream));
+    info_cached_ = true;
+    HC(hipGetLastError());
+    float tf = 0, a = 0, b = 0, c = 0, d = 0, tail = 0;
+    HC(hipEventElapsedTime(&tf, ev_[0], ev_[1]));
+    HC(hipEventElapsedTime(&a, ev[0], ev[1]));
+    HC(hipEventElapsedTime(&b, ev_[1], ev[2]));          // what is left of the forward sweep once the factor is complete
+    HC(hipEventElapsedTime(&c, ev[2], ev[3]));
+    HC(hipEventElapsedTime(&d, ev[3], ev[4]));
+    HC(hipEventElapsedTime(&tail, ev_[1], ev_lane_[1][0]));
+    ms_factor = tf;
+    ms_perm = a + d; ms_fwd = std::max(b, 0.0f); ms_bwd = b >= 0 ? c : c + b;
+    ms_solve = tail;                                     // device time behind the factorisation: ms_factor + ms_solve = the step
+    syrk_times_pending_ = true;
+    last_nrhs = nrhs;
 }
 
 void Device::refactorize(const double *nzval, bool on_device) {
@@ -931,6 +1095,12 @@ void Device::ensure_rdiag() {
 
 void Device::forward(int nr, int ldx, int lo, int hi) {
     if (level_mark_ && lo == 0) { launch_level_mark(stream, 1, -1); level_event(1, 0); }
+    // pipelined factor + solve (refactorize_solve): the bottom waits for the highest level a task / subtree reaches, every level
+    // above for its own "factored" event; the dense inverses are built level by level instead of all at once
+    if (fused_fwd_) {
+        HC(hipStreamWaitEvent(stream, ev_flevel_[fused_gate_level_], 0));
+        if (nr <= wave_max_nr_ && nswt_ > 0) rdiag_for_ = 0;      // 1 / L_jj of the task fronts: their diagonals are final now, the rest is never read
+    }
     if (lo == 0) sweep_tasks(1, nr, ldx);
     if (lo == 0)
         for (int k = 0, off = 0; k < 3; off += nsub_cls_[k], k++)
@@ -939,7 +1109,10 @@ void Device::forward(int nr, int ldx, int lo, int hi) {
     for (int lev = lo; lev < hi; lev++) {
         auto &L = swlevels_[lev];
         if (level_mark_) { launch_level_mark(stream, 1, lev); level_event(1, 1 + lev); }
-        if (lev == std::max(lo, first_multiblock_level_)) wait_inverse();
+        if (fused_fwd_) {
+            if (lev > fused_gate_level_) HC(hipStreamWaitEvent(stream, ev_flevel_[lev], 0));
+            invert_level(stream, lev);
+        } else if (lev == std::max(lo, first_multiblock_level_)) wait_inverse();
         for (int k = 0, off = 0; k < 4; off += L.ncls[k], k++)
             launch_fwd_small(stream, ds_, d_sw_levellist_ + L.first + off, L.ncls[k], kClsRows[k], d_L_, d_X_, d_W_, nr, ldx);
         const int *list = d_sw_levellist_ + L.first + L.nsmall;

@@ -143,6 +143,10 @@ public:
     void clone_from(const Device &o, const Symbolic &S);
 
     void refactorize(const double *nzval, bool on_device);
+    // numeric factorisation + solve as ONE pipelined call (gmrfx_refactorize_solve): the forward sweep follows the factorisation
+    // up the tree, one level behind, on the side stream
+    void refactorize_solve(const double *nzval, bool nz_on_device, const double *B, long long ldb, long long nrhs, double *X, long long ldx,
+                           bool b_on_device);
     // Newton loop with Q resident on the device: set_prior uploads the prior's values (and the
     // Hessian -> Q index map) once; refactorize_update forms nz = prior, nz[map[k]] -= h[k] on the device from the
     // cnt Hessian values (host or device) and refactorises -- only h crosses PCIe per iterate.
@@ -284,6 +288,16 @@ private:
     // inversion needs the full inverses and runs the remaining stages on demand (B from inv_cap_ up).
     int inv_cap_ = 2048;     // measured: cfg 2 flat between 1024 and 4096 (6.18 vs 6.26 ms), 3-D 100^3 solve 44 vs 54 ms
     bool inverse_full_ = false;
+    // pipelined factor + solve: per-level "level is factored" events, the dense-inverse stages per level, the highest level a
+    // sweep task / small subtree reaches
+    bool fused_ = false, fused_fwd_ = false;
+    std::vector<hipEvent_t> ev_flevel_;
+    int bottom_top_level_ = 0, fused_gate_level_ = 0;
+    int *d_inv_lvl_list_ = nullptr;
+    std::vector<int> inv_lvl_first_, inv_lvl_maxc_;
+    std::vector<std::vector<int>> inv_lvl_nact_;              // [level][stage]
+    std::vector<long long *> d_inv_lvl_toff_;                  // per stage: offsets into d_invT_, aligned with d_inv_lvl_list_
+    void invert_level(hipStream_t st, int lev);
     bool fact_event_valid_ = false;   // ev_fact_ was recorded at the end of the last factorisation
     int *h_info_ = nullptr;           // pinned: the pivot report of the last factorisation
     bool info_cached_ = false;

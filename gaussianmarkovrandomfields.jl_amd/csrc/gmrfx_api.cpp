@@ -155,6 +155,31 @@ static int32_t refactorize_impl(gmrfx_handle *h, const double *nz, int64_t *info
 }
 extern "C" int32_t gmrfx_refactorize(gmrfx_handle *h, const double *nzval, int64_t *info) { return refactorize_impl(h, nzval, info, false); }
 
+// workspace_solve with a stale factorisation (src/workspace/gmrf_workspace.jl:170-178, 207-215: ensure_numeric! -> refactorize!,
+// then backend_solve) as one pipelined call: Device::refactorize_solve. X is only meaningful when *info == 0.
+static int32_t refactorize_solve_impl(gmrfx_handle *h, const double *nz, const double *B, int64_t ldb, int64_t nrhs, double *X, int64_t ldx,
+                                      int64_t *info, bool dev) {
+    return guarded(h, [&]() -> int32_t {
+        if (int32_t e = need_device(h, false)) return e;
+        if (!nz) throw std::invalid_argument("nzval is null");
+        if (nrhs < 0) throw std::invalid_argument("nrhs < 0");
+        if (nrhs > 0 && (!B || !X)) throw std::invalid_argument("B/X is null");
+        if (nrhs > 0 && (ldb < h->S.n || ldx < h->S.n)) throw std::invalid_argument("leading dimension smaller than n");
+        h->D->refactorize_solve(nz, dev, B, ldb, nrhs, X, ldx, dev);
+        long long fc = h->D->fail_col();
+        if (info) *info = fc < 0 ? 0 : fc + 1;
+        if (fc >= 0 && h->opts.check_posdef) {
+            h->err = "matrix is not positive definite (non-positive pivot at elimination step " + std::to_string(fc + 1) + ")";
+            return GMRFX_ERR_NOT_POSDEF;
+        }
+        return GMRFX_OK;
+    });
+}
+extern "C" int32_t gmrfx_refactorize_solve(gmrfx_handle *h, const double *nzval, const double *B, int64_t ldb, int64_t nrhs, double *X,
+                                           int64_t ldx, int64_t *info) { return refactorize_solve_impl(h, nzval, B, ldb, nrhs, X, ldx, info, false); }
+extern "C" int32_t gmrfx_refactorize_solve_dev(gmrfx_handle *h, const double *d_nzval, const double *d_B, int64_t ldb, int64_t nrhs, double *d_X,
+                                               int64_t ldx, int64_t *info) { return refactorize_solve_impl(h, d_nzval, d_B, ldb, nrhs, d_X, ldx, info, true); }
+
 // ---- Newton loop on the device -----------------------------------------------------------
 extern "C" int32_t gmrfx_set_prior(gmrfx_handle *h, const double *prior_nzval, const int64_t *map, int64_t cnt, int32_t index_base) {
     return guarded(h, [&]() -> int32_t {

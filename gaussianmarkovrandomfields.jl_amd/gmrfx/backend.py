@@ -342,6 +342,34 @@ class MI355XBackend:
         self.last_info = info.value
         return info.value
 
+    def refactorize_solve_dev(self, d_nzval_ptr: int, d_B: int, ldb: int, nrhs: int, d_X: int, ldx: int) -> int:
+        """`workspace_solve` on a workspace with new values (gmrf_workspace.jl:170-178, 207-215): numeric factorisation and
+        solve as one pipelined call; same bits as refactorize_dev + solve_dev."""
+        info = C.c_int64(0)
+        check(lib().gmrfx_refactorize_solve_dev(self._h, d_nzval_ptr, d_B, ldb, nrhs, d_X, ldx, C.byref(info)), self._h)
+        self._selinv_cache = None
+        self._selinv_diag_cache = None
+        self.last_info = info.value
+        return info.value
+
+    def refactorize_solve(self, nzval, rhs):
+        """Host-array form of refactorize_solve_dev: new values of Q (pattern order) and right-hand sides -> X (fresh array)."""
+        nz = np.ascontiguousarray(nzval, dtype=np.float64)
+        if nz.shape != (self._nnz,):
+            raise ValueError("nzval length does not match the pattern")
+        B = np.asarray(rhs, dtype=np.float64)
+        if B.shape[0] != self.n:
+            raise ValueError("dimension mismatch")
+        vec = B.ndim == 1
+        Bf = np.asfortranarray(B.reshape(self.n, -1))
+        X = np.empty_like(Bf, order="F")
+        info = C.c_int64(0)
+        check(lib().gmrfx_refactorize_solve(self._h, ptr(nz), ptr(Bf), self.n, Bf.shape[1], ptr(X), self.n, C.byref(info)), self._h)
+        self._selinv_cache = None
+        self._selinv_diag_cache = None
+        self.last_info = info.value
+        return X[:, 0].copy() if vec else X
+
     # -- Newton loop on the device (SURVEY 8 f4; src/workspace/gaussian_approximation.jl:63-129) --------
     def set_prior(self, prior_nzval, hess_map) -> None:
         """prior_nzval: values of the prior precision in the pattern's CSC order; hess_map: 0-based positions

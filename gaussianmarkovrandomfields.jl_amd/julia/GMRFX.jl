@@ -103,6 +103,23 @@ function refactorize!(b::MI355XBackend, Q::Symmetric)
     return nothing                                  # never throws on indefiniteness (backend.jl:184)
 end
 
+# workspace_solve(ws, B) on a workspace whose values were just updated (gmrf_workspace.jl:170-178, 207-215: ensure_numeric! then
+# backend_solve) as ONE pipelined call: the forward sweep follows the factorisation up the tree. Same bits as refactorize! +
+# backend_solve. A GMRFWorkspace method would be:
+#   workspace_solve(ws, B) = ws.numeric_valid ? backend_solve(ws.backend, B) :
+#       (X = refactorize_solve!(ws.backend, Symmetric(ws.Q), B); ws.numeric_valid = true; ws.selinv_valid = ws.logdet_valid = false; X)
+function refactorize_solve!(b::MI355XBackend, Q::Symmetric, rhs::AbstractVecOrMat)
+    nz = nonzeros(parent(Q))
+    B = Matrix{Float64}(reshape(rhs, b.n, :)); X = similar(B)
+    info = Ref{Int64}(0)
+    GC.@preserve nz B X check(ccall((:gmrfx_refactorize_solve, LIB), Int32,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64, Ref{Int64}),
+        b.h.ptr, nz, B, b.n, size(B, 2), X, b.n, info), b.h)
+    b.selinv_cache = nothing
+    b.selinv_diag_cache = nothing
+    return rhs isa AbstractVector ? vec(X) : X
+end
+
 function backend_solve(b::MI355XBackend, rhs::AbstractVector)
     B = Vector{Float64}(rhs); X = similar(B)
     GC.@preserve B X check(ccall((:gmrfx_solve, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64),

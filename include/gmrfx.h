@@ -114,6 +114,16 @@ int32_t gmrfx_clone(const gmrfx_handle *h, gmrfx_handle **out);
  * in the elimination order. */
 int32_t gmrfx_refactorize(gmrfx_handle *h, const double *nzval, int64_t *info);
 int32_t gmrfx_refactorize_dev(gmrfx_handle *h, const double *d_nzval, int64_t *info);
+/* Numeric refactorisation AND solve Q X = B in one call. Replaces `workspace_solve(ws, B)` on a workspace whose values have
+ * just been updated (src/workspace/gmrf_workspace.jl:170-178 `ensure_numeric!` -> `refactorize!`, :207-215 `backend_solve`):
+ * the Newton / hyper-parameter loops always run the two back to back. Same results, bit for bit, as gmrfx_refactorize followed
+ * by gmrfx_solve -- but pipelined: the forward sweep follows the factorisation up the elimination tree on a second stream
+ * (level l of the sweep starts when level l is factored), so the bottom of the sweep fills the chip while the top of the
+ * factorisation is a chain of small dependent launches. X is only meaningful when *info == 0. B / X column-major n x nrhs. */
+int32_t gmrfx_refactorize_solve(gmrfx_handle *h, const double *nzval, const double *B, int64_t ldb, int64_t nrhs, double *X, int64_t ldx,
+                                int64_t *info);
+int32_t gmrfx_refactorize_solve_dev(gmrfx_handle *h, const double *d_nzval, const double *d_B, int64_t ldb, int64_t nrhs, double *d_X,
+                                    int64_t ldx, int64_t *info);
 
 /* ---- Newton loop with Q resident on the device -----------------------------------
  * Replaces `_update_hessian!` + `ensure_numeric!` of the Gaussian-approximation loop

@@ -41,6 +41,11 @@ def test_single_gpu_line_has_the_contract_fields():
     ph = d["phases_ms"]
     assert ph["factor"] > 0 and ph["solve"] > 0 and abs(ph["solve"] - (ph["solve_fwd"] + ph["solve_bwd"] + ph["solve_perm"])) < 0.3 * ph["solve"]
     assert d["logpdf_ms"] > 0 and d["logpdf_relerr_vs_host"] < 1e-12
+    # the timed step is the one pipelined call; the phases one after the other are measured beside it
+    assert "gmrfx_refactorize_solve_dev" in d["step_call"] and d["ms_per_step_separate_calls"] > 0
+    pp = d["pipelined_phases_ms"]
+    assert pp["factor"] > 0 and pp["behind_factor"] > 0 and pp["forward_left_behind_factor"] <= ph["solve_fwd"] + 0.05
+    assert d["roofline"]["achieved_alone"] > 0
 
 
 def test_two_rank_rehearsal_line_is_sharded_strong_scaling():

@@ -1040,3 +1040,66 @@ def test_lookahead_panel_chain_matches_the_oracle(monkeypatch):
     B = rng.standard_normal((n, 3))
     assert relerr(be.backend_solve(B), F.solve(B)) < 1e-10
     assert abs(be.compute_logdet() - F.logdet()) < 1e-11 * abs(F.logdet())
+
+
+@pytest.mark.parametrize("mesh_kind", ["2d", "3d"])
+def test_refactorize_solve_pipelined_equals_separate_calls(mesh_kind):
+    """gmrfx_refactorize_solve[_dev] (workspace_solve on a workspace with new values, gmrf_workspace.jl:170-178 + 207-215; the
+    forward sweep follows the factorisation up the tree on a second stream) against gmrfx_refactorize + gmrfx_solve on a second
+    handle: factor, X and log-determinant bit for bit, for 1 / 17 / 64 / 100 right-hand sides (wave tasks, workgroup tasks, a
+    second pass), repeated (events and buffers are reused), then the oracle's solve to 1e-10, a plain solve on the pipelined
+    handle afterwards (its dense inverses must be complete) and the pivot report of an indefinite matrix."""
+    import torch
+    if mesh_kind == "2d":
+        mesh = spde.grid_mesh_2d(150, 140, jitter=0.25, seed=5)
+        Q = spde.matern_precision(mesh, 0, 0.2)
+    else:
+        mesh = spde.grid_mesh_3d(22, 21, 20)
+        Q = spde.matern_precision(mesh, 0, 0.4)
+    n = Q.shape[0]
+    dev = torch.device("cuda", 0)
+    a = gmrfx.MI355XBackend(Q, coords=mesh.points, factorize=False)
+    b = gmrfx.MI355XBackend(Q, coords=mesh.points, factorize=False)
+    rng = np.random.default_rng(8)
+    for rep, nrhs in enumerate((64, 1, 17, 100, 64)):
+        scale = 1.0 + 0.25 * rep                                  # new values every time
+        d_nz = torch.from_numpy(np.ascontiguousarray(Q.data * scale)).to(dev)
+        Bh = rng.standard_normal((nrhs, n))
+        d_B = torch.from_numpy(Bh).to(dev)
+        d_Xa, d_Xb = torch.zeros_like(d_B), torch.zeros_like(d_B)
+        torch.cuda.synchronize()
+        assert a.refactorize_solve_dev(d_nz.data_ptr(), d_B.data_ptr(), n, nrhs, d_Xa.data_ptr(), n) == 0
+        assert b.refactorize_dev(d_nz.data_ptr()) == 0
+        b.solve_dev(d_B.data_ptr(), n, nrhs, d_Xb.data_ptr(), n)
+        torch.cuda.synchronize()
+        assert torch.equal(d_Xa, d_Xb), f"nrhs={nrhs}: pipelined and separate solves differ by {float((d_Xa - d_Xb).abs().max()):.3e}"
+        assert np.array_equal(a.factor_values(), b.factor_values())
+        assert a.compute_logdet() == b.compute_logdet()
+        resid = np.linalg.norm((Q * scale) @ d_Xa.cpu().numpy().T - Bh.T) / np.linalg.norm(Bh)
+        assert resid < 1e-10
+        # a plain solve on the pipelined handle: same bits again (the per-level inverses are all there)
+        d_Xc = torch.zeros_like(d_B)
+        a.solve_dev(d_B.data_ptr(), n, nrhs, d_Xc.data_ptr(), n)
+        torch.cuda.synchronize()
+        assert torch.equal(d_Xc, d_Xb)
+    # selected inversion after a pipelined call (it needs the full inverses of the diagonal blocks)
+    assert np.array_equal(a.get_selinv_diag(), b.get_selinv_diag())
+    # host-array form, against the oracle
+    F = orc.OracleFactor(Q, a.ordering_permutation())
+    Bh = rng.standard_normal((n, 3))
+    X = a.refactorize_solve(Q.data, Bh)
+    Xo = F.solve(Bh)
+    assert np.abs(X - Xo).max() <= 1e-10 * np.abs(Xo).max()
+    # an indefinite matrix: the pivot is reported like gmrfx_refactorize reports it, nothing hangs
+    bad = Q.copy().tocsc(); bad.sort_indices()
+    vals = bad.data.copy()
+    col = n // 2
+    k = bad.indptr[col] + int(np.searchsorted(bad.indices[bad.indptr[col]:bad.indptr[col + 1]], col))
+    vals[k] = -abs(vals[k])
+    d_bad = torch.from_numpy(vals).to(dev)
+    d_B = torch.from_numpy(rng.standard_normal((4, n))).to(dev); d_X = torch.zeros_like(d_B)
+    torch.cuda.synchronize()
+    ia = a.refactorize_solve_dev(d_bad.data_ptr(), d_B.data_ptr(), n, 4, d_X.data_ptr(), n)
+    ib = b.refactorize_dev(d_bad.data_ptr())
+    assert ia == ib > 0
+    a.close(); b.close()
