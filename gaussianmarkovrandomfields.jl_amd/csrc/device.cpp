@@ -797,7 +797,7 @@ void Device::refactorize_solve(const double *nzval, bool nz_on_device, const dou
                                bool b_on_device) {
     HC(hipSetDevice(device));
     if (sharded()) throw std::invalid_argument("sharded handle: use the phase entry points (gmrfx/shard.py)");
-    if (nrhs <= 0 || level_mark_ || stream != own_stream_) {      // nothing to pipeline / profiling marks / caller's stream: the plain sequence
+    if (nrhs <= 0 || stream != own_stream_) {      // nothing to pipeline / the caller's stream: the plain sequence
         refactorize(nzval, nz_on_device);
         if (nrhs > 0) solve(B, ldb, nrhs, X, ldx_out, b_on_device, 0);
         return;
@@ -1028,6 +1028,21 @@ void Device::refactorize_update(const double *h, bool on_device) {
     }
     launch_newton_update(stream, d_prior_, d_nz_, S_->nnz_in, d_hmap_, dh, hmap_cnt_);
     refactorize(d_nz_, true);
+}
+
+// One Newton iterate as one pipelined call: Q_k = Q_prior - H_k on the device, numeric factorisation, solve
+// (gaussian_approximation.jl:103-129: _update_hessian!, ensure_numeric!, then the solve for the new mean)
+void Device::refactorize_update_solve(const double *h, bool h_on_device, const double *B, long long ldb, long long nrhs, double *X, long long ldx,
+                                      bool b_on_device) {
+    HC(hipSetDevice(device));
+    if (!d_prior_) throw std::invalid_argument("gmrfx_set_prior has not been called");
+    const double *dh = h;
+    if (!h_on_device && hmap_cnt_ > 0) {
+        HC(hipMemcpyAsync(d_h_, h, (size_t)hmap_cnt_ * sizeof(double), hipMemcpyHostToDevice, stream));
+        dh = d_h_;
+    }
+    launch_newton_update(stream, d_prior_, d_nz_, S_->nnz_in, d_hmap_, dh, hmap_cnt_);
+    refactorize_solve(d_nz_, true, B, ldb, nrhs, X, ldx, b_on_device);
 }
 
 double Device::syrk_ms() {

@@ -147,6 +147,8 @@ public:
     // up the tree, one level behind, on the side stream
     void refactorize_solve(const double *nzval, bool nz_on_device, const double *B, long long ldb, long long nrhs, double *X, long long ldx,
                            bool b_on_device);
+    void refactorize_update_solve(const double *h, bool h_on_device, const double *B, long long ldb, long long nrhs, double *X, long long ldx,
+                                  bool b_on_device);
     // Newton loop with Q resident on the device: set_prior uploads the prior's values (and the
     // Hessian -> Q index map) once; refactorize_update forms nz = prior, nz[map[k]] -= h[k] on the device from the
     // cnt Hessian values (host or device) and refactorises -- only h crosses PCIe per iterate.

@@ -204,6 +204,28 @@ static int32_t refactorize_update_impl(gmrfx_handle *h, const double *hv, int64_
         return GMRFX_OK;
     });
 }
+// One Newton iterate in one pipelined call (Device::refactorize_update_solve): Hessian values in, new mean's solve out.
+static int32_t refactorize_update_solve_impl(gmrfx_handle *h, const double *hv, const double *B, int64_t ldb, int64_t nrhs, double *X, int64_t ldx,
+                                             int64_t *info, bool dev) {
+    return guarded(h, [&]() -> int32_t {
+        if (int32_t e = need_device(h, false)) return e;
+        if (nrhs < 0) throw std::invalid_argument("nrhs < 0");
+        if (nrhs > 0 && (!B || !X)) throw std::invalid_argument("B/X is null");
+        if (nrhs > 0 && (ldb < h->S.n || ldx < h->S.n)) throw std::invalid_argument("leading dimension smaller than n");
+        h->D->refactorize_update_solve(hv, dev, B, ldb, nrhs, X, ldx, dev);
+        long long fc = h->D->fail_col();
+        if (info) *info = fc < 0 ? 0 : fc + 1;
+        if (fc >= 0 && h->opts.check_posdef) {
+            h->err = "matrix is not positive definite (non-positive pivot at elimination step " + std::to_string(fc + 1) + ")";
+            return GMRFX_ERR_NOT_POSDEF;
+        }
+        return GMRFX_OK;
+    });
+}
+extern "C" int32_t gmrfx_refactorize_update_solve(gmrfx_handle *h, const double *hvals, const double *B, int64_t ldb, int64_t nrhs, double *X,
+                                                  int64_t ldx, int64_t *info) { return refactorize_update_solve_impl(h, hvals, B, ldb, nrhs, X, ldx, info, false); }
+extern "C" int32_t gmrfx_refactorize_update_solve_dev(gmrfx_handle *h, const double *d_hvals, const double *d_B, int64_t ldb, int64_t nrhs,
+                                                      double *d_X, int64_t ldx, int64_t *info) { return refactorize_update_solve_impl(h, d_hvals, d_B, ldb, nrhs, d_X, ldx, info, true); }
 extern "C" int32_t gmrfx_refactorize_update(gmrfx_handle *h, const double *hvals, int64_t *info) { return refactorize_update_impl(h, hvals, info, false); }
 extern "C" int32_t gmrfx_refactorize_update_dev(gmrfx_handle *h, const double *d_hvals, int64_t *info) { return refactorize_update_impl(h, d_hvals, info, true); }
 

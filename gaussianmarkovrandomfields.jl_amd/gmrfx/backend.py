@@ -393,6 +393,24 @@ class MI355XBackend:
         self.last_info = info.value
         return info.value
 
+    def refactorize_update_solve(self, hvals, rhs):
+        """One Newton iterate in one pipelined call: Q <- Q_prior - H, refactorise, solve Q X = rhs (gmrfx_refactorize_update_solve)."""
+        hv = np.ascontiguousarray(hvals, dtype=np.float64)
+        if hv.size != getattr(self, "_hess_cnt", -1):
+            raise ValueError("Hessian values do not match the index map passed to set_prior")
+        B = np.asarray(rhs, dtype=np.float64)
+        if B.shape[0] != self.n:
+            raise ValueError("dimension mismatch")
+        vec = B.ndim == 1
+        Bf = np.asfortranarray(B.reshape(self.n, -1))
+        X = np.empty_like(Bf, order="F")
+        info = C.c_int64(0)
+        check(lib().gmrfx_refactorize_update_solve(self._h, ptr(hv), ptr(Bf), self.n, Bf.shape[1], ptr(X), self.n, C.byref(info)), self._h)
+        self._selinv_cache = None
+        self._selinv_diag_cache = None
+        self.last_info = info.value
+        return X[:, 0].copy() if vec else X
+
     # -- sharded factorisation (include/gmrfx.h "sharded factorisation"; driver: gmrfx/shard.py) -------
     def refactorize_phase_dev(self, d_nzval_ptr: int, phase: int) -> None:
         check(lib().gmrfx_refactorize_phase(self._h, d_nzval_ptr, phase), self._h)

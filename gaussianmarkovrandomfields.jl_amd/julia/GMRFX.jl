@@ -237,6 +237,17 @@ function refactorize_update!(b::MI355XBackend, hvals::Vector{Float64})
     return nothing
 end
 
+# one Newton iterate (gaussian_approximation.jl:103-129) in one pipelined call: Hessian values in, solve for the new mean out
+function refactorize_update_solve!(b::MI355XBackend, hvals::Vector{Float64}, rhs::AbstractVecOrMat)
+    B = Matrix{Float64}(reshape(rhs, b.n, :)); X = similar(B)
+    info = Ref{Int64}(0)
+    GC.@preserve hvals B X check(ccall((:gmrfx_refactorize_update_solve, LIB), Int32,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64, Ref{Int64}),
+        b.h.ptr, hvals, B, b.n, size(B, 2), X, b.n, info), b.h)
+    b.selinv_cache = nothing; b.selinv_diag_cache = nothing
+    return rhs isa AbstractVector ? vec(X) : X
+end
+
 # dot(r, Q * r), r = x - mean, on the device with the values of the last refactorize! (the quadratic form of
 # logpdf(::WorkspaceGMRF, z), src/workspace/workspace_gmrf.jl:288-292, and sqmahal, src/gmrf.jl:94-97).
 # X: n vector or n x k matrix (one value per column).

@@ -134,6 +134,13 @@ int32_t gmrfx_refactorize_solve_dev(gmrfx_handle *h, const double *d_nzval, cons
 int32_t gmrfx_set_prior(gmrfx_handle *h, const double *prior_nzval, const int64_t *map, int64_t cnt, int32_t index_base);
 int32_t gmrfx_refactorize_update(gmrfx_handle *h, const double *hvals, int64_t *info);
 int32_t gmrfx_refactorize_update_dev(gmrfx_handle *h, const double *d_hvals, int64_t *info);
+/* One whole Newton iterate (gaussian_approximation.jl:103-129: `_update_hessian!`, `ensure_numeric!`, the solve for the new mean) as
+ * one pipelined call: gmrfx_refactorize_update followed by gmrfx_solve, with the forward sweep running beside the factorisation
+ * like gmrfx_refactorize_solve; same bits as the two calls. */
+int32_t gmrfx_refactorize_update_solve(gmrfx_handle *h, const double *hvals, const double *B, int64_t ldb, int64_t nrhs, double *X, int64_t ldx,
+                                       int64_t *info);
+int32_t gmrfx_refactorize_update_solve_dev(gmrfx_handle *h, const double *d_hvals, const double *d_B, int64_t ldb, int64_t nrhs, double *d_X,
+                                           int64_t ldx, int64_t *info);
 
 /* ---- sharded factorisation (opts.shard_world > 1); SURVEY section 8(e) -------------------------------
  * ONE factorisation over several GPUs, one process each, driven by the host language over its collective library

@@ -65,6 +65,17 @@ class GMRFWorkspace:
             self.selinv_valid = True
 
     def workspace_solve(self, b):
+        # gmrf_workspace.jl:207-215. With stale values the reference's ensure_numeric! + backend_solve become the backend's ONE
+        # pipelined call (gmrfx_refactorize_solve, julia/GMRFX.jl refactorize_solve!); same bits as the two calls.
+        if (not self.numeric_valid and hasattr(self.backend, "refactorize_solve") and sp.isspmatrix_csc(self.Q)
+                and self.Q.has_sorted_indices):
+            if self.Q.nnz != self.backend._nnz:
+                raise ValueError("the sparsity pattern must be invariant across refactorizations")
+            x = self.backend.refactorize_solve(self.Q.data, b)
+            self.numeric_valid = True
+            self.selinv_valid = False
+            self.logdet_valid = False
+            return x
         self.ensure_numeric()
         return self.backend.backend_solve(b)
 

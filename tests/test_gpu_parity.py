@@ -775,6 +775,16 @@ def test_newton_update_on_device_matches_host_update():
     against_oracle(nz)
     with pytest.raises(ValueError):
         be.refactorize_update(np.zeros(3))
+    # the whole iterate as ONE pipelined call (gmrfx_refactorize_update_solve): same factor, same solve, bit for bit
+    B3 = rng.standard_normal((n, 3))
+    hk = 0.5 * H.data[keep]
+    Xf = be.refactorize_update_solve(hk, B3)
+    nz = Q.data.copy(); nz[keep] -= hk
+    ref.refactorize_values(nz)
+    assert np.array_equal(Xf, ref.backend_solve(B3))
+    assert np.array_equal(be.factor_values(), ref.factor_values())      # (after the solve on both: see the note above)
+    with pytest.raises(ValueError):
+        be.refactorize_update_solve(np.zeros(3), B3)
 
 
 # ---- KL (Vecchia) sparse approximate Cholesky: kl_cholesky.jl:32-55 and :74-113 -------------------

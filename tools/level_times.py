@@ -12,6 +12,9 @@ import numpy as np, torch
 import gmrfx
 from gmrfx import spde
 
+pipelined = "pipelined" in sys.argv      # the one-call step (gmrfx_refactorize_solve_dev): the levels of the factorisation with the forward sweep beside them
+if pipelined:
+    sys.argv.remove("pipelined")
 cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
 if cfg == "cfg4":
     N = int(sys.argv[2]) if len(sys.argv) > 2 else 126
@@ -33,8 +36,11 @@ d_X = torch.empty_like(d_B)
 torch.cuda.synchronize()
 runs = []
 for k in range(3):
-    be.refactorize_dev(d_nz.data_ptr())
-    be.solve_dev(d_B.data_ptr(), n, 64, d_X.data_ptr(), n)
+    if pipelined:
+        be.refactorize_solve_dev(d_nz.data_ptr(), d_B.data_ptr(), n, 64, d_X.data_ptr(), n)
+    else:
+        be.refactorize_dev(d_nz.data_ptr())
+        be.solve_dev(d_B.data_ptr(), n, 64, d_X.data_ptr(), n)
     s = be.stats()
     runs.append({"factor": be.level_times(0).tolist(), "fwd": be.level_times(1).tolist(), "bwd": be.level_times(2).tolist(),
                  "ms_factor": s["ms_factor"], "ms_solve": s["ms_solve"]})
@@ -43,5 +49,5 @@ for k in range(3):
 out = {"workload": name, "n": int(n), "nrhs": 64, "note": "[0] = the sweep tasks, [1 + l] = tree level l (height above the leaves); the last of 3 steps",
        **runs[-1]}
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"level_ms_{name}.json"), "w"))
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"level_ms_{name}{'_pipelined' if pipelined else ''}.json"), "w"))
 print(json.dumps(out))
