@@ -61,6 +61,42 @@ static void one_handle(const std::vector<int64_t> &cp, const std::vector<int64_t
     gmrfx_destroy(h);
 }
 
+// a sharded plan (symbolic only): per-rank layouts, groups of the distributed top fronts, the column-range transfer list.
+// Every range must lie inside its child's block, start at whole columns, and join two different ranks.
+static void sharded_handles(const std::vector<int64_t> &cp, const std::vector<int64_t> &ri, const double *coords, int64_t n, int world) {
+    setenv("GMRFX_DIST_MIN", "128", 1);       // small enough for the test grid's top separators
+    for (int rank = 0; rank < world; rank++) {
+        gmrfx_opts o;
+        std::memset(&o, 0, sizeof(o));
+        o.struct_size = (int32_t)sizeof(o);
+        o.device = -1; o.symbolic_only = 1; o.ordering = 0; o.shard_rank = rank; o.shard_world = world;
+        if (coords) { o.coord_dim = 2; o.coords = coords; }
+        gmrfx_handle *h = nullptr;
+        EXPECT(gmrfx_create(n, cp.data(), ri.data(), 0, nullptr, &o, &h) == GMRFX_OK);
+        if (!h) continue;
+        int64_t cnt[4] = {0, 0, 0, 0};
+        EXPECT(gmrfx_shard_dist_fronts(h, cnt, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr) == GMRFX_OK);
+        EXPECT(cnt[3] == world && cnt[0] >= 1);
+        std::vector<int64_t> front(cnt[0]), cols(cnt[0]), rows(cnt[0]), po(cnt[0]), pl(cnt[0]), lv(cnt[0]), gp(cnt[0] + 1), gr(cnt[1]);
+        EXPECT(gmrfx_shard_dist_fronts(h, cnt, front.data(), cols.data(), rows.data(), po.data(), pl.data(), lv.data(), gp.data(), gr.data()) == GMRFX_OK);
+        for (int64_t k = 0; k < cnt[0]; k++) {
+            EXPECT(gp[k + 1] - gp[k] >= 2 && cols[k] >= 128 && rows[k] >= cols[k] && pl[k] >= rows[k]);
+            for (int64_t q = gp[k]; q < gp[k + 1]; q++) EXPECT(gr[q] >= 0 && gr[q] < world && (q == gp[k] || gr[q] > gr[q - 1]));
+        }
+        std::vector<int64_t> ch(cnt[2]), src(cnt[2]), dst(cnt[2]), lev(cnt[2]), off(cnt[2]), num(cnt[2]), c0(cnt[2]);
+        EXPECT(gmrfx_shard_transfers(h, ch.data(), src.data(), dst.data(), lev.data(), off.data(), num.data(), c0.data()) == GMRFX_OK);
+        gmrfx_stats st;
+        EXPECT(gmrfx_get_stats(h, &st, (int32_t)sizeof(st)) == GMRFX_OK);
+        for (int64_t k = 0; k < cnt[2]; k++) {
+            EXPECT(src[k] != dst[k] && src[k] >= 0 && src[k] < world && dst[k] >= 0 && dst[k] < world);
+            EXPECT(num[k] > 0 && off[k] >= 0 && c0[k] >= 0 && (off[k] + num[k]) * 8.0 <= st.bytes_cb_arena + 1.0);
+            EXPECT(k == 0 || lev[k] >= lev[k - 1]);
+        }
+        gmrfx_destroy(h);
+    }
+    unsetenv("GMRFX_DIST_MIN");
+}
+
 int main() {
     std::vector<int64_t> cp, ri;
     std::vector<double> xy;
@@ -70,6 +106,8 @@ int main() {
     one_handle(cp, ri, xy.data(), n, 0);      // geometric nested dissection
     one_handle(cp, ri, nullptr, n, 0);        // graph nested dissection
     one_handle(cp, ri, nullptr, n, 1);        // natural ordering
+    sharded_handles(cp, ri, xy.data(), n, 2);
+    sharded_handles(cp, ri, xy.data(), n, 4);
     // distinct handles are used concurrently from different host threads (WorkspacePool contract)
     {
         std::vector<int64_t> cp2, ri2; std::vector<double> xy2;
