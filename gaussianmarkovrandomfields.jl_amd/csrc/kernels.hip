@@ -17,6 +17,8 @@
 
 #include <climits>
 
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace gmrfx {
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(DevSym S, const FrontView *__re
     // Operand rows are clamped (always-valid addresses, values masked afterwards) so that the
     // loads of a whole batch of KU k-steps issue back to back; the next batch is fetched into
     // a second register set before the current batch's MFMAs (software double buffering).
-    constexpr int KU = TW == 2 ? 4 : 8;
+    constexpr int KU = TW == 2 ? 4 : 16;      // TW = 1 (latency variant): a K = 64 update is ONE batch -- one round trip for all operands
     // TW = 2: operand rows in PAIRS -- MFMA row lm of tile 0 / 1 is row 2 lm / 2 lm + 1 of the wave's 32 -- so one 16-byte
     // load per lane feeds both tiles, and C is read and written 16 bytes at a time as well: half the vector memory
     // instructions (the CU's address unit, not the MFMA pipe, is the busiest unit of this kernel). Lanes past the last
@@ -309,6 +311,21 @@ __global__ __launch_bounds__(256) void k_gemm_nt(DevSym S, const FrontView *__re
                 for (int b = 0; b < TW; b++)
                     acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[u][b], xa[u][a], acc[a][b], 0, 0, 0);
     };
+    // TW = 1: the tile's own values are requested BEFORE the operands (they only meet in the epilogue): one round trip less
+    // on the latency-bound levels this variant serves
+    double cv[TW][TW][4];
+    if constexpr (TW != 2) {
+#pragma unroll
+        for (int a = 0; a < TW; a++)
+#pragma unroll
+            for (int b = 0; b < TW; b++)
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) {
+                    const int i = min(i0 + a * 16 + lm, M - 1);
+                    const int j = min(j0 + b * 16 + lk + 4 * rr, N - 1);
+                    cv[a][b][rr] = C[i + (long long)j * ldc];
+                }
+    }
     const int kfull = K / (4 * KU) * (4 * KU);
     // single-buffered batches: latency is hidden by the other resident waves (4-5 per SIMD at
     // this register budget); hipcc turns a register double-buffer into vmcnt(0) at the loop head
@@ -357,17 +374,6 @@ __global__ __launch_bounds__(256) void k_gemm_nt(DevSym S, const FrontView *__re
                 }
             }
     } else {
-        double cv[TW][TW][4];
-#pragma unroll
-        for (int a = 0; a < TW; a++)
-#pragma unroll
-            for (int b = 0; b < TW; b++)
-#pragma unroll
-                for (int rr = 0; rr < 4; rr++) {
-                    const int i = min(i0 + a * 16 + lm, M - 1);
-                    const int j = min(j0 + b * 16 + lk + 4 * rr, N - 1);
-                    cv[a][b][rr] = C[i + (long long)j * ldc];
-                }
 #pragma unroll
         for (int a = 0; a < TW; a++)
 #pragma unroll
