@@ -57,6 +57,8 @@ Device::~Device() {
     for (auto &e : ev_la_t_) (void)hipEventDestroy(e);
     for (auto &l : ev_lane_) for (auto &e : l) if (e) (void)hipEventDestroy(e);
     if (h_info_) (void)hipHostFree(h_info_);
+    if (h_logdet_) (void)hipHostFree(h_logdet_);
+    if (ev_logdet_) (void)hipEventDestroy(ev_logdet_);
     if (ev_ready_) (void)hipEventDestroy(ev_ready_);
     if (ev_ready2_) (void)hipEventDestroy(ev_ready2_);
     if (ev_done1_) (void)hipEventDestroy(ev_done1_);
@@ -855,6 +857,7 @@ void Device::refactorize_solve(const double *nzval, bool nz_on_device, const dou
     }
     inverse_pending = false;
     inverse_full_ = inv_maxc_ <= inv_cap_;
+    enqueue_logdet(stream2, false);                     // behind the forward sweep on the side stream: beside the backward sweep
     HC(hipStreamWaitEvent(stream, ev[2], 0));
     backward(nr, ldx, true, nl, 0);
     HC(hipEventRecord(ev[3], stream));
@@ -1358,17 +1361,29 @@ void Device::solve(const double *B, long long ldb, long long nrhs, double *X, lo
     last_nrhs = nrhs;
 }
 
+// log det Q = 2 sum log L_jj: two small kernels over the factor's diagonal + one scalar copied to pinned host memory. The result
+// is kept per factorisation; the pipelined factor + solve call enqueues it on the side stream beside the backward sweep.
+void Device::enqueue_logdet(hipStream_t st, bool timed) {
+    if (!h_logdet_) {
+        HC(hipHostMalloc((void **)&h_logdet_, sizeof(double), hipHostMallocDefault));
+        HC(hipEventCreateWithFlags(&ev_logdet_, hipEventDisableTiming));
+    }
+    const int nparts = (int)std::min<long long>(1024, std::max<long long>(1, (S_->n + 255) / 256));
+    if (timed) HC(hipEventRecord(ev_[0], st));
+    launch_logdet(st, d_L_, ds_.diagoff, d_owncol_, (int)S_->n, d_part_, nparts, d_part_ + 1024);
+    if (timed) HC(hipEventRecord(ev_[1], st));
+    HC(hipMemcpyAsync(h_logdet_, d_part_ + 1024, sizeof(double), hipMemcpyDeviceToHost, st));
+    HC(hipEventRecord(ev_logdet_, st));
+    logdet_for_ = factor_serial_;
+}
 double Device::logdet() {
     HC(hipSetDevice(device));
-    const int nparts = (int)std::min<long long>(1024, std::max<long long>(1, (S_->n + 255) / 256));
-    HC(hipEventRecord(ev_[0], stream));
-    launch_logdet(stream, d_L_, ds_.diagoff, d_owncol_, (int)S_->n, d_part_, nparts, d_part_ + 1024);
-    HC(hipEventRecord(ev_[1], stream));
-    double out = 0;
-    HC(hipMemcpyAsync(&out, d_part_ + 1024, sizeof(double), hipMemcpyDeviceToHost, stream));
-    HC(hipStreamSynchronize(stream));
-    float ms; HC(hipEventElapsedTime(&ms, ev_[0], ev_[1])); ms_logdet = ms;
-    return out;
+    if (logdet_for_ != factor_serial_ || !h_logdet_) {
+        enqueue_logdet(stream, true);
+        HC(hipEventSynchronize(ev_logdet_));
+        float ms; HC(hipEventElapsedTime(&ms, ev_[0], ev_[1])); ms_logdet = ms;
+    } else HC(hipEventSynchronize(ev_logdet_));
+    return *h_logdet_;
 }
 
 void Device::quadform(const double *d_nz, const double *d_X, long long ldx, long long nvec, const double *d_mu, double *out_host) {

@@ -302,6 +302,10 @@ private:
     void invert_level(hipStream_t st, int lev);
     bool fact_event_valid_ = false;   // ev_fact_ was recorded at the end of the last factorisation
     int *h_info_ = nullptr;           // pinned: the pivot report of the last factorisation
+    double *h_logdet_ = nullptr;      // pinned: log det of factorisation logdet_for_ (valid once ev_logdet_ has passed)
+    unsigned long long logdet_for_ = 0;
+    hipEvent_t ev_logdet_ = nullptr;
+    void enqueue_logdet(hipStream_t st, bool timed);
     bool info_cached_ = false;
     void invert_diag_blocks(hipStream_t st, int b_from, int b_to);
     void start_inverse_async();
