@@ -183,8 +183,19 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
     std::vector<i32> nchild(n, 0);
     for (i64 j = 0; j < n; j++) if (parent[j] != -1) nchild[parent[j]]++;
     sfirst.push_back(0);
+    // A WIDE run of columns that ends below a BRANCHING column j (j has other children besides j - 1) stays a supernode of its
+    // own although its structure nests into j's: merged, its panel chain -- one dependent potrf / trsm / gemm step per 64
+    // columns -- would run AFTER the sibling subtrees' instead of beside them (cfg 2: the root absorbed the 1000-column
+    // separator of one half of the mesh: 47 chain steps behind the 16 of the other half's separator, instead of 31 behind 16
+    // for both in parallel). Same fill, same flops.
+    // Only where the chain is what a front costs: runs of 128 .. 4096 columns. A wider one (the 15 876-column separators of
+    // cfg 4) is throughput work, and merged into its parent it saves a contribution block and an assembly: cfg 4 on one GPU
+    // 5.27 s merged, 5.50 s split.
+    const i64 merge_wide = opt.merge_wide >= 0 ? opt.merge_wide : 128;
+    const i64 merge_wide_max = opt.merge_wide_max >= 0 ? opt.merge_wide_max : 4096;
     for (i64 j = 1; j < n; j++) {
         bool join = parent[j - 1] == j && cc[j - 1] == cc[j] + 1;
+        if (join && nchild[j] >= 2 && j - sfirst.back() >= merge_wide && j - sfirst.back() <= merge_wide_max) join = false;
         if (!join) sfirst.push_back((i32)j);
     }
     i32 ns0 = (i32)sfirst.size();
@@ -204,6 +215,8 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
         i64 c = sfirst[s + 1] - sfirst[s], r = cc[sfirst[s]];
         sn[s] = {sfirst[s], sfirst[s + 1], r, (double)(r * c - c * (c - 1) / 2), sp0[s], true};
     }
+    std::vector<i32> nkids0(ns0, 0);
+    for (i32 s = 0; s < ns0; s++) if (sp0[s] != -1) nkids0[sp0[s]]++;
     // merged_into[s]: representative after merges (child merged into parent => parent's id)
     std::vector<i32> rep(ns0);
     std::iota(rep.begin(), rep.end(), 0);
@@ -225,6 +238,11 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
             double z = (total - nnz) / total;
             bool merge = (c <= 4) || (c <= relax_cols && z <= 0.8 * 0.5) || (z <= relax_zeros && c <= 4 * relax_cols) ||
                          (z <= 0.02);
+            // A WIDE child with siblings stays a front of its own even when the merge is free of zeros (its rows cover the
+            // parent): merged, its panel chain -- one dependent potrf / trsm / gemm step per 64 columns -- runs AFTER its
+            // siblings' instead of beside them. (cfg 2: the root absorbed the 1000-column separator of one half: 47 chain
+            // steps behind the 16 of the other half's separator instead of 31 behind 16 for both.)
+            if (merge && cd >= merge_wide && cd <= merge_wide_max && nkids0[p] >= 2) merge = false;
             if (!merge) break;
             sn[p].first = sn[d].first;
             sn[p].r = r;

@@ -18,6 +18,8 @@ struct SymOptions {
     int nd_leaf = 0;         // 0 = default
     int relax_cols = 0;      // 0 = default
     double relax_zeros = 0;  // 0 = default
+    int merge_wide = -1;     // a child at least this wide that has siblings is never merged into its parent; -1 = default (128), huge = always merge
+    int merge_wide_max = -1; // ... and at most this wide (wider fronts are throughput work: merged as usual); -1 = default (4096)
     int coord_dim = 0;
     const double *coords = nullptr;
     int subtree_max = -1;      // max fronts per subtree task; -1 = default (0 = off: bit-identical, measured slower than level batching)

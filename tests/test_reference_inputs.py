@@ -182,14 +182,19 @@ def test_cfg4_single_gpu_size_100_cubed():
     assert st["max_cols"] == 30000 and st["nnz_l"] > 3.5e9
 
 
-def test_3d_28_matches_oracle_value_by_value():
-    """28^3 nodes: the root separator (3 x 28^2 = 2352 columns) is wider than the 2048-column cap of the dense
-    inverses, so the blocked substitution inside a front runs -- checked against the oracle entry by entry."""
+@pytest.mark.parametrize("supernodes", ["maximal", "default"])
+def test_3d_28_matches_oracle_value_by_value(supernodes, monkeypatch):
+    """28^3 nodes, checked against the oracle entry by entry. With MAXIMAL supernodes (GMRFX_MERGE_WIDE huge: the root absorbs
+    the separator of one half, 3 x 28^2 = 2352 columns) the root is wider than the 2048-column cap of the dense inverses, so the
+    blocked substitution inside a front runs; the default keeps that separator (784 columns: inside the 128 .. 4096 window where the panel chain is what a front costs) a
+    front of its own (root 2 x 28^2 = 1568)."""
+    if supernodes == "maximal":
+        monkeypatch.setenv("GMRFX_MERGE_WIDE", "1000000000")
     m3 = spde.grid_mesh_3d(28, 28, 28)
     Q = sp.csc_matrix(spde.matern_precision(m3, 0, 0.5))
     n = Q.shape[0]
     be = gmrfx.MI355XBackend(Q, coords=m3.points)
-    assert be.stats()["max_cols"] > 2048
+    assert be.stats()["max_cols"] == (3 if supernodes == "maximal" else 2) * 28 * 28
     F = orc.OracleFactor(Q, be.ordering_permutation())
     Lg, Lo = be.factor_csc(), F.L()
     assert abs(Lg - Lo).max() <= 1e-10 * abs(Lo).max()
