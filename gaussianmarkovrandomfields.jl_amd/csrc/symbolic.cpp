@@ -377,6 +377,21 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
     }
     S.nlevels = 0;
     for (i32 s = 0; s < ns; s++) S.nlevels = std::max(S.nlevels, S.level[s] + 1);
+    // Levels by DEPTH below the root instead of height above the leaves. A level costs the longest panel chain among its
+    // fronts (one dependent potrf / trsm / gemm step per 64 columns), and sibling subtrees differ in height by a level or two:
+    // by height the separators of one dissection generation are spread over two or three levels, each of which then pays that
+    // generation's chain. By depth every generation sits on ONE level (cfg 2: 1, 2, 4, ..., 2^k fronts from the root down; sum
+    // over the levels of the longest chain 116 -> 107 steps, the tree's critical path is 105) and leaves sit right below their
+    // parents. Measured at cfg 2: factorisation 10.63 -> 10.32 ms, pipelined step 14.72 -> 14.39 ms (the top 6 / 9 / 12 levels
+    // only: 14.65 / 14.46 / 14.45). top_by_depth (GMRFX_TOP_BY_DEPTH): how many levels from the root down; 0 = all by height.
+    {
+        const int K = opt.top_by_depth >= 0 ? opt.top_by_depth : (1 << 30);
+        const i32 H = S.nlevels - 1;
+        std::vector<i32> depth_level(ns, 0);
+        for (i32 s = ns - 1; s >= 0; s--) depth_level[s] = S.sparent[s] == -1 ? H : depth_level[S.sparent[s]] - 1;   // parents have larger ids
+        for (i32 s = 0; s < ns; s++)
+            if (K > 0 && (long long)depth_level[s] >= (long long)H - K + 1) S.level[s] = depth_level[s];   // (an upward-closed set: children stay below parents)
+    }
     // ---- sharding over ranks (multi-GPU): split the tree top-down into subtrees, deal them out ----
     S.shard_rank = opt.shard_rank;
     S.shard_world = std::max(1, opt.shard_world);

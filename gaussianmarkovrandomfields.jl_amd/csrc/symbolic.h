@@ -19,6 +19,7 @@ struct SymOptions {
     int relax_cols = 0;      // 0 = default
     double relax_zeros = 0;  // 0 = default
     int merge_wide = -1;     // a child at least this wide that has siblings is never merged into its parent; -1 = default (128), huge = always merge
+    int top_by_depth = -1;   // this many levels from the root down are levelled by depth below the root (0: all by height); -1 = default (all)
     int merge_wide_max = -1; // ... and at most this wide (wider fronts are throughput work: merged as usual); -1 = default (4096)
     int coord_dim = 0;
     const double *coords = nullptr;
