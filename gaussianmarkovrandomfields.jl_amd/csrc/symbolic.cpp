@@ -577,7 +577,7 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
         S.wptr[ns] = w;
     }
     // small fronts (fused LDS kernels, small.hip): r <= 96 or r <= 128 rows and <= 64 columns
-    S.small_rows = opt.small_front_rows >= 0 ? opt.small_front_rows : 96;    // measured on cfg 2: 96 beats 128 and 64 (tools/sweep notes in DESIGN.md)
+    S.small_rows = opt.small_front_rows >= 0 ? opt.small_front_rows : 64;    // measured on cfg 2 with the depth-levelled tree (round 3): 32 -> 14.47, 48 -> 14.20, 64 -> 14.14, 72 -> 14.18, 96 -> 14.32, 128 -> 14.98 ms per step
     S.is_small.resize(ns);
     static const int kClsRows[4] = {48, 64, 96, 128};
     auto cls = [&](i32 s) -> int {

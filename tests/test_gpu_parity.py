@@ -395,7 +395,7 @@ def test_generic_path_matches_fused_small_front_path(name, monkeypatch):
     assert relerr(ws.workspace_solve(B), F.solve(B)) < 1e-10
     assert relerr(ws.backward_solve(B), F.backward_solve(B)) < 1e-10
     assert relerr(ws.selinv_diag(), F.selinv_diag()) < 1e-8
-    for rows in ("64", "128"):      # the other size-class cut-offs (default: 96)
+    for rows in ("96", "128"):      # the other size-class cut-offs (default: 64)
         monkeypatch.setenv("GMRFX_SMALL_ROWS", rows)
         wsr = GMRFWorkspace(Q, **kw)
         assert relerr(wsr.workspace_solve(B), F.solve(B)) < 1e-10

@@ -23,7 +23,7 @@ def run():
     be = gmrfx.MI355XBackend(Q, coords=mesh.points, device=0, factorize=False)
     sy = be.symbolic()
     c = np.diff(sy.super_first); r = np.diff(sy.row_ptr); m = r - c
-    small = int(os.environ.get("GMRFX_SMALL_ROWS", "96"))
+    small = int(os.environ.get("GMRFX_SMALL_ROWS", "64"))
     big = (r > small) & (m > 0)
     levels = []
     for lv in range(int(sy.level.max()) + 1):
