@@ -21,6 +21,8 @@ synchronisation after every exchange, 2K + 2 host round trips per step). The per
 once. Every rank keeps only its own part of the factor (panels, arena, update vectors: csrc/symbolic.cpp)."""
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 
@@ -292,13 +294,20 @@ def plan_summary(be, level_ms=None) -> dict:
            "distributed_fronts": [{"supernode": s_, "cols": int(c[s_]), "rows": int(r[s_]), "group": gsz[s_], "flops": float(fl[s_])}
                                   for s_ in sorted(dset)]}
     if level_ms is not None:
-        # levels of the UNSHARDED schedule: height above the leaves (a sharded handle re-levels its top fronts)
+        # levels of the UNSHARDED schedule (a sharded handle re-levels its top fronts): depth below the root, counted down from
+        # the tree's height (csrc/symbolic.cpp "Levels by DEPTH below the root")
         ns = len(c)
         par = np.asarray(sy.super_parent)
-        h = np.zeros(ns, np.int64)
+        hgt = np.zeros(ns, np.int64)
         for s in range(ns):                         # children have smaller ids than their parents (postorder)
             if par[s] >= 0:
-                h[par[s]] = max(h[par[s]], h[s] + 1)
+                hgt[par[s]] = max(hgt[par[s]], hgt[s] + 1)
+        H = int(hgt.max())
+        h = np.zeros(ns, np.int64)
+        for s in range(ns - 1, -1, -1):
+            h[s] = H if par[s] < 0 else h[par[s]] - 1
+        if os.environ.get("GMRFX_TOP_BY_DEPTH") == "0":
+            h = hgt
         lm = np.asarray(level_ms, dtype=np.float64)
         nl = int(h.max()) + 1
         if lm.size < nl + 1:

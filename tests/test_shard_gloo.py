@@ -200,10 +200,13 @@ def test_plan_summary_time_bounds_from_level_times():
         sy = be.symbolic()
         c = np.diff(sy.super_first).astype(float); m = np.diff(sy.row_ptr).astype(float) - c
         fl = c ** 3 / 3 + c * c * m + c * m * m
-        par = np.asarray(sy.super_parent); h = np.zeros(len(c), int)
+        par = np.asarray(sy.super_parent); hg = np.zeros(len(c), int)
         for s in range(len(c)):
             if par[s] >= 0:
-                h[par[s]] = max(h[par[s]], h[s] + 1)
+                hg[par[s]] = max(hg[par[s]], hg[s] + 1)
+        h = np.zeros(len(c), int)                   # the unsharded schedule's levels: depth below the root, counted down from the height
+        for s in range(len(c) - 1, -1, -1):
+            h[s] = hg.max() if par[s] < 0 else h[par[s]] - 1
         level_ms = np.concatenate([[0.0], [fl[h == l].sum() * 1e-9 for l in range(h.max() + 1)]])
         p = shard.plan_summary(be, level_ms)
         assert abs(p["measured_ms_one_gpu"] - level_ms.sum()) < 1e-9 * level_ms.sum()
