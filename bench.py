@@ -386,15 +386,16 @@ def main():
     if rank == 0 and not args.no_logpdf:
         d_z = d_B[0]
         def logpdf_eval():
-            be.refactorize_dev(d_nz.data_ptr())
-            q = be.quadform_dev(d_nz.data_ptr(), d_z.data_ptr(), n, 1)[0]
-            return -0.5 * q + 0.5 * be.compute_logdet() - 0.5 * n * np.log(2.0 * np.pi)
+            # ONE call: factorisation, r'Qr beside it, logdet behind it, one synchronisation (gmrfx_refactorize_logpdf_dev)
+            q, ld = be.refactorize_logpdf_dev(d_nz.data_ptr(), d_z.data_ptr(), n, 1)
+            return -0.5 * q[0] + 0.5 * ld - 0.5 * n * np.log(2.0 * np.pi)
         lp = logpdf_eval(); torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(5):
             lp = logpdf_eval()
         torch.cuda.synchronize()
         logpdf_ms = 1e3 * (time.perf_counter() - t1) / 5
+        be.quadform_dev(d_nz.data_ptr(), d_z.data_ptr(), n, 1)      # (the kernel alone, for its event time)
         ms_quadform = be.stats()["ms_quadform"]
 
     # ---- untimed correctness evidence on this very run -------------------------------------

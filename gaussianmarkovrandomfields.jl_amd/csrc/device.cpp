@@ -58,6 +58,8 @@ Device::~Device() {
     for (auto &l : ev_lane_) for (auto &e : l) if (e) (void)hipEventDestroy(e);
     if (h_info_) (void)hipHostFree(h_info_);
     if (h_logdet_) (void)hipHostFree(h_logdet_);
+    if (h_qf_) (void)hipHostFree(h_qf_);
+    if (ev_qf_) (void)hipEventDestroy(ev_qf_);
     if (ev_logdet_) (void)hipEventDestroy(ev_logdet_);
     if (ev_ready_) (void)hipEventDestroy(ev_ready_);
     if (ev_ready2_) (void)hipEventDestroy(ev_ready2_);
@@ -1386,6 +1388,79 @@ double Device::logdet() {
     return *h_logdet_;
 }
 
+// pattern of Q and the partial-sum buffers of the quadratic-form kernels (grown geometrically)
+void Device::prepare_quadform(long long nvec) {
+    const Symbolic &S = *S_;
+    if (!d_in_colptr_) {
+        d_in_colptr_ = dalloc<long long>(S.in_colptr.size());
+        d_in_row_ = dalloc<int>(std::max<size_t>(S.in_row.size(), 1));
+        HC(hipMemcpyAsync(d_in_colptr_, S.in_colptr.data(), S.in_colptr.size() * sizeof(long long), hipMemcpyHostToDevice, stream));
+        HC(hipMemcpyAsync(d_in_row_, S.in_row.data(), S.in_row.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+        HC(hipStreamSynchronize(stream));      // (the host vectors may move; first call only)
+    }
+    const int nblk = quadform_blocks((int)S.n);
+    if (nvec > qf_cap_) {
+        const long long cap = std::max<long long>(nvec, 2 * qf_cap_);     // geometric growth, the old buffers are freed
+        qf_cap_ = 0;        // (a failed second allocation must not leave the pair with different sizes behind one capacity)
+        d_qf_part_ = dregrow(d_qf_part_, (size_t)cap * nblk);
+        d_qf_out_ = dregrow(d_qf_out_, (size_t)cap);
+        qf_cap_ = cap;
+    }
+}
+
+// One evaluation of the hyper-parameter loop as ONE call (gmrfx_refactorize_logpdf_dev): new values -> numeric factorisation,
+// r' Q r for nvec vectors and log det Q -- logpdf(::WorkspaceGMRF, z) = -r'Qr / 2 + logdet(Q) / 2 - n log(2 pi) / 2,
+// src/workspace/workspace_gmrf.jl:288-292, with ensure_numeric! inside (gmrf_workspace.jl:170-178). The quadratic forms only
+// need Q's values: they run on the side stream beside the factorisation; the log-determinant follows the factorisation on the
+// main stream; ONE synchronisation, the scalars arrive in pinned memory. Same kernels: same bits as the three calls.
+void Device::refactorize_logpdf(const double *d_nz, const double *d_X, long long ldx, long long nvec, const double *d_mu, double *quad_out,
+                                double *logdet_out) {
+    HC(hipSetDevice(device));
+    const Symbolic &S = *S_;
+    if (sharded()) throw std::invalid_argument("sharded handle: use the phase entry points (gmrfx/shard.py)");
+    if (nvec < 0 || nvec > 65535) throw std::invalid_argument("refactorize_logpdf: 0..65535 vectors per call");
+    if (nvec > 0 && ldx < S.n) throw std::invalid_argument("refactorize_logpdf: ldx < n");
+    if (stream != own_stream_) throw std::invalid_argument("refactorize_logpdf: not on a caller's stream");
+    if (nvec > 0) {
+        prepare_quadform(nvec);
+        if (nvec > h_qf_cap_) {
+            if (h_qf_) HC(hipHostFree(h_qf_));
+            h_qf_ = nullptr; h_qf_cap_ = 0;
+            HC(hipHostMalloc((void **)&h_qf_, (size_t)std::max<long long>(nvec, 16) * sizeof(double), hipHostMallocDefault));
+            h_qf_cap_ = std::max<long long>(nvec, 16);
+        }
+        HC(hipEventRecord(ev_ready_, stream));
+        HC(hipStreamWaitEvent(stream2, ev_ready_, 0));
+        launch_quadform(stream2, (int)S.n, d_in_colptr_, d_in_row_, d_nz, S.in_use, d_X, ldx, (int)nvec, d_mu, d_qf_part_, d_qf_out_);
+        HC(hipMemcpyAsync(h_qf_, d_qf_out_, (size_t)nvec * sizeof(double), hipMemcpyDeviceToHost, stream2));
+        if (!ev_qf_) HC(hipEventCreateWithFlags(&ev_qf_, hipEventDisableTiming));
+        HC(hipEventRecord(ev_qf_, stream2));
+    }
+    nz_held_ = false;
+    nz_src_ = d_nz;
+    factor_serial_++;
+    HC(hipEventRecord(ev_[0], stream));
+    factor_levels(0, (int)levels_.size());
+    HC(hipEventRecord(ev_[1], stream));
+    HC(hipEventRecord(ev_fact_, stream));
+    fact_event_valid_ = true;
+    inverse_pending = true;
+    HC(hipMemcpyAsync(h_info_, d_info_, sizeof(int), hipMemcpyDeviceToHost, stream));
+    factorized = true;
+    selinv_valid = false;
+    float tf = 0;
+    enqueue_logdet(stream, false);
+    if (nvec > 0) HC(hipStreamWaitEvent(stream, ev_qf_, 0));
+    HC(hipStreamSynchronize(stream));
+    info_cached_ = true;
+    HC(hipGetLastError());
+    HC(hipEventElapsedTime(&tf, ev_[0], ev_[1]));
+    ms_factor = tf;
+    syrk_times_pending_ = true;
+    for (long long k = 0; k < nvec; k++) quad_out[k] = h_qf_[k];
+    if (logdet_out) *logdet_out = *h_logdet_;
+}
+
 void Device::quadform(const double *d_nz, const double *d_X, long long ldx, long long nvec, const double *d_mu, double *out_host) {
     HC(hipSetDevice(device));
     const Symbolic &S = *S_;
@@ -1396,20 +1471,7 @@ void Device::quadform(const double *d_nz, const double *d_X, long long ldx, long
         if (!nz_held_) throw std::invalid_argument("quadform: the handle does not hold Q's values (last refactorisation read a caller device buffer): pass them");
         d_nz = d_nz_;
     }
-    if (!d_in_colptr_) {
-        d_in_colptr_ = dalloc<long long>(S.in_colptr.size());
-        d_in_row_ = dalloc<int>(std::max<size_t>(S.in_row.size(), 1));
-        HC(hipMemcpyAsync(d_in_colptr_, S.in_colptr.data(), S.in_colptr.size() * sizeof(long long), hipMemcpyHostToDevice, stream));
-        HC(hipMemcpyAsync(d_in_row_, S.in_row.data(), S.in_row.size() * sizeof(int), hipMemcpyHostToDevice, stream));
-    }
-    const int nblk = quadform_blocks((int)S.n);
-    if (nvec > qf_cap_) {
-        const long long cap = std::max<long long>(nvec, 2 * qf_cap_);     // geometric growth, the old buffers are freed
-        qf_cap_ = 0;        // (a failed second allocation must not leave the pair with different sizes behind one capacity)
-        d_qf_part_ = dregrow(d_qf_part_, (size_t)cap * nblk);
-        d_qf_out_ = dregrow(d_qf_out_, (size_t)cap);
-        qf_cap_ = cap;
-    }
+    prepare_quadform(nvec);
     HC(hipEventRecord(ev_[0], stream));
     launch_quadform(stream, (int)S.n, d_in_colptr_, d_in_row_, d_nz, S.in_use, d_X, ldx, (int)nvec, d_mu, d_qf_part_, d_qf_out_);
     HC(hipEventRecord(ev_[1], stream));

@@ -147,6 +147,8 @@ public:
     // up the tree, one level behind, on the side stream
     void refactorize_solve(const double *nzval, bool nz_on_device, const double *B, long long ldb, long long nrhs, double *X, long long ldx,
                            bool b_on_device);
+    void refactorize_logpdf(const double *d_nz, const double *d_X, long long ldx, long long nvec, const double *d_mu, double *quad_out,
+                            double *logdet_out);
     void refactorize_update_solve(const double *h, bool h_on_device, const double *B, long long ldb, long long nrhs, double *X, long long ldx,
                                   bool b_on_device);
     // Newton loop with Q resident on the device: set_prior uploads the prior's values (and the
@@ -302,6 +304,10 @@ private:
     void invert_level(hipStream_t st, int lev);
     bool fact_event_valid_ = false;   // ev_fact_ was recorded at the end of the last factorisation
     int *h_info_ = nullptr;           // pinned: the pivot report of the last factorisation
+    double *h_qf_ = nullptr;          // pinned: quadratic forms of refactorize_logpdf
+    long long h_qf_cap_ = 0;
+    hipEvent_t ev_qf_ = nullptr;
+    void prepare_quadform(long long nvec);
     double *h_logdet_ = nullptr;      // pinned: log det of factorisation logdet_for_ (valid once ev_logdet_ has passed)
     unsigned long long logdet_for_ = 0;
     hipEvent_t ev_logdet_ = nullptr;

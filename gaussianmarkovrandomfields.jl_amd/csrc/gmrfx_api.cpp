@@ -207,6 +207,23 @@ static int32_t refactorize_update_impl(gmrfx_handle *h, const double *hv, int64_
         return GMRFX_OK;
     });
 }
+// One logpdf evaluation of the hyper-parameter loop in one call (Device::refactorize_logpdf): device pointers.
+extern "C" int32_t gmrfx_refactorize_logpdf_dev(gmrfx_handle *h, const double *d_nzval, const double *d_X, int64_t ldx, int64_t nvec,
+                                                const double *d_mu, double *quad, double *logdet, int64_t *info) {
+    return guarded(h, [&]() -> int32_t {
+        if (int32_t e = need_device(h, false)) return e;
+        if (!d_nzval) throw std::invalid_argument("nzval is null");
+        if (nvec > 0 && (!d_X || !quad)) throw std::invalid_argument("X / quad is null");
+        h->D->refactorize_logpdf(d_nzval, d_X, ldx, nvec, d_mu, quad, logdet);
+        long long fc = h->D->fail_col();
+        if (info) *info = fc < 0 ? 0 : fc + 1;
+        if (fc >= 0 && h->opts.check_posdef) {
+            h->err = "matrix is not positive definite (non-positive pivot at elimination step " + std::to_string(fc + 1) + ")";
+            return GMRFX_ERR_NOT_POSDEF;
+        }
+        return GMRFX_OK;
+    });
+}
 // One Newton iterate in one pipelined call (Device::refactorize_update_solve): Hessian values in, new mean's solve out.
 static int32_t refactorize_update_solve_impl(gmrfx_handle *h, const double *hv, const double *B, int64_t ldb, int64_t nrhs, double *X, int64_t ldx,
                                              int64_t *info, bool dev) {

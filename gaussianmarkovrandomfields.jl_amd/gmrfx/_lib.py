@@ -55,7 +55,7 @@ _lib = None
 EXPORTS = [
     "gmrfx_last_create_error", "gmrfx_last_error", "gmrfx_create", "gmrfx_destroy", "gmrfx_clone",
     "gmrfx_refactorize", "gmrfx_refactorize_dev", "gmrfx_refactorize_solve", "gmrfx_refactorize_solve_dev",
-    "gmrfx_refactorize_update_solve", "gmrfx_refactorize_update_solve_dev", "gmrfx_solve", "gmrfx_solve_dev", "gmrfx_backward_solve",
+    "gmrfx_refactorize_update_solve", "gmrfx_refactorize_update_solve_dev", "gmrfx_refactorize_logpdf_dev", "gmrfx_solve", "gmrfx_solve_dev", "gmrfx_backward_solve",
     "gmrfx_backward_solve_dev", "gmrfx_logdet", "gmrfx_selinv_compute", "gmrfx_selinv_diag", "gmrfx_selinv_nnz",
     "gmrfx_selinv_csc", "gmrfx_selinv_extract", "gmrfx_get_perm", "gmrfx_get_stats", "gmrfx_symbolic_sizes",
     "gmrfx_symbolic_get", "gmrfx_get_factor_values", "gmrfx_refactorize_phase", "gmrfx_shard_info",
@@ -96,6 +96,7 @@ def lib():
         L.gmrfx_refactorize_dev.argtypes = [vp, vp, C.POINTER(i64)]
         L.gmrfx_refactorize_solve.argtypes = [vp, vp, vp, i64, i64, vp, i64, C.POINTER(i64)]
         L.gmrfx_refactorize_solve_dev.argtypes = [vp, vp, vp, i64, i64, vp, i64, C.POINTER(i64)]
+        L.gmrfx_refactorize_logpdf_dev.argtypes = [vp, vp, vp, i64, i64, vp, vp, C.POINTER(dbl), C.POINTER(i64)]
         L.gmrfx_refactorize_update_solve.argtypes = [vp, vp, vp, i64, i64, vp, i64, C.POINTER(i64)]
         L.gmrfx_refactorize_update_solve_dev.argtypes = [vp, vp, vp, i64, i64, vp, i64, C.POINTER(i64)]
         for nm in ("gmrfx_solve", "gmrfx_solve_dev", "gmrfx_backward_solve", "gmrfx_backward_solve_dev"):

@@ -352,6 +352,19 @@ class MI355XBackend:
         self.last_info = info.value
         return info.value
 
+    def refactorize_logpdf_dev(self, d_nzval_ptr: int, d_X: int, ldx: int, nvec: int, d_mu: int = 0):
+        """One logpdf evaluation of the hyper-parameter loop in one call (gmrfx_refactorize_logpdf_dev): new values -> numeric
+        factorisation; returns (quadratic forms (x_k - mu)' Q (x_k - mu), log det Q). logpdf = -q / 2 + logdet / 2 - n log(2 pi) / 2
+        (workspace_gmrf.jl:288-292)."""
+        quad = np.empty(max(nvec, 0))
+        ld = C.c_double(0.0)
+        info = C.c_int64(0)
+        check(lib().gmrfx_refactorize_logpdf_dev(self._h, d_nzval_ptr, d_X or None, ldx, nvec, d_mu or None, ptr(quad), C.byref(ld), C.byref(info)), self._h)
+        self._selinv_cache = None
+        self._selinv_diag_cache = None
+        self.last_info = info.value
+        return quad, ld.value
+
     def refactorize_solve(self, nzval, rhs):
         """Host-array form of refactorize_solve_dev: new values of Q (pattern order) and right-hand sides -> X (fresh array)."""
         nz = np.ascontiguousarray(nzval, dtype=np.float64)

@@ -125,6 +125,15 @@ int32_t gmrfx_refactorize_solve(gmrfx_handle *h, const double *nzval, const doub
 int32_t gmrfx_refactorize_solve_dev(gmrfx_handle *h, const double *d_nzval, const double *d_B, int64_t ldb, int64_t nrhs, double *d_X,
                                     int64_t ldx, int64_t *info);
 
+/* One evaluation of the hyper-parameter loop (docs/src/literate-tutorials/workspace_factorization_reuse.jl:94-102) in ONE call:
+ * new values -> numeric factorisation, quad[k] = (x_k - mu)' Q (x_k - mu) for nvec vectors and *logdet = log det Q, i.e. everything
+ * `logpdf(::WorkspaceGMRF, z)` needs (src/workspace/workspace_gmrf.jl:288-292 with `ensure_numeric!` inside,
+ * gmrf_workspace.jl:170-178). Device pointers for Q's values, X (column-major n x nvec) and mu (nullable); the quadratic forms run
+ * beside the factorisation, one synchronisation, both results arrive through pinned memory. Same bits as gmrfx_refactorize_dev +
+ * gmrfx_quadform_dev + gmrfx_logdet. */
+int32_t gmrfx_refactorize_logpdf_dev(gmrfx_handle *h, const double *d_nzval, const double *d_X, int64_t ldx, int64_t nvec,
+                                     const double *d_mu, double *quad /* host, nvec */, double *logdet /* host */, int64_t *info);
+
 /* ---- Newton loop with Q resident on the device -----------------------------------
  * Replaces `_update_hessian!` + `ensure_numeric!` of the Gaussian-approximation loop
  * (src/workspace/gaussian_approximation.jl:103-129: copyto!(ws.Q.nzval, prior_nzval); nzval[map[k]] -= H.nzval[k]).

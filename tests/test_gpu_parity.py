@@ -1113,3 +1113,38 @@ def test_refactorize_solve_pipelined_equals_separate_calls(mesh_kind):
     ib = b.refactorize_dev(d_bad.data_ptr())
     assert ia == ib > 0
     a.close(); b.close()
+
+
+def test_refactorize_logpdf_one_call_equals_three_calls():
+    """gmrfx_refactorize_logpdf_dev (one evaluation of the hyper-parameter loop: factorisation, r'Qr beside it on the side stream,
+    log-determinant behind it, one synchronisation) against gmrfx_refactorize_dev + gmrfx_quadform_dev + gmrfx_logdet: quadratic
+    forms, log-determinant and factor bit for bit, with and without a mean, for 1 and 5 vectors; and the logpdf against the oracle."""
+    import torch
+    mesh = spde.grid_mesh_2d(140, 130, jitter=0.25, seed=6)
+    Q = sp.csc_matrix(spde.matern_precision(mesh, 0, 0.2))
+    n = Q.shape[0]
+    dev = torch.device("cuda", 0)
+    a = gmrfx.MI355XBackend(Q, coords=mesh.points, factorize=False)
+    b = gmrfx.MI355XBackend(Q, coords=mesh.points, factorize=False)
+    rng = np.random.default_rng(4)
+    for rep, nvec in enumerate((1, 5, 1)):
+        d_nz = torch.from_numpy(np.ascontiguousarray(Q.data * (1.0 + 0.5 * rep))).to(dev)
+        Zh = rng.standard_normal((nvec, n))
+        d_Z = torch.from_numpy(Zh).to(dev)
+        mu = rng.standard_normal(n) if rep == 1 else None
+        d_mu = torch.from_numpy(mu).to(dev) if mu is not None else None
+        torch.cuda.synchronize()
+        q1, ld1 = a.refactorize_logpdf_dev(d_nz.data_ptr(), d_Z.data_ptr(), n, nvec, d_mu.data_ptr() if d_mu is not None else 0)
+        assert b.refactorize_dev(d_nz.data_ptr()) == 0
+        q2 = b.quadform_dev(d_nz.data_ptr(), d_Z.data_ptr(), n, nvec, d_mu.data_ptr() if d_mu is not None else 0)
+        ld2 = b.compute_logdet()
+        assert a.last_info == 0 and np.array_equal(q1, q2) and ld1 == ld2
+        assert np.array_equal(a.factor_values(), b.factor_values())
+        assert a.compute_logdet() == ld1                          # kept for this factorisation
+        Qk = Q * (1.0 + 0.5 * rep)
+        F = orc.OracleFactor(sp.csc_matrix(Qk), a.ordering_permutation())
+        for k in range(nvec):
+            lp = -0.5 * q1[k] + 0.5 * ld1 - 0.5 * n * np.log(2.0 * np.pi)
+            lpo = orc.logpdf(F, sp.csc_matrix(Qk), Zh[k], mu)
+            assert abs(lp - lpo) <= 1e-10 * abs(lpo)
+    a.close(); b.close()
