@@ -239,8 +239,8 @@ class _NoLock:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--grid", type=int, default=1000, help="nodes per side of the 2-D mesh (cfg 2: 1000)")
     ap.add_argument("--nrhs", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
