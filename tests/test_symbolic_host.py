@@ -218,3 +218,48 @@ def test_sweep_tasks_structure_and_local_vector_walk(shape):
             tt = V[o:o + c[s]] - P[c[s]:].T @ V[lrow[sy.row_ptr[s] + c[s]:sy.row_ptr[s + 1]]]
             V[o:o + c[s]] = np.linalg.solve(np.tril(P[:c[s]]).T, tt)
         assert np.allclose(V[:nt], Xref[col0:col1], rtol=1e-9, atol=1e-12)
+
+
+def test_schedule_shape_levels_by_depth_and_wide_supernodes_end_at_branching_columns(monkeypatch):
+    """Round 3 (csrc/symbolic.cpp): (a) every front sits exactly one level below its parent (levels by depth below the root; with
+    GMRFX_TOP_BY_DEPTH=0 by height above the leaves: leaves on level 0) and both schedules factor to the same log-determinant on
+    the host walk; (b) a run of 128 .. 4096 columns ends below a branching column: with the rule on, the root of a 2-D mesh is
+    the root separator alone and the separators of BOTH halves are fronts of their own on the level below; with the rule off
+    (GMRFX_MERGE_WIDE huge) one of them is absorbed by the root. Same fill, same flops, same log-determinant."""
+    mesh = spde.grid_mesh_2d(150, 150, jitter=0.25, seed=3)
+    Q = spde.matern_precision(mesh, 0, 0.2)
+    n = Q.shape[0]
+
+    def analyse():
+        be = gmrfx.MI355XBackend(Q, coords=mesh.points, symbolic_only=True)
+        sy, st = be.symbolic(), be.stats()
+        be.close()
+        return sy, st
+
+    sy, st = analyse()
+    par, lv = np.asarray(sy.super_parent), np.asarray(sy.level)
+    c = np.diff(sy.super_first)
+    has = par >= 0
+    assert (lv[has] == lv[par[has]] - 1).all() and (lv[~has] == lv.max()).all()
+    root = int(np.flatnonzero(~has)[-1])
+    kids = np.flatnonzero(par == root)
+    assert len(kids) == 2 and (c[kids] >= 128).all() and c[root] < c[kids].sum() + c[root]      # both halves' separators are separate fronts
+    ld = HostSim(sy, n, np.asarray(Q.data)).factor().logdet()
+
+    monkeypatch.setenv("GMRFX_TOP_BY_DEPTH", "0")
+    sy0, st0 = analyse()
+    lv0, par0 = np.asarray(sy0.level), np.asarray(sy0.super_parent)
+    leaves = np.setdiff1d(np.arange(len(lv0)), par0[par0 >= 0])
+    assert (lv0[leaves] == 0).all() and (lv0[par0 >= 0] < lv0[par0[par0 >= 0]]).all() and lv0.max() == lv.max()
+    ld0 = HostSim(sy0, n, np.asarray(Q.data)).factor().logdet()
+    assert abs(ld - ld0) <= 1e-12 * abs(ld)
+    monkeypatch.delenv("GMRFX_TOP_BY_DEPTH")
+
+    monkeypatch.setenv("GMRFX_MERGE_WIDE", "1000000000")
+    sy1, st1 = analyse()
+    c1, par1 = np.diff(sy1.super_first), np.asarray(sy1.super_parent)
+    root1 = int(np.flatnonzero(par1 < 0)[-1])
+    assert len(c1) == len(c) - 1 and c1[root1] == c[root] + c[kids].min() or c1[root1] == c[root] + c[kids].max()
+    assert st1["nnz_l"] == st["nnz_l"] and abs(st1["factor_flops"] - st["factor_flops"]) <= 1e-9 * st["factor_flops"]
+    ld1 = HostSim(sy1, n, np.asarray(Q.data)).factor().logdet()
+    assert abs(ld - ld1) <= 1e-12 * abs(ld)
