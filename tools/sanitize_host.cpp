@@ -108,6 +108,7 @@ int main() {
     one_handle(cp, ri, nullptr, n, 1);        // natural ordering
     sharded_handles(cp, ri, xy.data(), n, 2);
     sharded_handles(cp, ri, xy.data(), n, 4);
+    sharded_handles(cp, ri, xy.data(), n, 8);      // the width the driver scales to
     // distinct handles are used concurrently from different host threads (WorkspacePool contract)
     {
         std::vector<int64_t> cp2, ri2; std::vector<double> xy2;
