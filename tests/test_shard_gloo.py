@@ -170,7 +170,7 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3, 5])
+@pytest.mark.parametrize("world", [2, 3, 5, 8])
 def test_sharded_factor_plan_and_logdet_gloo(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
