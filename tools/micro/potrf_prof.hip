@@ -11,7 +11,7 @@ using namespace gmrfx;
 int main(){
   const int n=64;
   std::vector<double> A(n*n,0.0);
-  for(int j=0;j<n;j++) for(int i=j;i<n;i++) A[i+j*n]= (i==j)? 4.0+0.01*i : -1.0/(1+abs(i-j));
+  for(int j=0;j<n;j++) for(int i=j;i<n;i++) A[i+j*n]= (i==j)? 9.0+0.01*i : -1.0/(1+abs(i-j));   // strictly diagonally dominant: SPD (4.0 was indefinite: NaNs that fmax() hid)
   double *dL,*dA; int *dlist,*dsf,*dld,*dinfo; long long *dpp;
   HC(hipMalloc(&dL,n*n*8)); HC(hipMalloc(&dA,n*n*8)); HC(hipMemcpy(dA,A.data(),n*n*8,hipMemcpyHostToDevice));
   int list0=0, sf[2]={0,n}, ldv=n, info=INT_MAX; long long pp[2]={0,(long long)n*n};
@@ -37,9 +37,9 @@ int main(){
 #endif
     std::vector<double> Lh(n*n); HC(hipMemcpy(Lh.data(),dL,n*n*8,hipMemcpyDeviceToHost));
     double err=0, errx=0, errpad=0;
-    for(int j=0;j<wv;j++) for(int i=j;i<wv;i++){ double s=0; for(int k=0;k<=j;k++) s+=Lh[i+k*n]*Lh[j+k*n]; err=fmax(err,fabs(s-A[i+j*n])); }
+    for(int j=0;j<wv;j++) for(int i=j;i<wv;i++){ double s=0; for(int k=0;k<=j;k++) s+=Lh[i+k*n]*Lh[j+k*n]; { double e_=fabs(s-A[i+j*n]); if(!(e_<=err)) err=e_; } }
     // X = L^-1 lower, stored transposed in the strict upper part: X[i][b] at (b, i); diag(X) = 1/diag(L)
-    for(int i=0;i<wv;i++) for(int b=0;b<=i;b++){ double s=0; for(int k=b;k<=i;k++){ double x = (k==b)? 1.0/Lh[b+b*n] : Lh[b+k*n]; s+=Lh[i+k*n]*x; } errx=fmax(errx,fabs(s-(i==b?1.0:0.0))); }
+    for(int i=0;i<wv;i++) for(int b=0;b<=i;b++){ double s=0; for(int k=b;k<=i;k++){ double x = (k==b)? 1.0/Lh[b+b*n] : Lh[b+k*n]; s+=Lh[i+k*n]*x; } { double e_=fabs(s-(i==b?1.0:0.0)); if(!(e_<=errx)) errx=e_; } }
     for(int j=0;j<n;j++) for(int i=0;i<n;i++) if(i>=wv||j>=wv) errpad=fmax(errpad,fabs(Lh[i+j*n]-A[i+j*n]));
     printf("  max |LL'-A| = %.3e, max |L X - I| = %.3e, untouched outside w: %.1e\n", err, errx, errpad);
     HC(hipEventRecord(e0,st));
