@@ -258,6 +258,8 @@ def main():
     ap.add_argument("--no-logpdf", action="store_true",
                     help="skip the (untimed) logpdf loop after the timed steps: keeps kernel traces / PMC passes to whole "
                          "refactorise+solve steps (tools/prof_summary.py, tools/pmc_traffic.py)")
+    ap.add_argument("--no-host-io", action="store_true",
+                    help="skip the (untimed) host-I/O block: the step through gmrfx_refactorize_solve with host B / X")
     ap.add_argument("--no-cfg3", action="store_true",
                     help="skip the (untimed) cfg-3 block after the timed steps: selected inverse + 256 samples on the same factor")
     ap.add_argument("--cfg4-grid", type=int, default=126,
@@ -361,6 +363,12 @@ def main():
     # kernels, same launches, same results.
     pipelined_phases = None
     ms_step_separate = None
+    # the output of the call that was TIMED is kept before anything else writes d_X: the residual / logdet checks below and
+    # the bit-for-bit comparison with the two separate calls are made on it
+    d_X_timed = d_X.clone()
+    logdet_timed = be.compute_logdet()
+    fail_col_timed = be.stats()["fail_col"]
+    pipelined_equals_separate = None
     if not args.separate_calls:
         pipelined_phases = {"factor": float(np.median(t_factor)), "behind_factor": float(np.median(t_solve)),
                             "forward_left_behind_factor": float(np.median(t_fwd)), "backward": float(np.median(t_bwd)),
@@ -377,6 +385,7 @@ def main():
         torch.cuda.synchronize()
         ms_step_separate = 1e3 * (time.perf_counter() - t1) / args.steps
         pipelined_phases["syrk_launches_separate"] = float(np.median(t_syrk_sep))
+        pipelined_equals_separate = bool(torch.equal(d_X_timed, d_X)) and be.compute_logdet() == logdet_timed
 
     # hyper-parameter loop (docs/.../workspace_factorization_reuse.jl:94-102): new values -> numeric
     # factorisation -> logpdf(z) = -r'Qr/2 + logdet(Q)/2 - n log(2 pi)/2, Q's values and z resident in HBM.
@@ -398,11 +407,39 @@ def main():
         be.quadform_dev(d_nz.data_ptr(), d_z.data_ptr(), n, 1)      # (the kernel alone, for its event time)
         ms_quadform = be.stats()["ms_quadform"]
 
-    # ---- untimed correctness evidence on this very run -------------------------------------
-    X = d_X.cpu().numpy().T            # n x nrhs
+    # ---- host I/O: the same step through the HOST entry point, gmrfx_refactorize_solve(nzval, B, X) with column-major host arrays --
+    # what the reference's workspace_solve(ws, B::Matrix) hands over (src/workspace/gmrf_workspace.jl:170-178, 207-215, backend.jl:207-209).
+    # The upload of B runs beside the factorisation, X leaves in slices behind the backward sweep (Device::host_upload / host_download).
+    # Untimed by `value`; pageable arrays (a Julia Matrix) and page-locked ones.
+    host_io = None
+    if rank == 0 and not args.no_host_io:
+        nzh = np.ascontiguousarray(Q.data)
+        host_io = {}
+        for kind in ("pageable", "pinned"):
+            if kind == "pageable":
+                Bf = np.asfortranarray(Bh.numpy().T)                      # n x nrhs, column-major
+                Xf = np.zeros_like(Bf, order="F")                         # (touched: no page faults inside the timed calls)
+                bp, xp = Bf.ctypes.data, Xf.ctypes.data
+            else:
+                Bp = Bh.clone().pin_memory()                              # row j of (nrhs, n) = column j of the column-major n x nrhs B
+                Xp = torch.zeros_like(Bp).pin_memory()
+                bp, xp = Bp.data_ptr(), Xp.data_ptr()
+            be.refactorize_solve_ptr(nzh.ctypes.data, bp, n, args.nrhs, xp, n)          # warm-up: staging buffer, copy stream
+            reps = max(3, min(args.steps, 10))
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                be.refactorize_solve_ptr(nzh.ctypes.data, bp, n, args.nrhs, xp, n)
+            ms = 1e3 * (time.perf_counter() - t1) / reps
+            Xh = torch.from_numpy(Xf.T) if kind == "pageable" else Xp
+            host_io[kind] = {"ms_per_step": ms, "dof_per_s": n / (ms * 1e-3), "reps": reps,
+                             "equals_device_resident_call": bool(torch.equal(Xh, d_X_timed.cpu()))}
+        be.refactorize_dev(d_nz.data_ptr())
+
+    # ---- untimed correctness evidence on this very run: the output of the TIMED call ---------
+    X = d_X_timed.cpu().numpy().T            # n x nrhs
     Bn = Bh.numpy().T
     resid = float(np.linalg.norm(Q @ X - Bn) / np.linalg.norm(Bn))
-    logdet = be.compute_logdet()
+    logdet = logdet_timed
     st = be.stats()
     if logpdf_ms is not None:
         zz = Bh[0].numpy()
@@ -580,11 +617,19 @@ def main():
             "step_call": "gmrfx_refactorize_dev + gmrfx_solve_dev" if args.separate_calls else
                          "gmrfx_refactorize_solve_dev (one pipelined call; include/gmrfx.h)",
             "ms_per_step_separate_calls": ms_step_separate, "pipelined_phases_ms": pipelined_phases,
+            # the same step through the HOST entry point (what the reference's seam hands over): never `value`
+            "ms_per_step_host_io": host_io["pageable"]["ms_per_step"] if host_io else None,
+            "value_host_io": host_io["pageable"]["dof_per_s"] if host_io else None,
+            "host_io": ({**host_io, "call": "gmrfx_refactorize_solve(nzval, B, X): column-major HOST arrays, n x nrhs doubles each way over PCIe "
+                                            "inside the timed call; upload beside the factorisation, X out in slices behind the backward sweep"}
+                        if host_io else None),
             "phases_ms": {"factor": mf, "solve": ms_, "solve_fwd": mfw, "solve_bwd": mbw, "solve_perm": med(t_perm),
                           "symbolic_host": st0["ms_symbolic"], **extras},
             "logpdf_per_s": (1e3 / logpdf_ms) if logpdf_ms else None, "logpdf_ms": logpdf_ms, "ms_quadform": ms_quadform,
             "logpdf_relerr_vs_host": logpdf_relerr,
-            "check": {"rel_residual": resid, "logdet": logdet, "fail_col": st["fail_col"]},
+            "check": {"rel_residual": resid, "logdet": logdet, "fail_col": fail_col_timed,
+                      "of": "the output of the timed call (copied out before any other call wrote d_X)",
+                      "pipelined_equals_separate": pipelined_equals_separate},
             "supernodes": int(st["nsuper"]), "levels": int(st["nlevels"]),
             "hbm_bytes_allocated": st["bytes_device_total"],
         }

@@ -3,10 +3,15 @@
 #include "device.h"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <climits>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <stdexcept>
+#include <thread>
 
 #include "kernels.h"
 
@@ -57,6 +62,12 @@ Device::~Device() {
     for (auto &e : ev_la_t_) (void)hipEventDestroy(e);
     for (auto &l : ev_lane_) for (auto &e : l) if (e) (void)hipEventDestroy(e);
     if (h_info_) (void)hipHostFree(h_info_);
+    if (h_stage_) (void)hipHostFree(h_stage_);
+    if (h_nzstage_) (void)hipHostFree(h_nzstage_);
+    if (ev_up_) (void)hipEventDestroy(ev_up_);
+    if (ev_x_) (void)hipEventDestroy(ev_x_);
+    for (auto &e : ev_dn_) (void)hipEventDestroy(e);
+    if (stream_io_) (void)hipStreamDestroy(stream_io_);
     if (h_logdet_) (void)hipHostFree(h_logdet_);
     if (h_qf_) (void)hipHostFree(h_qf_);
     if (ev_qf_) (void)hipEventDestroy(ev_qf_);
@@ -603,6 +614,183 @@ void Device::clone_from(const Device &o, const Symbolic &S) {
     }
 }
 
+// ---- host I/O of the pipelined factor + solve call (gmrfx_refactorize_solve with HOST B / X: what the reference's
+// workspace_solve(ws, B::Matrix) hands over, src/workspace/backend.jl:207-209) ---------------------------------------------
+// n x nrhs doubles each way (2 x 512 MB at cfg 2: ~9 ms each at the link's 57 GB/s, tools/pcie_probe.py) around a 14 ms step.
+// MEASURED (tools/host_io_step.py, cfg 2): the upload must NOT run beside the factorisation. Next to a 512 MB transfer on
+// another queue the factorisation takes 18-24 ms instead of 11.7 when the DMA engines move the bytes, and 25-30 ms when ONE
+// long kernel of 16 / 48 / 128 workgroups reads the page-locked buffer over PCIe (k_stream_copy; one launch, no DMA packets) --
+// the panel chain's ~500 dependent dispatches lose the command processor to whatever else is active (tools/interference.py
+// shows the same for every kind of concurrent work). So the transfers are serial -- B in, then the pipelined step, then X out --
+// at the full rate of the DMA engines, and what is overlapped is the host side: pageable memory is staged through a page-locked
+// buffer of the handle by several host threads (a single thread moves ~10 GB/s, the link 57), slice k's staging beside the DMA
+// of slice k-1, and on the way out slice k's copy to the caller's array beside the DMA of slice k+1. Page-locked caller memory
+// (hipHostMalloc / hipHostRegister, torch pin_memory) is handed to the DMA engine as it is.
+static bool host_ptr_is_pinned(const void *p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+// the address the GPU uses for a page-locked host pointer
+static double *host_ptr_device_view(const void *p) {
+    void *d = nullptr;
+    if (hipHostGetDevicePointer(&d, const_cast<void *>(p), 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return (double *)d;
+}
+static int host_io_threads() {
+    static const int nt = [] {
+        if (const char *e = std::getenv("GMRFX_IO_THREADS")) return std::max(1, std::atoi(e));
+        const unsigned hc = std::thread::hardware_concurrency();
+        return (int)std::min<unsigned>(8, std::max<unsigned>(1, hc / 2));
+    }();
+    return nt;
+}
+static int host_io_upload_wgs() {      // > 0: the upload as ONE kernel of that many workgroups (measurement only; default DMA)
+    static const int v = [] { const char *e = std::getenv("GMRFX_IO_UPLOAD_WGS"); return e ? std::max(0, std::atoi(e)) : 0; }();
+    return v;
+}
+static bool host_io_beside() {         // GMRFX_IO_BESIDE=1 (measurement only): the upload beside the factorisation instead of in front of it
+    static const bool v = [] { const char *e = std::getenv("GMRFX_IO_BESIDE"); return e && std::atoi(e) != 0; }();
+    return v;
+}
+static constexpr long long kIoSliceBytes = 32ll << 20;     // staging granularity
+
+// count doubles copied by up to T host threads (used for values that must arrive before anything can start)
+static void parallel_memcpy(double *dst, const double *src, long long count) {
+    const int T = (int)std::min<long long>(host_io_threads(), std::max<long long>(1, count >> 18));
+    if (T <= 1) { std::memcpy(dst, src, (size_t)count * sizeof(double)); return; }
+    std::vector<std::thread> th;
+    const long long per = (count + T - 1) / T;
+    for (int t = 1; t < T; t++) {
+        const long long a = t * per, e = std::min(count, a + per);
+        if (a < e) th.emplace_back([=] { std::memcpy(dst + a, src + a, (size_t)(e - a) * sizeof(double)); });
+    }
+    std::memcpy(dst, src, (size_t)std::min(per, count) * sizeof(double));
+    for (auto &x : th) x.join();
+}
+
+void Device::host_io_reserve(long long count) {
+    if (!stream_io_) {
+        HC(hipStreamCreateWithFlags(&stream_io_, hipStreamNonBlocking));
+        HC(hipEventCreateWithFlags(&ev_up_, hipEventDisableTiming));
+        HC(hipEventCreateWithFlags(&ev_x_, hipEventDisableTiming));
+    }
+    if (count <= h_stage_cap_) return;
+    if (h_stage_) { HC(hipDeviceSynchronize()); (void)hipHostFree(h_stage_); h_stage_ = nullptr; h_stage_cap_ = 0; }
+    HC(hipHostMalloc((void **)&h_stage_, (size_t)count * sizeof(double), hipHostMallocDefault));
+    h_stage_cap_ = count;
+    d_stage_view_ = host_ptr_device_view(h_stage_);
+    if (!d_stage_view_) throw std::runtime_error("page-locked staging buffer is not visible to the device");
+}
+
+// Q's values from a host array to d_nz_, ahead of the factorisation (nothing else runs yet: plain DMA)
+void Device::host_upload_values(const double *nzval) {
+    const long long cnt = S_->nnz_in;
+    if (host_ptr_is_pinned(nzval)) {
+        HC(hipMemcpyAsync(d_nz_, nzval, (size_t)cnt * sizeof(double), hipMemcpyHostToDevice, stream));
+        return;
+    }
+    if (!h_nzstage_) HC(hipHostMalloc((void **)&h_nzstage_, (size_t)std::max<long long>(cnt, 1) * sizeof(double), hipHostMallocDefault));
+    HC(hipStreamSynchronize(stream));                 // (an earlier call's copy out of the staging buffer has finished long ago; cheap)
+    parallel_memcpy(h_nzstage_, nzval, cnt);
+    HC(hipMemcpyAsync(d_nz_, h_nzstage_, (size_t)cnt * sizeof(double), hipMemcpyHostToDevice, stream));
+}
+
+// B (host, column-major n x nrhs, leading dimension ldb) -> d_dst (device, column-major, leading dimension n), on the copy
+// stream; returns after every copy has been ENQUEUED and ev_up_ recorded behind the last one.
+void Device::host_upload(const double *B, long long ldb, long long nrhs, double *d_dst) {
+    const long long n = S_->n;
+    host_io_reserve(0);
+    const int nwg = host_io_upload_wgs();
+    const bool by_kernel = nwg > 0;       // GMRFX_IO_UPLOAD_WGS > 0 (measurement only): k_stream_copy instead of the DMA engines
+    if (host_ptr_is_pinned(B)) {
+        const double *dv = by_kernel ? host_ptr_device_view(B) : nullptr;
+        if (dv) {
+            launch_stream_copy(stream_io_, dv, ldb, d_dst, n, n, nrhs, nwg);
+            HC(hipGetLastError());
+        } else if (ldb == n) HC(hipMemcpyAsync(d_dst, B, (size_t)(n * nrhs) * sizeof(double), hipMemcpyHostToDevice, stream_io_));
+        else HC(hipMemcpy2DAsync(d_dst, n * sizeof(double), B, ldb * sizeof(double), n * sizeof(double), nrhs, hipMemcpyHostToDevice, stream_io_));
+        HC(hipEventRecord(ev_up_, stream_io_));
+        return;
+    }
+    host_io_reserve(n * nrhs);
+    // column slices of ~64 MB; slice k is staged by host thread k mod T, which then launches its copy kernel
+    const long long cols_per = std::max<long long>(1, kIoSliceBytes / (n * (long long)sizeof(double)));
+    const long long nsl = (nrhs + cols_per - 1) / cols_per;
+    const int T = (int)std::min<long long>(host_io_threads(), nsl);
+    std::vector<std::thread> th;
+    std::exception_ptr err;
+    std::atomic<bool> failed{false};
+    const int dev = device;
+    auto work = [&](int t) {
+        try {
+            HC(hipSetDevice(dev));
+            for (long long k = t; k < nsl && !failed.load(); k += T) {
+                const long long j0 = k * cols_per, nc = std::min(cols_per, nrhs - j0);
+                for (long long j = 0; j < nc; j++)
+                    std::memcpy(h_stage_ + (j0 + j) * n, B + (j0 + j) * ldb, (size_t)n * sizeof(double));
+                if (by_kernel) {
+                    launch_stream_copy(stream_io_, d_stage_view_ + j0 * n, n, d_dst + j0 * n, n, n, nc, nwg);
+                    HC(hipGetLastError());
+                } else HC(hipMemcpyAsync(d_dst + j0 * n, h_stage_ + j0 * n, (size_t)(nc * n) * sizeof(double), hipMemcpyHostToDevice, stream_io_));
+            }
+        } catch (...) {
+            if (!failed.exchange(true)) err = std::current_exception();
+        }
+    };
+    for (int t = 1; t < T; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+    if (err) std::rethrow_exception(err);
+    HC(hipEventRecord(ev_up_, stream_io_));
+}
+
+// d_src (device, column-major n x nrhs, leading dimension n; final once `after` has passed) -> X (host); returns when X is complete
+void Device::host_download(const double *d_src, long long nrhs, double *X, long long ldx, hipStream_t after) {
+    const long long n = S_->n;
+    host_io_reserve(0);
+    // the copies are enqueued only once their source is final: a device-to-host copy that has to wait for an event on another
+    // stream took 21 ms instead of 9 here (512 MB; the runtime leaves the DMA path for it)
+    HC(hipStreamSynchronize(after));
+    if (host_ptr_is_pinned(X)) {
+        if (ldx == n) HC(hipMemcpyAsync(X, d_src, (size_t)(n * nrhs) * sizeof(double), hipMemcpyDeviceToHost, stream_io_));
+        else HC(hipMemcpy2DAsync(X, ldx * sizeof(double), d_src, n * sizeof(double), n * sizeof(double), nrhs, hipMemcpyDeviceToHost, stream_io_));
+        HC(hipStreamSynchronize(stream_io_));
+        return;
+    }
+    host_io_reserve(n * nrhs);
+    const long long cols_per = std::max<long long>(1, (kIoSliceBytes / 2) / (n * (long long)sizeof(double)));
+    const long long nsl = (nrhs + cols_per - 1) / cols_per;
+    while ((long long)ev_dn_.size() < nsl) { hipEvent_t e; HC(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ev_dn_.push_back(e); }
+    for (long long k = 0; k < nsl; k++) {
+        const long long j0 = k * cols_per, nc = std::min(cols_per, nrhs - j0);
+        HC(hipMemcpyAsync(h_stage_ + j0 * n, d_src + j0 * n, (size_t)(nc * n) * sizeof(double), hipMemcpyDeviceToHost, stream_io_));
+        HC(hipEventRecord(ev_dn_[k], stream_io_));
+    }
+    const int T = (int)std::min<long long>(host_io_threads(), nsl);
+    std::vector<std::thread> th;
+    std::exception_ptr err;
+    std::atomic<bool> failed{false};
+    const int dev = device;
+    auto work = [&](int t) {
+        try {
+            HC(hipSetDevice(dev));
+            for (long long k = t; k < nsl; k += T) {
+                const long long j0 = k * cols_per, nc = std::min(cols_per, nrhs - j0);
+                HC(hipEventSynchronize(ev_dn_[k]));
+                for (long long j = 0; j < nc; j++)
+                    std::memcpy(X + (j0 + j) * ldx, h_stage_ + (j0 + j) * n, (size_t)n * sizeof(double));
+            }
+        } catch (...) {
+            if (!failed.exchange(true)) err = std::current_exception();
+        }
+    };
+    for (int t = 1; t < T; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+    if (err) std::rethrow_exception(err);
+}
+
 static const int kClsRows[4] = {48, 64, 96, 128};
 static const int OBK = 4;   // 64-column blocks per outer (256-column) block of the panel factorisation
 static inline int level_max_trail(const LevelInfo &L) { return L.active.back(); }
@@ -808,9 +996,16 @@ void Device::refactorize_solve(const double *nzval, bool nz_on_device, const dou
     }
     const long long n = S_->n;
     const int nl = (int)levels_.size();
+    // GMRFX_IO_TRACE=1: host-side timestamps of the call's stages on stderr (measurement aid)
+    static const bool io_trace = [] { const char *e = std::getenv("GMRFX_IO_TRACE"); return e && std::atoi(e) != 0; }();
+    const auto tr0 = std::chrono::steady_clock::now();
+    auto trace = [&](const char *what) {
+        if (io_trace) std::fprintf(stderr, "[gmrfx io] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count());
+    };
     const double *src = nzval;
     if (!nz_on_device) {
-        HC(hipMemcpyAsync(d_nz_, nzval, (size_t)S_->nnz_in * sizeof(double), hipMemcpyHostToDevice, stream));
+        host_upload_values(nzval);
+        trace("values enqueued");
         src = d_nz_;
     }
     nz_held_ = (src == d_nz_);
@@ -822,24 +1017,31 @@ void Device::refactorize_solve(const double *nzval, bool nz_on_device, const dou
     if (!b_on_device) {
         const long long need = n * nrhs;
         if (need > io_cap_) { const long long cap = std::max(need, 2 * io_cap_); d_io_ = dregrow(d_io_, (size_t)cap); io_cap_ = cap; }
-        if (ldb == n) HC(hipMemcpyAsync(d_io_, B, (size_t)need * sizeof(double), hipMemcpyHostToDevice, stream));
-        else HC(hipMemcpy2DAsync(d_io_, n * sizeof(double), B, ldb * sizeof(double), n * sizeof(double), nrhs, hipMemcpyHostToDevice, stream));
         dB = d_io_; dXo = d_io_; ldin = n; ldout = n;
     }
     while ((int)ev_flevel_.size() < nl + 1) { hipEvent_t e; HC(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ev_flevel_.push_back(e); }
     factor_serial_++;
+    // host right-hand sides: in FRONT of the factorisation (see the measurements above host_upload), unless asked otherwise
+    const bool up_first = !b_on_device && !host_io_beside();
+    if (up_first) {
+        host_upload(B, ldb, nrhs, d_io_);
+        HC(hipStreamWaitEvent(stream, ev_up_, 0));
+        trace("B upload enqueued");
+    }
     HC(hipEventRecord(ev_[0], stream));
     HC(hipEventRecord(ev_ready_, stream));                 // the side stream starts behind the uploads / whatever precedes this call
     struct Flag { bool &f; ~Flag() { f = false; } } f1{fused_}, f2{fused_fwd_};
     fused_ = true;
     factor_levels(0, nl);
     fused_ = false;
+    trace("factorisation enqueued");
     HC(hipEventRecord(ev_[1], stream));
     HC(hipEventRecord(ev_fact_, stream));
     fact_event_valid_ = true;
     HC(hipMemcpyAsync(h_info_, d_info_, sizeof(int), hipMemcpyDeviceToHost, stream));
     factorized = true;
     selinv_valid = false;
+    if (!b_on_device && !up_first) host_upload(B, ldb, nrhs, d_io_);     // (measurement switch: beside the factorisation just enqueued)
     // ---- first pass of up to 64 columns: forward sweep on the side stream, behind the level events
     const int nr = (int)std::min<long long>(64, nrhs), ldx = nr;
     hipEvent_t *ev = ev_lane_[0];
@@ -848,6 +1050,7 @@ void Device::refactorize_solve(const double *nzval, bool nz_on_device, const dou
         struct Restore { Device &D; hipStream_t st; ~Restore() { D.stream = st; } } restore{*this, main_stream};
         stream = stream2;
         HC(hipStreamWaitEvent(stream, ev_ready_, 0));
+        if (!b_on_device) HC(hipStreamWaitEvent(stream, ev_up_, 0));
         HC(hipEventRecord(ev[0], stream));
         launch_permute(stream, d_iperm_, (int)n, const_cast<double *>(dB), ldin, d_X_, nr, ldx, 0);
         HC(hipEventRecord(ev[1], stream));
@@ -874,11 +1077,9 @@ void Device::refactorize_solve(const double *nzval, bool nz_on_device, const dou
         launch_permute(stream, d_iperm_, (int)n, dXo + j0 * ldout, ldout, d_X_, nr2, nr2, 1);
     }
     HC(hipEventRecord(ev_lane_[1][0], stream));
-    if (!b_on_device) {
-        const long long need = n * nrhs;
-        if (ldx_out == n) HC(hipMemcpyAsync(X, d_io_, (size_t)need * sizeof(double), hipMemcpyDeviceToHost, stream));
-        else HC(hipMemcpy2DAsync(X, ldx_out * sizeof(double), d_io_, n * sizeof(double), n * sizeof(double), nrhs, hipMemcpyDeviceToHost, stream));
-    }
+    trace("sweeps enqueued");
+    if (!b_on_device) host_download(d_io_, nrhs, X, ldx_out, stream);
+    trace("X downloaded");
     HC(hipStreamSynchronize(stream));
     info_cached_ = true;
     HC(hipGetLastError());

@@ -329,6 +329,16 @@ private:
     hipEvent_t ev_lane_[2][5] = {};
     hipEvent_t ev_ready_ = nullptr, ev_ready2_ = nullptr, ev_done1_ = nullptr;
     int *d_info_ = nullptr;
+    // host I/O of the pipelined factor + solve call: copy stream, page-locked staging buffer, events
+    hipStream_t stream_io_ = nullptr;
+    double *h_stage_ = nullptr, *d_stage_view_ = nullptr, *h_nzstage_ = nullptr;
+    long long h_stage_cap_ = 0;
+    void host_upload_values(const double *nzval);
+    hipEvent_t ev_up_ = nullptr, ev_x_ = nullptr;
+    std::vector<hipEvent_t> ev_dn_;
+    void host_io_reserve(long long count);
+    void host_upload(const double *B, long long ldb, long long nrhs, double *d_dst);
+    void host_download(const double *d_src, long long nrhs, double *X, long long ldx, hipStream_t after);
     struct RowDiagPlan { long long nseg = 0, cnt = 0, nvals = 0; long long *seg = nullptr, *off = nullptr; int *p = nullptr, *q = nullptr; double *vals = nullptr, *out = nullptr; };
     std::vector<RowDiagPlan> rd_plans_;
     // caller's CSC pattern, uploaded on the first quadform call

@@ -383,6 +383,16 @@ class MI355XBackend:
         self.last_info = info.value
         return X[:, 0].copy() if vec else X
 
+    def refactorize_solve_ptr(self, nzval_ptr: int, B_ptr: int, ldb: int, nrhs: int, X_ptr: int, ldx: int) -> int:
+        """gmrfx_refactorize_solve on raw HOST pointers (column-major B / X the caller keeps alive; page-locked memory is handed to
+        the DMA engine directly, pageable memory is staged by the library): the call a Julia `workspace_solve(ws, B::Matrix)` makes."""
+        info = C.c_int64(0)
+        check(lib().gmrfx_refactorize_solve(self._h, nzval_ptr, B_ptr, ldb, nrhs, X_ptr, ldx, C.byref(info)), self._h)
+        self._selinv_cache = None
+        self._selinv_diag_cache = None
+        self.last_info = info.value
+        return info.value
+
     # -- Newton loop on the device (SURVEY 8 f4; src/workspace/gaussian_approximation.jl:63-129) --------
     def set_prior(self, prior_nzval, hess_map) -> None:
         """prior_nzval: values of the prior precision in the pattern's CSC order; hess_map: 0-based positions

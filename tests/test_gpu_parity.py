@@ -1115,6 +1115,81 @@ def test_refactorize_solve_pipelined_equals_separate_calls(mesh_kind):
     a.close(); b.close()
 
 
+def test_refactorize_solve_host_io_paths_equal_device_call():
+    """gmrfx_refactorize_solve with HOST right-hand sides (what the reference's seam hands over, backend.jl:207-209): the
+    upload runs on a copy stream beside the factorisation and the result leaves in slices (Device::host_upload / host_download).
+    Pageable arrays (staged through the handle's page-locked buffer by several host threads, more than one 32 MB slice),
+    page-locked arrays (direct DMA) and a leading dimension larger than n must all give the bits of the device-resident call."""
+    import torch
+    mesh = spde.grid_mesh_2d(300, 290, jitter=0.25, seed=7)
+    Q = spde.matern_precision(mesh, 0, 0.2)
+    n = Q.shape[0]
+    dev = torch.device("cuda", 0)
+    be = gmrfx.MI355XBackend(Q, coords=mesh.points, factorize=False)
+    rng = np.random.default_rng(3)
+    nrhs = 100                                                      # 87 000 x 100 doubles = 70 MB: three staging slices, two passes of the sweeps
+    nz = np.ascontiguousarray(Q.data * 1.5)
+    Bf = np.asfortranarray(rng.standard_normal((n, nrhs)))
+    d_nz = torch.from_numpy(nz).to(dev)
+    d_B = torch.from_numpy(np.ascontiguousarray(Bf.T)).to(dev)
+    d_X = torch.zeros_like(d_B)
+    assert be.refactorize_solve_dev(d_nz.data_ptr(), d_B.data_ptr(), n, nrhs, d_X.data_ptr(), n) == 0
+    torch.cuda.synchronize()
+    ref = d_X.cpu().numpy().T                                       # n x nrhs
+    assert np.linalg.norm((Q * 1.5) @ ref - Bf) / np.linalg.norm(Bf) < 1e-10
+    # pageable, contiguous
+    Xf = np.zeros_like(Bf, order="F")
+    for _ in range(2):                                              # (second call: staging buffer and events reused)
+        Xf[:] = 0.0
+        assert be.refactorize_solve_ptr(nz.ctypes.data, Bf.ctypes.data, n, nrhs, Xf.ctypes.data, n) == 0
+        assert np.array_equal(Xf, ref)
+    # pageable, leading dimensions larger than n (views into taller arrays)
+    Bt = np.asfortranarray(np.zeros((n + 5, nrhs))); Bt[:n] = Bf
+    Xt = np.asfortranarray(np.full((n + 3, nrhs), -7.0))
+    assert be.refactorize_solve_ptr(nz.ctypes.data, Bt.ctypes.data, n + 5, nrhs, Xt.ctypes.data, n + 3) == 0
+    assert np.array_equal(Xt[:n], ref) and np.all(Xt[n:] == -7.0)
+    # page-locked: (nrhs, n) row-major = column-major n x nrhs
+    Bp = torch.from_numpy(np.ascontiguousarray(Bf.T)).pin_memory()
+    Xp = torch.zeros_like(Bp).pin_memory()
+    assert be.refactorize_solve_ptr(nz.ctypes.data, Bp.data_ptr(), n, nrhs, Xp.data_ptr(), n) == 0
+    assert np.array_equal(Xp.numpy().T, ref)
+    be.close()
+
+
+def test_full_size_cfg2_pipelined_equals_separate_calls():
+    """The call bench.py times, at the size it is timed (BASELINE cfg 2: 1000 x 1000 nodes): gmrfx_refactorize_solve_dev against
+    gmrfx_refactorize_dev + gmrfx_solve_dev on a second handle -- factor, X and log-determinant bit for bit for 64 and 17
+    right-hand sides (the gate that holds the bottom of the forward sweep back sits at a different level of an 18-level tree
+    than of the 10-level trees of the small cases), and the residual of the pipelined X below 1e-9."""
+    import torch
+    m = spde.grid_mesh_2d(1000, 1000, jitter=0.25, seed=0)
+    Q = spde.matern_precision(m, 0, 0.2)
+    n = Q.shape[0]
+    dev = torch.device("cuda", 0)
+    a = gmrfx.MI355XBackend(Q, coords=m.points, factorize=False)
+    b = gmrfx.MI355XBackend(Q, ordering=a.ordering_permutation(), factorize=False)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    for rep, nrhs in enumerate((64, 17)):
+        scale = 1.0 + 0.5 * rep
+        d_nz = torch.from_numpy(np.ascontiguousarray(Q.data * scale)).to(dev)
+        Bh = torch.randn((nrhs, n), generator=g, dtype=torch.float64)
+        d_B = Bh.to(dev)
+        d_Xa, d_Xb = torch.zeros_like(d_B), torch.zeros_like(d_B)
+        torch.cuda.synchronize()
+        for _ in range(2):                                          # twice: the second call reuses events, buffers and inverses' storage
+            assert a.refactorize_solve_dev(d_nz.data_ptr(), d_B.data_ptr(), n, nrhs, d_Xa.data_ptr(), n) == 0
+        assert b.refactorize_dev(d_nz.data_ptr()) == 0
+        b.solve_dev(d_B.data_ptr(), n, nrhs, d_Xb.data_ptr(), n)
+        torch.cuda.synchronize()
+        assert torch.equal(d_Xa, d_Xb), f"nrhs={nrhs}: pipelined and separate solves differ by {float((d_Xa - d_Xb).abs().max()):.3e}"
+        assert a.compute_logdet() == b.compute_logdet()
+        assert np.array_equal(a.factor_values(), b.factor_values())
+        X = d_Xa.cpu().numpy().T
+        Bn = Bh.numpy().T
+        assert np.linalg.norm((Q * scale) @ X - Bn) / np.linalg.norm(Bn) < 1e-9
+    a.close(); b.close()
+
+
 def test_refactorize_logpdf_one_call_equals_three_calls():
     """gmrfx_refactorize_logpdf_dev (one evaluation of the hyper-parameter loop: factorisation, r'Qr beside it on the side stream,
     log-determinant behind it, one synchronisation) against gmrfx_refactorize_dev + gmrfx_quadform_dev + gmrfx_logdet: quadratic

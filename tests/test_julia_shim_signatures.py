@@ -14,6 +14,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 JL = os.path.join(ROOT, "gaussianmarkovrandomfields.jl_amd", "julia", "GMRFX.jl")
+JL_EXT = os.path.join(ROOT, "gaussianmarkovrandomfields.jl_amd", "julia", "ext", "GMRFXAMDGPUExt.jl")      # ROCArray methods (*_dev entry points)
 HDR = os.path.join(ROOT, "include", "gmrfx.h")
 sys.path.insert(0, os.path.join(ROOT, "gaussianmarkovrandomfields.jl_amd"))
 
@@ -57,8 +58,10 @@ def _balanced(text, start):
     raise AssertionError("unbalanced parentheses in GMRFX.jl")
 
 
-def julia_ccalls():
-    src = open(JL).read()
+def julia_ccalls(path=None):
+    if path is None:
+        return julia_ccalls(JL) + julia_ccalls(JL_EXT)
+    src = open(path).read()
     calls = []
     for m in re.finditer(r"ccall\(\(:(gmrfx_\w+),\s*LIB\)\s*,", src):
         end = _balanced(src, m.start() + len("ccall"))
@@ -68,7 +71,7 @@ def julia_ccalls():
         assert types.startswith("(") and types.endswith(")"), (m.group(1), types)
         tlist = _split_top(types[1:-1])
         nargs = len(parts) - 2
-        calls.append((m.group(1), ret, tlist, nargs, src.count("\n", 0, m.start()) + 1))
+        calls.append((m.group(1), ret, tlist, nargs, f"{os.path.basename(path)}:{src.count(chr(10), 0, m.start()) + 1}"))
     return calls
 
 
@@ -103,17 +106,17 @@ def test_every_ccall_matches_its_prototype():
     calls = julia_ccalls()
     assert len(calls) >= 20, "the shim binds at least the seam-B protocol"
     for name, ret, tlist, nargs, line in calls:
-        assert name in protos, f"GMRFX.jl:{line}: {name} is not declared in include/gmrfx.h"
+        assert name in protos, f"{line}: {name} is not declared in include/gmrfx.h"
         cret, cargs = protos[name]
-        assert JL2C[ret] == cret, f"GMRFX.jl:{line}: {name} returns {cret}, the shim says {ret}"
-        assert len(tlist) == len(cargs), f"GMRFX.jl:{line}: {name} takes {len(cargs)} arguments, the type tuple has {len(tlist)}"
-        assert nargs == len(tlist), f"GMRFX.jl:{line}: {name}: {nargs} values passed for {len(tlist)} types"
+        assert JL2C[ret] == cret, f"{line}: {name} returns {cret}, the shim says {ret}"
+        assert len(tlist) == len(cargs), f"{line}: {name} takes {len(cargs)} arguments, the type tuple has {len(tlist)}"
+        assert nargs == len(tlist), f"{line}: {name}: {nargs} values passed for {len(tlist)} types"
         for k, (jt, ct) in enumerate(zip(tlist, cargs)):
-            assert jt in JL2C, f"GMRFX.jl:{line}: {name} argument {k}: unknown Julia type {jt}"
+            assert jt in JL2C, f"{line}: {name} argument {k}: unknown Julia type {jt}"
             want = JL2C[jt]
             # a `const gmrfx_handle *` and a `gmrfx_handle *` are the same pointer; void* scratch / device pointers too
             ok = want == ct or (want == "HANDLE*" and ct in ("void*",))
-            assert ok, f"GMRFX.jl:{line}: {name} argument {k}: header has {ct}, the shim passes {jt}"
+            assert ok, f"{line}: {name} argument {k}: header has {ct}, the shim passes {jt}"
 
 
 def test_seam_b_protocol_is_bound():
@@ -149,3 +152,32 @@ def test_opts_struct_matches_gmrfx_opts():
         assert getattr(_lib.GmrfxOpts, n).offset == off, n
         off += a
     assert (off + 7) // 8 * 8 == ctypes.sizeof(_lib.GmrfxOpts)
+
+
+def test_device_entry_points_are_bound_for_rocarrays():
+    """the *_dev calls (operands resident in HBM: the call bench.py times) are bound in the AMDGPU.jl extension, with device
+    pointers passed as Ptr{Float64}"""
+    names = {c[0] for c in julia_ccalls(JL_EXT)}
+    for need in ("gmrfx_refactorize_dev", "gmrfx_refactorize_solve_dev", "gmrfx_solve_dev", "gmrfx_backward_solve_dev",
+                 "gmrfx_refactorize_logpdf_dev"):
+        assert need in names, need
+    src = open(JL_EXT).read()
+    assert "module GMRFXAMDGPUExt" in src and "using AMDGPU" in src
+    # every function the extension adds methods to exists in the parent module
+    parent = open(JL).read()
+    for fn in ("refactorize_solve!", "backend_solve!", "backend_backward_solve!", "logpdf_terms"):
+        assert re.search(r"function\s+" + re.escape(fn), parent), fn
+
+
+def test_workspace_solve_is_a_real_method_on_this_backend():
+    """the reference's workspace_solve (gmrf_workspace.jl:207-215) is overloaded for workspaces on MI355XBackend -- as code, not as a
+    comment -- for vectors and matrices separately (one AbstractVecOrMat method would be ambiguous with the reference's two), and a
+    stale factorisation goes down as the pipelined host call gmrfx_refactorize_solve"""
+    code = "\n".join(l for l in open(JL).read().splitlines() if not l.lstrip().startswith("#"))
+    assert re.search(r"G\.workspace_solve\(ws::GMRFWorkspace\{<:Any,\s*MI355XBackend\},\s*b::AbstractVector\)", code)
+    assert re.search(r"G\.workspace_solve\(ws::GMRFWorkspace\{<:Any,\s*MI355XBackend\},\s*B::AbstractMatrix\)", code)
+    body = code[code.index("function _workspace_solve"):]
+    body = body[:body.index("\nend")]
+    assert "refactorize_solve!(ws.backend, Symmetric(ws.Q), B)" in body and "ws.numeric_valid = true" in body
+    assert "ws.selinv_valid = false" in body and "ws.logdet_valid = false" in body
+    assert any(c[0] == "gmrfx_refactorize_solve" for c in julia_ccalls(JL))
