@@ -1876,6 +1876,19 @@ void Device::rowdiag_plan_free(long long id) {
     P = RowDiagPlan{};
 }
 
+void Device::dense_apply(const double *d_D, const double *d_T, double *d_R, long long n1, long long n2) {
+    HC(hipSetDevice(device));
+    launch_dense_apply(stream, d_D, d_T, d_R, (int)n1, n2);
+    HC(hipGetLastError());
+    HC(hipStreamSynchronize(stream));
+}
+void Device::transpose(const double *d_src, double *d_dst, long long rows, long long cols) {
+    HC(hipSetDevice(device));
+    launch_transpose(stream, d_src, d_dst, rows, cols);
+    HC(hipGetLastError());
+    HC(hipStreamSynchronize(stream));
+}
+
 void Device::copy_factor(double *out_host) {
     HC(hipSetDevice(device));
     HC(hipMemcpy(out_host, d_L_, (size_t)l_size_ * sizeof(double), hipMemcpyDeviceToHost));

@@ -192,6 +192,9 @@ public:
     void rowdiag_plan_apply(long long id, const double *values_host, double *out_host);
     void rowdiag_plan_free(long long id);
     void copy_factor(double *out_host);
+    // dense-operator leg of the Kronecker path (dense.hip): R = D T, all row-major device arrays; dst = src' (rows x cols)
+    void dense_apply(const double *d_D, const double *d_T, double *d_R, long long n1, long long n2);
+    void transpose(const double *d_src, double *d_dst, long long rows, long long cols);
     long long fail_col();
 
     bool factorized = false, selinv_valid = false;

@@ -756,6 +756,29 @@ extern "C" int32_t gmrfx_quadform_dev(gmrfx_handle *h, const double *d_nzval, co
     return quadform_impl(h, d_nzval, d_X, ldx, nvec, d_mu, out, true);
 }
 
+// ---- dense-operator leg of the separable (Kronecker) path, SURVEY 8 f3 (separable.jl:122-172) -------------
+extern "C" int32_t gmrfx_dense_apply_dev(gmrfx_handle *h, int64_t n1, int64_t n2, const double *d_D, const double *d_T, double *d_R) {
+    return guarded(h, [&]() -> int32_t {
+        if (int32_t e = need_device(h, false)) return e;
+        if (n1 < 0 || n2 < 0 || n1 > 0x7fffffffLL) throw std::invalid_argument("dense_apply: bad dimensions");
+        if (n1 > 0 && n2 > 0 && (!d_D || !d_T || !d_R)) throw std::invalid_argument("dense_apply: null pointer");
+        if (d_T == d_R) throw std::invalid_argument("dense_apply: T and R must not alias");
+        if (n1 > 0 && n2 > 0 && (n2 + 63) / 64 * ((n1 + 63) / 64) > 0x0fffffffLL) throw std::invalid_argument("dense_apply: too many tiles");
+        h->D->dense_apply(d_D, d_T, d_R, n1, n2);
+        return GMRFX_OK;
+    });
+}
+extern "C" int32_t gmrfx_transpose_dev(gmrfx_handle *h, int64_t rows, int64_t cols, const double *d_src, double *d_dst) {
+    return guarded(h, [&]() -> int32_t {
+        if (int32_t e = need_device(h, false)) return e;
+        if (rows < 0 || cols < 0) throw std::invalid_argument("transpose: bad dimensions");
+        if (rows > 0 && cols > 0 && (!d_src || !d_dst || d_src == d_dst)) throw std::invalid_argument("transpose: null or aliased pointers");
+        if (((rows + 63) >> 6) * ((cols + 63) >> 6) > 0x7fffffffLL) throw std::invalid_argument("transpose: too many tiles");
+        h->D->transpose(d_src, d_dst, rows, cols);
+        return GMRFX_OK;
+    });
+}
+
 namespace gmrfx {
 struct KlTask { long long rows_off; long long cols_off; int nrows, ncols; };
 long long kl_cholesky_run(int device, long long n, const double *theta, long long ldt, bool theta_on_device,

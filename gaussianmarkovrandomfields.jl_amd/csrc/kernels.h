@@ -411,6 +411,10 @@ void launch_logdet(hipStream_t st, const double *L, const long long *diagoff, co
 void launch_gather(hipStream_t st, const double *src, const long long *off, long long cnt, double *out);
 void launch_gather_diag(hipStream_t st, const double *src, const long long *diagoff, const int *perm, int n, double *out);
 
+// dense.hip -- the dense-operator leg of the Kronecker path: R = D T (row-major, D n1 x n1, T / R n1 x n2) and a transpose
+void launch_dense_apply(hipStream_t st, const double *D, const double *T, double *R, int n1, long long n2);
+void launch_transpose(hipStream_t st, const double *src, double *dst, long long rows, long long cols);
+
 // small.hip -- fused kernels for fronts with r <= 96 / 128 rows and c <= 64 columns
 void launch_factor_small(hipStream_t st, const DevSym &S, const int *list, int nfronts, int rmax,
                          const double *nzval, double *L, double *CB, int *info);

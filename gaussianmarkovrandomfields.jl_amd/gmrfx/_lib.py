@@ -54,6 +54,7 @@ class PosDefException(GmrfxError):
 _lib = None
 EXPORTS = [
     "gmrfx_last_create_error", "gmrfx_last_error", "gmrfx_create", "gmrfx_destroy", "gmrfx_clone",
+    "gmrfx_dense_apply_dev", "gmrfx_transpose_dev",
     "gmrfx_refactorize", "gmrfx_refactorize_dev", "gmrfx_refactorize_solve", "gmrfx_refactorize_solve_dev",
     "gmrfx_refactorize_update_solve", "gmrfx_refactorize_update_solve_dev", "gmrfx_refactorize_logpdf_dev", "gmrfx_solve", "gmrfx_solve_dev", "gmrfx_backward_solve",
     "gmrfx_backward_solve_dev", "gmrfx_logdet", "gmrfx_selinv_compute", "gmrfx_selinv_diag", "gmrfx_selinv_nnz",
@@ -94,6 +95,8 @@ def lib():
         L.gmrfx_clone.argtypes = [vp, C.POINTER(vp)]
         L.gmrfx_refactorize.argtypes = [vp, vp, C.POINTER(i64)]
         L.gmrfx_refactorize_dev.argtypes = [vp, vp, C.POINTER(i64)]
+        L.gmrfx_dense_apply_dev.argtypes = [vp, i64, i64, vp, vp, vp]
+        L.gmrfx_transpose_dev.argtypes = [vp, i64, i64, vp, vp]
         L.gmrfx_refactorize_solve.argtypes = [vp, vp, vp, i64, i64, vp, i64, C.POINTER(i64)]
         L.gmrfx_refactorize_solve_dev.argtypes = [vp, vp, vp, i64, i64, vp, i64, C.POINTER(i64)]
         L.gmrfx_refactorize_logpdf_dev.argtypes = [vp, vp, vp, i64, i64, vp, vp, C.POINTER(dbl), C.POINTER(i64)]

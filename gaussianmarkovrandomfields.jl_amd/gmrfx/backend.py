@@ -383,6 +383,15 @@ class MI355XBackend:
         self.last_info = info.value
         return X[:, 0].copy() if vec else X
 
+    def dense_apply_dev(self, d_D: int, n1: int, d_T: int, n2: int, d_R: int) -> None:
+        """R = D T on the device (gmrfx_dense_apply_dev): row-major D (n1 x n1), T and R (n1 x n2); the dense-operator leg of the
+        Kronecker path (separable.jl:122-172). T needs 8 readable bytes behind it when n2 is odd."""
+        check(lib().gmrfx_dense_apply_dev(self._h, n1, n2, d_D, d_T, d_R), self._h)
+
+    def transpose_dev(self, d_src: int, rows: int, cols: int, d_dst: int) -> None:
+        """dst (cols x rows) = src' for a row-major rows x cols device array (gmrfx_transpose_dev)."""
+        check(lib().gmrfx_transpose_dev(self._h, rows, cols, d_src, d_dst), self._h)
+
     def refactorize_solve_ptr(self, nzval_ptr: int, B_ptr: int, ldb: int, nrhs: int, X_ptr: int, ldx: int) -> int:
         """gmrfx_refactorize_solve on raw HOST pointers (column-major B / X the caller keeps alive; page-locked memory is handed to
         the DMA engine directly, pageable memory is staged by the library): the call a Julia `workspace_solve(ws, B::Matrix)` makes."""

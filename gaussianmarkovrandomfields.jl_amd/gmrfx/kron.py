@@ -52,13 +52,15 @@ class KroneckerWorkspace:
         """diag(Q^-1) = kron(diag(Q_1^-1), diag(Q_2^-1))."""
         return np.kron(self.ws1.get_selinv_diag(), self.ws2.get_selinv_diag())
 
-    # ---- device-resident path (round 3) ---------------------------------------------------------------------------
+    # ---- device-resident path ------------------------------------------------------------------------------------
     # x[i1 * n2 + i2] IS the column-major n2 x n1 matrix X with leading dimension n2, so the sweep over factor 2 takes the
     # flat device vector as it is (n1 right-hand sides, passes of 64 on the device). Its result, seen as the ROW-major
     # n1 x n2 matrix T, is then multiplied from the left by the small factor's DENSE operator D1 (n1 x n1: Q_1^-1 for solves,
     # A_1 = P_1' L_1^-T for samples -- n1 solves of the small factor, once): R = D1 T is already laid out as the answer,
-    # R[i1, i2] = out[i1 * n2 + i2]. No host panel, no transpose. D1 T is a plain library GEMM (torch.matmul -> rocBLAS).
-    # The dense operator is used when the first factor is small (the time factor of cfg 5: 512); otherwise both factors sweep.
+    # R[i1, i2] = out[i1 * n2 + i2]. No host panel, no transpose. D1 T runs on the library's own FP64-MFMA kernel
+    # (gmrfx_dense_apply_dev, csrc/dense.hip) -- round 3 used torch.matmul (rocBLAS) here.
+    # The dense operator is used when the first factor is small (the time factor of cfg 5: 512); otherwise both factors sweep,
+    # with the layout change between them done by gmrfx_transpose_dev. torch only allocates the buffers.
     DENSE_MAX = 4096
 
     def _dense_op(self, kind: str):
@@ -74,23 +76,35 @@ class KroneckerWorkspace:
         import torch
         return torch.device("cuda", self.ws2.device if self.ws2.device >= 0 else torch.cuda.current_device())
 
+    @staticmethod
+    def _buf(like, count):
+        """count doubles on like's device, with 16 bytes of slack behind them (the kernels load operands in 16-byte pairs)"""
+        import torch
+        return torch.empty(count + 2, dtype=torch.float64, device=like.device)[:count]
+
     def _apply_dev(self, x, kind: str):
         import torch
         n1, n2 = self.n1, self.n2
         if x.dtype != torch.float64 or x.numel() != n1 * n2 or not x.is_contiguous() or not x.is_cuda:
             raise ValueError("expected a contiguous float64 CUDA tensor with n1 * n2 entries")
-        w = torch.empty_like(x)
+        w = self._buf(x, n1 * n2)
         torch.cuda.synchronize(x.device)            # torch's stream -> the library's own streams
         f2 = self.ws2.solve_dev if kind == "solve" else self.ws2.backward_solve_dev
         f2(x.data_ptr(), n2, n1, w.data_ptr(), n2)                       # factor 2 on all n1 columns (returns synchronised)
         if n1 <= self.DENSE_MAX:
-            return (self._dense_op(kind) @ w.view(n1, n2)).reshape(-1)
-        wt = w.view(n1, n2).t().contiguous()                            # column-major n1 x n2, leading dimension n1
-        y = torch.empty_like(wt)
+            D = self._dense_op(kind)
+            out = self._buf(x, n1 * n2)
+            torch.cuda.synchronize(x.device)
+            self.ws2.dense_apply_dev(D.data_ptr(), n1, w.data_ptr(), n2, out.data_ptr())       # R = D1 T, row-major
+            return out
+        wt = self._buf(x, n1 * n2)                                      # column-major n1 x n2 (= row-major n2 x n1), leading dimension n1
+        y = self._buf(x, n1 * n2)
         torch.cuda.synchronize(x.device)
+        self.ws2.transpose_dev(w.data_ptr(), n1, n2, wt.data_ptr())
         f1 = self.ws1.solve_dev if kind == "solve" else self.ws1.backward_solve_dev
         f1(wt.data_ptr(), n1, n2, y.data_ptr(), n1)
-        return y.t().contiguous().reshape(-1)
+        self.ws2.transpose_dev(y.data_ptr(), n2, n1, w.data_ptr())       # back to row-major n1 x n2 = the flat answer
+        return w
 
     def solve_dev(self, x):
         """(Q_1 (x) Q_2)^-1 x for a device-resident x (torch CUDA tensor, float64, n1 n2 entries); returns a new tensor."""

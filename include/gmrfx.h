@@ -252,6 +252,18 @@ int32_t gmrfx_quadform(gmrfx_handle *h, const double *nzval, const double *X, in
 int32_t gmrfx_quadform_dev(gmrfx_handle *h, const double *d_nzval, const double *d_X, int64_t ldx, int64_t nvec,
                            const double *d_mu, double *out);
 
+/* ---- dense-operator leg of the separable (Kronecker) path ---------------------------
+ * `Q = kron(Q_1, Q_2)` (SeparableModel, src/latent_models/separable.jl:143-156; logdet rule :122-141): a solve / a sample of all
+ * n1 n2 unknowns is ONE sweep over the large factor with n1 right-hand sides (the flat vector x[i1 n2 + i2] is its column-major
+ * n2 x n1 panel) followed by the small factor applied as a DENSE n1 x n1 operator D (Q_1^-1, or P_1' L_1^-T for samples) to the
+ * row-major n1 x n2 result T:  R = D T.  gmrfx_dense_apply_dev computes that product on the FP64 matrix cores with the library's
+ * own kernels (csrc/dense.hip; no vendor GEMM). All three arrays are row-major device arrays, T and R must not overlap, and T
+ * must be followed by at least 8 readable bytes when n2 is odd (16-byte operand loads). gmrfx_transpose_dev writes the
+ * transpose of a row-major rows x cols device array (dst: cols x rows) -- the layout change between the two sweeps when BOTH
+ * factors are large. `h` is any numeric handle of the device the arrays live on; both calls return when the result is complete. */
+int32_t gmrfx_dense_apply_dev(gmrfx_handle *h, int64_t n1, int64_t n2, const double *d_D, const double *d_T, double *d_R);
+int32_t gmrfx_transpose_dev(gmrfx_handle *h, int64_t rows, int64_t cols, const double *d_src, double *d_dst);
+
 /* Takahashi selected inverse; computed lazily once per refactorisation and cached on the
  * device. Replaces SelectedInversion.selinv / selinv_diag: src/workspace/backend.jl:215-257,
  * src/solvers/selinv.jl:70-125. */

@@ -908,6 +908,33 @@ def test_kronecker_workspace_device_path_matches_dense_kron(dense_max):
         kw.solve_dev(torch.zeros(n + 1, dtype=torch.float64).cuda())
 
 
+@pytest.mark.parametrize("n1,n2", [(9, 110), (64, 64), (70, 1001), (130, 4099), (512, 777)])
+def test_dense_apply_and_transpose_kernels(n1, n2):
+    """gmrfx_dense_apply_dev (R = D T, row-major; the dense-operator leg of the Kronecker path, separable.jl:122-172) and
+    gmrfx_transpose_dev against a float64 torch reference of the same ops: odd and even widths, sizes that are not multiples of
+    the 64 x 64 tiles, more column tiles than one XCD round; bit-reproducible."""
+    import torch
+    be = gmrfx.MI355XBackend(sp.identity(4, format="csc"))          # any numeric handle of the device
+    g = torch.Generator(device="cpu").manual_seed(n1 * 131 + n2)
+    D = torch.randn((n1, n1), generator=g, dtype=torch.float64).cuda()
+    Tb = torch.zeros(n1 * n2 + 2, dtype=torch.float64).cuda()
+    T = Tb[:n1 * n2].view(n1, n2); T.copy_(torch.randn((n1, n2), generator=g, dtype=torch.float64))
+    R = torch.full((n1, n2), float("nan"), dtype=torch.float64).cuda()
+    torch.cuda.synchronize()
+    be.dense_apply_dev(D.data_ptr(), n1, T.data_ptr(), n2, R.data_ptr())
+    ref = D.cpu().numpy() @ T.cpu().numpy()
+    assert np.abs(R.cpu().numpy() - ref).max() <= 1e-12 * np.abs(ref).max() * n1 ** 0.5
+    R2 = torch.empty_like(R)
+    be.dense_apply_dev(D.data_ptr(), n1, T.data_ptr(), n2, R2.data_ptr())
+    assert torch.equal(R, R2)
+    Tt = torch.full((n2, n1), float("nan"), dtype=torch.float64).cuda()
+    be.transpose_dev(T.data_ptr(), n1, n2, Tt.data_ptr())
+    assert torch.equal(Tt, T.t().contiguous())
+    with pytest.raises(ValueError):
+        be.dense_apply_dev(D.data_ptr(), n1, T.data_ptr(), n2, T.data_ptr())
+    be.close()
+
+
 @pytest.mark.parametrize("cap", ["64", "128", "256"])
 def test_blocked_substitution_in_wide_fronts(cap, monkeypatch):
     """Fronts wider than the inverse cap (2048 columns by default; GMRFX_INV_CAP lowers it here) only hold the
