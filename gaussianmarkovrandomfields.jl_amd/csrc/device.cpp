@@ -1728,6 +1728,7 @@ void Device::selinv_levels(int hi, int lo) {
         // (geometry over the level's fronts of the SELECTED-INVERSION list: the factor's level list of a sharded handle
         //  leaves out the distributed root, which the owner still inverts)
         (void)L;
+        if (level_mark_) launch_level_mark(stream, 4, l);      // (profiling aid: tools/cfg3_profile.py cuts the trace into levels)
         launch_sel_gather(stream, d_selrec_, dsz, list, nf, sel_max_trail_[l], d_Z_, d_cb_);
         for (int phase = 0; phase < 3; phase++)
             launch_sel_dense(stream, dsz, list, nf, phase, sel_max_cols_[l], sel_max_trail_[l], d_L_, d_Z_, d_cb_, d_tmp_,

@@ -393,7 +393,7 @@ void launch_fwd_own_update(hipStream_t st, const DevSym &S, const int *list, int
 void launch_assemble_cyclic(hipStream_t st, const DevSym &S, const int *list, int ncols, const double *nzval, double *L, double *CB,
                             int cyc_w, int cyc_r);
 void launch_syrk_cb_cyclic(hipStream_t st, const DevSym &S, const int *list, int trail, const double *L, double *CB, int cyc_w, int cyc_r, int cyc_b0);
-void launch_level_mark(hipStream_t st, int phase, int level);   // phase 1 = forward sweep, 2 = backward sweep, 3 = factorisation
+void launch_level_mark(hipStream_t st, int phase, int level);   // phase 1 = forward sweep, 2 = backward sweep, 3 = factorisation, 4 = selected inversion
 void launch_permute(hipStream_t st, const int *iperm, int n, double *Bc, long long ldb, double *X, int nr, int ldx, int dir);
 // column-major block copy by nwg workgroups (one side may be page-locked host memory: PCIe traffic inside a kernel)
 void launch_stream_copy(hipStream_t st, const double *src, long long lds, double *dst, long long ldd, long long rows, long long cols, int nwg);
