@@ -124,8 +124,9 @@ void Device::init(const Symbolic &S, int dev) {
     HC(hipEventCreateWithFlags(&ev_inv_, hipEventDisableTiming));
     for (auto &ev : ev_) HC(hipEventCreate(&ev));
     for (auto &l : ev_lane_) for (auto &ev : l) HC(hipEventCreate(&ev));
-    HC(hipHostMalloc((void **)&h_info_, sizeof(int), hipHostMallocDefault));
-    *h_info_ = INT_MAX;
+    HC(hipHostMalloc((void **)&h_info_, 2 * sizeof(int), hipHostMallocDefault));
+    h_info_[0] = INT_MAX;
+    h_info_[1] = 0;
     HC(hipEventCreateWithFlags(&ev_ready_, hipEventDisableTiming));
     HC(hipEventCreateWithFlags(&ev_ready2_, hipEventDisableTiming));
     HC(hipEventCreateWithFlags(&ev_done1_, hipEventDisableTiming));
@@ -328,6 +329,7 @@ void Device::upload(const Symbolic &S) {
             if (const char *e = std::getenv("GMRFX_TWO_CHAINS")) two_chains_ = std::atoi(e) != 0;
             if (const char *e = std::getenv("GMRFX_LEVEL_MARK")) level_mark_ = std::atoi(e) != 0;
             if (const char *e = std::getenv("GMRFX_LOOKAHEAD")) lookahead_ = std::atoi(e) != 0;
+            if (const char *e = std::getenv("GMRFX_CHAIN_MAX_FRONTS")) chain_max_fronts_ = std::max(0, std::atoi(e));
             if (const char *e = std::getenv("GMRFX_SMALL_ON_SIDE")) small_on_side_ = std::atoi(e) != 0;
         }
         const int *a; up(a, S.sub_first); d_sub_first_ = const_cast<int *>(a);
@@ -598,6 +600,8 @@ void Device::upload(const Symbolic &S) {
     d_cb_ = dalloc<double>((size_t)S.cb_arena);
     d_nz_ = dalloc<double>((size_t)S.nnz_in);
     d_info_ = dalloc<int>(2);
+    d_chain_ = dalloc<int>(kChainErrWord + 8);          // persistent panel chain: 8 flag words per front + the error word
+    HC(hipMemset(d_chain_, 0, (kChainErrWord + 8) * sizeof(int)));
     d_part_ = dalloc<double>(1024 + 8);
     HC(hipMemsetAsync(d_L_, 0, (size_t)l_size_ * sizeof(double) + kPairSlackBytes, stream));
     HC(hipStreamSynchronize(stream));
@@ -836,7 +840,47 @@ void Device::factor_levels(int lo, int hi) {
         // streams, so one half's trsm / gemm fills the chip while the other half sits in potrf64. Same arithmetic per
         // front: bit-identical factor.
         const bool la = lookahead_ && nf >= 1 && nblk >= 2;
-        const bool two = !la && two_chains_ && nf >= 2 && nblk >= 4 && !sharded();
+        // PERSISTENT panel chain (panel_chain.hip): levels with a handful of wide fronts -- where potrf64 -> trsm -> gemm per
+        // 64-column block is a chain of ~350 small dependent launches per factorisation -- run ONE persistent launch per
+        // 256-column outer block (flags between its workgroups, look-ahead on the diagonal block) plus the K = 256 update of
+        // the columns beyond it. Same arithmetic per entry in the same order: the same bits as the launch chain.
+        const bool chain = !la && chain_max_fronts_ > 0 && nf >= 1 && nf <= chain_max_fronts_ && nblk >= 1 && !sharded();
+        if (chain) {
+            const FrontView *hl = d_frec_ + L.first + L.nsmall;
+            const i32 s1 = S_->levellist[L.first + L.nsmall];
+            const FrontArg f1{1, (int)s1, S_->ncols(s1), S_->nrows(s1), (int)S_->ld[s1], (int)S_->sfirst[s1], (long long)S_->panelptr[s1]};
+            const FrontArg f0{0, 0, 0, 0, 0, 0, 0};
+            for (int J0 = 0; J0 < nblk; J0 += OBK) {
+                const int na = L.active[J0];
+                if (na <= 0) break;
+                long long tiles = 0;
+                for (int f = 0; f < na; f++) {
+                    const i32 s = S_->levellist[L.first + L.nsmall + f];
+                    tiles += (S_->nrows(s) - NB * J0 + NB - 1) / NB;
+                }
+                const int stride = (int)std::max<long long>(1, (tiles + kChainMaxWgs - 1) / kChainMaxWgs);
+                int nwg = 0;
+                for (int f = 0; f < na; f++) {
+                    const i32 s = S_->levellist[L.first + L.nsmall + f];
+                    nwg += ((S_->nrows(s) - NB * J0 + NB - 1) / NB + stride - 1) / stride;
+                }
+                chain_base_ += 8;
+                static const bool ctrace = [] { const char *e = std::getenv("GMRFX_CHAIN_TRACE"); return e && std::atoi(e) != 0; }();
+                long long *trace = nullptr;
+                if (ctrace && lev + 1 == (int)levels_.size() && J0 == 0) {        // (the root's first outer block)
+                    if (!d_chain_trace_) d_chain_trace_ = dalloc<long long>(8 * 8 * 8);
+                    HC(hipMemsetAsync(d_chain_trace_, 0, 8 * 8 * 8 * sizeof(long long), stream));
+                    trace = d_chain_trace_;
+                }
+                launch_panel_chain(stream, hl, na, J0, stride, nwg, chain_base_, d_chain_, d_chain_ + kChainErrWord, d_L_, d_info_, trace);
+                chain_used_ = true;
+                const int J1 = J0 + OBK;
+                if (J1 < nblk && L.active[J1] > 0)
+                    launch_gemm_nt(stream, ds_, hl, L.active[J1], J0 * NB, OBK * NB, J1 * NB, INT_MAX, L.max_rows - J1 * NB,
+                                   L.max_cols - J1 * NB, d_L_, L.active[J1] == 1 ? f1 : f0);
+            }
+        }
+        const bool two = !la && !chain && two_chains_ && nf >= 2 && nblk >= 4 && !sharded();
         const int nhalf = two ? 2 : 1;
         if (la) {
             // LOOK-AHEAD chain (potrf64.hip): the diagonal chain P(b) on the main stream keeps its own band up to date; the
@@ -889,7 +933,7 @@ void Device::factor_levels(int lo, int hi) {
             HC(hipEventRecord(ev_ready2_, stream));               // (after the assembly of this level's panels)
             HC(hipStreamWaitEvent(stream3, ev_ready2_, 0));
         }
-        for (int hf = 0; hf < nhalf && !la; hf++) {
+        for (int hf = 0; hf < nhalf && !la && !chain; hf++) {
             hipStream_t st = hf == 0 ? stream : stream3;
             const FrontView *hl = two ? d_frec2_ + L.first + L.nsmall + (hf == 0 ? 0 : (nf + 1) / 2) : d_frec_ + L.first + L.nsmall;
             auto act = [&](int b) { const int a = L.active[b]; return two ? (hf == 0 ? (a + 1) / 2 : a / 2) : a; };
@@ -941,6 +985,32 @@ void Device::factor_levels(int lo, int hi) {
 // fronts, never by logdet: they are computed lazily (first solve / selinv after a
 // refactorisation) on a side stream, so that in a refactorise+solve step they overlap the
 // small-front levels at the bottom of the forward sweep.
+// a bounded spin of the persistent panel chain ran out (its grid was not fully resident, or a workgroup died): the factor is garbage
+void Device::check_chain_error() {
+    if (d_chain_trace_) {
+        std::vector<long long> t(8 * 8 * 8);
+        HC(hipMemcpy(t.data(), d_chain_trace_, t.size() * sizeof(long long), hipMemcpyDeviceToHost));
+        long long t0 = 0;
+        for (long long v : t) if (v && (!t0 || v < t0)) t0 = v;
+        std::fprintf(stderr, "[gmrfx chain trace] root, first outer block; us since the first stamp (2.1 GHz assumed); slots: 0 step top, 1 P flag seen, 2 Linv staged, 3 pass-0 tiles done, 4 next diagonal block factored + published, 5 pass-1 tiles done\n");
+        for (int wg = 0; wg < 8; wg++)
+            for (int q = 0; q < 7; q++) {
+                const long long *r = &t[(wg * 8 + q) * 8];
+                bool any = false;
+                for (int k = 0; k < 6; k++) any = any || r[k];
+                if (!any) continue;
+                std::fprintf(stderr, "  wg %d step %2d:", wg, q - 1);
+                for (int k = 0; k < 6; k++) std::fprintf(stderr, " %8.2f", r[k] ? (double)(r[k] - t0) / 2100.0 : -1.0);
+                std::fprintf(stderr, "\n");
+            }
+    }
+    if (!chain_used_ || h_info_[1] == 0) return;
+    h_info_[1] = 0;
+    (void)hipMemsetAsync(d_chain_ + kChainErrWord, 0, sizeof(int), stream);
+    factorized = false;
+    throw std::runtime_error("persistent panel-chain kernel timed out waiting for a flag (GMRFX_CHAIN_MAX_FRONTS=0 selects the launch chain)");
+}
+
 void Device::start_inverse_async() {
     if (!inverse_pending) return;
     // ev_fact_ = "the factor is final": recorded at the end of the factorisation, so that whatever the caller has put on
@@ -1039,6 +1109,7 @@ void Device::refactorize_solve(const double *nzval, bool nz_on_device, const dou
     HC(hipEventRecord(ev_fact_, stream));
     fact_event_valid_ = true;
     HC(hipMemcpyAsync(h_info_, d_info_, sizeof(int), hipMemcpyDeviceToHost, stream));
+    if (chain_used_) HC(hipMemcpyAsync(h_info_ + 1, d_chain_ + kChainErrWord, sizeof(int), hipMemcpyDeviceToHost, stream));
     factorized = true;
     selinv_valid = false;
     if (!b_on_device && !up_first) host_upload(B, ldb, nrhs, d_io_);     // (measurement switch: beside the factorisation just enqueued)
@@ -1082,6 +1153,7 @@ void Device::refactorize_solve(const double *nzval, bool nz_on_device, const dou
     trace("X downloaded");
     HC(hipStreamSynchronize(stream));
     info_cached_ = true;
+    check_chain_error();
     HC(hipGetLastError());
     float tf = 0, a = 0, b = 0, c = 0, d = 0, tail = 0;
     HC(hipEventElapsedTime(&tf, ev_[0], ev_[1]));
@@ -1118,8 +1190,10 @@ void Device::refactorize(const double *nzval, bool on_device) {
     inverse_pending = true;
     // the pivot report travels with the factorisation (pinned host word): no blocking copy after the synchronisation
     HC(hipMemcpyAsync(h_info_, d_info_, sizeof(int), hipMemcpyDeviceToHost, stream));
+    if (chain_used_) HC(hipMemcpyAsync(h_info_ + 1, d_chain_ + kChainErrWord, sizeof(int), hipMemcpyDeviceToHost, stream));
     HC(hipStreamSynchronize(stream));
     info_cached_ = true;
+    check_chain_error();
     HC(hipGetLastError());
     float ms = 0;
     HC(hipEventElapsedTime(&ms, ev_[0], ev_[1]));
@@ -1647,6 +1721,7 @@ void Device::refactorize_logpdf(const double *d_nz, const double *d_X, long long
     fact_event_valid_ = true;
     inverse_pending = true;
     HC(hipMemcpyAsync(h_info_, d_info_, sizeof(int), hipMemcpyDeviceToHost, stream));
+    if (chain_used_) HC(hipMemcpyAsync(h_info_ + 1, d_chain_ + kChainErrWord, sizeof(int), hipMemcpyDeviceToHost, stream));
     factorized = true;
     selinv_valid = false;
     float tf = 0;
@@ -1654,6 +1729,7 @@ void Device::refactorize_logpdf(const double *d_nz, const double *d_X, long long
     if (nvec > 0) HC(hipStreamWaitEvent(stream, ev_qf_, 0));
     HC(hipStreamSynchronize(stream));
     info_cached_ = true;
+    check_chain_error();
     HC(hipGetLastError());
     HC(hipEventElapsedTime(&tf, ev_[0], ev_[1]));
     ms_factor = tf;

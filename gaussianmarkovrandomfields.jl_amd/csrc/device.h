@@ -247,6 +247,18 @@ private:
     FrontView *d_frec_ = nullptr, *d_frec2_ = nullptr, *d_sel_frec_ = nullptr;   // geometry records parallel to the level lists
     int *d_levellist2_ = nullptr;   // per level: the big fronts re-ordered [even positions..., odd positions...] (two-stream panel chains)
     bool two_chains_ = true;
+    // persistent panel chain (panel_chain.hip): levels with at most this many wide fronts (GMRFX_CHAIN_MAX_FRONTS; 0: never).
+    // OFF by default -- measured at cfg 2 (round 4, tools/chain_ab.py, GMRFX_CHAIN_TRACE): same bits as the launch chain, but
+    // factorisation 10.1 -> 13.2 ms: inside the persistent kernel a chain step costs ~50 us (diagonal block 27 us instead of
+    // 16 -- write-through stores, their drain before the flag, register spills around the inlined body; flag hop + staging
+    // the inverse 5 us; the look-ahead tile's T + G 19 us on one CU) against 30 us for the three launches it replaces.
+    static constexpr int kChainErrWord = 8 * 64, kChainMaxWgs = 512;
+    int chain_max_fronts_ = 0;
+    int *d_chain_ = nullptr;
+    long long *d_chain_trace_ = nullptr;
+    int chain_base_ = 0;
+    bool chain_used_ = false;
+    void check_chain_error();
     bool lookahead_ = false;      // GMRFX_LOOKAHEAD=1: look-ahead panel chain (potrf64.hip k_potrf64_la). OFF by default: measured at cfg 2
                                   // (round 3) the left-looking band prologue costs 12 us + 6 us per earlier block of the outer block
                                   // on top of the 15 us factorisation, more than the trsm + gemm launches (5 + 5 us) it takes off

@@ -411,6 +411,10 @@ void launch_logdet(hipStream_t st, const double *L, const long long *diagoff, co
 void launch_gather(hipStream_t st, const double *src, const long long *off, long long cnt, double *out);
 void launch_gather_diag(hipStream_t st, const double *src, const long long *diagoff, const int *perm, int n, double *out);
 
+// panel_chain.hip -- one persistent launch per 256-column outer block of a level's wide fronts (potrf / trsm / K = 64 updates)
+void launch_panel_chain(hipStream_t st, const FrontView *frec, int nfront, int J0, int stride_cap, int nwg, int base, int *flags, int *err,
+                        double *L, int *info, long long *trace = nullptr);
+
 // dense.hip -- the dense-operator leg of the Kronecker path: R = D T (row-major, D n1 x n1, T / R n1 x n2) and a transpose
 void launch_dense_apply(hipStream_t st, const double *D, const double *T, double *R, int n1, long long n2);
 void launch_transpose(hipStream_t st, const double *src, double *dst, long long rows, long long cols);

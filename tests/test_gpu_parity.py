@@ -1217,6 +1217,39 @@ def test_full_size_cfg2_pipelined_equals_separate_calls():
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("mesh_kind", ["2d", "2d_wide", "3d"])
+def test_panel_chain_persistent_kernel_equals_launch_chain(mesh_kind, monkeypatch):
+    """The persistent panel-chain kernel (csrc/panel_chain.hip, GMRFX_CHAIN_MAX_FRONTS > 0: one launch per 256-column outer block of
+    a level's wide fronts, flags between its workgroups, look-ahead on the diagonal block; off by default, measured slower) against
+    the launch chain potrf64 -> trsm -> gemm: the factor bit for bit (fronts with partial last blocks, several fronts per launch,
+    teams with more tiles than workgroups), log-determinant and a solve; and an indefinite matrix reports the same pivot."""
+    if mesh_kind == "2d":
+        mesh = spde.grid_mesh_2d(300, 290, jitter=0.25, seed=5); Q = spde.matern_precision(mesh, 0, 0.2)
+    elif mesh_kind == "2d_wide":
+        mesh = spde.grid_mesh_2d(120, 500, jitter=0.2, seed=2); Q = spde.matern_precision(mesh, 0, 0.3)
+    else:
+        mesh = spde.grid_mesh_3d(26, 25, 24); Q = spde.matern_precision(mesh, 0, 0.4)
+    monkeypatch.setenv("GMRFX_CHAIN_MAX_FRONTS", "0")
+    a = gmrfx.MI355XBackend(Q, coords=mesh.points)
+    monkeypatch.setenv("GMRFX_CHAIN_MAX_FRONTS", "32")
+    b = gmrfx.MI355XBackend(Q, coords=mesh.points)
+    assert a.last_info == 0 and b.last_info == 0
+    assert np.array_equal(a.factor_values(), b.factor_values())
+    assert a.compute_logdet() == b.compute_logdet()
+    B = np.random.default_rng(2).standard_normal((Q.shape[0], 5))
+    X = b.backend_solve(B)
+    assert np.array_equal(X, a.backend_solve(B))
+    assert np.linalg.norm(Q @ X - B) / np.linalg.norm(B) < 1e-10
+    bad = sp.csc_matrix(Q).copy(); bad.sort_indices()
+    vals = bad.data.copy()
+    col = Q.shape[0] - 3
+    k = bad.indptr[col] + int(np.searchsorted(bad.indices[bad.indptr[col]:bad.indptr[col + 1]], col))
+    vals[k] = -abs(vals[k])
+    a.refactorize_values(vals); b.refactorize_values(vals)
+    assert a.last_info == b.last_info > 0
+    a.close(); b.close()
+
+
 def test_refactorize_logpdf_one_call_equals_three_calls():
     """gmrfx_refactorize_logpdf_dev (one evaluation of the hyper-parameter loop: factorisation, r'Qr beside it on the side stream,
     log-determinant behind it, one synchronisation) against gmrfx_refactorize_dev + gmrfx_quadform_dev + gmrfx_logdet: quadratic
