@@ -1000,7 +1000,7 @@ void Device::check_chain_error() {
                 for (int k = 0; k < 6; k++) any = any || r[k];
                 if (!any) continue;
                 std::fprintf(stderr, "  wg %d step %2d:", wg, q - 1);
-                for (int k = 0; k < 6; k++) std::fprintf(stderr, " %8.2f", r[k] ? (double)(r[k] - t0) / 2100.0 : -1.0);
+                for (int k = 0; k < 7; k++) std::fprintf(stderr, " %8.2f", r[k] ? (double)(r[k] - t0) / 2100.0 : -1.0);
                 std::fprintf(stderr, "\n");
             }
     }

@@ -249,10 +249,12 @@ private:
     bool two_chains_ = true;
     // persistent panel chain (panel_chain.hip): levels with at most this many wide fronts (GMRFX_CHAIN_MAX_FRONTS; 0: never).
     // OFF by default -- measured at cfg 2 (round 4, tools/chain_ab.py, GMRFX_CHAIN_TRACE): same bits as the launch chain, but
-    // factorisation 10.1 -> 13.2 ms: inside the persistent kernel a chain step costs ~50 us (diagonal block 27 us instead of
-    // 16 -- write-through stores, their drain before the flag, register spills around the inlined body; flag hop + staging
-    // the inverse 5 us; the look-ahead tile's T + G 19 us on one CU) against 30 us for the three launches it replaces.
-    static constexpr int kChainErrWord = 8 * 64, kChainMaxWgs = 512;
+    // factorisation 10.1 -> 10.9 ms (13.2 ms in its first, eight-wave form, which spilled around the inlined diagonal-block body).
+    // Inside the persistent kernel a chain step costs ~40 us against 30 us for the three launches it replaces: the diagonal block
+    // 22 us (16.9 as its own launch: write-through stores and their drain before the flag), the look-ahead tile's T 7.7 us and
+    // G 9.5 us -- a 64 x 64 x 64 product on ONE compute unit with one wave per SIMD issues an FP64 MFMA every ~138 cycles, where
+    // the launch chain spreads the same rows over a hundred workgroups.
+    static constexpr int kChainErrWord = 8 * 64, kChainMaxWgs = 256;
     int chain_max_fronts_ = 0;
     int *d_chain_ = nullptr;
     long long *d_chain_trace_ = nullptr;

@@ -23,7 +23,7 @@
 // written through (agent-scope relaxed atomic stores = global_store ... sc1), every storing wave `s_waitcnt vmcnt(0)`, workgroup
 // barrier, ONE flag store; consumers poll relaxed with s_sleep, then ONE agent-scope acquire, `s_waitcnt vmcnt(0)`, barrier,
 // plain loads. Flags are monotone (a per-launch base, no resets). Every spin is bounded: a timeout raises an error word the
-// host turns into an exception -- the grid must be fully resident (<= 512 workgroups of 512 threads, 68 KB of LDS each).
+// host turns into an exception -- the grid must be fully resident (<= 256 workgroups of 256 threads, 68 KB of LDS, ~490 registers).
 // Replaces, for one dense front panel, cholesky!(F, Q) of the reference's backend (src/workspace/backend.jl:165-189).
 #include <hip/hip_runtime.h>
 
@@ -36,7 +36,8 @@ typedef gmrfx_d4 d4;
 
 namespace {
 
-constexpr int CHAIN_THREADS = 512;
+constexpr int CHAIN_THREADS = 256;        // four waves: the inlined diagonal-block body alone needs ~150 VGPRs (eight waves: 256 per lane, spills)
+constexpr int CHAIN_SUB = 16 / (CHAIN_THREADS / 64);   // 16 x 16 sub-tiles per wave in one row group of a 64 x 64 tile
 constexpr int CHAIN_SPIN_MAX = 1 << 18;        // x ~0.5 us per poll: ~0.1 s, then the error word (which ends every later wait at once)
 
 __device__ __forceinline__ void chain_publish(int *flag, int value) {
@@ -82,9 +83,9 @@ struct ChainArgs {
 };
 
 // Step q of one workgroup, pass 0 = the tile q + 1 alone (the look-ahead tile), pass 1 = its other tiles above q: T then G per tile.
-__device__ __attribute__((noinline)) void chain_tiles(double *__restrict__ P, const int ld, const int c, const int r, const int row00,
+__device__ __forceinline__ void chain_tiles(double *__restrict__ P, const int ld, const int c, const int r, const int row00,
                                                       const int nt, const int nbi, const int q, const int t0, const int team, const int pass,
-                                                      const int kb, const int w, int *fl, const int base, int *err) {
+                                                      const int kb, const int w, int *fl, const int base, int *err, long long *tr) {
     double *Ti = c_Ti, *Ls = c_Ls;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, lm = lane & 15, lk = lane >> 4;
@@ -94,17 +95,17 @@ __device__ __attribute__((noinline)) void chain_tiles(double *__restrict__ P, co
                 const bool critical = has_next && t == q + 1;
                 if (critical != (pass == 0)) continue;
                 const int row0 = row00 + NB * t;                  // first row of the tile (front-local)
-                // -- T: L(t, b) = A(t, b) Linv'. wave v: row group v & 3 (16 rows), column tiles 2 (v >> 2) and + 1
-                const int ri = wave & 3, ctp = wave >> 2;
+                // -- T: L(t, b) = A(t, b) Linv'. wave v: row group v & 3 (16 rows), column tiles CHAIN_SUB (v >> 2) .. + CHAIN_SUB - 1
+                const int ri = wave & 3, ctp = CHAIN_THREADS == 256 ? 0 : wave >> 2;      // (four waves: ct = e is a compile-time constant below)
                 const int i = row0 + 16 * ri + lm;
                 const double *pa = P + min(i, r - 1) + (long long)kb * ld;
                 double bv[16];
 #pragma unroll
                 for (int u = 0; u < 16; u++) bv[u] = pa[(long long)min(4 * u + lk, w - 1) * ld];
-                d4 acc[2];
+                d4 acc[CHAIN_SUB];
 #pragma unroll
-                for (int e = 0; e < 2; e++) {
-                    const int ct = 2 * ctp + e;
+                for (int e = 0; e < CHAIN_SUB; e++) {
+                    const int ct = CHAIN_SUB * ctp + e;
                     acc[e] = (d4){0.0, 0.0, 0.0, 0.0};
                     const int k = ct * 16 + lm;
 #pragma unroll
@@ -116,10 +117,10 @@ __device__ __attribute__((noinline)) void chain_tiles(double *__restrict__ P, co
                 __syncthreads();      // in place: the other waves have read the columns this wave overwrites; Ls is free
                 const bool shared_tile = has_next && t < nbi;     // an operand of other tiles' G: written through, then published
 #pragma unroll
-                for (int e = 0; e < 2; e++)
+                for (int e = 0; e < CHAIN_SUB; e++)
 #pragma unroll
                     for (int rr = 0; rr < 4; rr++) {
-                        const int kk = (2 * ctp + e) * 16 + lk + 4 * rr;
+                        const int kk = (CHAIN_SUB * ctp + e) * 16 + lk + 4 * rr;
                         Ls[kk * NB + 16 * ri + lm] = acc[e][rr];
                         if (kk < w && i < r && i >= kb + w) {
                             double *dst = P + i + (long long)(kb + kk) * ld;
@@ -137,11 +138,11 @@ __device__ __attribute__((noinline)) void chain_tiles(double *__restrict__ P, co
                         if (!diag) chain_wait(fl + 1 + jj, a.base + q + 1, a.err);
                         const int cj0 = row00 + NB * jj;          // first column of the block = first row of tile jj
                         const int ncol = min(NB, c - cj0);
-                        // 16 sub-tiles (si: rows, sj: columns); wave v: si = v & 3, sj = 2 (v >> 2) + e
+                        // 16 sub-tiles (si: rows, sj: columns); wave v: si = v & 3, sj = CHAIN_SUB (v >> 2) + e
                         const int si = wave & 3;
 #pragma unroll
-                        for (int e = 0; e < 2; e++) {
-                            const int sj = 2 * (wave >> 2) + e;
+                        for (int e = 0; e < CHAIN_SUB; e++) {
+                            const int sj = CHAIN_SUB * (CHAIN_THREADS == 256 ? 0 : wave >> 2) + e;
                             if (diag && sj > si) continue;        // strictly upper sub-tiles of a diagonal tile (wave-uniform)
                             const int ii = row0 + 16 * si + lm;   // row of C this lane holds
                             double cv[4];
@@ -225,7 +226,8 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_panel_chain(ChainArgs a) {
         }
         // two passes over the own tiles: pass 0 = the tile q + 1 alone (if it is ours), then the next diagonal block; pass 1 = the rest
         for (int pass = 0; pass < 2; pass++) {
-            if (work) chain_tiles(P, ld, c, r, row00, nt, nbi, q, t0, team, pass, kb, w, fl, a.base, a.err);
+            if (work) chain_tiles(P, ld, c, r, row00, nt, nbi, q, t0, team, pass, kb, w, fl, a.base, a.err,
+                                  (a.trace && blockIdx.x < 8 && q < 6) ? a.trace + ((int)blockIdx.x * 8 + (q + 1)) * 8 : nullptr);
             CHAIN_TR(3 + 2 * pass);
             if (pass == 0 && has_next && (q + 1) % team == local) {
                 // ---- the diagonal block q + 1: its tile is up to date (this workgroup's own updates, just stored; the body reads
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_panel_chain(ChainArgs a) {
                 __syncthreads();
                 const int kb1 = row00 + NB * (q + 1), w1 = min(NB, c - kb1), np1 = (w1 + 3) >> 2;
                 double *Pd = P + kb1 + (long long)kb1 * ld;
-                if (tid < 256) potrf64_body<true>(Pd, ld, Pd, ld, w1, Sb, a.info, fv.first + kb1, tid);
+                if (CHAIN_THREADS == 256 || tid < 256) potrf64_body<true>(Pd, ld, Pd, ld, w1, Sb, a.info, fv.first + kb1, tid);
                 else for (int k = 0; k < np1 + 1; k++) __syncthreads();  // (the body's barriers: one after the first strip, one per step)
                 chain_publish(fl + 0, a.base + q + 2);
                 CHAIN_TR(4);
