@@ -13,6 +13,8 @@
 // which is free once the factorisation is done.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace gmrfx {
@@ -201,8 +203,21 @@ __global__ __launch_bounds__(256) void k_sel_diag(DevSym S, const int *__restric
 __global__ __launch_bounds__(256) void k_sel_dense(DevSym S, const int *__restrict__ list, int phase,
                                                    const double *__restrict__ L, double *__restrict__ Z,
                                                    const double *__restrict__ ZB, double *__restrict__ Yt,
-                                                   double *__restrict__ Z21t, const long long *__restrict__ woff) {
-    const int s = list[blockIdx.z];
+                                                   double *__restrict__ Z21t, const long long *__restrict__ woff, int rgx, int rgy, int nfr) {
+    // rgx > 0: ONE-dimensional grid dealt by XCD (workgroup id mod 8 = XCD): the fronts at list positions xcd, xcd + 8, ... belong to
+    // that XCD, which walks them one after the other, all tiles of a front in a row -- the operand panels of a front (Z22 of the
+    // trailing rows, Y) are then streamed by ONE L2 instead of all eight (PMC, round 4: 19-38x the minimal bytes on the plain grid,
+    // the kernel ran at the L2-miss bandwidth). Fronts are sorted by decreasing width: dealing them modulo 8 balances the XCDs.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (rgx > 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int tpf = rgx * rgy;
+        bz = xcd + 8 * (slot / tpf);
+        if (bz >= nfr) return;
+        const int tt = slot % tpf;
+        bx = tt % rgx; by = tt / rgx;
+    }
+    const int s = list[bz];
     const int c = S.sfirst[s + 1] - S.sfirst[s];
     const int r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
     const int m = r - c;
@@ -217,7 +232,7 @@ __global__ __launch_bounds__(256) void k_sel_dense(DevSym S, const int *__restri
     const int M = phase == 0 ? m : c;        // extent of the MFMA "m" index
     const int N = phase == 1 ? m : c;        // extent of the MFMA "n" index (on the lanes)
     if (m == 0 && phase < 2) return;
-    const int bm = blockIdx.x, bn = blockIdx.y;
+    const int bm = bx, bn = by;
     if (bm * 64 >= M || bn * 64 >= N) return;
     if (phase == 2 && bn < bm) return;       // a-tile >= b-tile only
     const int m0 = bm * 64 + (wave & 1) * 32, n0 = bn * 64 + (wave >> 1) * 32;
@@ -355,7 +370,16 @@ void launch_sel_dense(hipStream_t st, const DevSym &S, const int *list, int nfro
     if (nfronts <= 0) return;
     const int M = phase == 0 ? max_trail : max_c, N = phase == 1 ? max_trail : max_c;
     if (M <= 0 || N <= 0) return;
-    hipLaunchKernelGGL(k_sel_dense, dim3((unsigned)(cdiv(M, 64) | 1), (unsigned)(cdiv(N, 64) | 1), nfronts), dim3(256), 0, st, S, list, phase, L, Z, ZB, Yt, Z21t, woff);
+    // GMRFX_SEL_XCD: levels with at least this many fronts deal their tiles by XCD (default 0: never -- measured at cfg 2, round 4:
+    // selected inversion 13.0 ms on the plain grid, 14.0-14.3 ms with whole fronts per XCD from 8 / 32 / 128 fronts up: the plain grid's
+    // 19-38x re-read traffic is served by the Infinity Cache through all eight L2s at ~4.7 TB/s, one L2 per front is the narrower pipe)
+    static const int xcd_min = [] { const char *e = getenv("GMRFX_SEL_XCD"); return e ? atoi(e) : 0; }();
+    const int gx = cdiv(M, 64), gy = cdiv(N, 64);
+    if (xcd_min > 0 && nfronts >= xcd_min) {
+        const long long groups = (nfronts + 7) / 8;
+        hipLaunchKernelGGL(k_sel_dense, dim3((unsigned)(groups * gx * gy * 8)), dim3(256), 0, st, S, list, phase, L, Z, ZB, Yt, Z21t, woff, gx, gy, nfronts);
+    } else
+        hipLaunchKernelGGL(k_sel_dense, dim3((unsigned)(gx | 1), (unsigned)(gy | 1), nfronts), dim3(256), 0, st, S, list, phase, L, Z, ZB, Yt, Z21t, woff, 0, 0, nfronts);
 }
 
 }  // namespace gmrfx
