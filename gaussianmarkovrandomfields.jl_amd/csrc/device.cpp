@@ -1266,17 +1266,20 @@ void Device::dist_front_phase(const double *d_nzval, int front, int what, int bl
             if (b + 1 < b1)
                 launch_gemm_nt(stream, ds_, nullptr, 1, kb, NB, kb + NB, b1 * NB, r - kb - NB, std::min(b1 * NB, c) - kb - NB, d_L_, fa);
         }
-    } else if (what == 2) {
+    } else if (what == 2 || what == 4 || what == 5) {
+        // 2: block -> all my later blocks; 4: -> block + 1 only (look-ahead: its owner factors and broadcasts it next, while
+        // everybody applies `block` to the rest); 5: -> my later blocks except block + 1. 4 then 5 = 2: same sums, same order per entry.
         if (block < 0 || block >= nob) throw std::invalid_argument("distributed front: block out of range");
         const int k0 = block * 256, K = std::min(256, c - k0);
-        for (int j = block + 1; j < nob; j++) {
+        const int jlo = what == 5 ? block + 2 : block + 1, jhi = what == 4 ? std::min(block + 2, nob) : nob;
+        for (int j = jlo; j < jhi; j++) {
             if (j % g != me) continue;
             const int c0 = j * 256;
             launch_gemm_nt(stream, ds_, nullptr, 1, k0, K, c0, c0 + 256, r - c0, std::min(256, c - c0), d_L_, fa);
         }
     } else if (what == 3) {
         if (r > c) launch_syrk_cb_cyclic(stream, ds_, list, r - c, d_L_, d_cb_, g, me, nob);
-    } else throw std::invalid_argument("distributed front phase must be 0 (assemble), 1 (factor block), 2 (apply block) or 3 (contribution block)");
+    } else throw std::invalid_argument("distributed front phase must be 0 (assemble), 1 (factor block), 2 / 4 / 5 (apply block: all / next / rest) or 3 (contribution block)");
     if (!async_phases_) HC(hipStreamSynchronize(stream));
     HC(hipGetLastError());
 }

@@ -50,6 +50,8 @@ class ShardedFactor:
         self.sub_rows = self.be.shard_rows(3)
         self.host_staging = dist.get_backend() == "gloo"      # rehearsal: gloo moves host tensors only
         self.last_info = 0
+        self._info_pending = False
+        self._df_views = {}
         # one stream orders everything: the library's kernels, torch's copies, the transfers torch.distributed enqueues
         self.be.set_stream(torch.cuda.current_stream(self.dev).cuda_stream, True, True)
         # per top level: the cross-edge transfers of the factorisation (contribution blocks) and of the forward sweep
@@ -107,30 +109,30 @@ class ShardedFactor:
             v.copy_(buf)                # host -> device on the current stream: ordered before the next phase
 
     def _bcast_rows(self, blocks, nrhs: int):
-        """blocks: (owner, first row, rows) of X row blocks; every owner broadcasts its blocks (one fused buffer per
-        owner and call)."""
-        t, dist = self.torch, self.dist
-        for src in sorted({int(o) for o, _, _ in blocks}):
-            mine = [(int(r0), int(nr)) for o, r0, nr in blocks if int(o) == src]
-            views = [self._view(2, r0 * nrhs, nr * nrhs) for r0, nr in mine]
-            total = sum(v.numel() for v in views)
-            if self.rank == src:
-                buf = t.cat([v.cpu() if self.host_staging else v for v in views]) if len(views) > 1 else (views[0].cpu() if self.host_staging else views[0])
-            else:
-                buf = t.empty(total, dtype=t.float64, device="cpu" if self.host_staging else self.dev)
-            dist.broadcast(buf, src=src)
-            if self.rank != src:
-                o = 0
-                for v in views:
-                    v.copy_(buf[o:o + v.numel()])
-                    o += v.numel()
+        """blocks: (owner, first row, rows) of X row blocks; every owner broadcasts its blocks IN PLACE -- the views of the
+        library's X buffer themselves, posted asynchronously and waited for together: no fused staging buffer, no copies back
+        (round 3 concatenated an owner's blocks into one buffer and copied them out again on every rank)."""
+        dist = self.dist
+        if self.host_staging:                      # gloo rehearsal: host tensors only
+            for o, r0, nr in blocks:
+                v = self._view(2, int(r0) * nrhs, int(nr) * nrhs)
+                buf = v.cpu()
+                dist.broadcast(buf, src=int(o))
+                if self.rank != int(o):
+                    v.copy_(buf)
+            return
+        works = [dist.broadcast(self._view(2, int(r0) * nrhs, int(nr) * nrhs), src=int(o), async_op=True) for o, r0, nr in blocks]
+        for w in works:
+            w.wait()                               # (RCCL: the current STREAM waits, the host does not)
 
     def _edges_of_level(self, lev: int):
         e = self.edges
         return np.flatnonzero(e["level"] == lev)
 
     # ---- factorisation ------------------------------------------------------------------------------
-    def refactorize_dev(self, d_nzval_ptr: int) -> int:
+    def refactorize_dev(self, d_nzval_ptr: int, check: bool = True) -> int:
+        """check = False leaves the pivot report (a host round trip: it would sit between the factorisation and the solve behind
+        it) to the next logdet() call, which needs the host anyway; `last_info` is then valid after that call."""
         be = self.be
         be.refactorize_phase_dev(d_nzval_ptr, 0)
         for k in range(self.K):
@@ -139,37 +141,60 @@ class ShardedFactor:
                 if self.rank in self.df["group"][i]:
                     self._factor_distributed_front(d_nzval_ptr, i)
             be.refactorize_phase_dev(d_nzval_ptr, 1 + k)
-        # first non-positive pivot over all ranks (0 = none), like the `info` of gmrfx_refactorize
+        self._info_pending = True
+        return self._reduce_info() if check else 0
+
+    def _reduce_info(self) -> int:
+        """first non-positive pivot over all ranks (0 = none), like the `info` of gmrfx_refactorize"""
         t = self.torch
-        fc = int(be.stats()["fail_col"])
+        fc = int(self.be.stats()["fail_col"])
         v = t.tensor([fc if fc >= 0 else 2 ** 62], dtype=t.int64, device="cpu" if self.host_staging else self.dev)
         self.dist.all_reduce(v, op=self.dist.ReduceOp.MIN)
         self.last_info = 0 if int(v.item()) >= 2 ** 62 else int(v.item()) + 1
+        self._info_pending = False
         return self.last_info
+
+    def _bcast_block(self, v, src: int, pg, async_: bool):
+        """broadcast of one panel block inside the front's group; returns a function that waits for it"""
+        if self.host_staging:
+            buf = v.cpu()
+            self.dist.broadcast(buf, src=src, group=pg)
+            if self.rank != src:
+                v.copy_(buf)
+            return lambda: None
+        if not async_:
+            self.dist.broadcast(v, src=src, group=pg)
+            return lambda: None
+        w = self.dist.broadcast(v, src=src, group=pg, async_op=True)
+        return w.wait
 
     def _factor_distributed_front(self, d_nzval_ptr: int, i: int) -> None:
         """A top front factored by its group: per 256-column panel block its owner factors the block column and broadcasts it
         inside the group (whole columns, one contiguous piece of the panel every member stores), every member updates its own
         later blocks; then every member computes its own column blocks of the contribution block. The children's blocks have
-        arrived as column ranges at the owners of the blocks they fall into (the level's transfers)."""
+        arrived as column ranges at the owners of the blocks they fall into (the level's transfers).
+        LOOK-AHEAD (round 4): once block b has arrived, the owner of block b + 1 applies b to that block FIRST (phase 4), factors
+        it and posts its broadcast asynchronously; everybody applies b to the rest of its blocks (phase 5) while that broadcast is
+        in flight. Per entry the same sums in the same order as the strictly sequential loop (factor -> broadcast -> update) of
+        round 3: bit-identical factor (tests/test_gpu_parity.py::test_distributed_top_fronts_rehearsal_on_one_gpu)."""
         be, df = self.be, self.df
         s, c, ld, G = int(df["front"][i]), int(df["cols"][i]), int(df["panel_ld"][i]), df["group"][i]
         pg = self._pg[tuple(G)]
         nb = (c + 255) // 256
+        views = self._df_views.get(i)
+        if views is None:                                           # built once per front
+            views = [self._view(1, int(df["panel_offset"][i]) + 256 * b * ld, min(256, c - 256 * b) * ld) for b in range(nb)]
+            self._df_views[i] = views
         be.dist_front_phase(d_nzval_ptr, s, 0)                      # assemble my panel blocks
+        be.dist_front_phase(d_nzval_ptr, s, 1, 0)                   # its owner factors block 0
+        wait = self._bcast_block(views[0], G[0], pg, async_=False)
         for b in range(nb):
-            be.dist_front_phase(d_nzval_ptr, s, 1, b)               # its owner factors block b
-            src = G[b % len(G)]
-            v = self._view(1, int(df["panel_offset"][i]) + 256 * b * ld, min(256, c - 256 * b) * ld)
-            if self.host_staging:
-                buf = v.cpu()
-                self.dist.broadcast(buf, src=src, group=pg)
-                if self.rank != src:
-                    v.copy_(buf)
-            else:
-                self.dist.broadcast(v, src=src, group=pg)
+            wait()                                                  # block b is complete on every member
             if b + 1 < nb:
-                be.dist_front_phase(d_nzval_ptr, s, 2, b)           # apply it to my later panel blocks
+                be.dist_front_phase(d_nzval_ptr, s, 4, b)           # b -> block b + 1 (its owner only)
+                be.dist_front_phase(d_nzval_ptr, s, 1, b + 1)       # its owner factors block b + 1 ...
+                wait = self._bcast_block(views[b + 1], G[(b + 1) % len(G)], pg, async_=True)     # ... and sends it off
+                be.dist_front_phase(d_nzval_ptr, s, 5, b)           # b -> my other later blocks, beside that broadcast
         be.dist_front_phase(d_nzval_ptr, s, 3)                      # my blocks of the contribution block
 
     # ---- solve --------------------------------------------------------------------------------------
@@ -238,6 +263,8 @@ class ShardedFactor:
         t = self.torch
         part = t.tensor([self.be.logdet_partial()], dtype=t.float64, device="cpu" if self.host_staging else self.dev)
         self.dist.all_reduce(part, op=self.dist.ReduceOp.SUM)
+        if self._info_pending:                      # the pivot report of refactorize_dev(check=False) rides with this host round trip
+            self._reduce_info()
         return float(part.item())
 
     def close(self):

@@ -211,7 +211,9 @@ int32_t gmrfx_set_stream(gmrfx_handle *h, void *hip_stream, int32_t use_external
  *     assembled (col0: the first of these columns). Replaces the cb_offset / cb_count columns of gmrfx_shard_edges for the factorisation.
  *   gmrfx_dist_front_phase(h, d_nzval, front, what, block): 0 = assemble this rank's panel blocks; 1 = factor panel block
  *     `block` (its owner; a no-op elsewhere) [then broadcast columns 256 block .. of the panel inside the group]; 2 = apply
- *     block `block` to this rank's later panel blocks; 3 = this rank's blocks of the contribution block. A no-op on ranks
+ *     block `block` to this rank's later panel blocks (4 = to block + 1 only, 5 = to the later blocks except block + 1: the
+ *     LOOK-AHEAD split -- the owner of block + 1 applies 4, factors and starts the broadcast of block + 1, and everybody
+ *     applies 5 while that broadcast is in flight); 3 = this rank's blocks of the contribution block. A no-op on ranks
  *     outside the group. Same kernels, same sums in the same order as an unsharded handle: bit-identical factor. */
 int32_t gmrfx_shard_dist_fronts(const gmrfx_handle *h, int64_t *counts /* 4 */, int64_t *front, int64_t *cols, int64_t *rows,
                                 int64_t *panel_offset, int64_t *panel_ld, int64_t *level, int64_t *gptr, int64_t *grank);

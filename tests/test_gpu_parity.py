@@ -566,7 +566,11 @@ def _shard_gpu_worker(rank, world, port, q, case="2d"):
             assert len(sf.df["front"]) >= 1 and max(sf.df["cols"]) >= 513 and sf.df["group"][-1] == list(range(world)), sf.df
         for _ in range(2):                               # twice: the second run reuses every buffer
             assert sf.refactorize_dev(d_nz.data_ptr()) == 0
+        # the form bench.py times: no pivot report (host round trip) between the factorisation and what follows; it rides with logdet()
+        sf.last_info = -1
+        assert sf.refactorize_dev(d_nz.data_ptr(), check=False) == 0 and sf._info_pending
         ld = sf.logdet()
+        assert sf.last_info == 0 and not sf._info_pending
         # sharded solve: B on every rank, X on rank 0; must equal the unsharded solve bit for bit
         nrhs = 64 if world == 2 else 7
         Bh = torch.randn((nrhs, Q.shape[0]), generator=torch.Generator().manual_seed(3), dtype=torch.float64)
