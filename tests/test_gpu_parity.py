@@ -547,6 +547,15 @@ def _shard_gpu_worker(rank, world, port, q, case="2d"):
             os.environ["GMRFX_DIST_MIN"] = "256"        # separators below it (~400 columns, with contribution blocks) by two ranks each
             m = sp_.grid_mesh_3d(28, 28, 28)
             Q = sp_.matern_precision(m, 0, 0.4)
+        elif case == "spacetime":  # BASELINE cfg 5 in small: AR(1) over 24 time steps (x) 2-D Matern + observation term, handed WHOLE to the
+            os.environ["GMRFX_DIST_MIN"] = "256"        # factorisation on the space-time dissection (separable.jl:143-172); the top
+            from gmrfx import spacetime as st_          # separators (time slabs / space cuts of ~600 columns) are DISTRIBUTED fronts
+            ms = sp_.grid_mesh_2d(24, 23, jitter=0.2, seed=4)
+            Qs = sp_.matern_precision(ms, 0, 0.4)
+            T = 24
+            Q = st_.spacetime_precision(sp_.ar1_precision(T, 0.8), Qs, obs_diag=np.random.default_rng(5).uniform(0.5, 2.0, T * Qs.shape[0]))
+            class _M: pass
+            m = _M(); m.points = st_.spacetime_coords(ms.points, T)
         else:
             m = sp_.grid_mesh_2d(120, 120, jitter=0.25, seed=2)
             Q = sp_.matern_precision(m, 0, 0.2)
@@ -564,6 +573,8 @@ def _shard_gpu_worker(rank, world, port, q, case="2d"):
 
         if case == "3d_dist":
             assert len(sf.df["front"]) >= 1 and max(sf.df["cols"]) >= 513 and sf.df["group"][-1] == list(range(world)), sf.df
+        if case == "spacetime":
+            assert len(sf.df["front"]) >= 1 and max(sf.df["cols"]) > 256, sf.df
         for _ in range(2):                               # twice: the second run reuses every buffer
             assert sf.refactorize_dev(d_nz.data_ptr()) == 0
         # the form bench.py times: no pivot report (host round trip) between the factorisation and what follows; it rides with logdet()
@@ -1287,3 +1298,27 @@ def test_refactorize_logpdf_one_call_equals_three_calls():
             lpo = orc.logpdf(F, sp.csc_matrix(Qk), Zh[k], mu)
             assert abs(lp - lpo) <= 1e-10 * abs(lpo)
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_spacetime_rehearsal_on_one_gpu(world):
+    """SURVEY 8 f3, "distributed separators": the space-time posterior precision kron(Q_t, Q_s) + diag(h) (block tridiagonal in
+    time; SeparableModel hands it whole to the solver, separable.jl:143-172) factored ONCE over `world` processes on the space-time
+    nested dissection -- time-slab / space separators at the top of the tree are distributed fronts (256-column blocks dealt over
+    their group, look-ahead broadcasts). Panels and log-determinant bit for bit against the unsharded handle, solves, backward
+    solves and the selected-inverse diagonal to rounding; all ranks on this one GPU."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_gpu_worker, args=(r, world, 29850 + world, q, "spacetime")) for r in range(world)]
+    [p.start() for p in procs]
+    got = []
+    for _ in range(world):
+        item = q.get(timeout=300)
+        assert item[0] != "error", f"rank {item[1]} failed:\n{item[2]}"
+        got.append(item)
+    [p.join(timeout=120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    for rank, ld, ld_ref, same, nmine, info in got:
+        assert same and nmine > 0 and info["n_dist"] >= 1, f"rank {rank}: {info.get('why')}"
+        assert abs(ld - ld_ref) <= 1e-12 * abs(ld_ref)

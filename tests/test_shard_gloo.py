@@ -220,7 +220,7 @@ def test_plan_summary_time_bounds_from_level_times():
         be.close()
 
 
-def _dist_fronts_worker(rank, world, port, q):
+def _dist_fronts_worker(rank, world, port, q, kind="dense"):
     """Host walk (numpy) of the DISTRIBUTED TOP FRONT protocol on the structures the library exports (gmrfx_shard_dist_fronts,
     gmrfx_shard_transfers): column ranges of the children's contribution blocks to the owners of the 256-column blocks they
     fall into, assembly of the own panel blocks, per panel block: owner factors its block column, broadcast inside the group,
@@ -251,7 +251,18 @@ def _dist_fronts_worker(rank, world, port, q):
                  [N, N, C[0].T, N, N, C[1].T, dense(nd)]], format="csc")
     Q.sort_indices()
     n = Q.shape[0]
-    be = gmrfx.MI355XBackend(Q, ordering=np.arange(n), symbolic_only=True, shard_rank=rank, shard_world=world)
+    if kind == "spacetime":
+        # SURVEY 8 f3 "distributed separators": the space-time posterior kron(Q_t, Q_s) + diag(h) (separable.jl:143-172) on the
+        # space-time nested dissection -- its top separators (time slabs / space cuts, > 256 columns) are distributed fronts
+        from gmrfx import spde, spacetime
+        ms = spde.grid_mesh_2d(18, 17, jitter=0.2, seed=4)
+        Qs = spde.matern_precision(ms, 0, 0.4)
+        T = 16
+        Q = spacetime.spacetime_precision(spde.ar1_precision(T, 0.8), Qs, obs_diag=np.random.default_rng(5).uniform(0.5, 2.0, T * Qs.shape[0]))
+        n = Q.shape[0]
+        be = gmrfx.MI355XBackend(Q, coords=spacetime.spacetime_coords(ms.points, T), symbolic_only=True, shard_rank=rank, shard_world=world)
+    else:
+        be = gmrfx.MI355XBackend(Q, ordering=np.arange(n), symbolic_only=True, shard_rank=rank, shard_world=world)
     sy = be.symbolic()
     owner, is_top = be.shard_owner(with_top=True)
     info, df, X = be.shard_info(), be.shard_dist_fronts(), be.shard_transfers()
@@ -260,9 +271,12 @@ def _dist_fronts_worker(rank, world, port, q):
     ns = sim.ns
     dfi = {int(s): i for i, s in enumerate(df["front"])}
     R = int(np.flatnonzero(sy.super_parent == -1)[-1])
-    assert R in dfi and df["cols"][dfi[R]] >= nd and df["group"][dfi[R]] == list(range(world))
-    if world >= 4:          # an M front below the root is distributed as well, by a sub-group (the other may be amalgamated into the root)
-        assert any(int(s) != R and len(df["group"][i]) < world and sim.r[int(s)] > sim.c[int(s)] for s, i in dfi.items())
+    if kind == "spacetime":
+        assert len(dfi) >= 1 and max(df["cols"]) > 256
+    else:
+        assert R in dfi and df["cols"][dfi[R]] >= nd and df["group"][dfi[R]] == list(range(world))
+        if world >= 4:      # an M front below the root is distributed as well, by a sub-group (the other may be amalgamated into the root)
+            assert any(int(s) != R and len(df["group"][i]) < world and sim.r[int(s)] > sim.c[int(s)] for s, i in dfi.items())
     groups = {tuple(G_): None for G_ in df["group"]}
     for key in groups:
         groups[key] = None if len(key) == world else dist.new_group(ranks=list(key))
@@ -384,3 +398,21 @@ def test_distributed_top_fronts_host_walk_gloo(world):
         assert err < 1e-10, (rank, err)
         assert abs(ld - ld_ref) < 1e-10 * abs(ld_ref)
         assert ndist >= (2 if world >= 4 else 1) and held > 0
+
+
+@pytest.mark.parametrize("world", [2])          # (world 4: the one-GPU rehearsal, tests/test_gpu_parity.py::test_sharded_spacetime_rehearsal_on_one_gpu)
+def test_distributed_separators_of_a_spacetime_precision_host_walk_gloo(world):
+    """SURVEY 8 f3, second half ("distributed separators"): the same host walk on the SPACE-TIME posterior precision
+    kron(AR(1), Matern) + diag(h) with the space-time nested dissection -- the separators at the top of its tree are distributed
+    fronts; panels against dense LAPACK on the permuted matrix, all-reduced log-determinant."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dist_fronts_worker, args=(r, world, 29950 + world, q, "spacetime")) for r in range(world)]
+    [p.start() for p in procs]
+    got = [q.get(timeout=300) for _ in range(world)]
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    for rank, err, ld, ld_ref, ndist, held in got:
+        assert err < 1e-10, (rank, err)
+        assert abs(ld - ld_ref) < 1e-10 * abs(ld_ref)
+        assert ndist >= 1 and held > 0
