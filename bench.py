@@ -547,7 +547,7 @@ def main():
         # runs, gfx950 FETCH_SIZE x2 correction): only valid for the workload they were collected on
         pmc = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")) as fh:
                 pj = json.load(fh)
             if pj["workload"] == {"grid": args.grid, "nrhs": args.nrhs}:
                 pmc = pj
@@ -570,7 +570,7 @@ def main():
                        "flops_per_launch": st["syrk_flops"] / n_launch, "ms_per_step": ms_syrk,
                        "note": "achieved = algorithmic flops of the launches of one step / their summed HIP-event time over the "
                                "timed (pipelined) steps -- the forward sweep of the same step runs beside some of them; "
-                               "traffic = PMC HBM bytes per launch (profiles/r03_pmc_traffic.json)"}
+                               "traffic = PMC HBM bytes per launch (profiles/r04_pmc_traffic.json)"}
         if pipelined_phases is not None:
             alone = pipelined_phases["syrk_launches_separate"]
             roof_kernel.update({"ms_per_step_alone": alone, "achieved_alone": st["syrk_flops"] / (alone * 1e-3) / 1e12,
@@ -587,11 +587,20 @@ def main():
             # the bytes the sweeps really move (PMC), W / x hand-off between the levels included, against the same peak
             roof_sweep["frac_of_peak_with_measured_traffic"] = roof_sweep["traffic"] / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         roof_cfg3 = {}
+        pmc3 = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r04_cfg3_pmc_traffic.json")) as fh:
+                p3 = json.load(fh)
+            if p3["workload"]["grid"] == args.grid:
+                pmc3 = p3
+        except Exception:
+            pmc3 = None
         if cfg3 is not None:
             sel_tf = cfg3["sel_flops"] / (extras["ms_selinv"] * 1e-3) / 1e12
             roof_cfg3["roofline_selinv"] = {
                 "bound": "mfma", "achieved": sel_tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": sel_tf / FP64_MFMA_PEAK_TF,
-                "traffic": None, "kernel": "selected inversion on pattern(L) (all launches; dominant: k_sel_dense, Z21 = -Z22 Y of the big fronts)",
+                "traffic": pmc3["selinv"]["total_bytes"] if pmc3 else None,
+                "kernel": "selected inversion on pattern(L) (all launches; dominant: k_sel_dense, Z21 = -Z22 Y of the big fronts)",
                 "ms": extras["ms_selinv"], "flops": cfg3["sel_flops"], "flops_over_factor_flops": cfg3["sel_flops"] / st["factor_flops"],
                 "bytes_min": 16.0 * nnzl, "gbs_on_bytes_min": 16.0 * nnzl / (extras["ms_selinv"] * 1e-3) / 1e9,
                 "note": "cfg 3: flops = sum_s 2 c m^2 + 4 c^2 m + 2 c^3 / 3 (Takahashi recursion through the dense inverse of L11); "
@@ -601,7 +610,7 @@ def main():
             rb = 4.0 * (8.0 * nnzl + 4.0 * st["sum_rows"] + 16.0 * n * 64 + 8.0 * n * 64)
             roof_cfg3["roofline_rand256"] = {
                 "bound": "hbm", "achieved": rb / (extras["ms_rand256"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": rb / (extras["ms_rand256"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                "frac": rb / (extras["ms_rand256"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc3["rand256"]["total_bytes"] if pmc3 else None,
                 "kernel": "256 samples P' L^-T z: 4 backward sweeps of 64 columns on two lanes", "ms": extras["ms_rand256"], "bytes": rb}
         out = {
             "metric": "factor+solve(64 RHS) throughput", "value": world * n / (elapsed / args.steps), "unit": "DoF/s",

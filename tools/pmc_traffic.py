@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Aggregate the HBM-traffic PMC passes into profiles/<name>.json.
 
-    rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_fetch --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-logpdf --no-cfg3
-    rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_write --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-logpdf --no-cfg3
+    rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_fetch --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-logpdf --no-cfg3 --no-host-io
+    rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_write --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-logpdf --no-cfg3 --no-host-io
     python3 tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_pmc_traffic.json 1000 64
 
 Counter unit: KB. FETCH_SIZE is doubled (MI355X_MICROARCH.md: gfx950 reports half of the wide
@@ -57,7 +57,7 @@ def main():
     walk(W, "write", 1.0)
     for v in res.values(): v["total_bytes"] = v["fetch_bytes"] + v["write_bytes"]
     res["per_kernel_GB_per_step"] = {k: {kk: (round(vv, 3) if kk != "launches" else vv) for kk, vv in v.items()} for k, v in sorted(per.items())}
-    res["note"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-logpdf --no-cfg3); counter unit KB; "
+    res["note"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-logpdf --no-cfg3 --no-host-io); counter unit KB; "
                    "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads); values per bench step "
                    "(refactorise + solve).")
     res["workload"] = {"grid": grid, "nrhs": nrhs}

@@ -35,5 +35,31 @@ def run(cfg):
     print(json.dumps(res))
 
 
-for c in (sys.argv[1:] or ["cfg2"]):
-    run(c)
+def memory(cfg, W=8):
+    """per-rank HBM of the sharded plan from symbolic-only handles (one analysis per rank): factor panels, contribution-block arena
+    (own blocks + the exchange region), right-hand-side panels X / X2 (n x 64 each)"""
+    if cfg == "cfg4":
+        mesh = spde.grid_mesh_3d(126, 126, 126); Q = spde.matern_precision(mesh, 0, 0.4); name = "cfg4_126cubed"
+    else:
+        mesh = spde.grid_mesh_2d(1000, 1000, jitter=0.25, seed=0); Q = spde.matern_precision(mesh, 0, 0.2); name = "cfg2_1000"
+    n = Q.shape[0]
+    one = gmrfx.MI355XBackend(Q, coords=mesh.points, symbolic_only=True)
+    s1 = one.stats(); perm = one.ordering_permutation(); one.close()
+    print(f"== {name}: per-rank memory at world {W} (GB): factor panels, contribution-block arena, X + X2; unsharded: "
+          f"{s1['bytes_factor'] / 1e9:.1f} + {s1['bytes_cb_arena'] / 1e9:.1f} + {2 * n * 64 * 8 / 1e9:.1f}", flush=True)
+    rows = []
+    for r in range(W):
+        be = gmrfx.MI355XBackend(Q, ordering=perm, symbolic_only=True, shard_rank=r, shard_world=W)
+        st = be.stats(); be.close()
+        rows.append((st["bytes_factor"] / 1e9, st["bytes_cb_arena"] / 1e9, 2 * n * 64 * 8 / 1e9))
+        print(f"  rank {r}: {rows[-1][0]:7.2f} + {rows[-1][1]:7.2f} + {rows[-1][2]:5.2f} = {sum(rows[-1]):7.2f} GB", flush=True)
+    print(f"  largest rank: {max(sum(x) for x in rows):.2f} GB; sum of the factor shares {sum(x[0] for x in rows):.2f} GB")
+
+
+args = sys.argv[1:] or ["cfg2"]
+if args[0] == "memory":
+    for c in (args[1:] or ["cfg2"]):
+        memory(c)
+else:
+    for c in args:
+        run(c)
