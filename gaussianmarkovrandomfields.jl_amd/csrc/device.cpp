@@ -330,6 +330,7 @@ void Device::upload(const Symbolic &S) {
             if (const char *e = std::getenv("GMRFX_LEVEL_MARK")) level_mark_ = std::atoi(e) != 0;
             if (const char *e = std::getenv("GMRFX_LOOKAHEAD")) lookahead_ = std::atoi(e) != 0;
             if (const char *e = std::getenv("GMRFX_CHAIN_MAX_FRONTS")) chain_max_fronts_ = std::max(0, std::atoi(e));
+            if (const char *e = std::getenv("GMRFX_INV_ON_MAIN")) inv_on_main_ = std::atoi(e) != 0;
             if (const char *e = std::getenv("GMRFX_SMALL_ON_SIDE")) small_on_side_ = std::atoi(e) != 0;
         }
         const int *a; up(a, S.sub_first); d_sub_first_ = const_cast<int *>(a);
@@ -975,6 +976,7 @@ void Device::factor_levels(int lo, int hi) {
             HC(hipEventRecord(ev_done1_, stream3));
             HC(hipStreamWaitEvent(stream, ev_done1_, 0));
         }
+        if (fused_ && inv_on_main_) invert_level(stream, lev);       // (A/B switch GMRFX_INV_ON_MAIN: the level's dense inverses behind its panels)
         if (fused_) HC(hipEventRecord(ev_flevel_[lev], stream));      // the panels of this level are final: its sweep may start
     }
     syrk_launches = nsy;
@@ -1409,7 +1411,7 @@ void Device::forward(int nr, int ldx, int lo, int hi) {
         if (level_mark_) { launch_level_mark(stream, 1, lev); level_event(1, 1 + lev); }
         if (fused_fwd_) {
             if (lev > fused_gate_level_) HC(hipStreamWaitEvent(stream, ev_flevel_[lev], 0));
-            invert_level(stream, lev);
+            if (!inv_on_main_) invert_level(stream, lev);
         } else if (lev == std::max(lo, first_multiblock_level_)) wait_inverse();
         for (int k = 0, off = 0; k < 4; off += L.ncls[k], k++)
             launch_fwd_small(stream, ds_, d_sw_levellist_ + L.first + off, L.ncls[k], kClsRows[k], d_L_, d_X_, d_W_, nr, ldx);
