@@ -331,6 +331,7 @@ void Device::upload(const Symbolic &S) {
             if (const char *e = std::getenv("GMRFX_LOOKAHEAD")) lookahead_ = std::atoi(e) != 0;
             if (const char *e = std::getenv("GMRFX_CHAIN_MAX_FRONTS")) chain_max_fronts_ = std::max(0, std::atoi(e));
             if (const char *e = std::getenv("GMRFX_INV_ON_MAIN")) inv_on_main_ = std::atoi(e) != 0;
+            if (const char *e = std::getenv("GMRFX_FUSED_CUT")) fused_cut_ = std::max(0, std::atoi(e));
             if (const char *e = std::getenv("GMRFX_SMALL_ON_SIDE")) small_on_side_ = std::atoi(e) != 0;
         }
         const int *a; up(a, S.sub_first); d_sub_first_ = const_cast<int *>(a);
@@ -1410,7 +1411,10 @@ void Device::forward(int nr, int ldx, int lo, int hi) {
         auto &L = swlevels_[lev];
         if (level_mark_) { launch_level_mark(stream, 1, lev); level_event(1, 1 + lev); }
         if (fused_fwd_) {
-            if (lev > fused_gate_level_) HC(hipStreamWaitEvent(stream, ev_flevel_[lev], 0));
+            // GMRFX_FUSED_CUT=k (A/B): the top k levels of the forward sweep (and their dense inverses) wait for the WHOLE
+            // factorisation instead of their own level: nothing runs beside the latency-bound top of the panel chains
+            if (fused_cut_ > 0 && lev >= (int)levels_.size() - fused_cut_) HC(hipStreamWaitEvent(stream, ev_fact_, 0));
+            else if (lev > fused_gate_level_) HC(hipStreamWaitEvent(stream, ev_flevel_[lev], 0));
             if (!inv_on_main_) invert_level(stream, lev);
         } else if (lev == std::max(lo, first_multiblock_level_)) wait_inverse();
         for (int k = 0, off = 0; k < 4; off += L.ncls[k], k++)

@@ -247,6 +247,7 @@ private:
     FrontView *d_frec_ = nullptr, *d_frec2_ = nullptr, *d_sel_frec_ = nullptr;   // geometry records parallel to the level lists
     int *d_levellist2_ = nullptr;   // per level: the big fronts re-ordered [even positions..., odd positions...] (two-stream panel chains)
     bool two_chains_ = true;
+    int fused_cut_ = 0;           // GMRFX_FUSED_CUT (A/B): top levels of the pipelined forward sweep that wait for the whole factorisation
     bool inv_on_main_ = false;    // GMRFX_INV_ON_MAIN=1 (A/B): pipelined call: a level's dense inverses on the main stream behind its panels
     // persistent panel chain (panel_chain.hip): levels with at most this many wide fronts (GMRFX_CHAIN_MAX_FRONTS; 0: never).
     // OFF by default -- measured at cfg 2 (round 4, tools/chain_ab.py, GMRFX_CHAIN_TRACE): same bits as the launch chain, but

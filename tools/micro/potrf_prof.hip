@@ -26,7 +26,7 @@ int main(){
   for(int wv : {64, 37}) {
     int sf2[2]={0,wv}; HC(hipMemcpy(dsf,sf2,8,hipMemcpyHostToDevice));
     HC(hipEventRecord(e0,st));
-    for(int r=0;r<reps;r++){ hipMemcpyAsync(dL,dA,n*n*8,hipMemcpyDeviceToDevice,st); hipLaunchKernelGGL(k_potrf64,dim3(1),dim3(256),0,st,S,dlist,0,dL,dinfo,FrontArg{0,0,0,0,0,0,0}); }
+    for(int r=0;r<reps;r++){ hipMemcpyAsync(dL,dA,n*n*8,hipMemcpyDeviceToDevice,st); hipLaunchKernelGGL(k_potrf64,dim3(1),dim3(256),0,st,S,(const FrontView*)nullptr,0,dL,dinfo,FrontArg{1,0,wv,wv,n,0,0}); }
     HC(hipEventRecord(e1,st)); HC(hipStreamSynchronize(st)); HC(hipEventElapsedTime(&ms,e0,e1));
     printf("k_potrf64 (w=%d) + d2d copy: %.2f us per launch\n", wv, ms*1000/reps);
 #ifdef GMRFX_CYC
@@ -47,5 +47,10 @@ int main(){
     HC(hipEventRecord(e1,st)); HC(hipStreamSynchronize(st)); HC(hipEventElapsedTime(&ms,e0,e1));
     printf("  d2d copy alone: %.2f us\n", ms*1000/reps);
   }
+  { HC(hipMemcpy(dL,dA,n*n*8,hipMemcpyDeviceToDevice));
+    HC(hipEventRecord(e0,st));
+    for(int r=0;r<reps;r++) hipLaunchKernelGGL(k_potrf64,dim3(1),dim3(256),0,st,S,(const FrontView*)nullptr,0,dL,dinfo,FrontArg{1,0,64,64,n,0,0});
+    HC(hipEventRecord(e1,st)); HC(hipStreamSynchronize(st)); HC(hipEventElapsedTime(&ms,e0,e1));
+    printf("k_potrf64 back to back (no copy; refactoring its own output: timing only): %.2f us per launch\n", ms*1000/reps); }
   return 0;
 }
