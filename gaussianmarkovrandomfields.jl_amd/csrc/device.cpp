@@ -80,6 +80,7 @@ Device::~Device() {
     if (ev_fact_) (void)hipEventDestroy(ev_fact_);
     if (ev_inv_) (void)hipEventDestroy(ev_inv_);
     if (stream2) (void)hipStreamDestroy(stream2);
+    for (auto d : dummy_streams_) (void)hipStreamDestroy(d);
     if (own_stream_) (void)hipStreamDestroy(own_stream_);
 }
 
@@ -110,9 +111,16 @@ void Device::init(const Symbolic &S, int dev) {
         HC(hipDeviceGetStreamPriorityRange(&lo, &hi));
         const char *e = std::getenv("GMRFX_STREAM_PRIO");
         const bool prio = !e || std::atoi(e) != 0;
+        // GMRFX_STREAM_SKIP=k (A/B): k idle streams created between the handle's streams -- the runtime deals streams to hardware
+        // queues (and those to the command processor's pipes) in creation order
+        const char *sk = std::getenv("GMRFX_STREAM_SKIP");
+        const int skip = sk ? std::max(0, std::atoi(sk)) : 0;
+        auto burn = [&]() { for (int k = 0; k < skip; k++) { hipStream_t d; HC(hipStreamCreateWithFlags(&d, hipStreamNonBlocking)); dummy_streams_.push_back(d); } };
         HC(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, prio ? hi : 0));
         own_stream_ = stream;
+        burn();
         HC(hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, prio ? lo : 0));
+        burn();
         HC(hipStreamCreateWithPriority(&stream3, hipStreamNonBlocking, prio ? hi : 0));
         if (const char *c = std::getenv("GMRFX_INV_CAP")) {      // testing knob: power of two >= 64
             int v = std::atoi(c), p2 = NB;

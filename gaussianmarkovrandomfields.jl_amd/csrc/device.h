@@ -213,6 +213,7 @@ public:
     bool async_phases_ = false;          // sharded phase entry points return after enqueueing (no host synchronisation, no timings)
     hipStream_t stream2 = nullptr;  // side stream: dense-inverse stages overlap the leaf levels of the forward sweep
     hipStream_t stream3 = nullptr;  // second sweep lane (solves with more than 64 right-hand sides)
+    std::vector<hipStream_t> dummy_streams_;   // GMRFX_STREAM_SKIP (A/B)
     hipEvent_t ev_fact_ = nullptr, ev_inv_ = nullptr;
 
 private:
