@@ -1384,7 +1384,15 @@ void Device::ensure_rhs_capacity(long long nrhs) {
 // wider passes: the workgroup tasks of sweep_task.hip (64 RHS: 4.90 vs 5.58 ms -- the general op pipeline of the wave form
 // issues ~2.5x the instructions per front). GMRFX_TASK_MODE = wg / wave forces one form.
 void Device::sweep_tasks(int phase, int nr, int ldx) {
-    if (nr > wave_max_nr_) { launch_sweep_tasks(stream, ds_, phase, d_swt_, nswt_, d_L_, d_X_, phase == 1 ? d_W_ : nullptr, nr, ldx); return; }
+    if (nr > wave_max_nr_) {
+        // pipelined call: the forward task kernel runs beside the top of the factorisation -- ONE resident workgroup per CU
+        // (GMRFX_FUSED_TASK_LDS KB of unused dynamic LDS on top of its 72 KB), so that the panel chain's kernels find LDS
+        // (measured at cfg 2, round 4: the level under which the task kernel runs 1.40 -> 1.15 ms (0.95 alone), step 14.19 -> 14.03 ms)
+        static const int pad_kb = [] { const char *e = std::getenv("GMRFX_FUSED_TASK_LDS"); return e ? std::max(0, std::atoi(e)) : 8; }();
+        const size_t extra = (fused_fwd_ && phase == 1) ? (size_t)pad_kb * 1024 : 0;
+        launch_sweep_tasks(stream, ds_, phase, d_swt_, nswt_, d_L_, d_X_, phase == 1 ? d_W_ : nullptr, nr, ldx, extra);
+        return;
+    }
     ensure_rdiag();
     for (int k = kWaveClasses - 1; k >= 0; k--)
         launch_wave_tasks(stream, ds_, phase, d_swt_, d_wave_order_ + wave_first_[k], wave_count_[k], kWaveRows[k], d_L_, d_rdiag_,

@@ -436,7 +436,7 @@ void launch_bwd_small(hipStream_t st, const DevSym &S, const int *list, int nfro
 
 // sweep_task.hip -- whole bottom subtrees on an LDS-resident local vector: phase 1 forward, 2 backward
 void launch_sweep_tasks(hipStream_t st, const DevSym &S, int phase, const SweepTask *tasks, int ntasks,
-                        const double *L, double *X, double *W, int nr, int ldx);
+                        const double *L, double *X, double *W, int nr, int ldx, size_t extra_lds = 0);
 
 // sweep_wave.hip -- the same tasks, one wave per (task, 16 right-hand sides); order = task ids of one LDS class
 void launch_wave_tasks(hipStream_t st, const DevSym &S, int phase, const SweepTask *tasks, const int *order, int ntasks, int rows_cap,

@@ -528,14 +528,17 @@ static int task_nc() {      // GMRFX_TASK_NC = 64: one 64-column workgroup per t
     return v;
 }
 void launch_sweep_tasks(hipStream_t st, const DevSym &S, int phase, const SweepTask *tasks, int ntasks,
-                        const double *L, double *X, double *W, int nr, int ldx) {
+                        const double *L, double *X, double *W, int nr, int ldx, size_t extra_lds) {
     if (ntasks <= 0) return;
+    // extra_lds: dynamic LDS nobody uses -- it only lowers the number of resident workgroups per compute unit (pipelined factor +
+    // solve: two resident 72 KB task workgroups leave 16 KB per CU, and the panel chain's trsm (32 KB) and SYRK (33 KB) workgroups
+    // queue behind them)
     if (task_nc() == 64) {
         if (phase == 1) hipLaunchKernelGGL(k_fwd_task<64>, dim3(ntasks), dim3(1024), 0, st, S, tasks, ntasks, L, X, W, nr, ldx);
         else hipLaunchKernelGGL(k_bwd_task<64>, dim3(ntasks), dim3(1024), 0, st, S, tasks, ntasks, L, X, nr, ldx);
     } else {
         const int grid = ((ntasks + 7) / 8) * 16;       // blocks b and b + 8 (same XCD): the two column halves of one task
-        if (phase == 1) hipLaunchKernelGGL(k_fwd_task<32>, dim3(grid), dim3(512), 0, st, S, tasks, ntasks, L, X, W, nr, ldx);
+        if (phase == 1) hipLaunchKernelGGL(k_fwd_task<32>, dim3(grid), dim3(512), extra_lds, st, S, tasks, ntasks, L, X, W, nr, ldx);
         else hipLaunchKernelGGL(k_bwd_task<32>, dim3(grid), dim3(512), 0, st, S, tasks, ntasks, L, X, nr, ldx);
     }
 }

@@ -3,6 +3,7 @@
 // build: hipcc -O3 -std=c++17 --offload-arch=gfx950 [-DGMRFX_CYC] -I../../gaussianmarkovrandomfields.jl_amd/csrc potrf_prof.hip -o potrf_prof
 #include "../../gaussianmarkovrandomfields.jl_amd/csrc/potrf64.hip"
 #include <cstdio>
+#include <chrono>
 #include <vector>
 #include <cmath>
 #include <climits>
@@ -52,5 +53,21 @@ int main(){
     for(int r=0;r<reps;r++) hipLaunchKernelGGL(k_potrf64,dim3(1),dim3(256),0,st,S,(const FrontView*)nullptr,0,dL,dinfo,FrontArg{1,0,64,64,n,0,0});
     HC(hipEventRecord(e1,st)); HC(hipStreamSynchronize(st)); HC(hipEventElapsedTime(&ms,e0,e1));
     printf("k_potrf64 back to back (no copy; refactoring its own output: timing only): %.2f us per launch\n", ms*1000/reps); }
+  // do two chains of dependent one-workgroup launches on two streams run side by side? (the two panel chains of a level)
+  { double *dL2; HC(hipMalloc(&dL2,n*n*8)); HC(hipMemcpy(dL2,dA,n*n*8,hipMemcpyDeviceToDevice)); HC(hipMemcpy(dL,dA,n*n*8,hipMemcpyDeviceToDevice));
+    hipStream_t st2; HC(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
+    hipEvent_t f0,f1; HC(hipEventCreate(&f0)); HC(hipEventCreate(&f1));
+    const FrontArg fa{1,0,64,64,n,0,0};
+    for (int two = 0; two < 2; two++) {
+      HC(hipDeviceSynchronize());
+      auto t0 = std::chrono::steady_clock::now();
+      for(int r=0;r<reps;r++){
+        hipLaunchKernelGGL(k_potrf64,dim3(1),dim3(256),0,st,S,(const FrontView*)nullptr,0,dL,dinfo,fa);
+        if (two) hipLaunchKernelGGL(k_potrf64,dim3(1),dim3(256),0,st2,S,(const FrontView*)nullptr,0,dL2,dinfo,fa);
+      }
+      HC(hipDeviceSynchronize());
+      const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+      printf("%d chain(s) of %d dependent k_potrf64 launches on %d stream(s): %.2f us per chain step (wall)\n", two + 1, reps, two + 1, us / reps);
+    } }
   return 0;
 }
