@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <functional>
 #include <stdexcept>
 #include <thread>
 
@@ -766,6 +767,7 @@ void Device::host_download(const double *d_src, long long nrhs, double *X, long 
     // the copies are enqueued only once their source is final: a device-to-host copy that has to wait for an event on another
     // stream took 21 ms instead of 9 here (512 MB; the runtime leaves the DMA path for it)
     HC(hipStreamSynchronize(after));
+    if (io_trace_cb_) io_trace_cb_("sweeps done (download starts)");
     if (host_ptr_is_pinned(X)) {
         if (ldx == n) HC(hipMemcpyAsync(X, d_src, (size_t)(n * nrhs) * sizeof(double), hipMemcpyDeviceToHost, stream_io_));
         else HC(hipMemcpy2DAsync(X, ldx * sizeof(double), d_src, n * sizeof(double), n * sizeof(double), nrhs, hipMemcpyDeviceToHost, stream_io_));
@@ -1083,6 +1085,8 @@ void Device::refactorize_solve(const double *nzval, bool nz_on_device, const dou
     auto trace = [&](const char *what) {
         if (io_trace) std::fprintf(stderr, "[gmrfx io] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count());
     };
+    io_trace_cb_ = io_trace ? std::function<void(const char *)>(trace) : std::function<void(const char *)>();
+    struct ClearCb { std::function<void(const char *)> &f; ~ClearCb() { f = nullptr; } } clear_cb{io_trace_cb_};
     const double *src = nzval;
     if (!nz_on_device) {
         host_upload_values(nzval);

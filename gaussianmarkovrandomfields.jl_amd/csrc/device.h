@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -356,6 +357,7 @@ private:
     void host_upload_values(const double *nzval);
     hipEvent_t ev_up_ = nullptr, ev_x_ = nullptr;
     std::vector<hipEvent_t> ev_dn_;
+    std::function<void(const char *)> io_trace_cb_;     // GMRFX_IO_TRACE
     void host_io_reserve(long long count);
     void host_upload(const double *B, long long ldb, long long nrhs, double *d_dst);
     void host_download(const double *d_src, long long nrhs, double *X, long long ldx, hipStream_t after);
