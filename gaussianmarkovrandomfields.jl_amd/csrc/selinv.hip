@@ -200,7 +200,10 @@ __global__ __launch_bounds__(256) void k_sel_diag(DevSym S, const int *__restric
 // 64x64 output tiles, 4 waves x 32x32, FP64 MFMA; operand orientations chosen so that all but
 // one operand stream (the upper half of the symmetric Z22) are contiguous along the lanes.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_sel_dense(DevSym S, const int *__restrict__ list, int phase,
+// WT: waves per side of the workgroup tile (32 WT squared): 2 = 64 x 64 (4 waves), 4 = 128 x 128 (16 waves) -- the waves of a workgroup
+// that share operand rows find them in the L1 of their CU, so the larger tile halves the bytes a workgroup pulls through L2 per flop
+template <int WT>
+__global__ __launch_bounds__(64 * WT * WT) void k_sel_dense(DevSym S, const int *__restrict__ list, int phase,
                                                    const double *__restrict__ L, double *__restrict__ Z,
                                                    const double *__restrict__ ZB, double *__restrict__ Yt,
                                                    double *__restrict__ Z21t, const long long *__restrict__ woff, int rgx, int rgy, int nfr) {
@@ -233,9 +236,9 @@ __global__ __launch_bounds__(256) void k_sel_dense(DevSym S, const int *__restri
     const int N = phase == 1 ? m : c;        // extent of the MFMA "n" index (on the lanes)
     if (m == 0 && phase < 2) return;
     const int bm = bx, bn = by;
-    if (bm * 64 >= M || bn * 64 >= N) return;
+    if (bm * (32 * WT) >= M || bn * (32 * WT) >= N) return;
     if (phase == 2 && bn < bm) return;       // a-tile >= b-tile only
-    const int m0 = bm * 64 + (wave & 1) * 32, n0 = bn * 64 + (wave >> 1) * 32;
+    const int m0 = bm * (32 * WT) + (wave % WT) * 32, n0 = bn * (32 * WT) + (wave / WT) * 32;
     if (m0 >= M || n0 >= N) return;
     d4 acc[2][2];
 #pragma unroll
@@ -374,12 +377,18 @@ void launch_sel_dense(hipStream_t st, const DevSym &S, const int *list, int nfro
     // selected inversion 13.0 ms on the plain grid, 14.0-14.3 ms with whole fronts per XCD from 8 / 32 / 128 fronts up: the plain grid's
     // 19-38x re-read traffic is served by the Infinity Cache through all eight L2s at ~4.7 TB/s, one L2 per front is the narrower pipe)
     static const int xcd_min = [] { const char *e = getenv("GMRFX_SEL_XCD"); return e ? atoi(e) : 0; }();
-    const int gx = cdiv(M, 64), gy = cdiv(N, 64);
-    if (xcd_min > 0 && nfronts >= xcd_min) {
+    // GMRFX_SEL_WT=4: 128 x 128 workgroup tiles (16 waves) for levels whose fronts are at least 256 wide in both tile dimensions
+    static const int wt_req = [] { const char *e = getenv("GMRFX_SEL_WT"); return e ? atoi(e) : 2; }();
+    const bool big = wt_req == 4 && M >= 256 && N >= 256;
+    const int T = big ? 128 : 64;
+    const int gx = cdiv(M, T), gy = cdiv(N, T);
+    if (!big && xcd_min > 0 && nfronts >= xcd_min) {
         const long long groups = (nfronts + 7) / 8;
-        hipLaunchKernelGGL(k_sel_dense, dim3((unsigned)(groups * gx * gy * 8)), dim3(256), 0, st, S, list, phase, L, Z, ZB, Yt, Z21t, woff, gx, gy, nfronts);
-    } else
-        hipLaunchKernelGGL(k_sel_dense, dim3((unsigned)(gx | 1), (unsigned)(gy | 1), nfronts), dim3(256), 0, st, S, list, phase, L, Z, ZB, Yt, Z21t, woff, 0, 0, nfronts);
+        hipLaunchKernelGGL(k_sel_dense<2>, dim3((unsigned)(groups * gx * gy * 8)), dim3(256), 0, st, S, list, phase, L, Z, ZB, Yt, Z21t, woff, gx, gy, nfronts);
+    } else if (big)
+        hipLaunchKernelGGL(k_sel_dense<4>, dim3((unsigned)(gx | 1), (unsigned)(gy | 1), nfronts), dim3(1024), 0, st, S, list, phase, L, Z, ZB, Yt, Z21t, woff, 0, 0, nfronts);
+    else
+        hipLaunchKernelGGL(k_sel_dense<2>, dim3((unsigned)(gx | 1), (unsigned)(gy | 1), nfronts), dim3(256), 0, st, S, list, phase, L, Z, ZB, Yt, Z21t, woff, 0, 0, nfronts);
 }
 
 }  // namespace gmrfx
