@@ -630,7 +630,7 @@ def main():
             "ms_per_step_host_io": host_io["pageable"]["ms_per_step"] if host_io else None,
             "value_host_io": host_io["pageable"]["dof_per_s"] if host_io else None,
             "host_io": ({**host_io, "call": "gmrfx_refactorize_solve(nzval, B, X): column-major HOST arrays, n x nrhs doubles each way over PCIe "
-                                            "inside the timed call; upload beside the factorisation, X out in slices behind the backward sweep"}
+                                            "inside the timed call; upload IN FRONT of the factorisation (staged by host threads when pageable), X out in slices behind the backward sweep"}
                         if host_io else None),
             "phases_ms": {"factor": mf, "solve": ms_, "solve_fwd": mfw, "solve_bwd": mbw, "solve_perm": med(t_perm),
                           "symbolic_host": st0["ms_symbolic"], **extras},

@@ -641,10 +641,12 @@ void Device::clone_from(const Device &o, const Symbolic &S) {
 // buffer of the handle by several host threads (a single thread moves ~10 GB/s, the link 57), slice k's staging beside the DMA
 // of slice k-1, and on the way out slice k's copy to the caller's array beside the DMA of slice k+1. Page-locked caller memory
 // (hipHostMalloc / hipHostRegister, torch pin_memory) is handed to the DMA engine as it is.
+// true for anything the DMA engines take as it is: page-locked host memory -- and device / managed memory handed to a host entry
+// point by mistake or convenience (the copy is then device-to-device; a host thread must never memcpy from it)
 static bool host_ptr_is_pinned(const void *p) {
     hipPointerAttribute_t a;
     if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return a.type == hipMemoryTypeHost;
+    return a.type == hipMemoryTypeHost || a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
 }
 // the address the GPU uses for a page-locked host pointer
 static double *host_ptr_device_view(const void *p) {
@@ -702,7 +704,7 @@ void Device::host_io_reserve(long long count) {
 void Device::host_upload_values(const double *nzval) {
     const long long cnt = S_->nnz_in;
     if (host_ptr_is_pinned(nzval)) {
-        HC(hipMemcpyAsync(d_nz_, nzval, (size_t)cnt * sizeof(double), hipMemcpyHostToDevice, stream));
+        HC(hipMemcpyAsync(d_nz_, nzval, (size_t)cnt * sizeof(double), hipMemcpyDefault, stream));
         return;
     }
     if (!h_nzstage_) HC(hipHostMalloc((void **)&h_nzstage_, (size_t)std::max<long long>(cnt, 1) * sizeof(double), hipHostMallocDefault));
@@ -723,8 +725,8 @@ void Device::host_upload(const double *B, long long ldb, long long nrhs, double 
         if (dv) {
             launch_stream_copy(stream_io_, dv, ldb, d_dst, n, n, nrhs, nwg);
             HC(hipGetLastError());
-        } else if (ldb == n) HC(hipMemcpyAsync(d_dst, B, (size_t)(n * nrhs) * sizeof(double), hipMemcpyHostToDevice, stream_io_));
-        else HC(hipMemcpy2DAsync(d_dst, n * sizeof(double), B, ldb * sizeof(double), n * sizeof(double), nrhs, hipMemcpyHostToDevice, stream_io_));
+        } else if (ldb == n) HC(hipMemcpyAsync(d_dst, B, (size_t)(n * nrhs) * sizeof(double), hipMemcpyDefault, stream_io_));
+        else HC(hipMemcpy2DAsync(d_dst, n * sizeof(double), B, ldb * sizeof(double), n * sizeof(double), nrhs, hipMemcpyDefault, stream_io_));
         HC(hipEventRecord(ev_up_, stream_io_));
         return;
     }
@@ -769,8 +771,8 @@ void Device::host_download(const double *d_src, long long nrhs, double *X, long 
     HC(hipStreamSynchronize(after));
     if (io_trace_cb_) io_trace_cb_("sweeps done (download starts)");
     if (host_ptr_is_pinned(X)) {
-        if (ldx == n) HC(hipMemcpyAsync(X, d_src, (size_t)(n * nrhs) * sizeof(double), hipMemcpyDeviceToHost, stream_io_));
-        else HC(hipMemcpy2DAsync(X, ldx * sizeof(double), d_src, n * sizeof(double), n * sizeof(double), nrhs, hipMemcpyDeviceToHost, stream_io_));
+        if (ldx == n) HC(hipMemcpyAsync(X, d_src, (size_t)(n * nrhs) * sizeof(double), hipMemcpyDefault, stream_io_));
+        else HC(hipMemcpy2DAsync(X, ldx * sizeof(double), d_src, n * sizeof(double), n * sizeof(double), nrhs, hipMemcpyDefault, stream_io_));
         HC(hipStreamSynchronize(stream_io_));
         return;
     }
