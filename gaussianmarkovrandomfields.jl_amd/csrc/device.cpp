@@ -339,6 +339,8 @@ void Device::upload(const Symbolic &S) {
             if (const char *e = std::getenv("GMRFX_LEVEL_MARK")) level_mark_ = std::atoi(e) != 0;
             if (const char *e = std::getenv("GMRFX_LOOKAHEAD")) lookahead_ = std::atoi(e) != 0;
             if (const char *e = std::getenv("GMRFX_CHAIN_MAX_FRONTS")) chain_max_fronts_ = std::max(0, std::atoi(e));
+            if (const char *e = std::getenv("GMRFX_POTRF")) potrf_form_ = std::atoi(e) == 1 ? 1 : 3;
+            if (chain_max_fronts_ > 0) potrf_form_ = 1;      // (the persistent chain carries the register-patch body: same bits as ITS launch chain)
             if (const char *e = std::getenv("GMRFX_INV_ON_MAIN")) inv_on_main_ = std::atoi(e) != 0;
             if (const char *e = std::getenv("GMRFX_FUSED_CUT")) fused_cut_ = std::max(0, std::atoi(e));
             if (const char *e = std::getenv("GMRFX_SMALL_ON_SIDE")) small_on_side_ = std::atoi(e) != 0;
@@ -923,7 +925,7 @@ void Device::factor_levels(int lo, int hi) {
                 const bool first_in_outer = b == J0;
                 const bool last_of_panel = b + 1 >= nblk || L.active[b + 1] <= 0;
                 const bool next_in_outer = !last_of_panel && b + 1 < J1;
-                if (first_in_outer) launch_potrf64(stream, ds_, hl, na, kb, d_L_, d_info_, fa);
+                if (first_in_outer) launch_potrf64(stream, ds_, hl, na, kb, d_L_, d_info_, fa, potrf_form_);
                 else {
                     if (b - 2 >= J0) HC(hipStreamWaitEvent(stream, ev_la_t_[b - 2], 0));
                     launch_potrf64_la(stream, ds_, hl, na, kb, J0 * NB, d_L_, d_info_, fa);
@@ -961,7 +963,7 @@ void Device::factor_levels(int lo, int hi) {
             for (int b = 0; b < nblk; b++) {
                 const int kb = b * NB;
                 if (act(b) <= 0) break;
-                launch_potrf64(st, ds_, hl, act(b), kb, d_L_, d_info_, act(b) == 1 ? f1 : f0);
+                launch_potrf64(st, ds_, hl, act(b), kb, d_L_, d_info_, act(b) == 1 ? f1 : f0, potrf_form_);
                 launch_trsm(st, ds_, hl, act(b), kb, 0, L.max_rows - kb - 1, d_L_, nullptr, nullptr, act(b) == 1 ? f1 : f0);
                 // two-level blocking: K = 64 updates only inside the current 256-column block, the
                 // rest of the panel once per block with K = 256
@@ -1278,7 +1280,7 @@ void Device::dist_front_phase(const double *d_nzval, int front, int what, int bl
         const int b0 = block * OBK, b1 = std::min(b0 + OBK, (c + NB - 1) / NB);
         for (int b = b0; b < b1; b++) {
             const int kb = b * NB;
-            launch_potrf64(stream, ds_, nullptr, 1, kb, d_L_, d_info_, fa);
+            launch_potrf64(stream, ds_, nullptr, 1, kb, d_L_, d_info_, fa, potrf_form_);
             launch_trsm(stream, ds_, nullptr, 1, kb, 0, r - kb - 1, d_L_, nullptr, nullptr, fa);
             if (b + 1 < b1)
                 launch_gemm_nt(stream, ds_, nullptr, 1, kb, NB, kb + NB, b1 * NB, r - kb - NB, std::min(b1 * NB, c) - kb - NB, d_L_, fa);

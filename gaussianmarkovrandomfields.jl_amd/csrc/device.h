@@ -260,6 +260,7 @@ private:
     // the launch chain spreads the same rows over a hundred workgroups.
     static constexpr int kChainErrWord = 8 * 64, kChainMaxWgs = 256;
     int chain_max_fronts_ = 0;
+    int potrf_form_ = 3;              // 64 x 64 diagonal blocks: 3 = 16-column steps (potrf64_blocked.h), 1 = register patches (GMRFX_POTRF=1)
     int *d_chain_ = nullptr;
     long long *d_chain_trace_ = nullptr;
     int chain_base_ = 0;

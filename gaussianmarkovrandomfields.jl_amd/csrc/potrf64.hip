@@ -23,6 +23,7 @@
 
 #include "kernels.h"
 #include "potrf64_body.h"
+#include "potrf64_blocked.h"
 
 namespace gmrfx {
 
@@ -38,6 +39,21 @@ __global__ __launch_bounds__(256) void k_potrf64(DevSym S, const FrontView *__re
     const int ld = fv.ld;
     double *P = L + fv.pp + kb + (long long)kb * ld;
     potrf64_body(P, ld, P, ld, w, Sb, info, fv.first + kb, threadIdx.x);
+}
+
+// ---- 16-COLUMN-STEP form (round 4; potrf64_blocked.h): one wave eliminates 16 x 16 diagonal blocks in registers, helper waves
+// keep the rest of the block and its inverse up to date on the MFMA beside it. The product path; GMRFX_POTRF=1 selects the
+// register-patch kernel above.
+__global__ __launch_bounds__(pb::THREADS) void k_potrf64_b(DevSym S, const FrontView *__restrict__ frec, int kb,
+                                                           double *__restrict__ L, int *__restrict__ info, FrontArg fa) {
+    __shared__ __attribute__((aligned(16))) pb::Smem sm;
+    const FrontView fv = front_view(frec, blockIdx.x, fa);
+    const int c = fv.c;
+    if (kb >= c) return;
+    const int w = min(NB, c - kb);
+    const int ld = fv.ld;
+    double *P = L + fv.pp + kb + (long long)kb * ld;
+    pb::potrf64_blocked(P, ld, P, ld, w, sm, info, fv.first + kb, threadIdx.x);
 }
 
 // ---- LOOK-AHEAD form (round 3) ------------------------------------------------------------------------------------------
@@ -160,9 +176,10 @@ __global__ __launch_bounds__(512) void k_potrf64_la(DevSym S, const FrontView *_
 }
 
 void launch_potrf64(hipStream_t st, const DevSym &S, const FrontView *frec, int nactive, int kb, double *L, int *info,
-                    const FrontArg &fa) {
+                    const FrontArg &fa, int form) {
     if (nactive <= 0) return;
-    hipLaunchKernelGGL(k_potrf64, dim3(nactive), dim3(256), 0, st, S, frec, kb, L, info, fa);
+    if (form == 3) hipLaunchKernelGGL(k_potrf64_b, dim3(nactive), dim3(pb::THREADS), 0, st, S, frec, kb, L, info, fa);
+    else hipLaunchKernelGGL(k_potrf64, dim3(nactive), dim3(256), 0, st, S, frec, kb, L, info, fa);
 }
 void launch_potrf64_la(hipStream_t st, const DevSym &S, const FrontView *frec, int nactive, int kb, int kb0, double *L, int *info,
                        const FrontArg &fa) {

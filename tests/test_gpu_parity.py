@@ -1245,6 +1245,7 @@ def test_panel_chain_persistent_kernel_equals_launch_chain(mesh_kind, monkeypatc
     else:
         mesh = spde.grid_mesh_3d(26, 25, 24); Q = spde.matern_precision(mesh, 0, 0.4)
     monkeypatch.setenv("GMRFX_CHAIN_MAX_FRONTS", "0")
+    monkeypatch.setenv("GMRFX_POTRF", "1")          # the persistent chain carries the register-patch diagonal block: compare with ITS launch chain
     a = gmrfx.MI355XBackend(Q, coords=mesh.points)
     monkeypatch.setenv("GMRFX_CHAIN_MAX_FRONTS", "32")
     b = gmrfx.MI355XBackend(Q, coords=mesh.points)

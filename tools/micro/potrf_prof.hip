@@ -24,10 +24,17 @@ int main(){
   hipStream_t st; HC(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   hipEvent_t e0,e1; HC(hipEventCreate(&e0)); HC(hipEventCreate(&e1));
   const int reps=200; float ms;
-  for(int wv : {64, 37}) {
+  for(int form : {3, 1}) {
+  auto launch = [&](hipStream_t q, double *dst, int wv) {
+    const FrontArg fa{1,0,wv,wv,n,0,0};
+    if (form == 3) hipLaunchKernelGGL(k_potrf64_b,dim3(1),dim3(pb::THREADS),0,q,S,(const FrontView*)nullptr,0,dst,dinfo,fa);
+    else hipLaunchKernelGGL(k_potrf64,dim3(1),dim3(256),0,q,S,(const FrontView*)nullptr,0,dst,dinfo,fa);
+  };
+  printf("==== %s\n", form == 3 ? "k_potrf64_b (16-column steps, 512 threads)" : "k_potrf64 (register patches, 256 threads)");
+  for(int wv : {64, 37, 16, 3, 61, 48}) {
     int sf2[2]={0,wv}; HC(hipMemcpy(dsf,sf2,8,hipMemcpyHostToDevice));
     HC(hipEventRecord(e0,st));
-    for(int r=0;r<reps;r++){ hipMemcpyAsync(dL,dA,n*n*8,hipMemcpyDeviceToDevice,st); hipLaunchKernelGGL(k_potrf64,dim3(1),dim3(256),0,st,S,(const FrontView*)nullptr,0,dL,dinfo,FrontArg{1,0,wv,wv,n,0,0}); }
+    for(int r=0;r<reps;r++){ hipMemcpyAsync(dL,dA,n*n*8,hipMemcpyDeviceToDevice,st); launch(st,dL,wv); }
     HC(hipEventRecord(e1,st)); HC(hipStreamSynchronize(st)); HC(hipEventElapsedTime(&ms,e0,e1));
     printf("k_potrf64 (w=%d) + d2d copy: %.2f us per launch\n", wv, ms*1000/reps);
 #ifdef GMRFX_CYC
@@ -35,6 +42,14 @@ int main(){
       HC(hipMemcpyFromSymbol(c, HIP_SYMBOL(g_cyc64), sizeof(c))); long long z[64]={0}; HC(hipMemcpyToSymbol(HIP_SYMBOL(g_cyc64), z, sizeof(z)));
       const char* nm[6]={"head","lds-read","chain","Y","update/out","barrier"};
       for(int w2=0;w2<4;w2++){ printf(" wave %d cycles/step (incl. ~350 per mark):",w2); double tot=0; for(int k=0;k<6;k++){ double v=c[w2][k]/(double)reps/((wv+3)/4); tot+=v; printf(" %s=%.0f",nm[k],v);} printf(" total=%.0f\n",tot); } }
+#endif
+#ifdef GMRFX_CYC
+    if (form == 3) { long long c[64]; HC(hipMemcpyFromSymbol(c, HIP_SYMBOL(pb::g_pb_cyc), sizeof(c)));
+      printf("  diagonal wave, cycles since kernel start: loaded %lld;", c[1]-c[0]);
+      for (int d = 0; d < (wv+15)/16; d++) printf(" [d=%d: top %lld, diag done %lld, B1 out %lld, window A done %lld, B2 out %lld]", d, c[2+8*d]-c[0], c[3+8*d]-c[0], c[4+8*d]-c[0], c[5+8*d]-c[0], c[6+8*d]-c[0]);
+      printf(" loop end %lld, stored %lld\n", c[40]-c[0], c[41]-c[0]);
+      long long cw[8][64]; HC(hipMemcpyFromSymbol(cw, HIP_SYMBOL(pb::g_pb_cycw), sizeof(cw)));
+      for (int v = 1; v < 8; v++) { printf("    wave %d:", v); for (int d = 0; d < (wv+15)/16; d++) printf(" [d=%d: B1 out %lld, A done %lld, B2 out %lld, ops done %lld, stores issued %lld]", d, cw[v][8*d]-c[0], cw[v][8*d+1]-c[0], cw[v][8*d+2]-c[0], cw[v][8*d+3]-c[0], cw[v][8*d+4]-c[0]); printf(" end %lld\n", cw[v][40]-c[0]); } }
 #endif
     std::vector<double> Lh(n*n); HC(hipMemcpy(Lh.data(),dL,n*n*8,hipMemcpyDeviceToHost));
     double err=0, errx=0, errpad=0;
@@ -50,9 +65,17 @@ int main(){
   }
   { HC(hipMemcpy(dL,dA,n*n*8,hipMemcpyDeviceToDevice));
     HC(hipEventRecord(e0,st));
-    for(int r=0;r<reps;r++) hipLaunchKernelGGL(k_potrf64,dim3(1),dim3(256),0,st,S,(const FrontView*)nullptr,0,dL,dinfo,FrontArg{1,0,64,64,n,0,0});
+    for(int r=0;r<reps;r++) launch(st,dL,64);
     HC(hipEventRecord(e1,st)); HC(hipStreamSynchronize(st)); HC(hipEventElapsedTime(&ms,e0,e1));
-    printf("k_potrf64 back to back (no copy; refactoring its own output: timing only): %.2f us per launch\n", ms*1000/reps); }
+    printf("  back to back (no copy; refactoring its own output: timing only): %.2f us per launch\n", ms*1000/reps); }
+  { // an indefinite block: the first non-positive pivot must be reported
+    std::vector<double> B(A); B[10+10*n] = -1.0;
+    int big = INT_MAX, got = 0;
+    HC(hipMemcpy(dL,B.data(),n*n*8,hipMemcpyHostToDevice)); HC(hipMemcpy(dinfo,&big,4,hipMemcpyHostToDevice));
+    launch(st,dL,64); HC(hipStreamSynchronize(st));
+    HC(hipMemcpy(&got,dinfo,4,hipMemcpyDeviceToHost)); HC(hipMemcpy(dinfo,&big,4,hipMemcpyHostToDevice));
+    printf("  bad pivot at column 10 -> info = %d\n", got); }
+  }
   // do two chains of dependent one-workgroup launches on two streams run side by side? (the two panel chains of a level)
   { double *dL2; HC(hipMalloc(&dL2,n*n*8)); HC(hipMemcpy(dL2,dA,n*n*8,hipMemcpyDeviceToDevice)); HC(hipMemcpy(dL,dA,n*n*8,hipMemcpyDeviceToDevice));
     hipStream_t st2; HC(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
