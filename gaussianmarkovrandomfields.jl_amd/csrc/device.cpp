@@ -120,7 +120,24 @@ void Device::init(const Symbolic &S, int dev) {
         HC(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, prio ? hi : 0));
         own_stream_ = stream;
         burn();
-        HC(hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, prio ? lo : 0));
+        // GMRFX_SIDE_CU_MASK=k (A/B): the side stream (forward sweep of the pipelined call, dense inverses) may not use the last k of
+        // every 32 mask bits -- compute units kept free for the dependent launch chain of the factorisation
+        const char *cm = std::getenv("GMRFX_SIDE_CU_MASK");
+        const int cu_off = cm ? std::min(31, std::max(0, std::atoi(cm))) : 0;
+        const char *cmm = std::getenv("GMRFX_SIDE_CU_MASK_MODE");        // 0: the last k bits of every word; 1: the last 8 k bits of the mask
+        if (cu_off > 0) {
+            hipDeviceProp_t prop;
+            HC(hipGetDeviceProperties(&prop, device));
+            const int ncu = prop.multiProcessorCount, nw = (ncu + 31) / 32;
+            std::vector<uint32_t> mask(nw, 0xffffffffu);
+            if (cmm && std::atoi(cmm) == 1) {
+                for (int b = ncu - 8 * cu_off; b < ncu; b++) if (b >= 0) mask[b / 32] &= ~(1u << (b % 32));
+            } else {
+                for (int w = 0; w < nw; w++) mask[w] = 0xffffffffu >> cu_off;
+            }
+            HC(hipExtStreamCreateWithCUMask(&stream2, (uint32_t)nw, mask.data()));
+        } else
+            HC(hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, prio ? lo : 0));
         burn();
         HC(hipStreamCreateWithPriority(&stream3, hipStreamNonBlocking, prio ? hi : 0));
         if (const char *c = std::getenv("GMRFX_INV_CAP")) {      // testing knob: power of two >= 64
@@ -949,33 +966,34 @@ void Device::factor_levels(int lo, int hi) {
             HC(hipEventRecord(ev_ready2_, stream));               // (after the assembly of this level's panels)
             HC(hipStreamWaitEvent(stream3, ev_ready2_, 0));
         }
-        for (int hf = 0; hf < nhalf && !la && !chain; hf++) {
-            hipStream_t st = hf == 0 ? stream : stream3;
-            const FrontView *hl = two ? d_frec2_ + L.first + L.nsmall + (hf == 0 ? 0 : (nf + 1) / 2) : d_frec_ + L.first + L.nsmall;
-            auto act = [&](int b) { const int a = L.active[b]; return two ? (hf == 0 ? (a + 1) / 2 : a / 2) : a; };
-            // geometry of the widest front of the (half-)list (fronts are sorted by decreasing width): when it is
-            // the only one still active, the panel kernels get it in their arguments (kernels.h, FrontArg)
-            FrontArg f1{0, 0, 0, 0, 0, 0, 0}, f0{0, 0, 0, 0, 0, 0, 0};
-            if (nf > hf) {
-                const i32 s1 = S_->levellist[L.first + L.nsmall + hf];
-                f1 = FrontArg{1, (int)s1, S_->ncols(s1), S_->nrows(s1), (int)S_->ld[s1], (int)S_->sfirst[s1], (long long)S_->panelptr[s1]};
-            }
-            for (int b = 0; b < nblk; b++) {
+        // (the two chains are enqueued block by block in turn, not one after the other: the host stays ahead of both)
+        static const bool interleave = [] { const char *e = std::getenv("GMRFX_CHAIN_INTERLEAVE"); return !e || std::atoi(e) != 0; }();
+        for (int it = 0; it < nblk * nhalf && !la && !chain; it++) {
+                const int b = interleave ? it / nhalf : it % nblk, hf = interleave ? it % nhalf : it / nblk;
+                hipStream_t st = hf == 0 ? stream : stream3;
+                const FrontView *hl = two ? d_frec2_ + L.first + L.nsmall + (hf == 0 ? 0 : (nf + 1) / 2) : d_frec_ + L.first + L.nsmall;
+                auto act = [&](int bb) { const int a = L.active[bb]; return two ? (hf == 0 ? (a + 1) / 2 : a / 2) : a; };
+                if (act(b) <= 0) continue;
+                // geometry of the widest front of the (half-)list (fronts are sorted by decreasing width): when it is
+                // the only one still active, the panel kernels get it in their arguments (kernels.h, FrontArg)
+                FrontArg f1{0, 0, 0, 0, 0, 0, 0}, f0{0, 0, 0, 0, 0, 0, 0};
+                if (nf > hf) {
+                    const i32 s1 = S_->levellist[L.first + L.nsmall + hf];
+                    f1 = FrontArg{1, (int)s1, S_->ncols(s1), S_->nrows(s1), (int)S_->ld[s1], (int)S_->sfirst[s1], (long long)S_->panelptr[s1]};
+                }
                 const int kb = b * NB;
-                if (act(b) <= 0) break;
                 launch_potrf64(st, ds_, hl, act(b), kb, d_L_, d_info_, act(b) == 1 ? f1 : f0, potrf_form_);
                 launch_trsm(st, ds_, hl, act(b), kb, 0, L.max_rows - kb - 1, d_L_, nullptr, nullptr, act(b) == 1 ? f1 : f0);
                 // two-level blocking: K = 64 updates only inside the current 256-column block, the
                 // rest of the panel once per block with K = 256
                 const int J1 = (b / OBK + 1) * OBK;   // first 64-block of the next 256-column block
-                if (b + 1 < nblk && b + 1 < J1)
+                if (b + 1 < nblk && b + 1 < J1 && act(b + 1) > 0)
                     launch_gemm_nt(st, ds_, hl, act(b + 1), kb, NB, kb + NB, J1 * NB, L.max_rows - kb - NB,
                                    std::min(J1 * NB, L.max_cols) - kb - NB, d_L_, act(b + 1) == 1 ? f1 : f0);
-                if (b + 1 == J1 && J1 < nblk)
+                if (b + 1 == J1 && J1 < nblk && act(J1) > 0)
                     launch_gemm_nt(st, ds_, hl, act(J1), (J1 - OBK) * NB, OBK * NB, J1 * NB, INT_MAX,
                                    L.max_rows - J1 * NB, L.max_cols - J1 * NB, d_L_, act(J1) == 1 ? f1 : f0);
             }
-        }
         if (two) {
             HC(hipEventRecord(ev_done1_, stream3));
             HC(hipStreamWaitEvent(stream, ev_done1_, 0));
