@@ -130,8 +130,8 @@ __device__ __forceinline__ void diag16_step(Diag16 &D, double *__restrict__ Wd, 
     PB_SB;
 }
 
-// in: D.a = the block (both triangles), Rs = 16 doubles of LDS scratch. out: L in Wd (LDS; lower triangle valid),
-// x[r] = (L^-1)[i][4 r + q], pivot_ok = this row's pivot was positive
+// in: D.a = the block (both triangles). out: the UNSCALED columns a[i][k] in Wd (LDS; L[i][k] = Wd[k][i] Rs[k], lower triangle valid),
+// Rs[k] = 1 / sqrt(pivot k) (LDS), x[r] = (L^-1)[i][4 r + q], pivot_ok = this row's pivot was positive
 __device__ __forceinline__ void diag16_factor(Diag16 &D, double *__restrict__ Wd, double *__restrict__ Rs, double (&x)[4], bool &pivot_ok,
                                               const int i, const int q) {
 #pragma unroll
@@ -146,18 +146,9 @@ __device__ __forceinline__ void diag16_factor(Diag16 &D, double *__restrict__ Wd
     pivot_ok = pi > 0.0;
     const double rs = rsqrt_nr2(pi);
     Rs[i] = rs;
-    // L[i][k] = a[i][k] rs_k, L^-1 = diag(rs) M
-    double lc[4], rk[4];
+    // L^-1 = diag(rs) M; L[i][k] = a[i][k] rs_k is applied to the LDS block by a helper wave (nobody reads L_dd before it leaves)
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        lc[r] = Wd[(4 * r + q) * LDW + i];
-        rk[r] = Rs[4 * r + q];
-    }
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        Wd[(4 * r + q) * LDW + i] = lc[r] * rk[r];
-        x[r] = rs * D.m[r];
-    }
+    for (int r = 0; r < 4; r++) x[r] = rs * D.m[r];
 }
 
 // One 16 x 16 x 16 product of a helper wave on LDS-resident blocks (block (br, bc) of matrix M at M + 16 bc LDW + 16 br):
@@ -250,7 +241,7 @@ __device__ __forceinline__ void potrf64_blocked(const double *src, const int sld
         __syncthreads();                                        // B1: X_dd, L_dd published; the helpers' blocks of step d-1 final
         PB_MARK(4 + 8 * d);
         PB_MARKW(8 * d);
-        if (d == 0) {
+        if (d == 0 && wave != 0) {
             // helpers: the waves that do not share the diagonal wave's SIMD (FP64 MFMA and FP64 VALU share a SIMD's arithmetic)
             const int s0 = S.simd[0];
 #pragma unroll
@@ -262,7 +253,6 @@ __device__ __forceinline__ void potrf64_blocked(const double *src, const int sld
             if (nh == 0) {          // (every wave on one SIMD: never seen; any wave helps then)
                 nh = 7; hidx = wave - 1;
             }
-            if (wave == 0) hidx = -1;
         }
         // ---- window A: the diagonal wave prepares the next diagonal block; helpers: strips with X_dd, finished rows of X
         if (wave == 0) {
@@ -290,11 +280,21 @@ __device__ __forceinline__ void potrf64_blocked(const double *src, const int sld
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int c = 4 * r + lq;
-                    const double v = li >= c ? Wdd[c * LDW + li] : Vdd[li * LDW + c];
+                    const double v = li >= c ? Wdd[c * LDW + li] * S.rs[c] : Vdd[li * LDW + c];
                     if (16 * d + li < w && 16 * d + c < w) P[16 * d + li + (long long)(16 * d + c) * ld] = v;
                 }
             }
         } else if (hidx >= 0) {
+            if (hidx == nh - 1 && !last) {                      // L_dd = (unscaled columns) diag(rs): before B2, where its block column leaves
+                double lc[4], rk[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    lc[r] = Wdd[(4 * r + lq) * LDW + li];
+                    rk[r] = S.rs[4 * r + lq];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) Wdd[(4 * r + lq) * LDW + li] = lc[r] * rk[r];
+            }
             int op = 0, mine = hidx;
             for (int i = d + 2; i < nd; i++, op++) {            // strips L[i][d] = A[i][d] X_dd'
                 if (op != mine) continue;
