@@ -1232,6 +1232,42 @@ def test_full_size_cfg2_pipelined_equals_separate_calls():
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 80, 97, 128, 129, 150, 200])
+def test_dense_fronts_of_every_width_through_the_diagonal_block_kernel(n, monkeypatch):
+    """One dense supernode of n columns on the generic big-front path (GMRFX_SMALL_ROWS=0: no fused small-front kernel, no subtree
+    tasks): the 64 x 64 diagonal-block kernel (k_potrf64_b: 16-column steps, one diagonal wave, helper waves;
+    csrc/potrf64_blocked.h) sees every number of 16 x 16 steps and every partial last block (n mod 64, n mod 16). Against
+    numpy's Cholesky of the permuted matrix: factor entry by entry, log-determinant, a solve; and a non-positive pivot planted in
+    three different columns is reported at exactly that column (info = column + 1 in the elimination order, LAPACK / CHOLMOD style:
+    /root/reference/src/workspace/backend.jl:184, cholesky!(...; check = false))."""
+    rng = np.random.default_rng(100 + n)
+    A = rng.standard_normal((n, n))
+    Qd = A @ A.T + n * np.eye(n)
+    Q = sp.csc_matrix(Qd)
+    monkeypatch.setenv("GMRFX_SMALL_ROWS", "0")
+    be = gmrfx.MI355XBackend(Q, ordering="natural")
+    assert be.last_info == 0 and be.stats()["n_small_fronts"] == 0
+    Lref = np.linalg.cholesky(Qd)
+    Lg = be.factor_csc().toarray()
+    assert abs(np.tril(Lg) - Lref).max() <= 1e-12 * abs(Lref).max()
+    assert abs(be.compute_logdet() - 2.0 * np.log(np.diag(Lref)).sum()) <= 1e-12 * n * max(1.0, np.log(n + 1.0))
+    B = rng.standard_normal((n, 3))
+    assert relerr(be.backend_solve(B), np.linalg.solve(Qd, B)) < 1e-11
+    # the first non-positive pivot: make the leading (k + 1) x (k + 1) minor indefinite by lowering entry (k, k) below its Schur bound
+    for k in sorted({0, n // 2, n - 1}):
+        Qb = Qd.copy()
+        if k == 0:
+            Qb[0, 0] = -1.0
+        else:
+            v = np.linalg.solve(Lref[:k, :k], Qd[:k, k])
+            Qb[k, k] = float(v @ v) - 0.5          # pivot k becomes -0.5, the pivots before it are untouched
+        be.refactorize(sp.csc_matrix(Qb))
+        assert be.last_info == k + 1, (n, k, be.last_info)
+    be.refactorize(Q)
+    assert be.last_info == 0
+    be.close()
+
+
 @pytest.mark.parametrize("mesh_kind", ["2d", "2d_wide", "3d"])
 def test_panel_chain_persistent_kernel_equals_launch_chain(mesh_kind, monkeypatch):
     """The persistent panel-chain kernel (csrc/panel_chain.hip, GMRFX_CHAIN_MAX_FRONTS > 0: one launch per 256-column outer block of
