@@ -982,7 +982,7 @@ void Device::factor_levels(int lo, int hi) {
                     f1 = FrontArg{1, (int)s1, S_->ncols(s1), S_->nrows(s1), (int)S_->ld[s1], (int)S_->sfirst[s1], (long long)S_->panelptr[s1]};
                 }
                 const int kb = b * NB;
-                launch_potrf64(st, ds_, hl, act(b), kb, d_L_, d_info_, act(b) == 1 ? f1 : f0, potrf_form_);
+                launch_potrf64(st, ds_, hl, act(b), kb, d_L_, d_info_, act(b) == 1 ? f1 : f0, potrf_form_, std::min(NB, L.max_cols - kb));
                 launch_trsm(st, ds_, hl, act(b), kb, 0, L.max_rows - kb - 1, d_L_, nullptr, nullptr, act(b) == 1 ? f1 : f0);
                 // two-level blocking: K = 64 updates only inside the current 256-column block, the
                 // rest of the panel once per block with K = 256

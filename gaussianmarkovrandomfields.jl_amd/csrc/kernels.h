@@ -426,7 +426,9 @@ void launch_factor_small(hipStream_t st, const DevSym &S, const int *list, int n
 void launch_subtree(hipStream_t st, const DevSym &S, int phase, const int *sub_first, const int *sub_last, int ntasks,
                     int rmax, const double *nzval, double *L, double *CB, int *info, double *X, double *W, int nr, int ldx);
 // form: 3 = 16-column steps (potrf64_blocked.h, the product path), 1 = register patches (potrf64_body.h; GMRFX_POTRF=1)
-void launch_potrf64(hipStream_t st, const DevSym &S, const FrontView *frec, int nactive, int kb, double *L, int *info, const FrontArg &fa, int form = 3);
+// wmax: the widest block of the launch (<= 64): picks the workgroup shape of the 16-column-step kernel
+void launch_potrf64(hipStream_t st, const DevSym &S, const FrontView *frec, int nactive, int kb, double *L, int *info, const FrontArg &fa, int form = 3,
+                    int wmax = 64);
 // look-ahead form: brings the band tiles (b, b-1), (b, b) up to date left-looking over columns kb0 .. kb-1, then factors (potrf64.hip)
 void launch_potrf64_la(hipStream_t st, const DevSym &S, const FrontView *frec, int nactive, int kb, int kb0, double *L, int *info,
                        const FrontArg &fa);   // potrf64.hip

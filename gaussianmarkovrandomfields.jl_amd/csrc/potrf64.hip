@@ -44,16 +44,17 @@ __global__ __launch_bounds__(256) void k_potrf64(DevSym S, const FrontView *__re
 // ---- 16-COLUMN-STEP form (round 4; potrf64_blocked.h): one wave eliminates 16 x 16 diagonal blocks in registers, helper waves
 // keep the rest of the block and its inverse up to date on the MFMA beside it. The product path; GMRFX_POTRF=1 selects the
 // register-patch kernel above.
-__global__ __launch_bounds__(pb::THREADS) void k_potrf64_b(DevSym S, const FrontView *__restrict__ frec, int kb,
-                                                           double *__restrict__ L, int *__restrict__ info, FrontArg fa) {
-    __shared__ __attribute__((aligned(16))) pb::Smem sm;
+template <int NW, int ND>
+__global__ __launch_bounds__(64 * NW) void k_potrf64_b(DevSym S, const FrontView *__restrict__ frec, int kb,
+                                                       double *__restrict__ L, int *__restrict__ info, FrontArg fa) {
+    __shared__ __attribute__((aligned(16))) pb::Smem<ND> sm;
     const FrontView fv = front_view(frec, blockIdx.x, fa);
     const int c = fv.c;
     if (kb >= c) return;
     const int w = min(NB, c - kb);
     const int ld = fv.ld;
     double *P = L + fv.pp + kb + (long long)kb * ld;
-    pb::potrf64_blocked(P, ld, P, ld, w, sm, info, fv.first + kb, threadIdx.x);
+    pb::potrf64_blocked<NW, ND>(P, ld, P, ld, w, sm, info, fv.first + kb, threadIdx.x);
 }
 
 // ---- LOOK-AHEAD form (round 3) ------------------------------------------------------------------------------------------
@@ -176,10 +177,15 @@ __global__ __launch_bounds__(512) void k_potrf64_la(DevSym S, const FrontView *_
 }
 
 void launch_potrf64(hipStream_t st, const DevSym &S, const FrontView *frec, int nactive, int kb, double *L, int *info,
-                    const FrontArg &fa, int form) {
+                    const FrontArg &fa, int form, int wmax) {
     if (nactive <= 0) return;
-    if (form == 3) hipLaunchKernelGGL(k_potrf64_b, dim3(nactive), dim3(pb::THREADS), 0, st, S, frec, kb, L, info, fa);
-    else hipLaunchKernelGGL(k_potrf64, dim3(nactive), dim3(256), 0, st, S, frec, kb, L, info, fa);
+    if (form == 3) {
+        // the workgroup shape follows the widest block of the launch (potrf64_blocked.h)
+        if (wmax <= 16) hipLaunchKernelGGL((k_potrf64_b<1, 1>), dim3(nactive), dim3(64), 0, st, S, frec, kb, L, info, fa);
+        else if (wmax <= 32) hipLaunchKernelGGL((k_potrf64_b<2, 2>), dim3(nactive), dim3(128), 0, st, S, frec, kb, L, info, fa);
+        else if (wmax <= 48) hipLaunchKernelGGL((k_potrf64_b<4, 3>), dim3(nactive), dim3(256), 0, st, S, frec, kb, L, info, fa);
+        else hipLaunchKernelGGL((k_potrf64_b<8, 4>), dim3(nactive), dim3(512), 0, st, S, frec, kb, L, info, fa);
+    } else hipLaunchKernelGGL(k_potrf64, dim3(nactive), dim3(256), 0, st, S, frec, kb, L, info, fa);
 }
 void launch_potrf64_la(hipStream_t st, const DevSym &S, const FrontView *frec, int nactive, int kb, int kb0, double *L, int *info,
                        const FrontArg &fa) {

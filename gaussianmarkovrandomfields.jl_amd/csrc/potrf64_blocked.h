@@ -27,8 +27,11 @@ namespace pb {
 
 typedef gmrfx_d4 d4;
 
-constexpr int LDW = 66;                 // leading dimension (doubles) of the two LDS matrices
-constexpr int THREADS = 512;            // 8 waves: the diagonal wave, up to 6 helpers on the other SIMDs, one idle
+// Workgroup shapes by the widest block of a launch (ND = 16-column steps, NW = waves): narrow fronts come by the thousand per level,
+// and what they need is many resident workgroups per CU, not helpers -- <1, 1>: w <= 16, the diagonal wave alone (2.5 KB of LDS);
+// <2, 2>: w <= 32, one helper (18 KB); <4, 3>: w <= 48, three helpers (39 KB); <8, 4>: up to 64 columns, the diagonal wave, up to six
+// helpers on the other SIMDs and one idle wave (68 KB). Every 16 x 16 product is done by one wave whatever the shape: same bits.
+constexpr int ldw_of(int nd) { return 16 * nd + 2; }        // leading dimension (doubles) of the two LDS matrices
 
 // time stamps of the diagonal wave for tools/micro/potrf_prof.hip (compiled out of the library)
 #ifdef GMRFX_CYC
@@ -41,9 +44,10 @@ __device__ long long g_pb_cycw[8][64];
 #define PB_MARKW(k)
 #endif
 
+template <int ND>
 struct Smem {
-    double W[64 * LDW];                 // the block: A, then L (lower blocks; strict upper part of diagonal blocks: scratch)
-    double V[64 * LDW];                 // the inverse: T_ij = sum_k L_ik X_kj, then X_ij; X_dd in the diagonal blocks
+    double W[16 * ND * ldw_of(ND)];     // the block: A, then L (lower blocks; strict upper part of diagonal blocks: scratch)
+    double V[16 * ND * ldw_of(ND)];     // the inverse: T_ij = sum_k L_ik X_kj, then X_ij; X_dd in the diagonal blocks
     double rs[16];                      // 1 / sqrt(pivot) of the diagonal block being finished
     int simd[8];
 };
@@ -102,7 +106,7 @@ __device__ __forceinline__ void diag16_fetch(Diag16 &D, const int i) {
 // by its instruction count: v_rcp_f64 + two Newton steps (4) for 1 / p, 2 + 1 for the masked multiplier, one LDS store of the
 // UNSCALED column (the square roots wait until the block is done: one v_rsq_f64 chain for all sixteen pivots at once), one
 // v_fmac_f64_dpp per live register of [A | M] (5 on average), 2 + 2 + 1 to fetch the next pivot and column.
-template <int K>
+template <int K, int LDW>
 __device__ __forceinline__ void diag16_step(Diag16 &D, double *__restrict__ Wd, const int i, const int q) {
     constexpr int KR = K >> 2, NR = ((K + 1) >> 2) & 3;
     const double y0 = D.y0, pv = D.pv, col = D.col;
@@ -132,15 +136,16 @@ __device__ __forceinline__ void diag16_step(Diag16 &D, double *__restrict__ Wd, 
 
 // in: D.a = the block (both triangles). out: the UNSCALED columns a[i][k] in Wd (LDS; L[i][k] = Wd[k][i] Rs[k], lower triangle valid),
 // Rs[k] = 1 / sqrt(pivot k) (LDS), x[r] = (L^-1)[i][4 r + q], pivot_ok = this row's pivot was positive
+template <int LDW>
 __device__ __forceinline__ void diag16_factor(Diag16 &D, double *__restrict__ Wd, double *__restrict__ Rs, double (&x)[4], bool &pivot_ok,
                                               const int i, const int q) {
 #pragma unroll
     for (int r = 0; r < 4; r++) D.m[r] = (4 * r + q == i) ? 1.0 : 0.0;
     diag16_fetch<0>(D, i);
-    diag16_step<0>(D, Wd, i, q);  diag16_step<1>(D, Wd, i, q);  diag16_step<2>(D, Wd, i, q);  diag16_step<3>(D, Wd, i, q);
-    diag16_step<4>(D, Wd, i, q);  diag16_step<5>(D, Wd, i, q);  diag16_step<6>(D, Wd, i, q);  diag16_step<7>(D, Wd, i, q);
-    diag16_step<8>(D, Wd, i, q);  diag16_step<9>(D, Wd, i, q);  diag16_step<10>(D, Wd, i, q); diag16_step<11>(D, Wd, i, q);
-    diag16_step<12>(D, Wd, i, q); diag16_step<13>(D, Wd, i, q); diag16_step<14>(D, Wd, i, q); diag16_step<15>(D, Wd, i, q);
+    diag16_step<0, LDW>(D, Wd, i, q);  diag16_step<1, LDW>(D, Wd, i, q);  diag16_step<2, LDW>(D, Wd, i, q);  diag16_step<3, LDW>(D, Wd, i, q);
+    diag16_step<4, LDW>(D, Wd, i, q);  diag16_step<5, LDW>(D, Wd, i, q);  diag16_step<6, LDW>(D, Wd, i, q);  diag16_step<7, LDW>(D, Wd, i, q);
+    diag16_step<8, LDW>(D, Wd, i, q);  diag16_step<9, LDW>(D, Wd, i, q);  diag16_step<10, LDW>(D, Wd, i, q); diag16_step<11, LDW>(D, Wd, i, q);
+    diag16_step<12, LDW>(D, Wd, i, q); diag16_step<13, LDW>(D, Wd, i, q); diag16_step<14, LDW>(D, Wd, i, q); diag16_step<15, LDW>(D, Wd, i, q);
     // the sixteen pivots p_i = a[i][i] as their steps left them (rows <= K are never touched again), all square roots at once
     const double pi = Wd[i * LDW + i];
     pivot_ok = pi > 0.0;
@@ -154,7 +159,7 @@ __device__ __forceinline__ void diag16_factor(Diag16 &D, double *__restrict__ Wd
 // One 16 x 16 x 16 product of a helper wave on LDS-resident blocks (block (br, bc) of matrix M at M + 16 bc LDW + 16 br):
 //   out[i][j] = (ACC ? acc[i][j] : 0) + (NEG ? -1 : 1) sum_c P[i][c] Q'[j][c],   Q' = QT ? Q' : Q
 // returned as reg r of lane (li, lq) = out[li][4 r + lq]; the MFMA computes D[m][n] = out[n][m].
-template <bool ACC, bool NEG, bool QT>
+template <bool ACC, bool NEG, bool QT, int LDW>
 __device__ __forceinline__ d4 blockop(const double *__restrict__ P, const double *__restrict__ Q, const double *__restrict__ A,
                                       const int li, const int lq) {
     double pv[4], qv[4];
@@ -172,6 +177,7 @@ __device__ __forceinline__ d4 blockop(const double *__restrict__ P, const double
     for (int u = 0; u < 4; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(NEG ? -qv[u] : qv[u], pv[u], acc, 0, 0, 0);
     return acc;
 }
+template <int LDW>
 __device__ __forceinline__ void block_store(double *__restrict__ O, const d4 v, const int li, const int lq) {
 #pragma unroll
     for (int r = 0; r < 4; r++) O[(4 * r + lq) * LDW + li] = v[r];
@@ -180,10 +186,12 @@ __device__ __forceinline__ void block_store(double *__restrict__ O, const d4 v, 
 // The THREADS threads of a workgroup factor the w x w block src[i + j * sld] (lower triangle read) and write L (lower
 // triangle) and (L^-1)' (strict upper triangle) to P (leading dimension ld). Returns through *info the first column with a
 // non-positive pivot (atomicMin of first_col + column).
+template <int NW, int ND>
 __device__ __forceinline__ void potrf64_blocked(const double *src, const int sld, double *__restrict__ P, const int ld, const int w,
-                                                Smem &S, int *__restrict__ info, const int first_col, const int tid) {
+                                                Smem<ND> &S, int *__restrict__ info, const int first_col, const int tid) {
+    constexpr int LDW = ldw_of(ND);
     const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lq = lane >> 4;
-    const int nd = (w + 15) >> 4;
+    const int nd = min((w + 15) >> 4, ND);
     PB_MARK(0);
     Diag16 D;
     int badcol = 0x7fffffff;
@@ -203,18 +211,20 @@ __device__ __forceinline__ void potrf64_blocked(const double *src, const int sld
     } else {
         // the other waves: the rest of the lower triangle (rows 16 .. 63) into LDS, the diagonal blocks mirrored (the elimination
         // reads rows as well as columns)
-        const int t = tid - 64, row = t & 63, cs = t >> 6;
-        double v[10];
-        // (all ten loads in flight at once: clamped addresses, the predicates only at the LDS writes)
+        // (all loads in flight at once: clamped addresses, the predicates only at the LDS writes)
+        constexpr int NR = 16 * ND - 16, NC = 16 * ND, NLD = (NR * NC + 64 * (NW - 1) - 1) / (64 * (NW > 1 ? NW - 1 : 1));
+        double v[NLD > 0 ? NLD : 1];
 #pragma unroll
-        for (int p = 0; p < 10; p++) {
-            const int c = min(cs + 7 * p, 63);
+        for (int p = 0; p < NLD; p++) {
+            const int e = tid - 64 + 64 * (NW - 1) * p;
+            const int row = 16 + e % (NR > 0 ? NR : 1), c = min(e / (NR > 0 ? NR : 1), NC - 1);
             v[p] = src[min(max(row, c), w - 1) + (long long)min(c, w - 1) * sld];
         }
 #pragma unroll
-        for (int p = 0; p < 10; p++) {
-            const int c = cs + 7 * p;
-            if (c < 64 && row >= 16 && row >= c) {
+        for (int p = 0; p < NLD; p++) {
+            const int e = tid - 64 + 64 * (NW - 1) * p;
+            const int row = 16 + e % (NR > 0 ? NR : 1), c = e / (NR > 0 ? NR : 1);
+            if (c < NC && row >= c) {
                 const double x = (row < w && c < w) ? v[p] : (row == c ? 1.0 : 0.0);
                 S.W[c * LDW + row] = x;
                 if (row > c && (row >> 4) == (c >> 4)) S.W[row * LDW + c] = x;
@@ -230,7 +240,7 @@ __device__ __forceinline__ void potrf64_blocked(const double *src, const int sld
         PB_MARK(2 + 8 * d);
         if (wave == 0) {
             bool pivot_ok;
-            diag16_factor(D, Wdd, S.rs, x, pivot_ok, li, lq);
+            diag16_factor<LDW>(D, Wdd, S.rs, x, pivot_ok, li, lq);
 #pragma unroll
             for (int r = 0; r < 4; r++) Vdd[(4 * r + lq) * LDW + li] = x[r];
             // first row of this block with a non-positive (or NaN) pivot
@@ -245,13 +255,13 @@ __device__ __forceinline__ void potrf64_blocked(const double *src, const int sld
             // helpers: the waves that do not share the diagonal wave's SIMD (FP64 MFMA and FP64 VALU share a SIMD's arithmetic)
             const int s0 = S.simd[0];
 #pragma unroll
-            for (int v = 1; v < 8; v++) {
+            for (int v = 1; v < NW; v++) {
                 const bool h = S.simd[v] != s0;
                 if (v == wave && h) hidx = nh;
                 nh += h ? 1 : 0;
             }
             if (nh == 0) {          // (every wave on one SIMD: never seen; any wave helps then)
-                nh = 7; hidx = wave - 1;
+                nh = NW - 1; hidx = wave - 1;
             }
         }
         // ---- window A: the diagonal wave prepares the next diagonal block; helpers: strips with X_dd, finished rows of X
@@ -300,15 +310,15 @@ __device__ __forceinline__ void potrf64_blocked(const double *src, const int sld
                 if (op != mine) continue;
                 mine += nh;
                 double *B = S.W + 16 * d * LDW + 16 * i;
-                const d4 v = blockop<false, false, false>(B, Vdd, nullptr, li, lq);
-                block_store(B, v, li, lq);
+                const d4 v = blockop<false, false, false, LDW>(B, Vdd, nullptr, li, lq);
+                block_store<LDW>(B, v, li, lq);
             }
             for (int j = 0; j < d; j++, op++) {                 // X[d][j] = -X_dd T[d][j]
                 if (op != mine) continue;
                 mine += nh;
                 double *B = S.V + 16 * j * LDW + 16 * d;
-                const d4 v = blockop<false, true, true>(Vdd, B, nullptr, li, lq);
-                if (!last) block_store(B, v, li, lq);
+                const d4 v = blockop<false, true, true, LDW>(Vdd, B, nullptr, li, lq);
+                if (!last) block_store<LDW>(B, v, li, lq);
                 else {
                     // nobody reads the last row of X again: straight to the panel (X[16 d + li][16 j + 4 r + lq], transposed)
 #pragma unroll
@@ -334,8 +344,8 @@ __device__ __forceinline__ void potrf64_blocked(const double *src, const int sld
                     if (op++ != mine) continue;
                     mine += nh;
                     double *B = S.W + 16 * j * LDW + 16 * i;
-                    const d4 v = blockop<true, true, false>(S.W + 16 * d * LDW + 16 * i, S.W + 16 * d * LDW + 16 * j, B, li, lq);
-                    block_store(B, v, li, lq);
+                    const d4 v = blockop<true, true, false, LDW>(S.W + 16 * d * LDW + 16 * i, S.W + 16 * d * LDW + 16 * j, B, li, lq);
+                    block_store<LDW>(B, v, li, lq);
                 }
             for (int i = d + 1; i < nd; i++)
                 for (int j = 0; j <= d; j++) {
@@ -343,22 +353,24 @@ __device__ __forceinline__ void potrf64_blocked(const double *src, const int sld
                     mine += nh;
                     double *B = S.V + 16 * j * LDW + 16 * i;
                     const double *Lid = S.W + 16 * d * LDW + 16 * i, *Xdj = S.V + 16 * j * LDW + 16 * d;
-                    const d4 v = j < d ? blockop<true, false, true>(Lid, Xdj, B, li, lq) : blockop<false, false, true>(Lid, Xdj, nullptr, li, lq);
-                    block_store(B, v, li, lq);
+                    const d4 v = j < d ? blockop<true, false, true, LDW>(Lid, Xdj, B, li, lq) : blockop<false, false, true, LDW>(Lid, Xdj, nullptr, li, lq);
+                    block_store<LDW>(B, v, li, lq);
                 }
         }
         PB_MARKW(8 * d + 3);
         if (wave != 0) {
-            double v[3];
+            constexpr int NS = (16 + NW - 2) / (NW > 1 ? NW - 1 : 1);
+            double v[NS];
+            const int row = min(lane, 16 * ND - 1);
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const int c = 16 * d + min(wave - 1 + 7 * k, 15), row = lane;
+            for (int k = 0; k < NS; k++) {
+                const int c = 16 * d + min(wave - 1 + (NW - 1) * k, 15);
                 v[k] = row >= c ? S.W[c * LDW + row] : S.V[row * LDW + c];
             }
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const int cc = wave - 1 + 7 * k, row = lane;
-                if (cc < 16 && row < w) P[row + (long long)(16 * d + cc) * ld] = v[k];
+            for (int k = 0; k < NS; k++) {
+                const int cc = wave - 1 + (NW - 1) * k;
+                if (cc < 16 && lane < w) P[lane + (long long)(16 * d + cc) * ld] = v[k];
             }
         }
         PB_MARKW(8 * d + 4);

@@ -27,7 +27,10 @@ int main(){
   for(int form : {3, 1}) {
   auto launch = [&](hipStream_t q, double *dst, int wv) {
     const FrontArg fa{1,0,wv,wv,n,0,0};
-    if (form == 3) hipLaunchKernelGGL(k_potrf64_b,dim3(1),dim3(pb::THREADS),0,q,S,(const FrontView*)nullptr,0,dst,dinfo,fa);
+    if (form == 3) { if (wv <= 16) hipLaunchKernelGGL((k_potrf64_b<1,1>),dim3(1),dim3(64),0,q,S,(const FrontView*)nullptr,0,dst,dinfo,fa);
+      else if (wv <= 32) hipLaunchKernelGGL((k_potrf64_b<2,2>),dim3(1),dim3(128),0,q,S,(const FrontView*)nullptr,0,dst,dinfo,fa);
+      else if (wv <= 48) hipLaunchKernelGGL((k_potrf64_b<4,3>),dim3(1),dim3(256),0,q,S,(const FrontView*)nullptr,0,dst,dinfo,fa);
+      else hipLaunchKernelGGL((k_potrf64_b<8,4>),dim3(1),dim3(512),0,q,S,(const FrontView*)nullptr,0,dst,dinfo,fa); }
     else hipLaunchKernelGGL(k_potrf64,dim3(1),dim3(256),0,q,S,(const FrontView*)nullptr,0,dst,dinfo,fa);
   };
   printf("==== %s\n", form == 3 ? "k_potrf64_b (16-column steps, 512 threads)" : "k_potrf64 (register patches, 256 threads)");
