@@ -428,6 +428,14 @@ void Device::upload(const Symbolic &S) {
                 }
                 L.active[b] = cnt;
             }
+            for (int q = 0; q < 3; q++) {
+                const int lim = 48 - 16 * q;
+                int cnt = 0;
+                for (int k = L.nsmall; k < L.count; k++) {
+                    if (S.ncols(llist[L.first + k]) > lim) cnt++; else break;
+                }
+                L.wider[q] = cnt;
+            }
             L.active.push_back(max_trail);  // stash: last element = max trailing rows of the level
         }
     };
@@ -982,7 +990,17 @@ void Device::factor_levels(int lo, int hi) {
                     f1 = FrontArg{1, (int)s1, S_->ncols(s1), S_->nrows(s1), (int)S_->ld[s1], (int)S_->sfirst[s1], (long long)S_->panelptr[s1]};
                 }
                 const int kb = b * NB;
-                launch_potrf64(st, ds_, hl, act(b), kb, d_L_, d_info_, act(b) == 1 ? f1 : f0, potrf_form_, std::min(NB, L.max_cols - kb));
+                if (b == 0 && act(0) > 1 && potrf_form_ == 3) {
+                    // first block of a level with many fronts: one launch per width class (the list is sorted by decreasing width;
+                    // the even / odd halves of two chains are sorted as well), each in the workgroup shape that fits it
+                    auto half = [&](int a) { return two ? (hf == 0 ? (a + 1) / 2 : a / 2) : a; };
+                    const int cut[5] = {0, half(L.wider[0]), half(L.wider[1]), half(L.wider[2]), act(0)};
+                    const int wcls[4] = {64, 48, 32, 16};
+                    for (int q = 0; q < 4; q++)
+                        if (cut[q + 1] > cut[q])
+                            launch_potrf64(st, ds_, hl + cut[q], cut[q + 1] - cut[q], kb, d_L_, d_info_, f0, potrf_form_, std::min(wcls[q], L.max_cols));
+                } else
+                    launch_potrf64(st, ds_, hl, act(b), kb, d_L_, d_info_, act(b) == 1 ? f1 : f0, potrf_form_, std::min(NB, L.max_cols - kb));
                 launch_trsm(st, ds_, hl, act(b), kb, 0, L.max_rows - kb - 1, d_L_, nullptr, nullptr, act(b) == 1 ? f1 : f0);
                 // two-level blocking: K = 64 updates only inside the current 256-column block, the
                 // rest of the panel once per block with K = 256

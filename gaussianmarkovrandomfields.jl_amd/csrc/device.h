@@ -122,6 +122,7 @@ struct LevelInfo {
     int max_rows;     // over big fronts
     int max_cols;     // over big fronts (they are sorted by decreasing column count)
     std::vector<int> active;  // active[k] = number of big fronts with ncols > k*NB
+    int wider[3] = {0, 0, 0}; // big fronts with more than 48 / 32 / 16 columns (first 64-column block: the diagonal-block kernel's shapes)
     // contribution-block SYRK: the level's 64 x 64 tiles in the order they are handed out, cut into one run per XCD
     long long syrk_off = 0;   // offset of the level's tiles in Device::d_syrk_recs_
     SyrkSplit syrk_split{};   // run of XCD x = [start[x], start[x + 1])
