@@ -134,20 +134,29 @@ __device__ __forceinline__ void diag16_step(Diag16 &D, double *__restrict__ Wd, 
     PB_SB;
 }
 
-// in: D.a = the block (both triangles). out: the UNSCALED columns a[i][k] in Wd (LDS; L[i][k] = Wd[k][i] Rs[k], lower triangle valid),
+// D.a holds a new block: M = I, and the first pivot and column on their way (as early as the caller can: right behind the MFMAs that
+// produce the block, in front of the barrier that follows them)
+__device__ __forceinline__ void diag16_begin(Diag16 &D, const int i, const int q) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) D.m[r] = (4 * r + q == i) ? 1.0 : 0.0;
+    diag16_fetch<0>(D, i);
+}
+
+// in: D.a = the block (both triangles), diag16_begin() called. out: the UNSCALED columns a[i][k] in Wd (LDS; L[i][k] = Wd[k][i] Rs[k], lower triangle valid),
 // Rs[k] = 1 / sqrt(pivot k) (LDS), x[r] = (L^-1)[i][4 r + q], pivot_ok = this row's pivot was positive
 template <int LDW>
 __device__ __forceinline__ void diag16_factor(Diag16 &D, double *__restrict__ Wd, double *__restrict__ Rs, double (&x)[4], bool &pivot_ok,
                                               const int i, const int q) {
-#pragma unroll
-    for (int r = 0; r < 4; r++) D.m[r] = (4 * r + q == i) ? 1.0 : 0.0;
-    diag16_fetch<0>(D, i);
     diag16_step<0, LDW>(D, Wd, i, q);  diag16_step<1, LDW>(D, Wd, i, q);  diag16_step<2, LDW>(D, Wd, i, q);  diag16_step<3, LDW>(D, Wd, i, q);
     diag16_step<4, LDW>(D, Wd, i, q);  diag16_step<5, LDW>(D, Wd, i, q);  diag16_step<6, LDW>(D, Wd, i, q);  diag16_step<7, LDW>(D, Wd, i, q);
     diag16_step<8, LDW>(D, Wd, i, q);  diag16_step<9, LDW>(D, Wd, i, q);  diag16_step<10, LDW>(D, Wd, i, q); diag16_step<11, LDW>(D, Wd, i, q);
-    diag16_step<12, LDW>(D, Wd, i, q); diag16_step<13, LDW>(D, Wd, i, q); diag16_step<14, LDW>(D, Wd, i, q); diag16_step<15, LDW>(D, Wd, i, q);
-    // the sixteen pivots p_i = a[i][i] as their steps left them (rows <= K are never touched again), all square roots at once
-    const double pi = Wd[i * LDW + i];
+    diag16_step<12, LDW>(D, Wd, i, q); diag16_step<13, LDW>(D, Wd, i, q); diag16_step<14, LDW>(D, Wd, i, q);
+    // the sixteen pivots p_i = a[i][i] as their steps left them (rows <= K are never touched again), all square roots at once; the
+    // first fifteen come back from this wave's own LDS stores while the last column is eliminated, the sixteenth is in D.pv
+    const double pl = Wd[min(i, 14) * LDW + min(i, 14)];
+    PB_SB;
+    diag16_step<15, LDW>(D, Wd, i, q);
+    const double pi = i == 15 ? D.pv : pl;
     pivot_ok = pi > 0.0;
     const double rs = rsqrt_nr2(pi);
     Rs[i] = rs;
@@ -208,6 +217,7 @@ __device__ __forceinline__ void potrf64_blocked(const double *src, const int sld
             const double v = src[min(hi, w - 1) + (long long)min(lo, w - 1) * sld];
             D.a[r] = hi < w ? v : (li == j ? 1.0 : 0.0);
         }
+        diag16_begin(D, li, lq);
     } else {
         // the other waves: the rest of the lower triangle (rows 16 .. 63) into LDS, the diagonal blocks mirrored (the elimination
         // reads rows as well as columns)
@@ -285,6 +295,7 @@ __device__ __forceinline__ void potrf64_blocked(const double *src, const int sld
                 for (int u = 0; u < 4; u++) dn = __builtin_amdgcn_mfma_f64_16x16x4f64(-acc[u], acc[u], dn, 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 4; r++) D.a[r] = dn[r];
+                diag16_begin(D, li, lq);
             } else {
                 // the last diagonal block of the panel: L_dd below / on the diagonal, X_dd' above it
 #pragma unroll
