@@ -531,21 +531,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
     // neither do lanes beyond its row range.
     const int la = lane;
     const int lb = __builtin_amdgcn_readfirstlane(wave);
-    int ti, rb;
-    double uv[16];
+    // BOTH of the first two children are requested up front (two register sets): the second child's round trip used to start
+    // only after the first child had been added -- on the narrow fronts of the mid levels a tile is little else than these
+    // round trips
+    int ti[2], rb[2];
+    double uv[2][16];
     auto fetch = [&](int q) {
         const int md = T.md[q];
         const int *reld = S.rel + T.reloff[q];
         const double *Ud = CB + T.cboff[q];
         const int a = T.a0[q] + la;
         const int ac = min(a, md - 1);
-        ti = reld[ac];
-        rb = reld[min(T.b0[q] + la, md - 1)];
+        ti[q] = reld[ac];
+        rb[q] = reld[min(T.b0[q] + la, md - 1)];
         const int nb = T.b1[q] - T.b0[q] - lb;          // this wave's columns: b0 + lb + 4 u < b1  <=>  4 u < nb
         if (a < T.a1[q]) {
 #pragma unroll
             for (int u = 0; u < 16; u++)
-                if (4 * u < nb) uv[u] = Ud[ac + (long long)(T.b0[q] + lb + 4 * u) * md];
+                if (4 * u < nb) uv[q][u] = Ud[ac + (long long)(T.b0[q] + lb + 4 * u) * md];
         }
     };
     auto add = [&](int q) {
@@ -554,8 +557,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
 #pragma unroll
         for (int u = 0; u < 16; u++) {
             if (4 * u < nb) {
-                const int tc = __builtin_amdgcn_readlane(rb, lb + 4 * u) - c - tj0;
-                if (a < T.a1[q] && a >= T.b0[q] + lb + 4 * u) Tl[(ti - c - ti0) + tc * 65] += uv[u];
+                const int tc = __builtin_amdgcn_readlane(rb[q], lb + 4 * u) - c - tj0;
+                if (a < T.a1[q] && a >= T.b0[q] + lb + 4 * u) Tl[(ti[q] - c - ti0) + tc * 65] += uv[q][u];
             }
         }
     };
@@ -576,6 +579,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
         }
     };
     if (T.nch > 0) fetch(0);
+    if (T.nch > 1) fetch(1);
     for (int idx = tid; idx < 64 * 65; idx += 256) Tl[idx] = 0.0;
     __syncthreads();
     if (T.nch > 0) {
@@ -583,7 +587,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
         __syncthreads();
     }
     if (T.nch > 1) {
-        fetch(1);
         add(1);
         __syncthreads();
     }
