@@ -579,8 +579,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
         }
     };
     if (T.nch > 0) fetch(0);
-    if (T.nch > 1) fetch(1);
     for (int idx = tid; idx < 64 * 65; idx += 256) Tl[idx] = 0.0;
+    // The product needs nothing from the children: it runs HERE, between the children's requests and their use, so that its
+    // MFMAs cover the children's round trips (the accumulators meet the gathered tile only in the epilogue). Measured by
+    // compiling parts out (profiles/r04_syrk_parts.txt): gather, product and store used to follow each other, a third of a
+    // mid-level tile's time each.
+    // D[m_ = j][n = i] = sum_q L21[j][q] L21[i][q]: rows i on the lanes (contiguous in column-major CB)
+    if (live)
+        for (int q0 = 0; q0 < c; q0 += 4 * KU) {
+            if (q0 > 0) request(q0);
+            mfma_batch(q0);
+        }
+    if (T.nch > 1) fetch(1);        // (the second child's registers would not fit beside the product's: behind it, before the first is added)
     __syncthreads();
     if (T.nch > 0) {
         add(0);
@@ -618,12 +628,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
         }
     }
     if (!live) return;
-    // D[m_ = j][n = i] = sum_q L21[j][q] L21[i][q]: rows i on the lanes (contiguous in column-major CB); the first
-    // batch arrived long ago
-    for (int q0 = 0; q0 < c; q0 += 4 * KU) {
-        if (q0 > 0) request(q0);
-        mfma_batch(q0);
-    }
     // rows i, i + 1 of column j leave together (16 bytes) wherever both lie inside the lower triangle
 #pragma unroll
     for (int a = 0; a < 2; a++)
