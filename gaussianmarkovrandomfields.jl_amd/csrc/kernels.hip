@@ -1355,42 +1355,91 @@ __global__ __launch_bounds__(256) void k_assemble_lds(DevSym S, const int *__res
     const int ld = S.ld[s];
     double *Cw = col_lds + wave * ldmax;
     double *Pc = L + S.panelptr[s] + (long long)tc * ld;
-    for (int i = lane; i < ld; i += 64) Cw[i] = 0.0;
-    {   // Q's entries of this column: [qcolptr[k], qcolptr[k + 1]) for column k of L (no search)
-        const int gk = S.sfirst[s] + tc;
-        const int lo = S.qcolptr[gk], hi = S.qcolptr[gk + 1];
-        for (int q = lo + lane; q < hi; q += 64) Cw[S.qdst[q]] = nzval[S.qsrc[q]];
-    }
-    for (long long ch = S.childptr[s]; ch < S.childptr[s + 1]; ch++) {
-        const EdgeRec er = S.edge[ch];
-        const int md = er.md;
-        const int *reld = S.rel + er.reloff;
-        const int j = S.erow[er.eoff + tc];       // the child's row that maps to column tc (table, no search)
-        if (j < 0) continue;                      // none
-        const double *Uc = CB + er.cboff + (long long)j * md;
-        // Rows in PAIRS per lane (one 16-byte value load + one 8-byte index load cover 128 rows of the column), four
-        // chunks in flight, and chunks past the end of the child's column issue nothing: the kernel is bound by the
-        // CU's address unit (a vector memory instruction costs it ~16 cycles whatever its lanes do), not by HBM.
-        // The pair that starts at the last row reads one element past the column: the next column, or the 16 bytes of
-        // slack every device array ends in (Device::dalloc); never used.
-        for (int base = j; base < md; base += 512) {
-            i2u ri[4];
-            d2u u[4];
+    // A column is a chain of dependent round trips (front -> Q's range / child records -> the child's row -> entries): everything
+    // the FIRST TWO children and Q's first 64 entries need is requested before any of it is used -- records and rows of both
+    // children side by side, then all entry loads -- and only then does the column build up in LDS, in the old order (zero, Q,
+    // child by child): same bits, five round trips instead of nine.
+    const long long ch0 = S.childptr[s], ch1 = S.childptr[s + 1];
+    const int nch = (int)(ch1 - ch0);
+    const int gk = S.sfirst[s] + tc;
+    const int qlo = S.qcolptr[gk], qhi = S.qcolptr[gk + 1];
+    EdgeRec er[2];
+    int jj[2] = {-1, -1};
 #pragma unroll
-            for (int q = 0; q < 4; q++)
-                if (base + 128 * q < md) {
-                    const int ic = min(base + 128 * q + 2 * lane, md - 1);
-                    ri[q] = *(const i2u *)(reld + ic);
-                    u[q] = *(const d2u *)(Uc + ic);
-                }
+    for (int q = 0; q < 2; q++)
+        if (q < nch) er[q] = S.edge[ch0 + q];
 #pragma unroll
-            for (int q = 0; q < 4; q++)
-                if (base + 128 * q < md) {
-                    const int i = base + 128 * q + 2 * lane;
-                    if (i < md) Cw[ri[q].x] += u[q].x;          // distinct rows within a child: no conflicts
-                    if (i + 1 < md) Cw[ri[q].y] += u[q].y;
+    for (int q = 0; q < 2; q++)
+        if (q < nch) jj[q] = S.erow[er[q].eoff + tc];       // the child's row that maps to column tc (table, no search); < 0: none
+    int qd0 = 0;
+    double qv0 = 0.0;
+    if (qlo + lane < qhi) { qd0 = S.qdst[qlo + lane]; qv0 = nzval[S.qsrc[qlo + lane]]; }
+    // Rows in PAIRS per lane (one 16-byte value load + one 8-byte index load cover 128 rows of the column), four
+    // chunks in flight, and chunks past the end of the child's column issue nothing: the kernel is bound by the
+    // CU's address unit (a vector memory instruction costs it ~16 cycles whatever its lanes do), not by HBM.
+    // The pair that starts at the last row reads one element past the column: the next column, or the 16 bytes of
+    // slack every device array ends in (Device::dalloc); never used.
+    i2u ri[2][4];
+    d2u u[2][4];
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+        if (jj[q] >= 0) {
+            const int md = er[q].md;
+            const int *reld = S.rel + er[q].reloff;
+            const double *Uc = CB + er[q].cboff + (long long)jj[q] * md;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (jj[q] + 128 * k < md) {
+                    const int ic = min(jj[q] + 128 * k + 2 * lane, md - 1);
+                    ri[q][k] = *(const i2u *)(reld + ic);
+                    u[q][k] = *(const d2u *)(Uc + ic);
                 }
         }
+    for (int i = lane; i < ld; i += 64) Cw[i] = 0.0;
+    // Q's entries of this column: [qcolptr[k], qcolptr[k + 1]) for column k of L (no search)
+    if (qlo + lane < qhi) Cw[qd0] = qv0;
+    for (int q = qlo + 64 + lane; q < qhi; q += 64) Cw[S.qdst[q]] = nzval[S.qsrc[q]];
+    auto chunk = [&](const int *reld, const double *Uc, int md, int base) {
+        i2u r2[4];
+        d2u u2[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (base + 128 * k < md) {
+                const int ic = min(base + 128 * k + 2 * lane, md - 1);
+                r2[k] = *(const i2u *)(reld + ic);
+                u2[k] = *(const d2u *)(Uc + ic);
+            }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (base + 128 * k < md) {
+                const int i = base + 128 * k + 2 * lane;
+                if (i < md) Cw[r2[k].x] += u2[k].x;          // distinct rows within a child: no conflicts
+                if (i + 1 < md) Cw[r2[k].y] += u2[k].y;
+            }
+    };
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+        if (jj[q] >= 0) {
+            const int md = er[q].md;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (jj[q] + 128 * k < md) {
+                    const int i = jj[q] + 128 * k + 2 * lane;
+                    if (i < md) Cw[ri[q][k].x] += u[q][k].x;
+                    if (i + 1 < md) Cw[ri[q][k].y] += u[q][k].y;
+                }
+            const int *reld = S.rel + er[q].reloff;
+            const double *Uc = CB + er[q].cboff + (long long)jj[q] * md;
+            for (int base = jj[q] + 512; base < md; base += 512) chunk(reld, Uc, md, base);
+        }
+    for (long long ch = ch0 + 2; ch < ch1; ch++) {          // further children: one at a time
+        const EdgeRec e3 = S.edge[ch];
+        const int md = e3.md;
+        const int *reld = S.rel + e3.reloff;
+        const int j = S.erow[e3.eoff + tc];
+        if (j < 0) continue;
+        const double *Uc = CB + e3.cboff + (long long)j * md;
+        for (int base = j; base < md; base += 512) chunk(reld, Uc, md, base);
     }
     for (int i = 2 * lane; i < ld; i += 128) *(d2u *)(Pc + i) = (d2u){Cw[i], Cw[i + 1]};      // ld is even
 }
