@@ -1343,17 +1343,20 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // to HBM ONCE. The HBM version above zero-fills the panel and then read-modify-writes it per child
 // (measured: k_assemble moved 6.5 GB per step and ran at ~4.6 TB/s, i.e. HBM bound on bytes it need
 // not move). Same summation order, bit-identical panels. Dynamic LDS: 4 * ldmax doubles.
+template <int WIDE>   // 0: one WAVE per column (four columns per workgroup); 1: one WORKGROUP per column (tall columns: top of the tree)
 __global__ __launch_bounds__(256) void k_assemble_lds(DevSym S, const int *__restrict__ list,
                                                       const double *__restrict__ nzval, double *__restrict__ L,
                                                       const double *__restrict__ CB, int ldmax) {
     extern __shared__ double col_lds[];
+    constexpr int NL = WIDE ? 256 : 64, PW = 2 * NL;       // lanes on one column; rows one pair-load of all of them covers
     const int s = list[blockIdx.y];
     const int c = S.sfirst[s + 1] - S.sfirst[s];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tc = blockIdx.x * ASM_CW + __builtin_amdgcn_readfirstlane(wave);
+    const int wave = threadIdx.x >> 6;
+    const int lane = WIDE ? (int)threadIdx.x : (int)(threadIdx.x & 63);         // position among the column's lanes
+    const int tc = WIDE ? (int)blockIdx.x : blockIdx.x * ASM_CW + __builtin_amdgcn_readfirstlane(wave);
     if (tc >= c) return;
     const int ld = S.ld[s];
-    double *Cw = col_lds + wave * ldmax;
+    double *Cw = WIDE ? col_lds : col_lds + wave * ldmax;
     double *Pc = L + S.panelptr[s] + (long long)tc * ld;
     // A column is a chain of dependent round trips (front -> Q's range / child records -> the child's row -> entries): everything
     // the FIRST TWO children and Q's first 64 entries need is requested before any of it is used -- records and rows of both
@@ -1374,6 +1377,7 @@ __global__ __launch_bounds__(256) void k_assemble_lds(DevSym S, const int *__res
     int qd0 = 0;
     double qv0 = 0.0;
     if (qlo + lane < qhi) { qd0 = S.qdst[qlo + lane]; qv0 = nzval[S.qsrc[qlo + lane]]; }
+    // (WIDE: the waves of the workgroup touch the same rows: a barrier between the phases; rows are distinct within a phase)
     // Rows in PAIRS per lane (one 16-byte value load + one 8-byte index load cover 128 rows of the column), four
     // chunks in flight, and chunks past the end of the child's column issue nothing: the kernel is bound by the
     // CU's address unit (a vector memory instruction costs it ~16 cycles whatever its lanes do), not by HBM.
@@ -1389,59 +1393,65 @@ __global__ __launch_bounds__(256) void k_assemble_lds(DevSym S, const int *__res
             const double *Uc = CB + er[q].cboff + (long long)jj[q] * md;
 #pragma unroll
             for (int k = 0; k < 4; k++)
-                if (jj[q] + 128 * k < md) {
-                    const int ic = min(jj[q] + 128 * k + 2 * lane, md - 1);
+                if (jj[q] + PW * k < md) {
+                    const int ic = min(jj[q] + PW * k + 2 * lane, md - 1);
                     ri[q][k] = *(const i2u *)(reld + ic);
                     u[q][k] = *(const d2u *)(Uc + ic);
                 }
         }
-    for (int i = lane; i < ld; i += 64) Cw[i] = 0.0;
+    for (int i = lane; i < ld; i += NL) Cw[i] = 0.0;
+    if (WIDE) __syncthreads();
     // Q's entries of this column: [qcolptr[k], qcolptr[k + 1]) for column k of L (no search)
     if (qlo + lane < qhi) Cw[qd0] = qv0;
-    for (int q = qlo + 64 + lane; q < qhi; q += 64) Cw[S.qdst[q]] = nzval[S.qsrc[q]];
+    for (int q = qlo + NL + lane; q < qhi; q += NL) Cw[S.qdst[q]] = nzval[S.qsrc[q]];
+    if (WIDE) __syncthreads();
     auto chunk = [&](const int *reld, const double *Uc, int md, int base) {
         i2u r2[4];
         d2u u2[4];
 #pragma unroll
         for (int k = 0; k < 4; k++)
-            if (base + 128 * k < md) {
-                const int ic = min(base + 128 * k + 2 * lane, md - 1);
+            if (base + PW * k < md) {
+                const int ic = min(base + PW * k + 2 * lane, md - 1);
                 r2[k] = *(const i2u *)(reld + ic);
                 u2[k] = *(const d2u *)(Uc + ic);
             }
 #pragma unroll
         for (int k = 0; k < 4; k++)
-            if (base + 128 * k < md) {
-                const int i = base + 128 * k + 2 * lane;
+            if (base + PW * k < md) {
+                const int i = base + PW * k + 2 * lane;
                 if (i < md) Cw[r2[k].x] += u2[k].x;          // distinct rows within a child: no conflicts
                 if (i + 1 < md) Cw[r2[k].y] += u2[k].y;
             }
     };
 #pragma unroll
-    for (int q = 0; q < 2; q++)
+    for (int q = 0; q < 2; q++) {
         if (jj[q] >= 0) {
             const int md = er[q].md;
 #pragma unroll
             for (int k = 0; k < 4; k++)
-                if (jj[q] + 128 * k < md) {
-                    const int i = jj[q] + 128 * k + 2 * lane;
+                if (jj[q] + PW * k < md) {
+                    const int i = jj[q] + PW * k + 2 * lane;
                     if (i < md) Cw[ri[q][k].x] += u[q][k].x;
                     if (i + 1 < md) Cw[ri[q][k].y] += u[q][k].y;
                 }
             const int *reld = S.rel + er[q].reloff;
             const double *Uc = CB + er[q].cboff + (long long)jj[q] * md;
-            for (int base = jj[q] + 512; base < md; base += 512) chunk(reld, Uc, md, base);
+            for (int base = jj[q] + 4 * PW; base < md; base += 4 * PW) chunk(reld, Uc, md, base);
         }
+        if (WIDE && q < nch) __syncthreads();
+    }
     for (long long ch = ch0 + 2; ch < ch1; ch++) {          // further children: one at a time
         const EdgeRec e3 = S.edge[ch];
         const int md = e3.md;
         const int *reld = S.rel + e3.reloff;
         const int j = S.erow[e3.eoff + tc];
-        if (j < 0) continue;
-        const double *Uc = CB + e3.cboff + (long long)j * md;
-        for (int base = j; base < md; base += 512) chunk(reld, Uc, md, base);
+        if (j >= 0) {
+            const double *Uc = CB + e3.cboff + (long long)j * md;
+            for (int base = j; base < md; base += 4 * PW) chunk(reld, Uc, md, base);
+        }
+        if (WIDE) __syncthreads();
     }
-    for (int i = 2 * lane; i < ld; i += 128) *(d2u *)(Pc + i) = (d2u){Cw[i], Cw[i + 1]};      // ld is even
+    for (int i = 2 * lane; i < ld; i += PW) *(d2u *)(Pc + i) = (d2u){Cw[i], Cw[i + 1]};      // ld is even
 }
 
 // Workgroups are handed to the 8 XCDs round-robin by linear id (x fastest). Rectangular grids whose
@@ -1456,11 +1466,27 @@ void launch_assemble(hipStream_t st, const DevSym &S, const int *list, int nfron
                      const double *nzval, double *L, double *CB) {
     if (nfronts <= 0) return;
     const int ldmax = (max_rows + 1) & ~1;       // Symbolic rounds ld up to even
-    if (ldmax <= 1280) {
-        hipLaunchKernelGGL(k_assemble_lds, dim3(odd(cdiv(max_cols, ASM_CW)), nfronts), dim3(256), (size_t)4 * ldmax * sizeof(double), st,
+    // Columns through LDS, written once: a wave per column while four columns of a workgroup fit in 40 KB, a workgroup per column
+    // for the tall columns of the top of the tree (up to 128 KB). Measured at cfg 2 (factorisation): HBM assembly above 1280 rows
+    // 9.33 ms; wave-per-column up to 2048 rows 9.10; + workgroup-per-column above: 9.03; wave-per-column up to 1280, workgroup-per-column
+    // above: 8.96. (GMRFX_ASM_LDS_MAX / GMRFX_ASM_LDS_WIDE_MAX: the two row limits, 0 = off.)
+    static const int lds_cols_max = [] { const char *e = std::getenv("GMRFX_ASM_LDS_MAX"); return e ? std::atoi(e) : 1280; }();
+    static const int lds_wide_max = [] { const char *e = std::getenv("GMRFX_ASM_LDS_WIDE_MAX"); return e ? std::atoi(e) : 16384; }();
+    if (ldmax <= lds_cols_max && ldmax <= 2048) {
+        hipLaunchKernelGGL(k_assemble_lds<0>, dim3(odd(cdiv(max_cols, ASM_CW)), nfronts), dim3(256), (size_t)4 * ldmax * sizeof(double), st,
                            S, list, nzval, L, CB, ldmax);
         return;
     }
+    if (ldmax <= lds_wide_max && ldmax <= 16384) {
+        const size_t lds = (size_t)ldmax * sizeof(double);
+        if (lds > 65536) {
+            static const bool once = [] { return hipFuncSetAttribute((const void *)k_assemble_lds<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) == hipSuccess; }();
+            if (!once) goto hbm;
+        }
+        hipLaunchKernelGGL(k_assemble_lds<1>, dim3(odd(max_cols), nfronts), dim3(256), lds, st, S, list, nzval, L, CB, ldmax);
+        return;
+    }
+hbm:
     if ((long long)cdiv(max_cols, ASM_CW) * nfronts <= 2200)
         hipLaunchKernelGGL(k_assemble<1>, dim3(odd(max_cols), nfronts), dim3(256), 0, st, S, list, nzval, L, CB, 0, 0);
     else
