@@ -618,6 +618,25 @@ void Device::upload(const Symbolic &S) {
         const FwdTile *fp; up(fp, ft); d_fwd_recs_ = const_cast<FwdTile *>(fp);
         HC(hipStreamSynchronize(stream));
         std::vector<long long>().swap(h_wptr_);
+        {   // panel-assembly records, one per level-list position
+            std::vector<AsmRec> ar(S.levellist.size());
+            for (size_t k = 0; k < S.levellist.size(); k++) {
+                const i32 s = S.levellist[k];
+                AsmRec a{};
+                a.pp = (long long)S.panelptr[s];
+                a.ch0 = (long long)S.childptr[s];
+                a.c = S.ncols(s); a.ld = (int)S.ld[s]; a.first = (int)S.sfirst[s];
+                a.nch = (int)(S.childptr[s + 1] - S.childptr[s]);
+                for (int q = 0; q < std::min(a.nch, 2); q++) {
+                    const EdgeRec &e = h_edges_[a.ch0 + q];
+                    a.reloff[q] = e.reloff; a.cboff[q] = e.cboff; a.eoff[q] = e.eoff; a.md[q] = e.md;
+                }
+                ar[k] = a;
+            }
+            if (ar.empty()) ar.push_back(AsmRec{});
+            const AsmRec *ap; up(ap, ar); d_arec_ = const_cast<AsmRec *>(ap);
+            HC(hipStreamSynchronize(stream));
+        }
         std::vector<EdgeRec>().swap(h_edges_);
         std::vector<int>().swap(h_etile_);
     }
@@ -873,7 +892,7 @@ void Device::factor_levels(int lo, int hi) {
             hipStream_t st_small = !split_small ? stream : (nf > 0 || k != widest) ? stream3 : stream;
             launch_factor_small(st_small, ds_, d_levellist_ + L.first + off, L.ncls[k], kClsRows[k], nz_src_, d_L_, d_cb_, d_info_);
         }
-        launch_assemble(stream, ds_, list, nf, L.max_cols, L.max_rows, nz_src_, d_L_, d_cb_);
+        launch_assemble(stream, ds_, list, d_arec_ + L.first + L.nsmall, nf, L.max_cols, L.max_rows, nz_src_, d_L_, d_cb_);
         const int nblk = level_nblk(L);
         // The panel factorisation of a level is a chain of small dependent launches per 64-column block (potrf64 on ONE
         // workgroup per front -> trsm -> gemm): while the diagonal blocks factor, the chip idles. Levels with several

@@ -72,6 +72,17 @@ struct SweepTask {
 struct FrontArg { int on, s, c, r, ld, first; long long pp; };
 struct FrontView { int s, c, r, ld, first, pad; long long pp; };   // 32 bytes
 
+// Everything a column of the panel assembly (k_assemble_lds) needs to know about its front and the front's first two children,
+// in ONE 96-byte record per level-list position (one scalar load) instead of front -> geometry arrays -> edge records.
+struct AsmRec {
+    long long pp;            // panel offset in the factor storage
+    long long ch0;           // first child edge (children beyond the second go the long way)
+    int c, ld, first, nch;   // columns, leading dimension, first global column, number of children
+    long long reloff[2], cboff[2], eoff[2];     // per child: rel[] offset of its trailing rows, arena offset of its contribution block, erow offset
+    int md[2];               // per child: trailing rows
+    int pad[2];
+};
+
 struct SyrkSplit { int start[9]; };   // tile runs of the 8 XCDs inside a level's tile list
 
 // Everything a workgroup of k_syrk_cb_rec needs for one 64 x 64 contribution-block tile, in ONE 128-byte record (one
@@ -242,6 +253,7 @@ private:
     const int *d_iperm_ = nullptr;   // inverse permutation (original row -> position), used by the RHS transposes
     int *d_levellist_ = nullptr;
     FwdTile *d_fwd_recs_ = nullptr;     // one record per 32-row tile of every big front's update vector (sweep levels)
+    AsmRec *d_arec_ = nullptr;          // one per position of the level lists (Symbolic::levellist order)
     SyrkTile *d_syrk_recs_ = nullptr;   // one record per contribution-block tile, level by level, in hand-out order
     std::vector<EdgeRec> h_edges_;      // host copies of the edge records / tile tables between upload() and init()
     std::vector<int> h_etile_;

@@ -1344,36 +1344,33 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // (measured: k_assemble moved 6.5 GB per step and ran at ~4.6 TB/s, i.e. HBM bound on bytes it need
 // not move). Same summation order, bit-identical panels. Dynamic LDS: 4 * ldmax doubles.
 template <int WIDE>   // 0: one WAVE per column (four columns per workgroup); 1: one WORKGROUP per column (tall columns: top of the tree)
-__global__ __launch_bounds__(256) void k_assemble_lds(DevSym S, const int *__restrict__ list,
+__global__ __launch_bounds__(256) void k_assemble_lds(DevSym S, const AsmRec *__restrict__ arec,
                                                       const double *__restrict__ nzval, double *__restrict__ L,
                                                       const double *__restrict__ CB, int ldmax) {
     extern __shared__ double col_lds[];
     constexpr int NL = WIDE ? 256 : 64, PW = 2 * NL;       // lanes on one column; rows one pair-load of all of them covers
-    const int s = list[blockIdx.y];
-    const int c = S.sfirst[s + 1] - S.sfirst[s];
+    const AsmRec R = arec[blockIdx.y];                     // the front and its first two children: one scalar load
+    const int c = R.c;
     const int wave = threadIdx.x >> 6;
     const int lane = WIDE ? (int)threadIdx.x : (int)(threadIdx.x & 63);         // position among the column's lanes
     const int tc = WIDE ? (int)blockIdx.x : blockIdx.x * ASM_CW + __builtin_amdgcn_readfirstlane(wave);
     if (tc >= c) return;
-    const int ld = S.ld[s];
+    const int ld = R.ld;
     double *Cw = WIDE ? col_lds : col_lds + wave * ldmax;
-    double *Pc = L + S.panelptr[s] + (long long)tc * ld;
+    double *Pc = L + R.pp + (long long)tc * ld;
     // A column is a chain of dependent round trips (front -> Q's range / child records -> the child's row -> entries): everything
     // the FIRST TWO children and Q's first 64 entries need is requested before any of it is used -- records and rows of both
     // children side by side, then all entry loads -- and only then does the column build up in LDS, in the old order (zero, Q,
-    // child by child): same bits, five round trips instead of nine.
-    const long long ch0 = S.childptr[s], ch1 = S.childptr[s + 1];
-    const int nch = (int)(ch1 - ch0);
-    const int gk = S.sfirst[s] + tc;
+    // child by child): same bits, four round trips (record | Q's range, the children's rows | entries | Q's values) instead of nine.
+    const int nch = R.nch;
+    const long long ch0 = R.ch0, ch1 = ch0 + nch;
+    const int gk = R.first + tc;
     const int qlo = S.qcolptr[gk], qhi = S.qcolptr[gk + 1];
-    EdgeRec er[2];
+    struct { int md; long long reloff, cboff; } er[2] = {{R.md[0], R.reloff[0], R.cboff[0]}, {R.md[1], R.reloff[1], R.cboff[1]}};
     int jj[2] = {-1, -1};
 #pragma unroll
     for (int q = 0; q < 2; q++)
-        if (q < nch) er[q] = S.edge[ch0 + q];
-#pragma unroll
-    for (int q = 0; q < 2; q++)
-        if (q < nch) jj[q] = S.erow[er[q].eoff + tc];       // the child's row that maps to column tc (table, no search); < 0: none
+        if (q < nch) jj[q] = S.erow[R.eoff[q] + tc];        // the child's row that maps to column tc (table, no search); < 0: none
     int qd0 = 0;
     double qv0 = 0.0;
     if (qlo + lane < qhi) { qd0 = S.qdst[qlo + lane]; qv0 = nzval[S.qsrc[qlo + lane]]; }
@@ -1462,7 +1459,7 @@ __global__ __launch_bounds__(256) void k_assemble_lds(DevSym S, const int *__res
 // once through the kernels' own range checks.
 static inline unsigned odd(int v) { return (unsigned)(v | 1); }
 
-void launch_assemble(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, int max_rows,
+void launch_assemble(hipStream_t st, const DevSym &S, const int *list, const AsmRec *arec, int nfronts, int max_cols, int max_rows,
                      const double *nzval, double *L, double *CB) {
     if (nfronts <= 0) return;
     const int ldmax = (max_rows + 1) & ~1;       // Symbolic rounds ld up to even
@@ -1474,7 +1471,7 @@ void launch_assemble(hipStream_t st, const DevSym &S, const int *list, int nfron
     static const int lds_wide_max = [] { const char *e = std::getenv("GMRFX_ASM_LDS_WIDE_MAX"); return e ? std::atoi(e) : 16384; }();
     if (ldmax <= lds_cols_max && ldmax <= 2048) {
         hipLaunchKernelGGL(k_assemble_lds<0>, dim3(odd(cdiv(max_cols, ASM_CW)), nfronts), dim3(256), (size_t)4 * ldmax * sizeof(double), st,
-                           S, list, nzval, L, CB, ldmax);
+                           S, arec, nzval, L, CB, ldmax);
         return;
     }
     if (ldmax <= lds_wide_max && ldmax <= 16384) {
@@ -1483,7 +1480,7 @@ void launch_assemble(hipStream_t st, const DevSym &S, const int *list, int nfron
             static const bool once = [] { return hipFuncSetAttribute((const void *)k_assemble_lds<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) == hipSuccess; }();
             if (!once) goto hbm;
         }
-        hipLaunchKernelGGL(k_assemble_lds<1>, dim3(odd(max_cols), nfronts), dim3(256), lds, st, S, list, nzval, L, CB, ldmax);
+        hipLaunchKernelGGL(k_assemble_lds<1>, dim3(odd(max_cols), nfronts), dim3(256), lds, st, S, arec, nzval, L, CB, ldmax);
         return;
     }
 hbm:
