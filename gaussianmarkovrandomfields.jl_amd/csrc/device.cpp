@@ -79,6 +79,8 @@ Device::~Device() {
     if (stream3) (void)hipStreamDestroy(stream3);
     for (auto &e : ev_syrk_) if (e) (void)hipEventDestroy(e);
     if (ev_fact_) (void)hipEventDestroy(ev_fact_);
+    if (ev_nzp_) (void)hipEventDestroy(ev_nzp_);
+    if (ev_nzp0_) (void)hipEventDestroy(ev_nzp0_);
     if (ev_inv_) (void)hipEventDestroy(ev_inv_);
     if (stream2) (void)hipStreamDestroy(stream2);
     for (auto d : dummy_streams_) (void)hipStreamDestroy(d);
@@ -214,6 +216,10 @@ void Device::upload(const Symbolic &S) {
                 qd[q] = (int)(rel % S.ld[s]);
             }
         up(ip, qs); ds_.qsrc = ip;
+        nq_ = (long long)qs.size();
+        d_nzp_ = dalloc<double>((size_t)std::max<long long>(nq_, 1));
+        HC(hipEventCreateWithFlags(&ev_nzp_, hipEventDisableTiming));
+        HC(hipEventCreateWithFlags(&ev_nzp0_, hipEventDisableTiming));
         up(ip, qd); ds_.qdst = ip;
         up(ip, qc); ds_.qcol = ip;
         // entries are sorted by column inside a front: one pointer per column of L replaces a search per panel column
@@ -870,6 +876,15 @@ void Device::factor_levels(int lo, int hi) {
             launch_subtree(stream, ds_, 0, d_sub_first_ + off, d_sub_last_ + off, nsub_cls_[k], kClsRows[k], nz_src_, d_L_, d_cb_,
                            d_info_, nullptr, nullptr, 0, 0);
     }
+    // Q's values in assembly order, on the second stream beside the first (small-front) levels; the first big-front assembly waits
+    // for them. (lo > 0: a later phase of a sharded factorisation -- the values were gathered by the phase that started at 0)
+    bool nzp_joined = lo != 0;
+    if (lo == 0) {
+        HC(hipEventRecord(ev_nzp0_, stream));
+        HC(hipStreamWaitEvent(stream3, ev_nzp0_, 0));
+        launch_gather_values(stream3, nz_src_, ds_.qsrc, d_nzp_, nq_);
+        HC(hipEventRecord(ev_nzp_, stream3));
+    }
     int nsy = (int)syrk_launches;
     for (int lev = lo; lev < hi; lev++) {
         auto &L = levels_[lev];
@@ -892,7 +907,8 @@ void Device::factor_levels(int lo, int hi) {
             hipStream_t st_small = !split_small ? stream : (nf > 0 || k != widest) ? stream3 : stream;
             launch_factor_small(st_small, ds_, d_levellist_ + L.first + off, L.ncls[k], kClsRows[k], nz_src_, d_L_, d_cb_, d_info_);
         }
-        launch_assemble(stream, ds_, list, d_arec_ + L.first + L.nsmall, nf, L.max_cols, L.max_rows, nz_src_, d_L_, d_cb_);
+        if (nf > 0 && !nzp_joined) { HC(hipStreamWaitEvent(stream, ev_nzp_, 0)); nzp_joined = true; }
+        launch_assemble(stream, ds_, list, d_arec_ + L.first + L.nsmall, d_nzp_, nf, L.max_cols, L.max_rows, nz_src_, d_L_, d_cb_);
         const int nblk = level_nblk(L);
         // The panel factorisation of a level is a chain of small dependent launches per 64-column block (potrf64 on ONE
         // workgroup per front -> trsm -> gemm): while the diagonal blocks factor, the chip idles. Levels with several

@@ -253,6 +253,9 @@ private:
     const int *d_iperm_ = nullptr;   // inverse permutation (original row -> position), used by the RHS transposes
     int *d_levellist_ = nullptr;
     FwdTile *d_fwd_recs_ = nullptr;     // one record per 32-row tile of every big front's update vector (sweep levels)
+    double *d_nzp_ = nullptr;           // Q's values in assembly order (nzp[q] = nzval[qsrc[q]]): gathered once per factorisation, one dependent load less per panel column
+    long long nq_ = 0;
+    hipEvent_t ev_nzp_ = nullptr, ev_nzp0_ = nullptr;
     AsmRec *d_arec_ = nullptr;          // one per position of the level lists (Symbolic::levellist order)
     SyrkTile *d_syrk_recs_ = nullptr;   // one record per contribution-block tile, level by level, in hand-out order
     std::vector<EdgeRec> h_edges_;      // host copies of the edge records / tile tables between upload() and init()

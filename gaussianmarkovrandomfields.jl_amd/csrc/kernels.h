@@ -16,7 +16,8 @@ constexpr int FWD_RB = 32;    // front rows owned by one forward-assembly workgr
 // two doubles that are only known to be 8-byte aligned (one 16-byte load; the hardware takes unaligned addresses)
 typedef double gmrfx_d2u __attribute__((ext_vector_type(2), aligned(8)));
 
-void launch_assemble(hipStream_t st, const DevSym &S, const int *list, const AsmRec *arec, int nfronts, int max_cols, int max_rows,
+void launch_gather_values(hipStream_t st, const double *nzval, const int *qsrc, double *out, long long cnt);
+void launch_assemble(hipStream_t st, const DevSym &S, const int *list, const AsmRec *arec, const double *nzp, int nfronts, int max_cols, int max_rows,
                      const double *nzval, double *L, double *CB);
 void launch_syrk_cb(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_trail, const double *L, double *CB);
 // The same tiles from self-contained records, one contiguous run per XCD (workgroup id mod 8 = XCD): see k_syrk_cb_rec.

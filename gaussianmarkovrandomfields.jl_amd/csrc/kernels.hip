@@ -1343,9 +1343,18 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // to HBM ONCE. The HBM version above zero-fills the panel and then read-modify-writes it per child
 // (measured: k_assemble moved 6.5 GB per step and ran at ~4.6 TB/s, i.e. HBM bound on bytes it need
 // not move). Same summation order, bit-identical panels. Dynamic LDS: 4 * ldmax doubles.
+// nzp[q] = nzval[qsrc[q]]: Q's values in the order the assembly reads them (once per factorisation, 56 MB at cfg 2)
+__global__ __launch_bounds__(256) void k_gather_values(const double *__restrict__ nzval, const int *__restrict__ qsrc, double *__restrict__ out, long long cnt) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < cnt; i += (long long)gridDim.x * 256) out[i] = nzval[qsrc[i]];
+}
+void launch_gather_values(hipStream_t st, const double *nzval, const int *qsrc, double *out, long long cnt) {
+    if (cnt <= 0) return;
+    hipLaunchKernelGGL(k_gather_values, dim3((unsigned)std::min<long long>(8192, (cnt + 255) / 256)), dim3(256), 0, st, nzval, qsrc, out, cnt);
+}
+
 template <int WIDE>   // 0: one WAVE per column (four columns per workgroup); 1: one WORKGROUP per column (tall columns: top of the tree)
 __global__ __launch_bounds__(256) void k_assemble_lds(DevSym S, const AsmRec *__restrict__ arec,
-                                                      const double *__restrict__ nzval, double *__restrict__ L,
+                                                      const double *__restrict__ nzp, double *__restrict__ L,
                                                       const double *__restrict__ CB, int ldmax) {
     extern __shared__ double col_lds[];
     constexpr int NL = WIDE ? 256 : 64, PW = 2 * NL;       // lanes on one column; rows one pair-load of all of them covers
@@ -1361,7 +1370,7 @@ __global__ __launch_bounds__(256) void k_assemble_lds(DevSym S, const AsmRec *__
     // A column is a chain of dependent round trips (front -> Q's range / child records -> the child's row -> entries): everything
     // the FIRST TWO children and Q's first 64 entries need is requested before any of it is used -- records and rows of both
     // children side by side, then all entry loads -- and only then does the column build up in LDS, in the old order (zero, Q,
-    // child by child): same bits, four round trips (record | Q's range, the children's rows | entries | Q's values) instead of nine.
+    // child by child): same bits, three round trips (record | Q's range, the children's rows | entries and Q's values) instead of nine.
     const int nch = R.nch;
     const long long ch0 = R.ch0, ch1 = ch0 + nch;
     const int gk = R.first + tc;
@@ -1373,7 +1382,7 @@ __global__ __launch_bounds__(256) void k_assemble_lds(DevSym S, const AsmRec *__
         if (q < nch) jj[q] = S.erow[R.eoff[q] + tc];        // the child's row that maps to column tc (table, no search); < 0: none
     int qd0 = 0;
     double qv0 = 0.0;
-    if (qlo + lane < qhi) { qd0 = S.qdst[qlo + lane]; qv0 = nzval[S.qsrc[qlo + lane]]; }
+    if (qlo + lane < qhi) { qd0 = S.qdst[qlo + lane]; qv0 = nzp[qlo + lane]; }        // (values in assembly order: no index in between)
     // (WIDE: the waves of the workgroup touch the same rows: a barrier between the phases; rows are distinct within a phase)
     // Rows in PAIRS per lane (one 16-byte value load + one 8-byte index load cover 128 rows of the column), four
     // chunks in flight, and chunks past the end of the child's column issue nothing: the kernel is bound by the
@@ -1400,7 +1409,7 @@ __global__ __launch_bounds__(256) void k_assemble_lds(DevSym S, const AsmRec *__
     if (WIDE) __syncthreads();
     // Q's entries of this column: [qcolptr[k], qcolptr[k + 1]) for column k of L (no search)
     if (qlo + lane < qhi) Cw[qd0] = qv0;
-    for (int q = qlo + NL + lane; q < qhi; q += NL) Cw[S.qdst[q]] = nzval[S.qsrc[q]];
+    for (int q = qlo + NL + lane; q < qhi; q += NL) Cw[S.qdst[q]] = nzp[q];
     if (WIDE) __syncthreads();
     auto chunk = [&](const int *reld, const double *Uc, int md, int base) {
         i2u r2[4];
@@ -1459,7 +1468,7 @@ __global__ __launch_bounds__(256) void k_assemble_lds(DevSym S, const AsmRec *__
 // once through the kernels' own range checks.
 static inline unsigned odd(int v) { return (unsigned)(v | 1); }
 
-void launch_assemble(hipStream_t st, const DevSym &S, const int *list, const AsmRec *arec, int nfronts, int max_cols, int max_rows,
+void launch_assemble(hipStream_t st, const DevSym &S, const int *list, const AsmRec *arec, const double *nzp, int nfronts, int max_cols, int max_rows,
                      const double *nzval, double *L, double *CB) {
     if (nfronts <= 0) return;
     const int ldmax = (max_rows + 1) & ~1;       // Symbolic rounds ld up to even
@@ -1471,7 +1480,7 @@ void launch_assemble(hipStream_t st, const DevSym &S, const int *list, const Asm
     static const int lds_wide_max = [] { const char *e = std::getenv("GMRFX_ASM_LDS_WIDE_MAX"); return e ? std::atoi(e) : 16384; }();
     if (ldmax <= lds_cols_max && ldmax <= 2048) {
         hipLaunchKernelGGL(k_assemble_lds<0>, dim3(odd(cdiv(max_cols, ASM_CW)), nfronts), dim3(256), (size_t)4 * ldmax * sizeof(double), st,
-                           S, arec, nzval, L, CB, ldmax);
+                           S, arec, nzp, L, CB, ldmax);
         return;
     }
     if (ldmax <= lds_wide_max && ldmax <= 16384) {
@@ -1480,7 +1489,7 @@ void launch_assemble(hipStream_t st, const DevSym &S, const int *list, const Asm
             static const bool once = [] { return hipFuncSetAttribute((const void *)k_assemble_lds<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072) == hipSuccess; }();
             if (!once) goto hbm;
         }
-        hipLaunchKernelGGL(k_assemble_lds<1>, dim3(odd(max_cols), nfronts), dim3(256), lds, st, S, arec, nzval, L, CB, ldmax);
+        hipLaunchKernelGGL(k_assemble_lds<1>, dim3(odd(max_cols), nfronts), dim3(256), lds, st, S, arec, nzp, L, CB, ldmax);
         return;
     }
 hbm:
