@@ -1036,7 +1036,19 @@ void Device::factor_levels(int lo, int hi) {
                             launch_potrf64(st, ds_, hl + cut[q], cut[q + 1] - cut[q], kb, d_L_, d_info_, f0, potrf_form_, std::min(wcls[q], L.max_cols));
                 } else
                     launch_potrf64(st, ds_, hl, act(b), kb, d_L_, d_info_, act(b) == 1 ? f1 : f0, potrf_form_, std::min(NB, L.max_cols - kb));
-                launch_trsm(st, ds_, hl, act(b), kb, 0, L.max_rows - kb - 1, d_L_, nullptr, nullptr, act(b) == 1 ? f1 : f0);
+                {
+                    // first block of a level with many fronts: the fronts at most 32 columns wide (the tail of the sorted list) go to
+                    // the narrow-block kernel (same arithmetic on half the registers: more resident waves)
+                    static const int narrow_min = [] { const char *e = std::getenv("GMRFX_TRSM_NARROW_MIN"); return e ? std::atoi(e) : 256; }();
+                    auto half = [&](int a) { return two ? (hf == 0 ? (a + 1) / 2 : a / 2) : a; };
+                    const int cut32 = b == 0 ? half(L.wider[1]) : act(b);
+                    const int nnarrow = act(b) - cut32;
+                    if (b == 0 && narrow_min > 0 && nnarrow >= narrow_min) {
+                        if (cut32 > 0) launch_trsm(st, ds_, hl, cut32, kb, 0, L.max_rows - kb - 1, d_L_, nullptr, nullptr, f0);
+                        launch_trsm_narrow(st, hl + cut32, nnarrow, kb, L.max_rows - kb - 1, d_L_);
+                    } else
+                        launch_trsm(st, ds_, hl, act(b), kb, 0, L.max_rows - kb - 1, d_L_, nullptr, nullptr, act(b) == 1 ? f1 : f0);
+                }
                 // two-level blocking: K = 64 updates only inside the current 256-column block, the
                 // rest of the panel once per block with K = 256
                 const int J1 = (b / OBK + 1) * OBK;   // first 64-block of the next 256-column block

@@ -229,6 +229,89 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
     }
 }
 
+// The same product for blocks at most 32 columns wide (the panels of the wide levels of the tree: thousands of narrow fronts per
+// launch). The general kernel holds 16 k-steps of operands and 8 accumulator tiles per wave and lives on three waves per SIMD;
+// half of that is never used here. 8 k-steps, 4 tiles, an 8 KB inverse block: five to six waves per SIMD. The k-steps that exist
+// are issued in the same order with the same operands: the same bits.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_trsm_narrow(const FrontView *__restrict__ frec, int kb, double *__restrict__ L) {
+    constexpr int W = 32;
+    __shared__ double Ti[W * W];
+    const FrontView fv = front_view(frec, blockIdx.y, FrontArg{0, 0, 0, 0, 0, 0, 0});
+    const int c = fv.c, r = fv.r;
+    if (kb >= c) return;
+    const int w = min(NB, c - kb);          // <= 32 by the launch's contract
+    const int row0 = kb + w + blockIdx.x * 128;
+    if (row0 >= r) return;
+    const int ld = fv.ld;
+    double *Pp = L + fv.pp;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lm = lane & 15, lk = lane >> 4;
+    double *A = Pp + (long long)kb * ld;
+    const int i0 = row0 + wave * 32;
+    const int i = i0 + 2 * lm;                     // this lane's row pair: i, i + 1
+    const double *pa = A + min(i, r - 1);
+    d2u bv[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const int q = 4 * u + lk;
+        bv[u] = *(const d2u *)(pa + (long long)min(q, w - 1) * ld);
+    }
+    {   // the inverse block: Ti[k * W + q] = Linv[k][q] (stored transposed in the strict upper triangle; diag = 1 / L[k][k])
+        const double *Dg = Pp + kb + (long long)kb * ld;
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int idx = threadIdx.x + 256 * u;
+            const int q = idx % W, k = idx / W;
+            const int qq = min(q, w - 1), kk = min(k, w - 1);
+            v[u] = Dg[min(qq, kk) + (long long)max(qq, kk) * ld];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int idx = threadIdx.x + 256 * u;
+            const int q = idx % W, k = idx / W;
+            const double mk = (k < w && q < k) ? 1.0 : 0.0;
+            double x = v[u] * mk;
+            if (q == k && k < w) x = fast_rcp(v[u]);
+            Ti[k * W + q] = x;
+        }
+    }
+    __syncthreads();
+    if (i0 >= r) return;
+    d4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int t = 0; t < 2; t++) acc[a][t] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const int q = 4 * u + lk;
+        if (4 * u < w) {
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                if (u <= 4 * t + 3) {
+                    const int k = t * 16 + lm;                                    // A[m=k][kk=q]
+                    const double av = Ti[k * W + q];
+                    acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[u].x, acc[0][t], 0, 0, 0);
+                    acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[u].y, acc[1][t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (i >= r) return;
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+            const int k = t * 16 + lk + 4 * rr;
+            if (k < w) {
+                double *dst = A + i + (long long)k * ld;
+                if (i + 1 < r) *(d2u *)dst = (d2u){acc[0][t][rr], acc[1][t][rr]};
+                else dst[0] = acc[0][t][rr];
+            }
+        }
+}
+
 // C[i,j] -= sum_k A[i,k] * B[j,k]  on 64x64 tiles (4 waves x 32x32), FP64 MFMA, operands read
 // straight from HBM/L2. The MFMA is issued "transposed" (first operand = rows of B) so that
 // the 16 lanes sharing a register index walk down a COLUMN of the column-major C.
@@ -1527,6 +1610,10 @@ void launch_trsm(hipStream_t st, const DevSym &S, const FrontView *frec, int nac
         if (split) hipLaunchKernelGGL((k_trsm<1, 1>), grid, dim3(256), 0, st, S, frec, kb, L, Yh, yoff, fa, la);
         else hipLaunchKernelGGL((k_trsm<1, 0>), grid, dim3(256), 0, st, S, frec, kb, L, Yh, yoff, fa, la);
     }
+}
+void launch_trsm_narrow(hipStream_t st, const FrontView *frec, int nactive, int kb, int max_rows_below, double *L) {
+    if (nactive <= 0 || max_rows_below <= 0) return;
+    hipLaunchKernelGGL(k_trsm_narrow, dim3(odd(cdiv(max_rows_below, 128)), nactive), dim3(256), 0, st, frec, kb, L);
 }
 void launch_gemm_nt(hipStream_t st, const DevSym &S, const FrontView *frec, int nactive, int k0, int K, int c0, int c1,
                     int maxM, int maxN, double *L, const FrontArg &fa, int band) {
