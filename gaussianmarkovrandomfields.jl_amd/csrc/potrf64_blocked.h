@@ -6,8 +6,11 @@
 //   * the DIAGONAL wave holds the current 16 x 16 diagonal block D and M (starts as I) in registers -- lane (i = lane & 15,
 //     q = lane >> 4) owns row i, columns 4 r + q -- and eliminates column by column (fully unrolled, every index static):
 //     pivot by v_readlane, column k to the four lanes of each row by ds_bpermute (the LDS crossbar, no LDS memory), row k
-//     inside each group of 16 lanes by DPP row_newbcast, then a[i][.] -= (a_ik / p) a[k][.] and the same on M. No barrier,
-//     no LDS round trip: ~35 instructions per column (tools/micro/diag16.hip). L[.][k] = a[.][k] rsqrt(p), L^-1 = diag(rsqrt p) M.
+//     inside each group of 16 lanes by a DPP row_newbcast that is PART of the update: a[i][.] -= (a_ik / p) a[k][.] is one
+//     v_fmac_f64_dpp per live register, and the same on M. 1 / p by v_rcp_f64 + two Newton steps; the columns are stored unscaled
+//     and the sixteen square roots taken once per block: L[.][k] = a[.][k] rsqrt(p_k), L^-1 = diag(rsqrt p) M. No barrier, no LDS
+//     round trip: 18 instructions per column, 150 cycles (a single wave issues one instruction per 6-8 cycles).
+//     (tools/micro/diag16.hip is the first form of this step: v_rsq_f64 per column and v_mov_dpp + v_fma_f64, 225 cycles per column.)
 //   * between two diagonal blocks the same wave forms the one strip block and the one update the NEXT diagonal block needs,
 //     L[d+1][d] = A[d+1][d] X_dd' and D_{d+1} -= L[d+1][d] L[d+1][d]', as 4 + 4 FP64 MFMAs whose operands are the registers it
 //     already holds (the register layout above IS an MFMA operand layout with the contraction index permuted)
@@ -15,8 +18,11 @@
 //     X_ij = -X_ii sum_k L_ik X_kj -- is 16 x 16 x 16 MFMA products on LDS-resident blocks, done by HELPER waves on the other
 //     three SIMDs while the diagonal wave eliminates the next block; two workgroup barriers per 16 columns hand over
 //     (X_dd published / L[d+1][d] published), and the helpers are waiting at both when the diagonal wave arrives.
+//     The helpers also scale L's columns, and every finished 64 x 16 block column of the panel leaves for memory while the next
+//     block is eliminated; the last row of the inverse goes from the helpers' registers straight to the panel.
 // Same results as the register-patch form up to rounding (LDL'-style elimination with reciprocal pivots instead of
 // square roots inside the updates): parity against the oracle as before, bit-identity only against itself.
+// 9.2 us per 64 x 64 block with its inverse (register-patch form: 16.0); cycle budget in DESIGN.md section 3.
 #pragma once
 #include <hip/hip_runtime.h>
 
