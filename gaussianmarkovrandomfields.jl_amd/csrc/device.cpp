@@ -24,6 +24,7 @@ void hip_check(hipError_t e, const char *what) {
 #define HC(x) hip_check((x), #x)
 
 static constexpr size_t kPairSlackBytes = 16;
+static constexpr size_t kChunkSlack = 16 * 320;      // doubles behind the factor storage (sweep_chunk.hip reads tiles without clamps)
 template <class T> T *Device::dalloc(size_t count) {
     // 16 bytes of slack behind every array: kernels that load rows in pairs (16 bytes per lane) may read one element
     // past the last one; the value is never used, but the address must be mapped
@@ -324,6 +325,35 @@ void Device::upload(const Symbolic &S) {
             T.rp0 = S.rowptr[f]; T.rp1 = S.rowptr[r + 1];
             T.rroot = S.rowptr[r] + S.ncols(r);
             T.woff = wp[r];
+            T.c0 = S.swc_ptr[t]; T.nch = S.swc_ptr[t + 1] - S.swc_ptr[t];
+            T.b0 = S.swc_bptr[t]; T.nbw = S.swc_bptr[t + 1] - S.swc_bptr[t];
+            for (int q = 0; q < 4; q++) { T.scnt[q] = S.swc_slot[(size_t)8 * t + q]; T.sbar[q] = S.swc_slot[(size_t)8 * t + 4 + q]; }
+        }
+        // chunk records and their target-row lists. The kernels take a target row as the BYTE offset of its column 0 in the
+        // local vector (row-major, NC columns, odd rows with their 16-column tiles swapped: sweep_chunk.hip, vbyte) and add
+        // the lane's column with one XOR; padding rows go to the spare row. Forward order per 32-row pair: [lk][tile][rr] =
+        // pair row 2 (lk + 4 rr) + tile; backward order per 16-row k-tile: [lk][h][e] = row 8 h + 2 lk + e.
+        nswc_ = S.swc_nchunks;
+        if (nswc_ > 0) {
+            const Symbolic::SwChunk *cp; up(cp, S.swc_fwd); d_swc_fwd_ = const_cast<Symbolic::SwChunk *>(cp);
+            up(cp, S.swc_bwd); d_swc_bwd_ = const_cast<Symbolic::SwChunk *>(cp);
+            const int nc = sweep_chunk_nc(), spare = sweep_chunk_spare_row();
+            auto enc = [&](i32 row) { const int r = row < 0 ? spare : row; return (r * nc + ((r & 1) << 4)) * 8; };
+            std::vector<int> lf(S.swc_rows.size()), lb(S.swc_rows.size());
+            for (size_t b0 = 0; b0 < S.swc_rows.size(); b0 += 32) {
+                const i32 *src = S.swc_rows.data() + b0;
+                for (int lk = 0; lk < 4; lk++)
+                    for (int tl = 0; tl < 2; tl++)
+                        for (int rr = 0; rr < 4; rr++) lf[b0 + lk * 8 + tl * 4 + rr] = enc(src[2 * (lk + 4 * rr) + tl]);
+                for (int kt = 0; kt < 2; kt++)
+                    for (int lk = 0; lk < 4; lk++)
+                        for (int h = 0; h < 2; h++)
+                            for (int e = 0; e < 2; e++) lb[b0 + 16 * kt + lk * 4 + h * 2 + e] = enc(src[16 * kt + 8 * h + 2 * lk + e]);
+            }
+            const int *a; up(a, lf); d_swc_listf_ = const_cast<int *>(a);
+            up(a, lb); d_swc_listb_ = const_cast<int *>(a);
+            HC(hipStreamSynchronize(stream));          // (the host vectors go out of scope)
+            d_dtile_ = dalloc<double>((size_t)nswc_ * 256);
         }
         const SweepTask *tp; up(tp, tk); d_swt_ = const_cast<SweepTask *>(tp);
         // wave tasks (sweep_wave.hip): the tasks by LDS class -- rows of the local vector <= kWaveRows[k] -- heaviest first inside
@@ -659,14 +689,16 @@ void Device::upload(const Symbolic &S) {
     // slack) and zeroed INCLUDING the slack, so the extra element is mapped and finite (it only ever meets a 0.0 mask).
     l_size_ = S.panelptr[ns];
     static_assert(kPairSlackBytes >= sizeof(double), "pair loads read one element past the end");
-    d_L_ = dalloc<double>((size_t)l_size_);
+    // (the chunk kernels of the sweep tasks read whole 16-column / 16-row tiles from a chunk's first element without clamps: for
+    //  the last task panel of the buffer that is up to 16 columns of <= 304 rows past its end -- mapped, zero, never used)
+    d_L_ = dalloc<double>((size_t)l_size_ + kChunkSlack);
     d_cb_ = dalloc<double>((size_t)S.cb_arena);
     d_nz_ = dalloc<double>((size_t)S.nnz_in);
     d_info_ = dalloc<int>(2);
     d_chain_ = dalloc<int>(kChainErrWord + 8);          // persistent panel chain: 8 flag words per front + the error word
     HC(hipMemset(d_chain_, 0, (kChainErrWord + 8) * sizeof(int)));
     d_part_ = dalloc<double>(1024 + 8);
-    HC(hipMemsetAsync(d_L_, 0, (size_t)l_size_ * sizeof(double) + kPairSlackBytes, stream));
+    HC(hipMemsetAsync(d_L_, 0, ((size_t)l_size_ + kChunkSlack) * sizeof(double) + kPairSlackBytes, stream));
     HC(hipStreamSynchronize(stream));
 }
 
@@ -1481,7 +1513,9 @@ void Device::sweep_tasks(int phase, int nr, int ldx) {
         // (measured at cfg 2, round 4: the level under which the task kernel runs 1.40 -> 1.15 ms (0.95 alone), step 14.19 -> 14.03 ms)
         static const int pad_kb = [] { const char *e = std::getenv("GMRFX_FUSED_TASK_LDS"); return e ? std::max(0, std::atoi(e)) : 8; }();
         const size_t extra = (fused_fwd_ && phase == 1) ? (size_t)pad_kb * 1024 : 0;
-        launch_sweep_tasks(stream, ds_, phase, d_swt_, nswt_, d_L_, d_X_, phase == 1 ? d_W_ : nullptr, nr, ldx, extra);
+        ensure_dtile();
+        launch_sweep_chunks(stream, ds_, phase, d_swt_, nswt_, d_swc_fwd_, d_swc_bwd_, d_swc_listf_, d_swc_listb_, d_dtile_, d_L_, d_X_,
+                            phase == 1 ? d_W_ : nullptr, nr, ldx, extra);
         return;
     }
     ensure_rdiag();
@@ -1501,6 +1535,14 @@ void Device::ensure_rdiag() {
     rdiag_for_ = factor_serial_;
 }
 
+// the chunks' inverse diagonal blocks in MFMA operand order, once per factorisation, on the current `stream` (solve() calls
+// this BEFORE its lanes fork; the pipelined call behind the gate event, when the task fronts are final)
+void Device::ensure_dtile() {
+    if (nswc_ <= 0 || dtile_for_ == factor_serial_) return;
+    launch_pack_diag(stream, d_swc_bwd_, nswc_, d_L_, d_dtile_);      // (the backward records hold every chunk once)
+    dtile_for_ = factor_serial_;
+}
+
 void Device::forward(int nr, int ldx, int lo, int hi) {
     if (level_mark_ && lo == 0) { launch_level_mark(stream, 1, -1); level_event(1, 0); }
     // pipelined factor + solve (refactorize_solve): the bottom waits for the highest level a task / subtree reaches, every level
@@ -1508,6 +1550,7 @@ void Device::forward(int nr, int ldx, int lo, int hi) {
     if (fused_fwd_) {
         HC(hipStreamWaitEvent(stream, ev_flevel_[fused_gate_level_], 0));
         if (nr <= wave_max_nr_ && nswt_ > 0) rdiag_for_ = 0;      // 1 / L_jj of the task fronts: their diagonals are final now, the rest is never read
+        dtile_for_ = 0;                                            // (the same for the chunks' inverse diagonal blocks)
     }
     if (lo == 0) sweep_tasks(1, nr, ldx);
     if (lo == 0)
@@ -1625,6 +1668,7 @@ void Device::solve_phase(const double *d_B, long long ldb, long long nrhs, doubl
         ensure_rhs_capacity(nrhs);
         start_inverse_async();
         ensure_rdiag();
+        ensure_dtile();
         launch_permute(stream, d_iperm_, (int)n, const_cast<double *>(d_B), ldb, d_X_, nr, ldx, 0);
         forward(nr, ldx, 0, split);
     } else if (phase >= 100 && phase < 100 + (nl - split)) {       // forward, top level split + (phase - 100)
@@ -1639,6 +1683,7 @@ void Device::solve_phase(const double *d_B, long long ldb, long long nrhs, doubl
         ensure_rhs_capacity(nrhs);
         start_inverse_async();
         ensure_rdiag();
+        ensure_dtile();
         launch_permute(stream, nullptr, (int)n, const_cast<double *>(d_B), ldb, d_X_, nr, ldx, 0);
     } else if (phase >= 300 && phase < 300 + (nl - split)) {       // backward-only solve, top level split + (phase - 300)
         const int lev = split + phase - 300;
@@ -1667,6 +1712,7 @@ void Device::solve(const double *B, long long ldb, long long nrhs, double *X, lo
     ensure_rhs_capacity(nrhs);
     start_inverse_async();
     ensure_rdiag();
+    ensure_dtile();
     const double *dB = B;
     double *dXo = X;
     long long ldin = ldb, ldout = ldx_out;

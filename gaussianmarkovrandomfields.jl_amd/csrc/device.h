@@ -66,6 +66,11 @@ struct SweepTask {
     long long rp0, rp1;    // its range in the row / local-row lists
     long long rroot;       // offset of the root's trailing rows in DevSym::rows
     long long woff;        // DevSym::wptr[root]
+    // chunk form (sweep_chunk.hip; Symbolic::swc_*): first chunk record / number of chunks, the backward programs of the four
+    // row-tile slots (chunks per slot, barriers behind a slot's last chunk)
+    int c0, nch;           // forward records
+    int b0, nbw;           // backward records (every chunk once)
+    int scnt[4], sbar[4];
 };
 
 // geometry of one front for the panel kernels: in the kernel arguments (FrontArg) or one record per level-list position
@@ -301,6 +306,12 @@ public:
     void dist_front_phase(const double *d_nzval, int front, int what, int block);
 private:
     void ensure_rdiag();
+    void ensure_dtile();
+    Symbolic::SwChunk *d_swc_fwd_ = nullptr, *d_swc_bwd_ = nullptr;   // chunk records of the sweep tasks (forward order / backward slot programs)
+    int *d_swc_listf_ = nullptr, *d_swc_listb_ = nullptr;               // their target rows as LDS byte offsets, in the lane order of the two kernels
+    double *d_dtile_ = nullptr;                   // inverse diagonal blocks of the chunks, packed (k_pack_diag): 256 doubles per chunk
+    int nswc_ = 0;
+    unsigned long long dtile_for_ = 0;            // d_dtile_ belongs to factorisation number dtile_for_
     double *d_rdiag_ = nullptr;                   // n reciprocals of L's diagonal (+ a zero word): operands of the wave tasks
     unsigned long long factor_serial_ = 1, rdiag_for_ = 0;    // d_rdiag_ belongs to factorisation number rdiag_for_
     std::vector<int> sel_max_cols_, sel_max_trail_;   // per level, over the big fronts of the selected-inversion list

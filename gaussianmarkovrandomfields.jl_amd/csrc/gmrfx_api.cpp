@@ -921,6 +921,28 @@ extern "C" int32_t gmrfx_symbolic_sweep_tasks(const gmrfx_handle *h, int64_t *nt
     return GMRFX_OK;
 }
 
+extern "C" int32_t gmrfx_symbolic_sweep_chunks(const gmrfx_handle *h, int64_t *nchunks, int64_t *nrows, int64_t *task_ptr,
+                                               int64_t *slot, int64_t *fwd, int64_t *bwd, int64_t *rows) {
+    if (!h || !nchunks) return GMRFX_ERR_INVALID_ARG;
+    const Symbolic &S = h->S;
+    nchunks[0] = (int64_t)S.swc_fwd.size();
+    nchunks[1] = (int64_t)S.swc_bwd.size();
+    if (nrows) *nrows = (int64_t)S.swc_rows.size();
+    if (task_ptr) for (size_t k = 0; k < S.swc_ptr.size(); k++) { task_ptr[2 * k] = S.swc_ptr[k]; task_ptr[2 * k + 1] = S.swc_bptr[k]; }
+    if (slot) for (size_t k = 0; k < S.swc_slot.size(); k++) slot[k] = S.swc_slot[k];
+    auto put = [](const std::vector<Symbolic::SwChunk> &v, int64_t *out) {
+        for (size_t k = 0; k < v.size(); k++) {
+            const Symbolic::SwChunk &c = v[k];
+            int64_t *o = out + 8 * k;
+            o[0] = c.pa; o[1] = c.ld; o[2] = c.o; o[3] = c.cc; o[4] = c.nt; o[5] = c.lr; o[6] = c.nbar; o[7] = c.id;
+        }
+    };
+    if (fwd) put(S.swc_fwd, fwd);
+    if (bwd) put(S.swc_bwd, bwd);
+    if (rows) for (size_t k = 0; k < S.swc_rows.size(); k++) rows[k] = S.swc_rows[k];
+    return GMRFX_OK;
+}
+
 extern "C" int32_t gmrfx_get_factor_values(gmrfx_handle *h, double *out) {
     return guarded(h, [&]() -> int32_t {
         if (int32_t e = need_device(h, true)) return e;

@@ -441,6 +441,13 @@ void launch_bwd_small(hipStream_t st, const DevSym &S, const int *list, int nfro
                       double *X, int nr, int ldx);
 
 // sweep_task.hip -- whole bottom subtrees on an LDS-resident local vector: phase 1 forward, 2 backward
+// chunk form of the sweep tasks (sweep_chunk.hip)
+void launch_pack_diag(hipStream_t st, const Symbolic::SwChunk *recs, int nchunks, const double *L, double *dtile);
+void launch_sweep_chunks(hipStream_t st, const DevSym &S, int phase, const SweepTask *tasks, int ntasks, const Symbolic::SwChunk *recs_fwd,
+                         const Symbolic::SwChunk *recs_bwd, const int *listf, const int *listb, const double *dtile, const double *L,
+                         double *X, double *W, int nr, int ldx, size_t extra_lds);
+int sweep_chunk_nc();
+int sweep_chunk_spare_row();
 void launch_sweep_tasks(hipStream_t st, const DevSym &S, int phase, const SweepTask *tasks, int ntasks,
                         const double *L, double *X, double *W, int nr, int ldx, size_t extra_lds = 0);
 

@@ -124,6 +124,13 @@ void colcounts(i64 n, const std::vector<i64> &up, const std::vector<i32> &ui,
 
 }  // namespace
 
+// Doubles a panel of c columns with leading dimension ld occupies in the factor storage: its columns are padded with zero
+// columns to a multiple of 4 (one FP64-MFMA k-step) and followed by at least 16 zero doubles, rounded to 128 bytes. The
+// padding is never written (the buffer is zeroed once): the chunk kernels of the sweep tasks (sweep_chunk.hip) read whole
+// k-steps and whole 16-row tiles without clamps, and what they read beyond a panel's entries is either the same panel's
+// next column or these zeros.
+static inline i64 panel_span(i64 ld, i64 c) { return (ld * ((c + 3) & ~i64(3)) + 16 + 15) & ~i64(15); }
+
 void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *user_perm,
              const SymOptions &opt, Symbolic &S) {
     auto t0 = std::chrono::steady_clock::now();
@@ -363,8 +370,7 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
         i64 ld = (r + 1) & ~i64(1);
         S.ld[s] = (i32)ld;
         S.panelptr[s] = off;
-        off += ld * c;
-        off = (off + 15) & ~i64(15);  // 128-byte aligned panels
+        off += panel_span(ld, c);     // 128-byte aligned panels, zero columns up to a multiple of 4, >= 16 zero doubles behind
         S.cbptr[s] = cb;
         i64 m = r - c;
         cb += m * m;
@@ -574,7 +580,7 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
         i64 off = 0;
         for (i32 s = 0; s < ns; s++) {
             S.panelptr[s] = off;
-            if (S.stored_here(s)) { off += (i64)S.ld[s] * S.ncols(s); off = (off + 15) & ~i64(15); }
+            if (S.stored_here(s)) off += panel_span(S.ld[s], S.ncols(s));
         }
         S.panelptr[ns] = off;
         for (i32 s = 0; s < ns; s++)
@@ -682,18 +688,21 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
         const int rcap = opt.subtree_max > 0 ? 0 : std::min(288,   // (not with the legacy subtree tasks)
                                                                                opt.sweep_task_rows >= 0 ? opt.sweep_task_rows : 288);   // 288 = TASK_ROWS of sweep_task.hip
         S.swt_rows = rcap;
-        std::vector<i32> cnt(ns, 1), ncol(ns, 0), maxc(ns, 0);
+        std::vector<i32> cnt(ns, 1), ncol(ns, 0), maxc(ns, 0), nchk(ns, 0);
         std::vector<double> work(ns, 0.0);
         std::vector<uint8_t> ok(ns, 0);
         for (i32 s = 0; s < ns; s++) {
             ncol[s] += S.ncols(s);
             maxc[s] = std::max(maxc[s], S.ncols(s));
+            for (i32 j0 = 0; j0 < S.ncols(s); j0 += 16)       // forward chunk records of this front (<= 128 target rows each)
+                nchk[s] += std::max(1, (S.nrows(s) - std::min(S.ncols(s), j0 + 16) + 127) / 128);
             work[s] += (double)S.nrows(s) * S.ncols(s);
             bool good = rcap > 0;
             for (i64 q = S.childptr[s]; q < S.childptr[s + 1]; q++) good = good && ok[S.children[q]];
-            ok[s] = good && !S.is_top[s] && maxc[s] <= 64 && ncol[s] + (S.nrows(s) - S.ncols(s)) <= rcap && cnt[s] <= 64;
+            // (chunk kernels: at most 96 chunk records per task in LDS)
+            ok[s] = good && !S.is_top[s] && maxc[s] <= 64 && ncol[s] + (S.nrows(s) - S.ncols(s)) <= rcap && cnt[s] <= 64 && nchk[s] <= 96;
             const i32 p = S.sparent[s];
-            if (p != -1) { cnt[p] += cnt[s]; ncol[p] += ncol[s]; maxc[p] = std::max(maxc[p], maxc[s]); work[p] += work[s]; }
+            if (p != -1) { cnt[p] += cnt[s]; ncol[p] += ncol[s]; maxc[p] = std::max(maxc[p], maxc[s]); work[p] += work[s]; nchk[p] += nchk[s]; }
         }
         std::vector<i32> roots;
         for (i32 s = 0; s < ns; s++) {
@@ -727,7 +736,75 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
                     }
                 }
             }
+            // ---- the task's chunks (symbolic.h: SwChunk) ----
+            S.swc_ptr.push_back((i32)S.swc_fwd.size());
+            S.swc_bptr.push_back((i32)S.swc_bwd.size());
+            std::vector<Symbolic::SwChunk> real;                    // the task's chunks, postorder (ids are global: one packed diagonal tile each)
+            std::vector<i32> first_chunk(t - f + 2, 0);             // per front of the task: index of its first chunk in `real`
+            for (i32 d = f; d <= t; d++) {
+                const i32 cd = S.ncols(d), rd = S.nrows(d), od = S.sfirst[d] - col0;
+                first_chunk[d - f] = (i32)real.size();
+                for (i32 j0 = 0; j0 < cd; j0 += 16) {
+                    Symbolic::SwChunk ch;
+                    const i32 cc = std::min(16, cd - j0), row0 = j0 + cc;
+                    ch.pa = S.panelptr[d] + (i64)j0 * S.ld[d] + row0;
+                    ch.ld = S.ld[d];
+                    ch.o = (int16_t)(od + j0);
+                    ch.cc = (int16_t)cc;
+                    ch.nt = rd - row0;
+                    ch.lr = (i32)S.swc_rows.size();
+                    ch.nbar = 0;
+                    ch.id = S.swc_nchunks++;
+                    for (i32 k = row0; k < rd; k++) S.swc_rows.push_back(k < cd ? od + k : S.lrow[S.rowptr[d] + k]);
+                    while ((S.swc_rows.size() - (size_t)ch.lr) % 32) S.swc_rows.push_back(-1);
+                    real.push_back(ch);
+                    // forward records: at most 128 target rows each (one pair of 16-row tiles per row-tile slot); a longer
+                    // chunk becomes several records with the same diagonal block -- every one recomputes the same y
+                    for (i32 k0 = 0; k0 == 0 || k0 < ch.nt; k0 += 128) {
+                        Symbolic::SwChunk part = ch;
+                        part.pa += k0; part.lr += k0; part.nt = std::min(128, ch.nt - k0);
+                        S.swc_fwd.push_back(part);
+                    }
+                }
+            }
+            first_chunk[t - f + 1] = (i32)real.size();
+            // backward programs: depth of a chunk in the chunk tree (root front's LAST chunk = depth 0; inside a front the
+            // chunks run last to first; a child front starts below its parent's first chunk)
+            const i32 nch = (i32)real.size();
+            std::vector<i32> depth(nch, 0), dstart(t - f + 1, 0);
+            i32 ngroups = 0;
+            for (i32 d = t; d >= f; d--) {
+                const i32 c0 = first_chunk[d - f], c1 = first_chunk[d - f + 1];
+                i32 ds = 0;
+                if (d != t) { const i32 p = S.sparent[d]; ds = dstart[p - f] + (first_chunk[p - f + 1] - first_chunk[p - f]); }
+                dstart[d - f] = ds;
+                for (i32 q = c1 - 1; q >= c0; q--) { depth[q] = ds + (c1 - 1 - q); ngroups = std::max(ngroups, depth[q] + 1); }
+            }
+            std::vector<i32> order(nch);
+            std::iota(order.begin(), order.end(), 0);
+            std::stable_sort(order.begin(), order.end(), [&](i32 a, i32 b) { return depth[a] != depth[b] ? depth[a] < depth[b] : a > b; });
+            std::vector<std::vector<i32>> prog(Symbolic::kSwSlots);
+            for (i32 k = 0, g0 = 0; k < nch; k++) {
+                if (k > 0 && depth[order[k]] != depth[order[k - 1]]) g0 = k;
+                prog[(k - g0) % Symbolic::kSwSlots].push_back(order[k]);
+            }
+            for (int q = 0; q < Symbolic::kSwSlots; q++) {
+                i32 passed = 0;
+                for (i32 ci : prog[q]) {
+                    Symbolic::SwChunk ch = real[ci];
+                    ch.nbar = depth[ci] - passed;
+                    passed = depth[ci];
+                    S.swc_bwd.push_back(ch);
+                }
+                S.swc_slot.push_back((i32)prog[q].size());
+            }
+            for (int q = 0; q < Symbolic::kSwSlots; q++) {
+                const i32 passed = prog[q].empty() ? 0 : depth[prog[q].back()];
+                S.swc_slot.push_back(ngroups - passed);
+            }
         }
+        S.swc_ptr.push_back((i32)S.swc_fwd.size());
+        S.swc_bptr.push_back((i32)S.swc_bwd.size());
     }
     S.sw_levelptr.assign(S.nlevels + 1, 0);
     for (i32 s = 0; s < ns; s++) if (!S.in_subtree[s] && !S.in_swt[s] && mine(s)) S.sw_levelptr[S.level[s] + 1]++;

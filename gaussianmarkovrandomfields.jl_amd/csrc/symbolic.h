@@ -97,6 +97,34 @@ struct Symbolic {
     int swt_rows = 0;
     std::vector<i64> sw_levelptr;
     std::vector<i32> sw_levellist, sw_level_nsmall, sw_level_ncls;
+    // CHUNKS of the sweep tasks (round 5, sweep_chunk.hip). Every task front is cut into column chunks of at most 16 columns;
+    // a chunk is a narrow front of its own: 16 x 16 diagonal block (its inverse is a diagonal block of L11^-1), targets = the
+    // panel rows below it (the own rows of the front's later chunks, then the front's trailing rows), K = its columns. The
+    // forward sweep runs a task's chunks one after the other (postorder; ONE barrier per chunk, all row-tile slots of the
+    // workgroup on the chunk's target rows). The backward sweep runs the chunk TREE (chain inside a front, the supernodal
+    // tree across fronts) depth by depth: chunks of one depth are independent (they write their own rows of the local vector
+    // and read rows of finished ancestors), slot q takes the chunks at positions q, q + 4, ... of a depth -- per slot a
+    // program of chunks, each with the number of workgroup barriers the slot passes before it (all slots pass the same
+    // number in total). Target rows are LOCAL rows of the task, padded to multiples of 32 with -1 (the kernels send those
+    // to a spare row), so the kernels need no clamps and no masks.
+    struct SwChunk {
+        i64 pa;        // offset (doubles) of element (first target row, first column) of the chunk in the factor storage
+        i32 ld;        // leading dimension of its panel
+        int16_t o;     // local row of its first own column
+        int16_t cc;    // columns (1..16)
+        i32 nt;        // target rows (panel rows below the chunk's diagonal block)
+        i32 lr;        // offset of its target rows in swc_rows (padded to a multiple of 32)
+        i32 nbar;      // backward programs: workgroup barriers this slot passes before the chunk
+        i32 id;        // number of the chunk (= its packed diagonal tile), 0 .. swc_nchunks - 1
+    };
+    static constexpr int kSwSlots = 4;
+    std::vector<SwChunk> swc_fwd;           // all tasks, task by task, postorder; a chunk with more than 128 target rows as several
+                                            // records of <= 128 (same diagonal block: each recomputes the same y)
+    std::vector<SwChunk> swc_bwd;           // every chunk once, per task the programs of slot 0, 1, 2, 3 one after the other
+    std::vector<i32> swc_ptr, swc_bptr;     // ntasks + 1: first record of a task in swc_fwd / swc_bwd
+    i32 swc_nchunks = 0;
+    std::vector<i32> swc_slot;              // ntasks x 8: chunks in the program of slot 0..3, then barriers behind the last chunk of slot 0..3
+    std::vector<i32> swc_rows;              // padded target-row lists (local rows, -1 = padding)
     // Sharding over `shard_world` ranks (every rank runs the same analysis and gets the same answer). The supernodal
     // tree is cut top-down into subtrees dealt to the ranks (LPT on factorisation flops); the fronts above them -- the
     // TOP, is_top[s] -- are owned ONE BY ONE by a rank of the group whose subtrees they join (the least loaded owner of

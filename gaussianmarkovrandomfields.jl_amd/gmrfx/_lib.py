@@ -65,7 +65,7 @@ EXPORTS = [
     "gmrfx_shard_rows", "gmrfx_set_prior", "gmrfx_refactorize_update", "gmrfx_refactorize_update_dev",
     "gmrfx_quadform", "gmrfx_quadform_dev", "gmrfx_selinv_dot", "gmrfx_selinv_row_diag", "gmrfx_kl_cholesky",
     "gmrfx_selinv_row_diag_plan", "gmrfx_selinv_row_diag_apply", "gmrfx_selinv_row_diag_free",
-    "gmrfx_symbolic_sweep_tasks", "gmrfx_selinv_phase",
+    "gmrfx_symbolic_sweep_tasks", "gmrfx_symbolic_sweep_chunks", "gmrfx_selinv_phase",
 ]
 
 
@@ -115,6 +115,7 @@ def lib():
         L.gmrfx_symbolic_sizes.argtypes = [vp, vp]
         L.gmrfx_symbolic_get.argtypes = [vp] + [vp] * 10
         L.gmrfx_symbolic_sweep_tasks.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), vp, vp, vp]
+        L.gmrfx_symbolic_sweep_chunks.argtypes = [vp, vp, C.POINTER(i64), vp, vp, vp, vp, vp]
         L.gmrfx_get_factor_values.argtypes = [vp, vp]
         L.gmrfx_refactorize_phase.argtypes = [vp, vp, i32]
         L.gmrfx_shard_info.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]

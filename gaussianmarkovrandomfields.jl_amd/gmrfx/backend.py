@@ -312,6 +312,18 @@ class MI355XBackend:
         check(lib().gmrfx_symbolic_sweep_tasks(self._h, C.byref(nt), C.byref(cap), ptr(first), ptr(last), ptr(lrow)))
         return int(cap.value), first, last, lrow
 
+    def sweep_chunks(self) -> dict:
+        """The tasks' chunks (include/gmrfx.h: gmrfx_symbolic_sweep_chunks): task_ptr (ntasks + 1 x 2: first forward / backward
+        record), slot (ntasks x 8), fwd / bwd (records x 8: pa, ld, o, cc, nt, lr, nbar, id), rows (padded target-row lists)."""
+        nc, nr = np.zeros(2, np.int64), C.c_int64(0)
+        check(lib().gmrfx_symbolic_sweep_chunks(self._h, ptr(nc), C.byref(nr), None, None, None, None, None))
+        nt = C.c_int64(0)
+        check(lib().gmrfx_symbolic_sweep_tasks(self._h, C.byref(nt), None, None, None, None))
+        out = dict(task_ptr=np.empty((nt.value + 1, 2), np.int64), slot=np.empty((nt.value, 8), np.int64),
+                   fwd=np.empty((int(nc[0]), 8), np.int64), bwd=np.empty((int(nc[1]), 8), np.int64), rows=np.empty(nr.value, np.int64))
+        check(lib().gmrfx_symbolic_sweep_chunks(self._h, ptr(nc), C.byref(nr), *[ptr(out[k]) for k in ("task_ptr", "slot", "fwd", "bwd", "rows")]))
+        return out
+
     def factor_values(self) -> np.ndarray:
         sizes = np.zeros(8, np.int64)
         check(lib().gmrfx_symbolic_sizes(self._h, ptr(sizes)))

@@ -211,3 +211,31 @@ def random_spd_precision(n: int, density: float = 0.3, seed: int = 42) -> sp.csc
     Q.indices = Q.indices.astype(np.int64)
     Q.indptr = Q.indptr.astype(np.int64)
     return Q
+
+
+def tall_front_precision(nblocks: int = 6, bw: int = 8, sep: int = 150, part: int = 30, seed: int = 7):
+    """A test precision whose natural order gives TALL, NARROW fronts: nblocks pairs of dense bw-node blocks (A_i, B_i); A_i is
+    coupled to B_i and to `part` nodes of a dense `sep`-node separator, B_i to the whole separator. In the order A_1, B_1, ...,
+    A_n, B_n, separator every B_i is a front of bw columns and bw + sep rows (more than 128 rows below its diagonal block: the
+    long-chunk path of the sweep tasks). Returns (Q, natural ordering keyword)."""
+    rng = np.random.default_rng(seed)
+    n = 2 * nblocks * bw + sep
+    A = sp.lil_matrix((n, n))
+    s0 = 2 * nblocks * bw
+    for i in range(nblocks):
+        a0, b0 = 2 * i * bw, (2 * i + 1) * bw
+        A[a0:a0 + bw, a0:a0 + bw] = rng.uniform(-1, 1, (bw, bw))
+        A[b0:b0 + bw, b0:b0 + bw] = rng.uniform(-1, 1, (bw, bw))
+        A[b0:b0 + bw, a0:a0 + bw] = rng.uniform(-1, 1, (bw, bw))
+        cols = s0 + rng.choice(sep, part, replace=False)
+        for cidx in cols:
+            A[cidx, a0:a0 + bw] = rng.uniform(-1, 1, bw)
+        A[s0:s0 + sep, b0:b0 + bw] = rng.uniform(-1, 1, (sep, bw))
+    A[s0:, s0:] = rng.uniform(-1, 1, (sep, sep))
+    A = sp.csc_matrix(A)
+    M = sp.tril(A) + sp.tril(A, -1).T
+    Q = (M + sp.diags(np.asarray(abs(M).sum(axis=1)).ravel() + 1.0)).tocsc()
+    Q.sort_indices()
+    Q.indices = Q.indices.astype(np.int64)
+    Q.indptr = Q.indptr.astype(np.int64)
+    return Q

@@ -323,6 +323,17 @@ int32_t gmrfx_symbolic_get(const gmrfx_handle *h, int64_t *super_first, int64_t 
  * every entry of the supernode row lists, the local row inside its task (-1 outside tasks / for own rows). */
 int32_t gmrfx_symbolic_sweep_tasks(const gmrfx_handle *h, int64_t *ntasks, int64_t *rows_cap, int64_t *first,
                                    int64_t *last, int64_t *lrow);
+/* The tasks' CHUNKS (csrc/sweep_chunk.hip; host analysis, testing / inspection): every task front cut into column blocks
+ * of at most 16 columns, each a narrow front of its own (targets = the panel rows below its diagonal block). nchunks (two
+ * values: forward records -- a chunk with more than 128 target rows is several records -- and backward records = chunks) /
+ * nrows always; when non-null: task_ptr (2 per task + 2: first forward / backward record of a task), slot (8 per task: chunks in the backward
+ * program of row-tile slot 0..3, then the barriers each slot passes behind its last chunk), fwd / bwd (8 per chunk:
+ * offset of (first target row, first column) in the factor storage, panel ld, local row of the first own column,
+ * columns, target rows, offset of its padded target-row list in rows, barriers passed before it (backward programs),
+ * number of the chunk; fwd = task by task in postorder, bwd = per task the programs of slot 0, 1, 2, 3), rows
+ * (nrows: local rows of the targets, every list padded with -1 to a multiple of 32). */
+int32_t gmrfx_symbolic_sweep_chunks(const gmrfx_handle *h, int64_t *nchunks, int64_t *nrows, int64_t *task_ptr,
+                                    int64_t *slot, int64_t *fwd, int64_t *bwd, int64_t *rows);
 int32_t gmrfx_get_factor_values(gmrfx_handle *h, double *out);
 
 /* KL-optimal sparse approximate Cholesky factor, L L' ~ Theta^-1: a batch of small dense problems, one

@@ -29,6 +29,7 @@ def _cases():
     yield "matern3d_10", spde.matern_precision(m3, 0, 0.5), {"coords": m3.points}
     yield "natural_chain", spde.matern_precision(spde.grid_mesh_2d(14, 14), 0, 0.3), {"ordering": "natural"}
     yield "dense70", sp.csc_matrix(np.cov(np.random.default_rng(3).standard_normal((70, 300))) + np.eye(70)), {}
+    yield "tall_fronts", spde.tall_front_precision(), {"ordering": "natural", "relax_cols": 1, "relax_zeros": 1e-9}
     yield "scalar", sp.csc_matrix(np.array([[2.5]])), {}
     yield "diag", sp.diags(np.arange(1.0, 40.0)).tocsc(), {}
 

@@ -263,3 +263,132 @@ def test_schedule_shape_levels_by_depth_and_wide_supernodes_end_at_branching_col
     assert st1["nnz_l"] == st["nnz_l"] and abs(st1["factor_flops"] - st["factor_flops"]) <= 1e-9 * st["factor_flops"]
     ld1 = HostSim(sy1, n, np.asarray(Q.data)).factor().logdet()
     assert abs(ld - ld1) <= 1e-12 * abs(ld)
+
+
+@pytest.mark.parametrize("shape", ["2d", "2d_wide", "3d", "rand", "tall"])
+def test_sweep_chunks_programs_walk(shape, monkeypatch):
+    """Round 5 (csrc/sweep_chunk.hip): the tasks' CHUNK programs restated in numpy on the exported structures. Forward: the
+    chunks of a task one after the other, y = (diagonal 16 x 16 block)^-1 V[own], V[targets] -= L[targets, chunk] y with the
+    padded target lists (padding goes to a spare row). Backward: the four slot programs with their barrier counts -- chunks
+    between the same pair of barriers must be independent (nobody reads a row another one writes) -- t = V[own] -
+    L[targets, chunk]' V[targets], x = (diagonal block)^-T t. Both against dense substitution with the host factor."""
+    from mf_hostsim import HostSim
+    if shape == "2d":
+        m = spde.grid_mesh_2d(60, 47, jitter=0.25, seed=4)
+        Q, kw = sp.csc_matrix(spde.matern_precision(m, 0, 0.3)), {"coords": m.points}
+    elif shape == "2d_wide":          # alpha = 3 (37-point stencil) and a coarse amalgamation: task fronts of 2-4 chunks
+        m = spde.grid_mesh_2d(40, 33, jitter=0.25, seed=5)
+        Q, kw = sp.csc_matrix(spde.matern_precision(m, 1, 0.3)), {"coords": m.points, "relax_cols": 64, "relax_zeros": 0.4}
+    elif shape == "3d":
+        m = spde.grid_mesh_3d(9, 8, 10)
+        Q, kw = sp.csc_matrix(spde.matern_precision(m, 0, 0.5)), {"coords": m.points}
+    elif shape == "tall":             # fronts of 8 columns and 158 rows: chunks with more than 128 target rows (several forward records)
+        Q, kw = spde.tall_front_precision(), {"ordering": "natural", "relax_cols": 1, "relax_zeros": 1e-9}
+    else:
+        Q, kw = spde.random_spd_precision(300, 0.01), {}
+    n = Q.shape[0]
+    b = gmrfx.MI355XBackend(Q, symbolic_only=True, **kw)
+    sy = b.symbolic()
+    cap, first, last, lrow = b.sweep_tasks()
+    ck = b.sweep_chunks()
+    if shape == "tall":
+        assert len(ck["fwd"]) > len(ck["bwd"]) > 0
+    c = np.diff(sy.super_first); r = np.diff(sy.row_ptr)
+    hs = HostSim(sy, n, Q.data).factor()
+    Ld = hs.dense_from_panels(hs.L)
+    rng = np.random.default_rng(0)
+    Bp = rng.standard_normal((n, 3))
+    Yref = np.linalg.solve(Ld, Bp)
+    Xref = np.linalg.solve(Ld.T, Yref)
+    Lflat = hs.L
+    SPARE = 304
+    assert len(ck["task_ptr"]) == len(first) + 1 and ck["task_ptr"][-1, 0] == len(ck["fwd"]) and ck["task_ptr"][-1, 1] == len(ck["bwd"])
+    assert len(ck["rows"]) % 32 == 0
+    wide = 0
+    for t, (f, l) in enumerate(zip(first, last)):
+        col0, col1 = sy.super_first[f], sy.super_first[l + 1]
+        nt = col1 - col0
+        mroot = r[l] - c[l]
+        (c0, b0), (c1, b1) = ck["task_ptr"][t], ck["task_ptr"][t + 1]
+        assert b1 - b0 == sum((c[s] + 15) // 16 for s in range(f, l + 1)) and b1 - b0 <= c1 - c0 <= 96
+        wide += int((c[f:l + 1] > 16).sum())
+
+        def operands(rec, part=False):
+            pa, ld, o, cc, ntg, lr, nbar, cid = (int(v) for v in rec)
+            assert 1 <= cc <= 16 and 0 <= o and o + cc <= nt and 0 <= ntg
+            npad = (ntg + 31) // 32 * 32
+            rows = ck["rows"][lr:lr + npad].copy()
+            assert (rows[:ntg] >= 0).all() and (rows[:ntg] < nt + mroot).all() and (rows[ntg:] == -1).all()
+            D = None if part else np.array([[Lflat[pa - cc + i + j * ld] for j in range(cc)] for i in range(cc)])   # cc rows above the first target row
+            A = np.array([[Lflat[pa + i + j * ld] for j in range(cc)] for i in range(ntg)]).reshape(ntg, cc)
+            return o, cc, ntg, rows, (None if part else np.tril(D)), A, cid
+
+        # ---- forward ----
+        V = np.zeros((SPARE + 1, 3))
+        V[:nt] = Bp[col0:col1]
+        ids, prev = [], None
+        for rec in ck["fwd"][c0:c1]:
+            # a chunk with more than 128 target rows comes as several records: the same diagonal block (found through the
+            # first record: the others start 128 rows further down), the next <= 128 target rows
+            part = prev is not None and int(rec[7]) == prev[0]
+            o, cc, ntg, rows, D, A, cid = operands(rec, part)
+            assert ntg <= 128
+            if part:
+                assert (o, cc) == prev[1:3] and int(rec[0]) == prev[3] + 128
+                y = prev[4]                                     # (the kernel recomputes it from rows no record of the chunk touches)
+            else:
+                ids.append(cid)
+                y = np.linalg.solve(D, V[o:o + cc])
+                V[o:o + cc] = y
+            prev = (cid, o, cc, int(rec[0]), y)
+            upd = np.full((len(rows), 3), 7.7e7)            # what the padding rows of a tile would produce: goes to the spare row
+            upd[:ntg] = A @ y
+            tgt = np.where(rows < 0, SPARE, rows)
+            assert len(set(tgt[:ntg])) == ntg               # distinct rows inside a chunk
+            np.subtract.at(V, tgt, upd)
+        assert ids == sorted(ids) and len(set(ids)) == b1 - b0
+        assert np.allclose(V[:nt], Yref[col0:col1], rtol=1e-10, atol=1e-12)
+        # ---- backward: the slot programs ----
+        slot = ck["slot"][t]
+        assert slot[:4].sum() == b1 - b0
+        progs, total = [], set()
+        p0 = b0
+        for q in range(4):
+            phase, items = 0, []
+            for rec in ck["bwd"][p0:p0 + slot[q]]:
+                phase += int(rec[6])
+                items.append((phase, rec))
+            total.add(phase + int(slot[4 + q]))
+            progs.append(items)
+            p0 += slot[q]
+        assert len(total) == 1 and min(slot[4:]) >= 1            # every slot passes the same number of barriers, one before the write-out
+        ngroups = total.pop()
+        root_trail = sy.rows[sy.row_ptr[l] + c[l]:sy.row_ptr[l + 1]]
+        V = np.zeros((SPARE + 1, 3))
+        V[:nt] = Yref[col0:col1]
+        V[nt:nt + mroot] = Xref[root_trail]
+        seen = []
+        for g in range(ngroups):
+            group = [rec for items in progs for (ph, rec) in items if ph == g]
+            assert 1 <= len(group)
+            writes, reads, results = [], [], []
+            for rec in group:
+                o, cc, ntg, rows, D, A, cid = operands(rec)
+                seen.append(cid)
+                tgt = np.where(rows < 0, SPARE, rows)
+                Apad = np.vstack([A, np.full((len(rows) - ntg, cc), 3.3e3)])       # garbage operand rows meet the zero spare row
+                tt = V[o:o + cc] - Apad.T @ V[tgt]
+                results.append((o, cc, np.linalg.solve(D.T, tt)))
+                writes.append(set(range(o, o + cc)))
+                reads.append(set(tgt[:ntg]) | set(range(o, o + cc)))
+            for a in range(len(group)):
+                for bb in range(len(group)):
+                    if a != bb:
+                        assert not (writes[a] & reads[bb])
+            for o, cc, x in results:
+                V[o:o + cc] = x
+        assert sorted(seen) == ids
+        assert np.allclose(V[:nt], Xref[col0:col1], rtol=1e-9, atol=1e-12)
+        assert (V[SPARE] == 0).all()
+    if shape == "2d_wide":
+        assert wide > 0
