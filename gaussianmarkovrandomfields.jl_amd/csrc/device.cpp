@@ -338,8 +338,9 @@ void Device::upload(const Symbolic &S) {
             const Symbolic::SwChunk *cp; up(cp, S.swc_fwd); d_swc_fwd_ = const_cast<Symbolic::SwChunk *>(cp);
             up(cp, S.swc_bwd); d_swc_bwd_ = const_cast<Symbolic::SwChunk *>(cp);
             const int nc = sweep_chunk_nc(), spare = sweep_chunk_spare_row();
-            auto enc = [&](i32 row) { const int r = row < 0 ? spare : row; return (r * nc + ((r & 1) << 4)) * 8; };
-            std::vector<int> lf(S.swc_rows.size()), lb(S.swc_rows.size());
+            auto enc = [&](i32 row) { const int r = row < 0 ? spare : row; return (r * nc + (nc >= 32 ? (r & 1) << 4 : 0)) * 8; };
+            // (64 entries of slack: the backward kernel requests a fixed number of k-tiles per chunk, the last chunk's past its list)
+            std::vector<int> lf(S.swc_rows.size() + 64, 0), lb(S.swc_rows.size() + 64, 0);
             for (size_t b0 = 0; b0 < S.swc_rows.size(); b0 += 32) {
                 const i32 *src = S.swc_rows.data() + b0;
                 for (int lk = 0; lk < 4; lk++)
@@ -1511,7 +1512,7 @@ void Device::sweep_tasks(int phase, int nr, int ldx) {
         // pipelined call: the forward task kernel runs beside the top of the factorisation -- ONE resident workgroup per CU
         // (GMRFX_FUSED_TASK_LDS KB of unused dynamic LDS on top of its 72 KB), so that the panel chain's kernels find LDS
         // (measured at cfg 2, round 4: the level under which the task kernel runs 1.40 -> 1.15 ms (0.95 alone), step 14.19 -> 14.03 ms)
-        static const int pad_kb = [] { const char *e = std::getenv("GMRFX_FUSED_TASK_LDS"); return e ? std::max(0, std::atoi(e)) : 8; }();
+        static const int pad_kb = [] { const char *e = std::getenv("GMRFX_FUSED_TASK_LDS"); return e ? std::max(0, std::atoi(e)) : 16; }();
         const size_t extra = (fused_fwd_ && phase == 1) ? (size_t)pad_kb * 1024 : 0;
         ensure_dtile();
         launch_sweep_chunks(stream, ds_, phase, d_swt_, nswt_, d_swc_fwd_, d_swc_bwd_, d_swc_listf_, d_swc_listb_, d_dtile_, d_L_, d_X_,

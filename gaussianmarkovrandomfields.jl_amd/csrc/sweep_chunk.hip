@@ -45,20 +45,24 @@ typedef gmrfx_d4 d4;
 typedef Symbolic::SwChunk Chunk;
 static_assert(sizeof(Chunk) == 32, "chunk records are read as two 16-byte words");
 
-constexpr int CH_ROWS = 305;         // 288 rows of the local vector + 16 (a chunk reads the 16 rows from its first own row) + the spare row
-constexpr int CH_SPARE = 304;
+constexpr int CH_ROWS = 289;         // 288 rows of the local vector (a chunk reads the 16 rows from its first own row: the analysis keeps
+constexpr int CH_SPARE = 288;        // own columns + max(root's trailing rows, 15) <= 288) + the spare row
 constexpr int CH_MAXC = 96;          // chunk records per task (symbolic.cpp enforces)
 
 int sweep_chunk_spare_row() { return CH_SPARE; }
 
-// byte offset of (row, column) of the local vector: row-major, NC columns; the 16-column tiles of odd rows are swapped
-// pairwise so that the two k-rows a ds_read_b64 lane group touches fall into different halves of the LDS banks
-template <int NC> __device__ __forceinline__ int vbyte(int row, int col) { return (row * NC + (col ^ ((row & 1) << 4))) * 8; }
+// byte offset of (row, column) of the local vector: row-major, NC columns. From 32 columns on the 16-column tiles of odd
+// rows are swapped pairwise, so that the two k-rows a ds_read_b64 lane group (lanes 0-31 = two k-rows x 16 columns) touches
+// fall into different halves of the LDS banks; with 16 columns a row is 128 bytes and consecutive rows do that by themselves.
+template <int NC> __device__ __forceinline__ int vbyte(int row, int col) { return (row * NC + (NC >= 32 ? (col ^ ((row & 1) << 4)) : col)) * 8; }
 
+// which (task, column slice) a workgroup runs: the NC-column slices of one task are blocks b, b + 8, ... (same XCD: the later
+// readers of the task's panels find them in that XCD's L2)
 template <int NC> __device__ __forceinline__ bool chunk_task_of_block(int ntasks, int nr, int &t, int &cbase) {
     const int b = blockIdx.x;
     if (NC == 64) { t = b; cbase = 0; }
-    else { t = ((b >> 4) << 3) | (b & 7); cbase = ((b >> 3) & 1) * NC; }     // blocks b and b + 8 (same XCD): the two column halves
+    else if (NC == 32) { t = ((b >> 4) << 3) | (b & 7); cbase = ((b >> 3) & 1) * NC; }
+    else { t = ((b >> 5) << 3) | (b & 7); cbase = ((b >> 3) & 3) * NC; }
     return t < ntasks && cbase < nr;
 }
 
@@ -78,18 +82,27 @@ __device__ __forceinline__ UChunk uniform_chunk(const Chunk *meta, int f) {
     return m;
 }
 
+typedef int i4v __attribute__((ext_vector_type(4)));
+// An operand load: scalar base (the same for every lane: it comes from a chunk's record) + 32-bit lane offset in bytes +
+// immediate -- the compiler keeps the base in scalar registers and spends no vector arithmetic per load.
+// (Measured and dropped: the same loads as inline asm with hand-counted s_waitcnt vmcnt(N). The compiler's own waits are
+//  conservative -- at the first use of an operand requested a chunk ahead it also waits for the request just issued for the next
+//  chunk -- but with four workgroups per compute unit that latency is covered by the other three: 587 / 693 us with the
+//  compiler's loads, 650-800 / 643 us with the asm ones, which also pin every buffer register for the whole chunk.)
+template <int OFF> __device__ __forceinline__ void gl_f64(double &dst, const void *sbase, unsigned voff) { dst = *(const double *)((const char *)sbase + voff + OFF); }
+template <int OFF> __device__ __forceinline__ void gl_d2(gmrfx_d2u &dst, const void *sbase, unsigned voff) { dst = *(const gmrfx_d2u *)((const char *)sbase + voff + OFF); }
+template <int OFF> __device__ __forceinline__ void gl_i4(i4v &dst, const void *sbase, unsigned voff) { dst = *(const i4v *)((const char *)sbase + voff + OFF); }
+
 __device__ __forceinline__ double lds_ld(const char *Vb, int off) { return *(const double *)(Vb + off); }
 __device__ __forceinline__ void lds_st(char *Vb, int off, double v) { *(double *)(Vb + off) = v; }
 
-// Records into LDS, the task's panels into L2 (contiguous: postorder), the task's slice of X into the local vector, zeros
-// behind it. Returns a value that keeps the warm-up loads alive.
-template <int NC, int NTHR> __device__ __forceinline__ double chunk_prologue(const SweepTask &T, const Chunk *__restrict__ recs, int nrec, Chunk *meta,
+// Records into LDS, the task's slice of X into the local vector. (Round 2's warm-up of the task's panels into L2 is gone: with
+// every operand requested a chunk ahead it cost 30-40 us per sweep.)
+template <int NC, int NTHR> __device__ __forceinline__ void chunk_prologue(const SweepTask &T, const Chunk *__restrict__ recs, int nrec, Chunk *meta,
                                                                               const double *__restrict__ L, const double *__restrict__ X,
                                                                               double *V, int nr, int ldx) {
     const int tid = threadIdx.x;
     for (int i = tid; i < 2 * nrec; i += NTHR) ((int4 *)meta)[i] = ((const int4 *)recs)[i];
-    double sink = 0.0;
-    for (long long q = T.p0 + (long long)tid * 16; q < T.p1; q += NTHR * 16) sink += L[q];
     constexpr int G = NTHR / NC;
     const int j = tid % NC, g = tid / NC;
     const int jc = min(j, nr - 1);
@@ -102,7 +115,6 @@ template <int NC, int NTHR> __device__ __forceinline__ double chunk_prologue(con
 #pragma unroll
         for (int u = 0; u < 4; u++) if (i0 + G * u < NT) V[vbyte<NC>(i0 + G * u, j) >> 3] = v[u] * jm;
     }
-    return sink;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -110,9 +122,9 @@ template <int NC, int NTHR> __device__ __forceinline__ double chunk_prologue(con
 // ------------------------------------------------------------------------------------------------------------
 // what a slot needs of a chunk from HBM: the packed inverse diagonal block, its pair of target tiles (pair w) with their rows
 // (a chunk has at most 128 target rows = four pairs, one per slot: symbolic.cpp)
-struct FBuf { double dt[4]; gmrfx_d2u a[4]; int4 l[2]; };
+struct FBuf { double dt[4]; gmrfx_d2u a[4]; i4v l[2]; };
 
-template <int NC, int TPW> __global__ __launch_bounds__(4 * (NC / 16 / TPW) * 64, (NC == 32 && TPW == 1) ? 4 : 2)
+template <int NC, int TPW> __global__ __launch_bounds__(4 * (NC / 16 / TPW) * 64, (TPW == 1 && NC <= 32) ? 4 : 2)
 void k_fwd_chunks(const SweepTask *__restrict__ tasks, int ntasks, const Chunk *__restrict__ recs, const int *__restrict__ listf,
                   const double *__restrict__ dtile, const double *__restrict__ L, double *__restrict__ X, double *__restrict__ W,
                   int nr_all, int ldx) {
@@ -126,7 +138,7 @@ void k_fwd_chunks(const SweepTask *__restrict__ tasks, int ntasks, const Chunk *
     const SweepTask T = tasks[tsk];
     const int col0 = T.col0, NT = T.nt, nch = T.nch, mroot = T.mroot;
     const int tid = threadIdx.x;
-    const double sink = chunk_prologue<NC, NTHR>(T, recs + T.c0, nch, meta, L, X, V, nr, ldx);
+    chunk_prologue<NC, NTHR>(T, recs + T.c0, nch, meta, L, X, V, nr, ldx);
     for (int i = NT * NC + tid; i < CH_ROWS * NC; i += NTHR) V[i] = 0.0;
     __syncthreads();
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -137,31 +149,30 @@ void k_fwd_chunks(const SweepTask *__restrict__ tasks, int ntasks, const Chunk *
     for (int t = 0; t < TPW; t++) clb[t] = ((th * TPW + t) * 16 + lm) * 8;
     char *Vb = (char *)V;
     FBuf A, B;
-    auto request = [&](int f, FBuf &x) {
-        const UChunk m = uniform_chunk(meta, f);
+    UChunk mA, mB;       // the records travel with the buffers: read from LDS once per chunk
+    auto request = [&](int f, FBuf &x, UChunk &m) {
+        m = uniform_chunk(meta, f);
         const int npair = (m.nt + 31) >> 5;
         if (!(w == 0 || w < npair)) return;
-        const double *dp = dtile + (long long)m.id * 256 + lane;
-#pragma unroll
-        for (int u = 0; u < 4; u++) x.dt[u] = dp[u * 64];
-        if (w < npair) {
-            const double *base = L + m.pa + (2 * lm + lk * m.ld) + 32 * w;
-            const int *lp = listf + m.lr + lk * 8 + 32 * w;
-#pragma unroll
-            for (int u = 0; u < 4; u++) x.a[u] = *(const gmrfx_d2u *)(base + (long long)(4 * u) * m.ld);
-            x.l[0] = *(const int4 *)(lp);
-            x.l[1] = *(const int4 *)(lp + 4);
-        }
+        const double *dp = dtile + (long long)m.id * 256;
+        gl_f64<0>(x.dt[0], dp, lane * 8); gl_f64<512>(x.dt[1], dp, lane * 8); gl_f64<1024>(x.dt[2], dp, lane * 8); gl_f64<1536>(x.dt[3], dp, lane * 8);
+        if (w >= npair) return;
+        const double *base = L + m.pa + 32 * w;
+        const unsigned vo = (unsigned)(2 * lm + lk * m.ld) * 8u;
+        const long long st = 4LL * m.ld;
+        gl_d2<0>(x.a[0], base, vo); gl_d2<0>(x.a[1], base + st, vo); gl_d2<0>(x.a[2], base + 2 * st, vo); gl_d2<0>(x.a[3], base + 3 * st, vo);
+        const int *lp = listf + m.lr + 32 * w;
+        gl_i4<0>(x.l[0], lp, lk * 32);
+        gl_i4<16>(x.l[1], lp, lk * 32);
     };
-    request(0, A);
-    auto chunk = [&](const int f, FBuf &cur, FBuf &nxt) {
-        const UChunk m = uniform_chunk(meta, f);
-        if (f + 1 < nch) request(f + 1, nxt);
+    request(0, A, mA);
+    auto chunk = [&](const int f, FBuf &cur, const UChunk &m, FBuf &nxt, UChunk &mn) {
+        if (f + 1 < nch) request(f + 1, nxt, mn);
         const int npair = (m.nt + 31) >> 5;
         if (w == 0 || w < npair) {
             const int ku = (m.cc + 3) >> 2;
             const int rowb = m.o + lk;
-            const int bb = rowb * NC * 8, sw = (rowb & 1) << 7;
+            const int bb = rowb * NC * 8, sw = NC >= 32 ? (rowb & 1) << 7 : 0;
             d4 y[TPW];
 #pragma unroll
             for (int t = 0; t < TPW; t++) y[t] = (d4){0.0, 0.0, 0.0, 0.0};
@@ -172,6 +183,8 @@ void k_fwd_chunks(const SweepTask *__restrict__ tasks, int ntasks, const Chunk *
                     for (int t = 0; t < TPW; t++)
                         y[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.dt[u], lds_ld(Vb, bb + u * 4 * NC * 8 + (clb[t] ^ sw)), y[t], 0, 0, 0);
                 }
+            // y straight to X (the local vector keeps b: the other slots may still be reading it for their own copy of y,
+            // and a chunk with more than 128 target rows comes as several records that each recompute y)
             if (w == 0) {
                 double *Xo = X + (long long)(col0 + m.o) * ldx;
 #pragma unroll
@@ -181,7 +194,7 @@ void k_fwd_chunks(const SweepTask *__restrict__ tasks, int ntasks, const Chunk *
                         if (lk + 4 * rr < m.cc && (clb[t] >> 3) < nr) Xo[(long long)(lk + 4 * rr) * ldx + (clb[t] >> 3)] = y[t][rr];
             }
             // V[rows of a pair of target tiles] -= (pair's operand rows) y
-            auto apply = [&](const gmrfx_d2u (&av)[4], const int4 &l0, const int4 &l1) {
+            auto apply = [&](const gmrfx_d2u (&av)[4], const i4v &l0, const i4v &l1) {
                 d4 a0[TPW], a1[TPW];
 #pragma unroll
                 for (int t = 0; t < TPW; t++) { a0[t] = (d4){0.0, 0.0, 0.0, 0.0}; a1[t] = (d4){0.0, 0.0, 0.0, 0.0}; }
@@ -215,10 +228,10 @@ void k_fwd_chunks(const SweepTask *__restrict__ tasks, int ntasks, const Chunk *
     };
     {
         int f = 0;
-        for (; f + 1 < nch; f += 2) { chunk(f, A, B); chunk(f + 1, B, A); }
-        if (f < nch) chunk(f, A, B);
+        for (; f + 1 < nch; f += 2) { chunk(f, A, mA, B, mB); chunk(f + 1, B, mB, A, mA); }
+        if (f < nch) chunk(f, A, mA, B, mB);
     }
-    // the root's update vector W (y went to X chunk by chunk)
+    // the root's update vector to W (y went to X chunk by chunk)
     {
         constexpr int G = NTHR / NC;
         const int j = tid % NC, g = tid / NC;
@@ -227,16 +240,15 @@ void k_fwd_chunks(const SweepTask *__restrict__ tasks, int ntasks, const Chunk *
             for (int i = g; i < mroot; i += G) Wr[(long long)i * ldx + j] = V[vbyte<NC>(NT + i, j) >> 3];
         }
     }
-    if (sink == 1.2345678e-300) X[(long long)col0 * ldx] = sink;      // keeps the warm-up loads alive; never true
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // backward: V <- [y of the subtree ; x of the root's trailing rows]; per chunk t = y - L[targets, chunk]' x[targets],
 // x = D^-T t; the slot programs (chunk tree depth by depth)
 // ------------------------------------------------------------------------------------------------------------
-template <int G> struct BBuf { double dt[4]; gmrfx_d2u a[G][2]; int4 l[G]; };
+template <int G> struct BBuf { double dt[4]; gmrfx_d2u a[G][2]; i4v l[G]; };
 
-template <int NC, int TPW, int G> __global__ __launch_bounds__(4 * (NC / 16 / TPW) * 64, (NC == 32 && TPW == 1) ? 4 : 2)
+template <int NC, int TPW, int G> __global__ __launch_bounds__(4 * (NC / 16 / TPW) * 64, (TPW == 1 && NC <= 32) ? 4 : 2)
 void k_bwd_chunks(DevSym S, const SweepTask *__restrict__ tasks, int ntasks, const Chunk *__restrict__ recs, const int *__restrict__ listb,
                   const double *__restrict__ dtile, const double *__restrict__ L, double *__restrict__ X, int nr_all, int ldx) {
     constexpr int CT = NC / 16 / TPW, NTHR = 4 * CT * 64;
@@ -249,7 +261,7 @@ void k_bwd_chunks(DevSym S, const SweepTask *__restrict__ tasks, int ntasks, con
     const SweepTask T = tasks[tsk];
     const int col0 = T.col0, NT = T.nt, mroot = T.mroot;
     const int tid = threadIdx.x;
-    const double sink = chunk_prologue<NC, NTHR>(T, recs + T.b0, T.nbw, meta, L, X, V, nr, ldx);
+    chunk_prologue<NC, NTHR>(T, recs + T.b0, T.nbw, meta, L, X, V, nr, ldx);
     {   // x of the root's trailing rows (ancestors of the subtree: final), zeros behind them
         constexpr int GR = NTHR / NC;
         const int j = tid % NC, g = tid / NC;
@@ -281,23 +293,25 @@ void k_bwd_chunks(DevSym S, const SweepTask *__restrict__ tasks, int ntasks, con
     const int cnt = w == 0 ? T.scnt[0] : w == 1 ? T.scnt[1] : w == 2 ? T.scnt[2] : T.scnt[3];
     const int endbar = w == 0 ? T.sbar[0] : w == 1 ? T.sbar[1] : w == 2 ? T.sbar[2] : T.sbar[3];
     BBuf<G> A, B;
-    auto request = [&](int f, BBuf<G> &x) {
-        const UChunk m = uniform_chunk(meta, f);
+    UChunk mA, mB;
+    auto request = [&](int f, BBuf<G> &x, UChunk &m) {
+        m = uniform_chunk(meta, f);
+        const double *dp = dtile + (long long)m.id * 256;
+        const unsigned vd = (unsigned)(16 * lm + lk) * 8u;
+        gl_f64<0>(x.dt[0], dp, vd); gl_f64<32>(x.dt[1], dp, vd); gl_f64<64>(x.dt[2], dp, vd); gl_f64<96>(x.dt[3], dp, vd);
+        const double *base = L + m.pa;
+        const unsigned vo = (unsigned)(2 * lk + lm * m.ld) * 8u;
+        const int *lp = listb + m.lr;
         const int nk = (m.nt + 15) >> 4;
-        const double *dp = dtile + (long long)m.id * 256 + (16 * lm + lk);
-#pragma unroll
-        for (int u = 0; u < 4; u++) x.dt[u] = dp[4 * u];
-        const double *base = L + m.pa + (2 * lk + (long long)lm * m.ld);
-        const int *lp = listb + m.lr + lk * 4;
 #pragma unroll
         for (int g = 0; g < G; g++)
             if (g < nk) {
-                x.a[g][0] = *(const gmrfx_d2u *)(base + 16 * g);
-                x.a[g][1] = *(const gmrfx_d2u *)(base + 16 * g + 8);
-                x.l[g] = *(const int4 *)(lp + 16 * g);
+                gl_d2<0>(x.a[g][0], base + 16 * g, vo);
+                gl_d2<64>(x.a[g][1], base + 16 * g, vo);
+                gl_i4<0>(x.l[g], lp + 16 * g, lk * 16);
             }
     };
-    auto tile = [&](d4 (&acc)[TPW], const gmrfx_d2u &a0, const gmrfx_d2u &a1, const int4 &l) {
+    auto tile = [&](d4 (&acc)[TPW], const gmrfx_d2u &a0, const gmrfx_d2u &a1, const i4v &l) {
 #pragma unroll
         for (int t = 0; t < TPW; t++) {
             const double b0 = lds_ld(Vb, l.x ^ clb[t]), b1 = lds_ld(Vb, l.y ^ clb[t]), b2 = lds_ld(Vb, l.z ^ clb[t]), b3 = lds_ld(Vb, l.w ^ clb[t]);
@@ -307,30 +321,37 @@ void k_bwd_chunks(DevSym S, const SweepTask *__restrict__ tasks, int ntasks, con
             acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, b3, acc[t], 0, 0, 0);
         }
     };
-    auto chunk = [&](const int f, const bool last, BBuf<G> &cur, BBuf<G> &nxt) {
-        const UChunk m = uniform_chunk(meta, f);
-        if (!last) request(f + 1, nxt);
+    auto chunk = [&](const int f, const bool last, BBuf<G> &cur, const UChunk &m, BBuf<G> &nxt, UChunk &mn) {
+        if (!last) request(f + 1, nxt, mn);
         for (int b = 0; b < m.nbar; b++) __syncthreads();
         const int nk = (m.nt + 15) >> 4;
         d4 acc[TPW];
 #pragma unroll
         for (int t = 0; t < TPW; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int g = 0; g < G; g++)
-            if (g < nk) tile(acc, cur.a[g][0], cur.a[g][1], cur.l[g]);
-        if (nk > G) {
-            const double *base = L + m.pa + (2 * lk + (long long)lm * m.ld);
-            const int *lp = listb + m.lr + lk * 4;
+        {   // the first G k-tiles came with the request; k-tile i + G is requested into the registers k-tile i leaves
+            const double *base = L + m.pa;
+            const unsigned vo = (unsigned)(2 * lk + lm * m.ld) * 8u;
+            const int *lp = listb + m.lr;
 #pragma unroll 1
-            for (int g = G; g < nk; g++) {
-                const gmrfx_d2u a0 = *(const gmrfx_d2u *)(base + 16 * g), a1 = *(const gmrfx_d2u *)(base + 16 * g + 8);
-                const int4 l = *(const int4 *)(lp + 16 * g);
-                tile(acc, a0, a1, l);
+            for (int g0 = 0; g0 < nk; g0 += G) {
+#pragma unroll
+                for (int j = 0; j < G; j++) {
+                    const int i = g0 + j;
+                    if (i < nk) {
+                        tile(acc, cur.a[j][0], cur.a[j][1], cur.l[j]);
+                        const int g = i + G;
+                        if (g < nk) {
+                            gl_d2<0>(cur.a[j][0], base + 16 * g, vo);
+                            gl_d2<64>(cur.a[j][1], base + 16 * g, vo);
+                            gl_i4<0>(cur.l[j], lp + 16 * g, lk * 16);
+                        }
+                    }
+                }
             }
         }
         const int ku = (m.cc + 3) >> 2;
         const int rowb = m.o + lk;
-        const int bb = rowb * NC * 8, sw = (rowb & 1) << 7;
+        const int bb = rowb * NC * 8, sw = NC >= 32 ? (rowb & 1) << 7 : 0;
         d4 x[TPW];
 #pragma unroll
         for (int t = 0; t < TPW; t++) x[t] = (d4){0.0, 0.0, 0.0, 0.0};
@@ -349,11 +370,11 @@ void k_bwd_chunks(DevSym S, const SweepTask *__restrict__ tasks, int ntasks, con
             for (int rr = 0; rr < 4; rr++)
                 if (lk + 4 * rr < m.cc) lds_st(Vb, bb + rr * 4 * NC * 8 + (clb[t] ^ sw), x[t][rr]);
     };
-    if (cnt > 0) request(i0, A);
+    if (cnt > 0) request(i0, A, mA);
     {
         int k = 0;
-        for (; k + 1 < cnt; k += 2) { chunk(i0 + k, false, A, B); chunk(i0 + k + 1, k + 2 >= cnt, B, A); }
-        if (k < cnt) chunk(i0 + k, true, A, B);
+        for (; k + 1 < cnt; k += 2) { chunk(i0 + k, false, A, mA, B, mB); chunk(i0 + k + 1, k + 2 >= cnt, B, mB, A, mA); }
+        if (k < cnt) chunk(i0 + k, true, A, mA, B, mB);
     }
     for (int b = 0; b < endbar; b++) __syncthreads();
     {
@@ -362,7 +383,6 @@ void k_bwd_chunks(DevSym S, const SweepTask *__restrict__ tasks, int ntasks, con
         if (j < nr)
             for (int i = g; i < NT; i += GR) X[(long long)(col0 + i) * ldx + j] = V[vbyte<NC>(i, j) >> 3];
     }
-    if (sink == 1.2345678e-300) X[(long long)col0 * ldx] = sink;
 }
 
 // The inverse of every chunk's diagonal block in MFMA A-operand order: element (lm, 4 u + lk) of D^-1 at [u][lane]
@@ -389,12 +409,13 @@ __global__ __launch_bounds__(256) void k_pack_diag(const Chunk *__restrict__ rec
     }
 }
 
-static int chunk_cfg() {      // GMRFX_TASK_CFG: 0 (default) = 32 columns per workgroup, one 16-column tile per wave (8 waves, two workgroups per CU);
-                              // 1 = 32 columns, two tiles per wave (4 waves); 2 = 64 columns, two tiles per wave (8 waves, one workgroup per CU)
-    static const int v = [] { const char *e = std::getenv("GMRFX_TASK_CFG"); const int x = e ? std::atoi(e) : 0; return x >= 0 && x <= 2 ? x : 0; }();
+static int chunk_cfg() {      // GMRFX_TASK_CFG: columns of the right-hand sides per workgroup / 16-column tiles per wave:
+                              // 0 (default) = 16 / 1 (4 waves, four workgroups per CU); 1 = 32 / 1 (8 waves, two per CU);
+                              // 2 = 32 / 2 (4 waves); 3 = 64 / 2 (8 waves, one per CU)
+    static const int v = [] { const char *e = std::getenv("GMRFX_TASK_CFG"); const int x = e ? std::atoi(e) : 0; return x >= 0 && x <= 3 ? x : 0; }();
     return v;
 }
-int sweep_chunk_nc() { return chunk_cfg() == 2 ? 64 : 32; }
+int sweep_chunk_nc() { const int c = chunk_cfg(); return c == 0 ? 16 : c == 3 ? 64 : 32; }
 
 void launch_pack_diag(hipStream_t st, const Symbolic::SwChunk *recs, int nchunks, const double *L, double *dtile) {
     if (nchunks <= 0) return;
@@ -406,14 +427,16 @@ void launch_sweep_chunks(hipStream_t st, const DevSym &S, int phase, const Sweep
                          double *X, double *W, int nr, int ldx, size_t extra_lds) {
     if (ntasks <= 0) return;
     const int cfg = chunk_cfg();
-    const int grid32 = ((ntasks + 7) / 8) * 16;      // blocks b and b + 8 (same XCD): the two column halves of one task
+    const int g8 = (ntasks + 7) / 8;
     if (phase == 1) {
-        if (cfg == 0) hipLaunchKernelGGL((k_fwd_chunks<32, 1>), dim3(grid32), dim3(512), extra_lds, st, tasks, ntasks, recs_fwd, listf, dtile, L, X, W, nr, ldx);
-        else if (cfg == 1) hipLaunchKernelGGL((k_fwd_chunks<32, 2>), dim3(grid32), dim3(256), extra_lds, st, tasks, ntasks, recs_fwd, listf, dtile, L, X, W, nr, ldx);
+        if (cfg == 0) hipLaunchKernelGGL((k_fwd_chunks<16, 1>), dim3(g8 * 32), dim3(256), extra_lds, st, tasks, ntasks, recs_fwd, listf, dtile, L, X, W, nr, ldx);
+        else if (cfg == 1) hipLaunchKernelGGL((k_fwd_chunks<32, 1>), dim3(g8 * 16), dim3(512), extra_lds, st, tasks, ntasks, recs_fwd, listf, dtile, L, X, W, nr, ldx);
+        else if (cfg == 2) hipLaunchKernelGGL((k_fwd_chunks<32, 2>), dim3(g8 * 16), dim3(256), extra_lds, st, tasks, ntasks, recs_fwd, listf, dtile, L, X, W, nr, ldx);
         else hipLaunchKernelGGL((k_fwd_chunks<64, 2>), dim3(ntasks), dim3(512), 0, st, tasks, ntasks, recs_fwd, listf, dtile, L, X, W, nr, ldx);
     } else {
-        if (cfg == 0) hipLaunchKernelGGL((k_bwd_chunks<32, 1, 2>), dim3(grid32), dim3(512), 0, st, S, tasks, ntasks, recs_bwd, listb, dtile, L, X, nr, ldx);
-        else if (cfg == 1) hipLaunchKernelGGL((k_bwd_chunks<32, 2, 4>), dim3(grid32), dim3(256), 0, st, S, tasks, ntasks, recs_bwd, listb, dtile, L, X, nr, ldx);
+        if (cfg == 0) hipLaunchKernelGGL((k_bwd_chunks<16, 1, 3>), dim3(g8 * 32), dim3(256), 0, st, S, tasks, ntasks, recs_bwd, listb, dtile, L, X, nr, ldx);
+        else if (cfg == 1) hipLaunchKernelGGL((k_bwd_chunks<32, 1, 3>), dim3(g8 * 16), dim3(512), 0, st, S, tasks, ntasks, recs_bwd, listb, dtile, L, X, nr, ldx);
+        else if (cfg == 2) hipLaunchKernelGGL((k_bwd_chunks<32, 2, 4>), dim3(g8 * 16), dim3(256), 0, st, S, tasks, ntasks, recs_bwd, listb, dtile, L, X, nr, ldx);
         else hipLaunchKernelGGL((k_bwd_chunks<64, 2, 4>), dim3(ntasks), dim3(512), 0, st, S, tasks, ntasks, recs_bwd, listb, dtile, L, X, nr, ldx);
     }
 }

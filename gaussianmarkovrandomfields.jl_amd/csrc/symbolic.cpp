@@ -700,7 +700,7 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
             bool good = rcap > 0;
             for (i64 q = S.childptr[s]; q < S.childptr[s + 1]; q++) good = good && ok[S.children[q]];
             // (chunk kernels: at most 96 chunk records per task in LDS)
-            ok[s] = good && !S.is_top[s] && maxc[s] <= 64 && ncol[s] + (S.nrows(s) - S.ncols(s)) <= rcap && cnt[s] <= 64 && nchk[s] <= 96;
+            ok[s] = good && !S.is_top[s] && maxc[s] <= 64 && ncol[s] + std::max(S.nrows(s) - S.ncols(s), 15) <= rcap && cnt[s] <= 64 && nchk[s] <= 96;
             const i32 p = S.sparent[s];
             if (p != -1) { cnt[p] += cnt[s]; ncol[p] += ncol[s]; maxc[p] = std::max(maxc[p], maxc[s]); work[p] += work[s]; nchk[p] += nchk[s]; }
         }

@@ -301,7 +301,7 @@ def test_sweep_chunks_programs_walk(shape, monkeypatch):
     Yref = np.linalg.solve(Ld, Bp)
     Xref = np.linalg.solve(Ld.T, Yref)
     Lflat = hs.L
-    SPARE = 304
+    SPARE = 288
     assert len(ck["task_ptr"]) == len(first) + 1 and ck["task_ptr"][-1, 0] == len(ck["fwd"]) and ck["task_ptr"][-1, 1] == len(ck["bwd"])
     assert len(ck["rows"]) % 32 == 0
     wide = 0
