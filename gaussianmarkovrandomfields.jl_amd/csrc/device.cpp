@@ -398,6 +398,7 @@ void Device::upload(const Symbolic &S) {
             if (const char *e = std::getenv("GMRFX_INV_ON_MAIN")) inv_on_main_ = std::atoi(e) != 0;
             if (const char *e = std::getenv("GMRFX_FUSED_CUT")) fused_cut_ = std::max(0, std::atoi(e));
             if (const char *e = std::getenv("GMRFX_SMALL_ON_SIDE")) small_on_side_ = std::atoi(e) != 0;
+            if (const char *e = std::getenv("GMRFX_BWD_FRONT")) bwd_front_min_ = std::atoi(e);    // fronts a level needs for the one-workgroup backward step (0: never)
         }
         const int *a; up(a, S.sub_first); d_sub_first_ = const_cast<int *>(a);
         const int *b; up(b, S.sub_last); d_sub_last_ = const_cast<int *>(b);
@@ -1601,9 +1602,23 @@ void Device::backward(int nr, int ldx, bool y_in_x2, int hi, int lo) {
         auto &L = swlevels_[l];
         if (level_mark_) { launch_level_mark(stream, 2, l); level_event(2, (int)levels_.size() - 1 - l); }
         const int *list = d_sw_levellist_ + L.first + L.nsmall;
-        const int nf = L.count - L.nsmall;
+        int nf = L.count - L.nsmall;
         for (int k = 0, off = 0; k < 4; off += L.ncls[k], k++)
             launch_bwd_small(stream, ds_, d_sw_levellist_ + L.first + off, L.ncls[k], kClsRows[k], d_L_, d_X_, nr, ldx);
+        // fronts of at most 128 columns (the tail of the list: sorted by decreasing width): the whole step as one workgroup and
+        // one launch (sweep_front.hip); in place when y sits in X (own rows are read and written by their front alone)
+        // Only on levels with enough such fronts to fill the chip: a workgroup walks its front's trailing rows batch after batch,
+        // and a level of a hundred fronts with 700 trailing rows each is faster as many small workgroups (the two launches).
+        if (bwd_front_min_ > 0) {
+            // (a front needs its WHOLE inverse for this: at most min(128, inv_cap_) columns)
+            const size_t kq = (size_t)std::min(bwd_front_max_cols(), inv_cap_) / NB;
+            const int nwide = kq + 1 < L.active.size() ? L.active[kq] : 0;   // fronts with more than kq NB columns (the last entry of `active` is the stash of level_max_trail)
+            if (nf - nwide >= bwd_front_min_) {
+                launch_bwd_front(stream, ds_, list + nwide, nf - nwide, d_L_, d_X_, y_in_x2 ? d_X2_ : d_X_, d_X_, nr, ldx);
+                nf = nwide;
+                if (nf == 0) continue;
+            }
+        }
         const int nbk = std::max(1, (L.max_cols + inv_cap_ - 1) / inv_cap_);
         if (y_in_x2) {
             if (level_max_trail(L) > 0) launch_bwd_gemm(stream, ds_, list, nf, L.max_cols, d_L_, d_X_, d_X2_, nr, ldx);

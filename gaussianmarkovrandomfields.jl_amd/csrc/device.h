@@ -307,6 +307,7 @@ public:
 private:
     void ensure_rdiag();
     void ensure_dtile();
+    int bwd_front_min_ = 192;                     // backward step of fronts <= 128 columns wide as one workgroup (sweep_front.hip) on levels with at least this many of them (0: never)
     Symbolic::SwChunk *d_swc_fwd_ = nullptr, *d_swc_bwd_ = nullptr;   // chunk records of the sweep tasks (forward order / backward slot programs)
     int *d_swc_listf_ = nullptr, *d_swc_listb_ = nullptr;               // their target rows as LDS byte offsets, in the lane order of the two kernels
     double *d_dtile_ = nullptr;                   // inverse diagonal blocks of the chunks, packed (k_pack_diag): 256 doubles per chunk

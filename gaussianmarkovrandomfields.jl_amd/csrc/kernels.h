@@ -441,6 +441,10 @@ void launch_bwd_small(hipStream_t st, const DevSym &S, const int *list, int nfro
                       double *X, int nr, int ldx);
 
 // sweep_task.hip -- whole bottom subtrees on an LDS-resident local vector: phase 1 forward, 2 backward
+// backward step of a front of at most bwd_front_max_cols() columns as one workgroup (sweep_front.hip): x[own] = L11^-T (Yin[own] - L21' Xt[trailing])
+void launch_bwd_front(hipStream_t st, const DevSym &S, const int *list, int nfronts, const double *L, const double *Xt, const double *Yin,
+                      double *Xout, int nr, int ldx);
+int bwd_front_max_cols();
 // chunk form of the sweep tasks (sweep_chunk.hip)
 void launch_pack_diag(hipStream_t st, const Symbolic::SwChunk *recs, int nchunks, const double *L, double *dtile);
 void launch_sweep_chunks(hipStream_t st, const DevSym &S, int phase, const SweepTask *tasks, int ntasks, const Symbolic::SwChunk *recs_fwd,

@@ -982,7 +982,7 @@ def test_blocked_substitution_in_wide_fronts(cap, monkeypatch):
 
 @pytest.mark.parametrize("name", ["matern64_coords", "cfg1_alpha3_65x65", "matern3d_10", "rand400", "natural_chain"])
 def test_sweep_tasks_on_and_off_agree(name, monkeypatch):
-    """Sweep tasks (whole bottom subtrees on an LDS-resident local vector, csrc/sweep_task.hip; the default) against
+    """Sweep tasks (whole bottom subtrees on an LDS-resident local vector, csrc/sweep_chunk.hip; the default) against
     the pure level schedule (GMRFX_SWEEP_TASK_ROWS=0): same solves / backward solves to rounding (the summation order
     of the updates differs), for full and ragged right-hand-side blocks, and both against the oracle."""
     Q, kw = next((sp.csc_matrix(q), k) for n, q, k in CASES if n == name)
@@ -1004,6 +1004,31 @@ def test_sweep_tasks_on_and_off_agree(name, monkeypatch):
         assert relerr(on.backend_backward_solve(B), Zo) < 1e-10
         assert relerr(on.backend_backward_solve(B), off.backend_backward_solve(B)) < 1e-11
     assert np.array_equal(on.backend_solve(B), on.backend_solve(B))        # still bit-reproducible
+
+
+@pytest.mark.parametrize("name", ["matern64_coords", "cfg1_alpha3_65x65", "matern3d_10", "rand400", "tall_fronts", "dense70"])
+def test_backward_step_one_workgroup_per_front_equals_two_launches(name, monkeypatch):
+    """Round 5 (csrc/sweep_front.hip): the backward step of a front of at most 128 columns as ONE workgroup -- trailing rows of x
+    gathered once through LDS, t = y - L21' x and x = L11^-T t in the same launch -- against the two launches it replaces
+    (GMRFX_BWD_FRONT=0) and against the oracle: solves and backward-only solves (y in the second buffer / in place), full and
+    ragged right-hand-side blocks. By default only levels with at least 192 such fronts take the new path (the 10^6-node
+    problems of the full-size tests); GMRFX_BWD_FRONT=1 sends every eligible front of these small cases through it."""
+    Q, kw = next((sp.csc_matrix(q), k) for n, q, k in CASES if n == name)
+    n = Q.shape[0]
+    rng = np.random.default_rng(11)
+    monkeypatch.setenv("GMRFX_BWD_FRONT", "1")
+    one = gmrfx.MI355XBackend(Q, **kw)
+    monkeypatch.setenv("GMRFX_BWD_FRONT", "0")
+    two = gmrfx.MI355XBackend(Q, ordering=one.ordering_permutation())
+    monkeypatch.delenv("GMRFX_BWD_FRONT")
+    F = orc.OracleFactor(Q, one.ordering_permutation())
+    for nrhs in (1, 3, 17, 64, 70):
+        B = rng.standard_normal((n, nrhs))
+        assert relerr(one.backend_solve(B), F.solve(B)) < 1e-10
+        assert relerr(one.backend_solve(B), two.backend_solve(B)) < 1e-11
+        assert relerr(one.backend_backward_solve(B), F.backward_solve(B)) < 1e-10
+        assert relerr(one.backend_backward_solve(B), two.backend_backward_solve(B)) < 1e-11
+    assert np.array_equal(one.backend_solve(B), one.backend_solve(B))       # bit-reproducible
 
 
 @pytest.mark.parametrize("name", ["matern64_coords", "cfg1_alpha3_65x65", "matern3d_10", "rand400"])
