@@ -409,7 +409,8 @@ def main():
 
     # ---- host I/O: the same step through the HOST entry point, gmrfx_refactorize_solve(nzval, B, X) with column-major host arrays --
     # what the reference's workspace_solve(ws, B::Matrix) hands over (src/workspace/gmrf_workspace.jl:170-178, 207-215, backend.jl:207-209).
-    # The upload of B runs beside the factorisation, X leaves in slices behind the backward sweep (Device::host_upload / host_download).
+    # The transfers are SERIAL: B goes up in front of the factorisation, X leaves in slices behind the backward sweep (Device::host_upload /
+    # host_download); nothing is overlapped with the factorisation (a transfer beside it slows its launch chain by more than it hides).
     # Untimed by `value`; pageable arrays (a Julia Matrix) and page-locked ones.
     host_io = None
     if rank == 0 and not args.no_host_io:
@@ -464,6 +465,15 @@ def main():
             t_rand.append(be.stats()["ms_backward_solve"])
         extras["ms_selinv"] = float(np.median(t_sel))
         extras["ms_rand256"] = float(np.median(t_rand))
+        # the same 256 samples the way the reference's rand(d, 256) reaches a backend WITHOUT the batched `_rand!` of julia/GMRFX.jl:
+        # one single-RHS backward solve per sample (src/gmrf.jl:271-281 under Distributions' column loop), operands resident in
+        # HBM (a host caller adds two PCIe round trips per sample); extrapolated from 16 calls
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for j in range(16):
+            be.backward_solve_dev(d_Z.data_ptr() + 8 * n * j, n, 1, d_S.data_ptr() + 8 * n * j, n)
+        torch.cuda.synchronize()
+        extras["ms_rand256_single_calls"] = 1e3 * (time.perf_counter() - t1) * 256.0 / 16.0
         sy = be.symbolic()
         cc = np.diff(sy.super_first).astype(np.float64)
         mm = np.diff(sy.row_ptr).astype(np.float64) - cc
@@ -545,12 +555,21 @@ def main():
         factor_tf = st["factor_flops"] / (mf * 1e-3) / 1e12
         # HBM traffic from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
         # runs, gfx950 FETCH_SIZE x2 correction): only valid for the workload they were collected on
-        pmc = None
+        # The counters cannot be read inside this process, so `traffic` is a COMMITTED counter pass (tools/pmc_traffic.py,
+        # tools/cfg3_profile.py): each file names the source tree it was collected on (csrc_hash = gmrfx._lib.source_tree_hash()),
+        # and its figures are quoted only while the tree being timed is that tree -- otherwise traffic is null.
+        from gmrfx._lib import source_tree_hash
+        tree_hash = source_tree_hash()
+        pmc, pmc_note = None, "no counter pass for this workload under profiles/"
         try:
-            with open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")) as fh:
                 pj = json.load(fh)
             if pj["workload"] == {"grid": args.grid, "nrhs": args.nrhs}:
-                pmc = pj
+                if pj.get("csrc_hash") == tree_hash:
+                    pmc, pmc_note = pj, f"profiles/r05_pmc_traffic.json, collected on source tree {tree_hash} = the tree being timed"
+                else:
+                    pmc_note = (f"null: profiles/r05_pmc_traffic.json belongs to source tree {pj.get('csrc_hash')}, the tree being timed is "
+                                f"{tree_hash} (re-run tools/final_profile.sh)")
         except Exception:
             pmc = None
         # ---- roofline of the DOMINANT KERNEL: k_syrk_cb_rec (contribution-block SYRK, ~18 % of the step) ----
@@ -570,7 +589,7 @@ def main():
                        "flops_per_launch": st["syrk_flops"] / n_launch, "ms_per_step": ms_syrk,
                        "note": "achieved = algorithmic flops of the launches of one step / their summed HIP-event time over the "
                                "timed (pipelined) steps -- the forward sweep of the same step runs beside some of them; "
-                               "traffic = PMC HBM bytes per launch (profiles/r04_pmc_traffic.json)"}
+                               "traffic = PMC HBM bytes per launch (" + pmc_note + ")"}
         if pipelined_phases is not None:
             alone = pipelined_phases["syrk_launches_separate"]
             roof_kernel.update({"ms_per_step_alone": alone, "achieved_alone": st["syrk_flops"] / (alone * 1e-3) / 1e12,
@@ -578,21 +597,25 @@ def main():
         roof_factor = {"bound": "mfma", "achieved": factor_tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                        "frac": factor_tf / FP64_MFMA_PEAK_TF, "traffic": pmc["factor"]["total_bytes"] if pmc else None,
                        "peak_measured": FP64_MFMA_MEASURED_TF, "frac_of_measured_peak": factor_tf / FP64_MFMA_MEASURED_TF,
-                       "kernel": "numeric factorisation (all ~500 launches)", "ms": mf, "flops": st["factor_flops"]}
+                       "kernel": "numeric factorisation (all ~500 launches)", "ms": mf, "flops": st["factor_flops"], "note": "traffic: " + pmc_note}
         roof_sweep = {"bound": "hbm", "achieved": sweep_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "frac": sweep_gbs / HBM_PEAK_GBS,
                       "traffic": 0.5 * (pmc["sweep_forward"]["total_bytes"] + pmc["sweep_backward"]["total_bytes"]) if pmc else None,
-                      "kernel": "triangular sweep (mean of forward and backward, all launches)", "ms": sweep_ms, "bytes": bytes_sweep}
+                      "kernel": "triangular sweep (mean of forward and backward, all launches)", "ms": sweep_ms, "bytes": bytes_sweep,
+                      "note": "traffic: " + pmc_note}
         if roof_sweep["traffic"]:
             # the bytes the sweeps really move (PMC), W / x hand-off between the levels included, against the same peak
             roof_sweep["frac_of_peak_with_measured_traffic"] = roof_sweep["traffic"] / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         roof_cfg3 = {}
-        pmc3 = None
+        pmc3, pmc3_note = None, "no counter pass for this workload under profiles/"
         try:
-            with open(os.path.join(ROOT, "profiles", "r04_cfg3_pmc_traffic.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r05_cfg3_pmc_traffic.json")) as fh:
                 p3 = json.load(fh)
             if p3["workload"]["grid"] == args.grid:
-                pmc3 = p3
+                if p3.get("csrc_hash") == tree_hash:
+                    pmc3, pmc3_note = p3, f"profiles/r05_cfg3_pmc_traffic.json, collected on source tree {tree_hash} = the tree being timed"
+                else:
+                    pmc3_note = f"null: profiles/r05_cfg3_pmc_traffic.json belongs to source tree {p3.get('csrc_hash')}, the tree being timed is {tree_hash}"
         except Exception:
             pmc3 = None
         if cfg3 is not None:
@@ -604,14 +627,15 @@ def main():
                 "ms": extras["ms_selinv"], "flops": cfg3["sel_flops"], "flops_over_factor_flops": cfg3["sel_flops"] / st["factor_flops"],
                 "bytes_min": 16.0 * nnzl, "gbs_on_bytes_min": 16.0 * nnzl / (extras["ms_selinv"] * 1e-3) / 1e9,
                 "note": "cfg 3: flops = sum_s 2 c m^2 + 4 c^2 m + 2 c^3 / 3 (Takahashi recursion through the dense inverse of L11); "
-                        "bytes_min = L read + Z written once"}
+                        "bytes_min = L read + Z written once; traffic: " + pmc3_note}
             # 256 samples = 4 passes of 64 columns, each one backward sweep + the transposes of its columns (SURVEY 8d:
             # bytes_backward_solve = bytes_sweep + 8 n nrhs)
             rb = 4.0 * (8.0 * nnzl + 4.0 * st["sum_rows"] + 16.0 * n * 64 + 8.0 * n * 64)
             roof_cfg3["roofline_rand256"] = {
                 "bound": "hbm", "achieved": rb / (extras["ms_rand256"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": rb / (extras["ms_rand256"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc3["rand256"]["total_bytes"] if pmc3 else None,
-                "kernel": "256 samples P' L^-T z: 4 backward sweeps of 64 columns on two lanes", "ms": extras["ms_rand256"], "bytes": rb}
+                "kernel": "256 samples P' L^-T z: 4 backward sweeps of 64 columns on two lanes", "ms": extras["ms_rand256"], "bytes": rb,
+                "note": "traffic: " + pmc3_note}
         out = {
             "metric": "factor+solve(64 RHS) throughput", "value": world * n / (elapsed / args.steps), "unit": "DoF/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,

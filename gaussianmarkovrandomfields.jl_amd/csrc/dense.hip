@@ -38,13 +38,15 @@ __global__ __launch_bounds__(256) void k_dense_apply(const double *__restrict__ 
 #pragma unroll
         for (int b = 0; b < 2; b++) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
     // clamped operand rows (lanes past the edge re-read the last valid pair; never stored). n2 odd: the pair that starts at the
-    // last element reads one double past the row -- the next row's first element, or the slack behind the array for the last row
-    // (callers allocate T with 16 bytes of slack; gmrfx_dense_apply_dev checks nothing it cannot see, the Python binding pads)
+    // last element of a row reads one double past it -- the next row's first element. For the LAST row of T that would be past
+    // the array: the pair path stops one row short (qpair) and the masked element path below takes the rest, so an exactly
+    // sized T is never over-read (no slack contract on the public entry point gmrfx_dense_apply_dev)
     const int i1a = min(m0 + 2 * lm, n1 - 1), i1b = min(m0 + 2 * lm + 1, n1 - 1);
     const long long i2 = min(n0 + 2 * lm, (n2 - 1) & ~1ll);
     const double *pa0 = D + (long long)i1a * n1, *pa1 = D + (long long)i1b * n1;
     const double *pb2 = T + i2;
-    int qd = wave_gemm_32x32_kr(acc, pa0, pa1, pb2, n2, 0, n1, lk);
+    const int qpair = (n2 & 1) ? n1 - 1 : n1;
+    int qd = wave_gemm_32x32_kr(acc, pa0, pa1, pb2, n2, 0, qpair, lk);
     if (qd < n1) {
         auto fa = [&](int i, int q) { return D[(long long)min(i, n1 - 1) * n1 + min(q, n1 - 1)]; };
         auto fb = [&](int q, int j) { return T[(long long)min(q, n1 - 1) * n2 + min((long long)j + n0, n2 - 1)]; };

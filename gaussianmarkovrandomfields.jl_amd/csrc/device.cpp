@@ -60,8 +60,6 @@ Device::~Device() {
     for (auto &e : ev_) if (e) (void)hipEventDestroy(e);
     for (auto &v : ev_level_) for (auto &e : v) (void)hipEventDestroy(e);
     for (auto &e : ev_flevel_) (void)hipEventDestroy(e);
-    for (auto &e : ev_la_p_) (void)hipEventDestroy(e);
-    for (auto &e : ev_la_t_) (void)hipEventDestroy(e);
     for (auto &l : ev_lane_) for (auto &e : l) if (e) (void)hipEventDestroy(e);
     if (h_info_) (void)hipHostFree(h_info_);
     if (h_stage_) (void)hipHostFree(h_stage_);
@@ -84,7 +82,6 @@ Device::~Device() {
     if (ev_nzp0_) (void)hipEventDestroy(ev_nzp0_);
     if (ev_inv_) (void)hipEventDestroy(ev_inv_);
     if (stream2) (void)hipStreamDestroy(stream2);
-    for (auto d : dummy_streams_) (void)hipStreamDestroy(d);
     if (own_stream_) (void)hipStreamDestroy(own_stream_);
 }
 
@@ -113,36 +110,12 @@ void Device::init(const Symbolic &S, int dev) {
         // stream (dense inverses) only fills idle capacity: lowest
         int lo = 0, hi = 0;
         HC(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        const char *e = std::getenv("GMRFX_STREAM_PRIO");
-        const bool prio = !e || std::atoi(e) != 0;
-        // GMRFX_STREAM_SKIP=k (A/B): k idle streams created between the handle's streams -- the runtime deals streams to hardware
-        // queues (and those to the command processor's pipes) in creation order
-        const char *sk = std::getenv("GMRFX_STREAM_SKIP");
-        const int skip = sk ? std::max(0, std::atoi(sk)) : 0;
-        auto burn = [&]() { for (int k = 0; k < skip; k++) { hipStream_t d; HC(hipStreamCreateWithFlags(&d, hipStreamNonBlocking)); dummy_streams_.push_back(d); } };
-        HC(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, prio ? hi : 0));
+        // (Measured and settled in round 4, DESIGN.md section 3: no priorities, idle streams between the handle's streams, a CU mask on
+        //  the side stream -- none of them helps; the three streams are created back to back: three distinct hardware queues.)
+        HC(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, hi));
         own_stream_ = stream;
-        burn();
-        // GMRFX_SIDE_CU_MASK=k (A/B): the side stream (forward sweep of the pipelined call, dense inverses) may not use the last k of
-        // every 32 mask bits -- compute units kept free for the dependent launch chain of the factorisation
-        const char *cm = std::getenv("GMRFX_SIDE_CU_MASK");
-        const int cu_off = cm ? std::min(31, std::max(0, std::atoi(cm))) : 0;
-        const char *cmm = std::getenv("GMRFX_SIDE_CU_MASK_MODE");        // 0: the last k bits of every word; 1: the last 8 k bits of the mask
-        if (cu_off > 0) {
-            hipDeviceProp_t prop;
-            HC(hipGetDeviceProperties(&prop, device));
-            const int ncu = prop.multiProcessorCount, nw = (ncu + 31) / 32;
-            std::vector<uint32_t> mask(nw, 0xffffffffu);
-            if (cmm && std::atoi(cmm) == 1) {
-                for (int b = ncu - 8 * cu_off; b < ncu; b++) if (b >= 0) mask[b / 32] &= ~(1u << (b % 32));
-            } else {
-                for (int w = 0; w < nw; w++) mask[w] = 0xffffffffu >> cu_off;
-            }
-            HC(hipExtStreamCreateWithCUMask(&stream2, (uint32_t)nw, mask.data()));
-        } else
-            HC(hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, prio ? lo : 0));
-        burn();
-        HC(hipStreamCreateWithPriority(&stream3, hipStreamNonBlocking, prio ? hi : 0));
+        HC(hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, lo));
+        HC(hipStreamCreateWithPriority(&stream3, hipStreamNonBlocking, hi));
         if (const char *c = std::getenv("GMRFX_INV_CAP")) {      // testing knob: power of two >= 64
             int v = std::atoi(c), p2 = NB;
             while (p2 < v) p2 *= 2;
@@ -389,15 +362,7 @@ void Device::upload(const Symbolic &S) {
                 for (i64 k = f + 1; k < e; k += 2) l2[w++] = S.levellist[k];
             }
             const int *l2p; up(l2p, l2); d_levellist2_ = const_cast<int *>(l2p);
-            if (const char *e = std::getenv("GMRFX_TWO_CHAINS")) two_chains_ = std::atoi(e) != 0;
             if (const char *e = std::getenv("GMRFX_LEVEL_MARK")) level_mark_ = std::atoi(e) != 0;
-            if (const char *e = std::getenv("GMRFX_LOOKAHEAD")) lookahead_ = std::atoi(e) != 0;
-            if (const char *e = std::getenv("GMRFX_CHAIN_MAX_FRONTS")) chain_max_fronts_ = std::max(0, std::atoi(e));
-            if (const char *e = std::getenv("GMRFX_POTRF")) potrf_form_ = std::atoi(e) == 1 ? 1 : 3;
-            if (chain_max_fronts_ > 0) potrf_form_ = 1;      // (the persistent chain carries the register-patch body: same bits as ITS launch chain)
-            if (const char *e = std::getenv("GMRFX_INV_ON_MAIN")) inv_on_main_ = std::atoi(e) != 0;
-            if (const char *e = std::getenv("GMRFX_FUSED_CUT")) fused_cut_ = std::max(0, std::atoi(e));
-            if (const char *e = std::getenv("GMRFX_SMALL_ON_SIDE")) small_on_side_ = std::atoi(e) != 0;
             if (const char *e = std::getenv("GMRFX_BWD_FRONT")) bwd_front_min_ = std::atoi(e);    // fronts a level needs for the one-workgroup backward step (0: never)
         }
         const int *a; up(a, S.sub_first); d_sub_first_ = const_cast<int *>(a);
@@ -549,10 +514,9 @@ void Device::upload(const Symbolic &S) {
         // The bottom of the forward sweep is throughput work whose workgroups hold a CU's LDS for their whole life; started
         // while the factorisation still is throughput work itself (the wide middle of the tree) it only takes the chip away
         // from it. It is held back until the factorisation reaches its latency-bound top: the first level from which on every
-        // level has at most 32 fronts (GMRFX_FUSED_GATE: levels below the root, overrides).
+        // level has at most 32 fronts (re-swept in round 4: 4 .. 10 levels below the root are within 0.2 ms of it).
         int gate = S.nlevels - 1;
         while (gate > 0 && levels_[gate - 1].count <= 32) gate--;
-        if (const char *e = std::getenv("GMRFX_FUSED_GATE")) gate = S.nlevels - 1 - std::atoi(e);
         fused_gate_level_ = std::min<int>(std::max(gate, bottom_top_level_), std::max<int>(S.nlevels - 1, 0));
     }
 
@@ -685,7 +649,7 @@ void Device::upload(const Symbolic &S) {
     //  out the distributed root, which its owner still sweeps)
     for (i32 l = 0; l < S.nlevels; l++) if (swlevels_[l].max_cols > NB) { first_multiblock_level_ = l; break; }
 
-    // INVARIANT (pair loads): the kernels that read operand rows in 16-byte pairs (sweep_task.hip, k_syrk_cb_rec, selinv.hip)
+    // INVARIANT (pair loads): the kernels that read operand rows in 16-byte pairs (sweep_front.hip, k_syrk_cb_rec, selinv.hip)
     // may read ONE double past a column's last row; for the last column of the last panel that is element l_size_ of the
     // buffer. Every buffer that holds panels (d_L_, d_Z_, a clone) is therefore allocated through dalloc (16 bytes of
     // slack) and zeroed INCLUDING the slack, so the extra element is mapped and finite (it only ever meets a 0.0 mask).
@@ -697,8 +661,6 @@ void Device::upload(const Symbolic &S) {
     d_cb_ = dalloc<double>((size_t)S.cb_arena);
     d_nz_ = dalloc<double>((size_t)S.nnz_in);
     d_info_ = dalloc<int>(2);
-    d_chain_ = dalloc<int>(kChainErrWord + 8);          // persistent panel chain: 8 flag words per front + the error word
-    HC(hipMemset(d_chain_, 0, (kChainErrWord + 8) * sizeof(int)));
     d_part_ = dalloc<double>(1024 + 8);
     HC(hipMemsetAsync(d_L_, 0, ((size_t)l_size_ + kChunkSlack) * sizeof(double) + kPairSlackBytes, stream));
     HC(hipStreamSynchronize(stream));
@@ -742,19 +704,10 @@ static double *host_ptr_device_view(const void *p) {
 }
 static int host_io_threads() {
     static const int nt = [] {
-        if (const char *e = std::getenv("GMRFX_IO_THREADS")) return std::max(1, std::atoi(e));
         const unsigned hc = std::thread::hardware_concurrency();
         return (int)std::min<unsigned>(8, std::max<unsigned>(1, hc / 2));
     }();
     return nt;
-}
-static int host_io_upload_wgs() {      // > 0: the upload as ONE kernel of that many workgroups (measurement only; default DMA)
-    static const int v = [] { const char *e = std::getenv("GMRFX_IO_UPLOAD_WGS"); return e ? std::max(0, std::atoi(e)) : 0; }();
-    return v;
-}
-static bool host_io_beside() {         // GMRFX_IO_BESIDE=1 (measurement only): the upload beside the factorisation instead of in front of it
-    static const bool v = [] { const char *e = std::getenv("GMRFX_IO_BESIDE"); return e && std::atoi(e) != 0; }();
-    return v;
 }
 static constexpr long long kIoSliceBytes = 32ll << 20;     // staging granularity
 
@@ -804,14 +757,8 @@ void Device::host_upload_values(const double *nzval) {
 void Device::host_upload(const double *B, long long ldb, long long nrhs, double *d_dst) {
     const long long n = S_->n;
     host_io_reserve(0);
-    const int nwg = host_io_upload_wgs();
-    const bool by_kernel = nwg > 0;       // GMRFX_IO_UPLOAD_WGS > 0 (measurement only): k_stream_copy instead of the DMA engines
     if (host_ptr_is_pinned(B)) {
-        const double *dv = by_kernel ? host_ptr_device_view(B) : nullptr;
-        if (dv) {
-            launch_stream_copy(stream_io_, dv, ldb, d_dst, n, n, nrhs, nwg);
-            HC(hipGetLastError());
-        } else if (ldb == n) HC(hipMemcpyAsync(d_dst, B, (size_t)(n * nrhs) * sizeof(double), hipMemcpyDefault, stream_io_));
+        if (ldb == n) HC(hipMemcpyAsync(d_dst, B, (size_t)(n * nrhs) * sizeof(double), hipMemcpyDefault, stream_io_));
         else HC(hipMemcpy2DAsync(d_dst, n * sizeof(double), B, ldb * sizeof(double), n * sizeof(double), nrhs, hipMemcpyDefault, stream_io_));
         HC(hipEventRecord(ev_up_, stream_io_));
         return;
@@ -832,10 +779,7 @@ void Device::host_upload(const double *B, long long ldb, long long nrhs, double 
                 const long long j0 = k * cols_per, nc = std::min(cols_per, nrhs - j0);
                 for (long long j = 0; j < nc; j++)
                     std::memcpy(h_stage_ + (j0 + j) * n, B + (j0 + j) * ldb, (size_t)n * sizeof(double));
-                if (by_kernel) {
-                    launch_stream_copy(stream_io_, d_stage_view_ + j0 * n, n, d_dst + j0 * n, n, n, nc, nwg);
-                    HC(hipGetLastError());
-                } else HC(hipMemcpyAsync(d_dst + j0 * n, h_stage_ + j0 * n, (size_t)(nc * n) * sizeof(double), hipMemcpyHostToDevice, stream_io_));
+                HC(hipMemcpyAsync(d_dst + j0 * n, h_stage_ + j0 * n, (size_t)(nc * n) * sizeof(double), hipMemcpyHostToDevice, stream_io_));
             }
         } catch (...) {
             if (!failed.exchange(true)) err = std::current_exception();
@@ -855,7 +799,6 @@ void Device::host_download(const double *d_src, long long nrhs, double *X, long 
     // the copies are enqueued only once their source is final: a device-to-host copy that has to wait for an event on another
     // stream took 21 ms instead of 9 here (512 MB; the runtime leaves the DMA path for it)
     HC(hipStreamSynchronize(after));
-    if (io_trace_cb_) io_trace_cb_("sweeps done (download starts)");
     if (host_ptr_is_pinned(X)) {
         if (ldx == n) HC(hipMemcpyAsync(X, d_src, (size_t)(n * nrhs) * sizeof(double), hipMemcpyDefault, stream_io_));
         else HC(hipMemcpy2DAsync(X, ldx * sizeof(double), d_src, n * sizeof(double), n * sizeof(double), nrhs, hipMemcpyDefault, stream_io_));
@@ -911,13 +854,16 @@ void Device::factor_levels(int lo, int hi) {
                            d_info_, nullptr, nullptr, 0, 0);
     }
     // Q's values in assembly order, on the second stream beside the first (small-front) levels; the first big-front assembly waits
-    // for them. (lo > 0: a later phase of a sharded factorisation -- the values were gathered by the phase that started at 0)
-    bool nzp_joined = lo != 0;
+    // for them. The gather stays PENDING (nzp_pending_) until some call has made the main stream wait for it: a later phase of a
+    // sharded factorisation joins it before its first assembly if the phase that started it never did (no big front below the
+    // shard level), and a call that started it and never needed it joins it before returning -- the kernel reads the CALLER's
+    // values, which must not be in use once the call is over.
     if (lo == 0) {
         HC(hipEventRecord(ev_nzp0_, stream));
         HC(hipStreamWaitEvent(stream3, ev_nzp0_, 0));
         launch_gather_values(stream3, nz_src_, ds_.qsrc, d_nzp_, nq_);
         HC(hipEventRecord(ev_nzp_, stream3));
+        nzp_pending_ = true;
     }
     int nsy = (int)syrk_launches;
     for (int lev = lo; lev < hi; lev++) {
@@ -932,7 +878,7 @@ void Device::factor_levels(int lo, int hi) {
         // non-empty class stays on the main stream, the others go to the second one.
         int ncls_used = 0, widest = -1;
         for (int k = 0; k < 4; k++) if (L.ncls[k] > 0) { ncls_used++; widest = k; }
-        const bool split_small = small_on_side_ && L.nsmall > 0 && (nf > 0 || ncls_used > 1);
+        const bool split_small = L.nsmall > 0 && (nf > 0 || ncls_used > 1);
         if (split_small) {
             HC(hipEventRecord(ev_ready_, stream));
             HC(hipStreamWaitEvent(stream3, ev_ready_, 0));
@@ -941,7 +887,7 @@ void Device::factor_levels(int lo, int hi) {
             hipStream_t st_small = !split_small ? stream : (nf > 0 || k != widest) ? stream3 : stream;
             launch_factor_small(st_small, ds_, d_levellist_ + L.first + off, L.ncls[k], kClsRows[k], nz_src_, d_L_, d_cb_, d_info_);
         }
-        if (nf > 0 && !nzp_joined) { HC(hipStreamWaitEvent(stream, ev_nzp_, 0)); nzp_joined = true; }
+        if (nf > 0 && nzp_pending_) { HC(hipStreamWaitEvent(stream, ev_nzp_, 0)); nzp_pending_ = false; }
         launch_assemble(stream, ds_, list, d_arec_ + L.first + L.nsmall, d_nzp_, nf, L.max_cols, L.max_rows, nz_src_, d_L_, d_cb_);
         const int nblk = level_nblk(L);
         // The panel factorisation of a level is a chain of small dependent launches per 64-column block (potrf64 on ONE
@@ -949,104 +895,18 @@ void Device::factor_levels(int lo, int hi) {
         // wide fronts run TWO independent chains -- the fronts at even / odd positions of the width-sorted list -- on two
         // streams, so one half's trsm / gemm fills the chip while the other half sits in potrf64. Same arithmetic per
         // front: bit-identical factor.
-        const bool la = lookahead_ && nf >= 1 && nblk >= 2;
-        // PERSISTENT panel chain (panel_chain.hip): levels with a handful of wide fronts -- where potrf64 -> trsm -> gemm per
-        // 64-column block is a chain of ~350 small dependent launches per factorisation -- run ONE persistent launch per
-        // 256-column outer block (flags between its workgroups, look-ahead on the diagonal block) plus the K = 256 update of
-        // the columns beyond it. Same arithmetic per entry in the same order: the same bits as the launch chain.
-        const bool chain = !la && chain_max_fronts_ > 0 && nf >= 1 && nf <= chain_max_fronts_ && nblk >= 1 && !sharded();
-        if (chain) {
-            const FrontView *hl = d_frec_ + L.first + L.nsmall;
-            const i32 s1 = S_->levellist[L.first + L.nsmall];
-            const FrontArg f1{1, (int)s1, S_->ncols(s1), S_->nrows(s1), (int)S_->ld[s1], (int)S_->sfirst[s1], (long long)S_->panelptr[s1]};
-            const FrontArg f0{0, 0, 0, 0, 0, 0, 0};
-            for (int J0 = 0; J0 < nblk; J0 += OBK) {
-                const int na = L.active[J0];
-                if (na <= 0) break;
-                long long tiles = 0;
-                for (int f = 0; f < na; f++) {
-                    const i32 s = S_->levellist[L.first + L.nsmall + f];
-                    tiles += (S_->nrows(s) - NB * J0 + NB - 1) / NB;
-                }
-                const int stride = (int)std::max<long long>(1, (tiles + kChainMaxWgs - 1) / kChainMaxWgs);
-                int nwg = 0;
-                for (int f = 0; f < na; f++) {
-                    const i32 s = S_->levellist[L.first + L.nsmall + f];
-                    nwg += ((S_->nrows(s) - NB * J0 + NB - 1) / NB + stride - 1) / stride;
-                }
-                chain_base_ += 8;
-                static const bool ctrace = [] { const char *e = std::getenv("GMRFX_CHAIN_TRACE"); return e && std::atoi(e) != 0; }();
-                long long *trace = nullptr;
-                if (ctrace && lev + 1 == (int)levels_.size() && J0 == 0) {        // (the root's first outer block)
-                    if (!d_chain_trace_) d_chain_trace_ = dalloc<long long>(8 * 8 * 8);
-                    HC(hipMemsetAsync(d_chain_trace_, 0, 8 * 8 * 8 * sizeof(long long), stream));
-                    trace = d_chain_trace_;
-                }
-                launch_panel_chain(stream, hl, na, J0, stride, nwg, chain_base_, d_chain_, d_chain_ + kChainErrWord, d_L_, d_info_, trace);
-                chain_used_ = true;
-                const int J1 = J0 + OBK;
-                if (J1 < nblk && L.active[J1] > 0)
-                    launch_gemm_nt(stream, ds_, hl, L.active[J1], J0 * NB, OBK * NB, J1 * NB, INT_MAX, L.max_rows - J1 * NB,
-                                   L.max_cols - J1 * NB, d_L_, L.active[J1] == 1 ? f1 : f0);
-            }
-        }
-        const bool two = !la && !chain && two_chains_ && nf >= 2 && nblk >= 4 && !sharded();
+        // (Measured and dropped -- DESIGN.md section 3: a look-ahead diagonal chain with the bulk one step behind on a second stream,
+        //  a persistent kernel per 256-column outer block, a pair chain, a rolling SYRK: the chain is bounded by the 64 x 64
+        //  factorisation and by single-CU tile rates, not by its dispatches.)
+        const bool two = nf >= 2 && nblk >= 4 && !sharded();
         const int nhalf = two ? 2 : 1;
-        if (la) {
-            // LOOK-AHEAD chain (potrf64.hip): the diagonal chain P(b) on the main stream keeps its own band up to date; the
-            // bulk -- G(b-1), the trailing update inside the 256-column outer block without the band tiles, then T(b), the
-            // rows below the band -- follows one step behind on the second stream:
-            //   main:  P(b) waits for T(b-2)                     bulk:  G(b-1), T(b) wait for P(b)
-            // and the main stream picks the bulk up again at the end of every outer block (the K = 256 update of the rest of
-            // the panel reads all of it) and of the panel (the SYRK does).
-            const FrontView *hl = d_frec_ + L.first + L.nsmall;
-            FrontArg f1{0, 0, 0, 0, 0, 0, 0}, f0{0, 0, 0, 0, 0, 0, 0};
-            {
-                const i32 s1 = S_->levellist[L.first + L.nsmall];
-                f1 = FrontArg{1, (int)s1, S_->ncols(s1), S_->nrows(s1), (int)S_->ld[s1], (int)S_->sfirst[s1], (long long)S_->panelptr[s1]};
-            }
-            while ((int)ev_la_p_.size() < nblk) {
-                hipEvent_t a, b;
-                HC(hipEventCreateWithFlags(&a, hipEventDisableTiming));
-                HC(hipEventCreateWithFlags(&b, hipEventDisableTiming));
-                ev_la_p_.push_back(a); ev_la_t_.push_back(b);
-            }
-            for (int b = 0; b < nblk; b++) {
-                const int kb = b * NB, na = L.active[b];
-                if (na <= 0) break;
-                const FrontArg &fa = na == 1 ? f1 : f0;
-                const int J0 = (b / OBK) * OBK, J1 = J0 + OBK;
-                const bool first_in_outer = b == J0;
-                const bool last_of_panel = b + 1 >= nblk || L.active[b + 1] <= 0;
-                const bool next_in_outer = !last_of_panel && b + 1 < J1;
-                if (first_in_outer) launch_potrf64(stream, ds_, hl, na, kb, d_L_, d_info_, fa, potrf_form_);
-                else {
-                    if (b - 2 >= J0) HC(hipStreamWaitEvent(stream, ev_la_t_[b - 2], 0));
-                    launch_potrf64_la(stream, ds_, hl, na, kb, J0 * NB, d_L_, d_info_, fa);
-                }
-                HC(hipEventRecord(ev_la_p_[b], stream));
-                HC(hipStreamWaitEvent(stream3, ev_la_p_[b], 0));
-                if (!first_in_outer)        // G(b-1): columns b .. J1-1 of the outer block -= L[:, b-1] L[., b-1]', band tiles left out
-                    launch_gemm_nt(stream3, ds_, hl, na, kb - NB, NB, kb, J1 * NB, L.max_rows - kb, std::min(J1 * NB, L.max_cols) - kb,
-                                   d_L_, fa, 1);
-                launch_trsm(stream3, ds_, hl, na, kb, 0, L.max_rows - kb - 1, d_L_, nullptr, nullptr, fa, next_in_outer ? 1 : 0);
-                HC(hipEventRecord(ev_la_t_[b], stream3));
-                if (!next_in_outer) {       // end of the outer block (or of the panel): the main stream needs all of it
-                    HC(hipStreamWaitEvent(stream, ev_la_t_[b], 0));
-                    if (!last_of_panel && J1 < nblk)
-                        launch_gemm_nt(stream, ds_, hl, L.active[J1], J0 * NB, OBK * NB, J1 * NB, INT_MAX, L.max_rows - J1 * NB,
-                                       L.max_cols - J1 * NB, d_L_, L.active[J1] == 1 ? f1 : f0);
-                }
-            }
-        }
         if (two) {
             HC(hipEventRecord(ev_ready2_, stream));               // (after the assembly of this level's panels)
             HC(hipStreamWaitEvent(stream3, ev_ready2_, 0));
         }
         // (the two chains are enqueued block by block in turn, not one after the other: the host stays ahead of both)
-        static const bool interleave = [] { const char *e = std::getenv("GMRFX_CHAIN_INTERLEAVE"); return !e || std::atoi(e) != 0; }();
-        for (int it = 0; it < nblk * nhalf && !la && !chain; it++) {
-                const int b = interleave ? it / nhalf : it % nblk, hf = interleave ? it % nhalf : it / nblk;
+        for (int it = 0; it < nblk * nhalf; it++) {
+                const int b = it / nhalf, hf = it % nhalf;
                 hipStream_t st = hf == 0 ? stream : stream3;
                 const FrontView *hl = two ? d_frec2_ + L.first + L.nsmall + (hf == 0 ? 0 : (nf + 1) / 2) : d_frec_ + L.first + L.nsmall;
                 auto act = [&](int bb) { const int a = L.active[bb]; return two ? (hf == 0 ? (a + 1) / 2 : a / 2) : a; };
@@ -1059,7 +919,7 @@ void Device::factor_levels(int lo, int hi) {
                     f1 = FrontArg{1, (int)s1, S_->ncols(s1), S_->nrows(s1), (int)S_->ld[s1], (int)S_->sfirst[s1], (long long)S_->panelptr[s1]};
                 }
                 const int kb = b * NB;
-                if (b == 0 && act(0) > 1 && potrf_form_ == 3) {
+                if (b == 0 && act(0) > 1) {
                     // first block of a level with many fronts: one launch per width class (the list is sorted by decreasing width;
                     // the even / odd halves of two chains are sorted as well), each in the workgroup shape that fits it
                     auto half = [&](int a) { return two ? (hf == 0 ? (a + 1) / 2 : a / 2) : a; };
@@ -1067,13 +927,13 @@ void Device::factor_levels(int lo, int hi) {
                     const int wcls[4] = {64, 48, 32, 16};
                     for (int q = 0; q < 4; q++)
                         if (cut[q + 1] > cut[q])
-                            launch_potrf64(st, ds_, hl + cut[q], cut[q + 1] - cut[q], kb, d_L_, d_info_, f0, potrf_form_, std::min(wcls[q], L.max_cols));
+                            launch_potrf64(st, ds_, hl + cut[q], cut[q + 1] - cut[q], kb, d_L_, d_info_, f0, std::min(wcls[q], L.max_cols));
                 } else
-                    launch_potrf64(st, ds_, hl, act(b), kb, d_L_, d_info_, act(b) == 1 ? f1 : f0, potrf_form_, std::min(NB, L.max_cols - kb));
+                    launch_potrf64(st, ds_, hl, act(b), kb, d_L_, d_info_, act(b) == 1 ? f1 : f0, std::min(NB, L.max_cols - kb));
                 {
                     // first block of a level with many fronts: the fronts at most 32 columns wide (the tail of the sorted list) go to
                     // the narrow-block kernel (same arithmetic on half the registers: more resident waves)
-                    static const int narrow_min = [] { const char *e = std::getenv("GMRFX_TRSM_NARROW_MIN"); return e ? std::atoi(e) : 256; }();
+                    constexpr int narrow_min = 256;
                     auto half = [&](int a) { return two ? (hf == 0 ? (a + 1) / 2 : a / 2) : a; };
                     const int cut32 = b == 0 ? half(L.wider[1]) : act(b);
                     const int nnarrow = act(b) - cut32;
@@ -1108,10 +968,10 @@ void Device::factor_levels(int lo, int hi) {
             HC(hipEventRecord(ev_done1_, stream3));
             HC(hipStreamWaitEvent(stream, ev_done1_, 0));
         }
-        if (fused_ && inv_on_main_) invert_level(stream, lev);       // (A/B switch GMRFX_INV_ON_MAIN: the level's dense inverses behind its panels)
         if (fused_) HC(hipEventRecord(ev_flevel_[lev], stream));      // the panels of this level are final: its sweep may start
     }
     syrk_launches = nsy;
+    if (lo == 0 && nzp_pending_) { HC(hipStreamWaitEvent(stream, ev_nzp_, 0)); nzp_pending_ = false; }     // (see above)
     if (level_mark_) level_event(0, hi);
 }
 
@@ -1119,32 +979,6 @@ void Device::factor_levels(int lo, int hi) {
 // fronts, never by logdet: they are computed lazily (first solve / selinv after a
 // refactorisation) on a side stream, so that in a refactorise+solve step they overlap the
 // small-front levels at the bottom of the forward sweep.
-// a bounded spin of the persistent panel chain ran out (its grid was not fully resident, or a workgroup died): the factor is garbage
-void Device::check_chain_error() {
-    if (d_chain_trace_) {
-        std::vector<long long> t(8 * 8 * 8);
-        HC(hipMemcpy(t.data(), d_chain_trace_, t.size() * sizeof(long long), hipMemcpyDeviceToHost));
-        long long t0 = 0;
-        for (long long v : t) if (v && (!t0 || v < t0)) t0 = v;
-        std::fprintf(stderr, "[gmrfx chain trace] root, first outer block; us since the first stamp (2.1 GHz assumed); slots: 0 step top, 1 P flag seen, 2 Linv staged, 3 pass-0 tiles done, 4 next diagonal block factored + published, 5 pass-1 tiles done\n");
-        for (int wg = 0; wg < 8; wg++)
-            for (int q = 0; q < 7; q++) {
-                const long long *r = &t[(wg * 8 + q) * 8];
-                bool any = false;
-                for (int k = 0; k < 6; k++) any = any || r[k];
-                if (!any) continue;
-                std::fprintf(stderr, "  wg %d step %2d:", wg, q - 1);
-                for (int k = 0; k < 7; k++) std::fprintf(stderr, " %8.2f", r[k] ? (double)(r[k] - t0) / 2100.0 : -1.0);
-                std::fprintf(stderr, "\n");
-            }
-    }
-    if (!chain_used_ || h_info_[1] == 0) return;
-    h_info_[1] = 0;
-    (void)hipMemsetAsync(d_chain_ + kChainErrWord, 0, sizeof(int), stream);
-    factorized = false;
-    throw std::runtime_error("persistent panel-chain kernel timed out waiting for a flag (GMRFX_CHAIN_MAX_FRONTS=0 selects the launch chain)");
-}
-
 void Device::start_inverse_async() {
     if (!inverse_pending) return;
     // ev_fact_ = "the factor is final": recorded at the end of the factorisation, so that whatever the caller has put on
@@ -1200,18 +1034,9 @@ void Device::refactorize_solve(const double *nzval, bool nz_on_device, const dou
     }
     const long long n = S_->n;
     const int nl = (int)levels_.size();
-    // GMRFX_IO_TRACE=1: host-side timestamps of the call's stages on stderr (measurement aid)
-    static const bool io_trace = [] { const char *e = std::getenv("GMRFX_IO_TRACE"); return e && std::atoi(e) != 0; }();
-    const auto tr0 = std::chrono::steady_clock::now();
-    auto trace = [&](const char *what) {
-        if (io_trace) std::fprintf(stderr, "[gmrfx io] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count());
-    };
-    io_trace_cb_ = io_trace ? std::function<void(const char *)>(trace) : std::function<void(const char *)>();
-    struct ClearCb { std::function<void(const char *)> &f; ~ClearCb() { f = nullptr; } } clear_cb{io_trace_cb_};
     const double *src = nzval;
     if (!nz_on_device) {
         host_upload_values(nzval);
-        trace("values enqueued");
         src = d_nz_;
     }
     nz_held_ = (src == d_nz_);
@@ -1227,12 +1052,11 @@ void Device::refactorize_solve(const double *nzval, bool nz_on_device, const dou
     }
     while ((int)ev_flevel_.size() < nl + 1) { hipEvent_t e; HC(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ev_flevel_.push_back(e); }
     factor_serial_++;
-    // host right-hand sides: in FRONT of the factorisation (see the measurements above host_upload), unless asked otherwise
-    const bool up_first = !b_on_device && !host_io_beside();
-    if (up_first) {
+    // host right-hand sides: in FRONT of the factorisation (see the measurements above host_upload): the transfers are serial --
+    // B in, the pipelined step, X out -- never beside the factorisation
+    if (!b_on_device) {
         host_upload(B, ldb, nrhs, d_io_);
         HC(hipStreamWaitEvent(stream, ev_up_, 0));
-        trace("B upload enqueued");
     }
     HC(hipEventRecord(ev_[0], stream));
     HC(hipEventRecord(ev_ready_, stream));                 // the side stream starts behind the uploads / whatever precedes this call
@@ -1240,15 +1064,12 @@ void Device::refactorize_solve(const double *nzval, bool nz_on_device, const dou
     fused_ = true;
     factor_levels(0, nl);
     fused_ = false;
-    trace("factorisation enqueued");
     HC(hipEventRecord(ev_[1], stream));
     HC(hipEventRecord(ev_fact_, stream));
     fact_event_valid_ = true;
     HC(hipMemcpyAsync(h_info_, d_info_, sizeof(int), hipMemcpyDeviceToHost, stream));
-    if (chain_used_) HC(hipMemcpyAsync(h_info_ + 1, d_chain_ + kChainErrWord, sizeof(int), hipMemcpyDeviceToHost, stream));
     factorized = true;
     selinv_valid = false;
-    if (!b_on_device && !up_first) host_upload(B, ldb, nrhs, d_io_);     // (measurement switch: beside the factorisation just enqueued)
     // ---- first pass of up to 64 columns: forward sweep on the side stream, behind the level events
     const int nr = (int)std::min<long long>(64, nrhs), ldx = nr;
     hipEvent_t *ev = ev_lane_[0];
@@ -1284,12 +1105,9 @@ void Device::refactorize_solve(const double *nzval, bool nz_on_device, const dou
         launch_permute(stream, d_iperm_, (int)n, dXo + j0 * ldout, ldout, d_X_, nr2, nr2, 1);
     }
     HC(hipEventRecord(ev_lane_[1][0], stream));
-    trace("sweeps enqueued");
     if (!b_on_device) host_download(d_io_, nrhs, X, ldx_out, stream);
-    trace("X downloaded");
     HC(hipStreamSynchronize(stream));
     info_cached_ = true;
-    check_chain_error();
     HC(hipGetLastError());
     float tf = 0, a = 0, b = 0, c = 0, d = 0, tail = 0;
     HC(hipEventElapsedTime(&tf, ev_[0], ev_[1]));
@@ -1326,10 +1144,8 @@ void Device::refactorize(const double *nzval, bool on_device) {
     inverse_pending = true;
     // the pivot report travels with the factorisation (pinned host word): no blocking copy after the synchronisation
     HC(hipMemcpyAsync(h_info_, d_info_, sizeof(int), hipMemcpyDeviceToHost, stream));
-    if (chain_used_) HC(hipMemcpyAsync(h_info_ + 1, d_chain_ + kChainErrWord, sizeof(int), hipMemcpyDeviceToHost, stream));
     HC(hipStreamSynchronize(stream));
     info_cached_ = true;
-    check_chain_error();
     HC(hipGetLastError());
     float ms = 0;
     HC(hipEventElapsedTime(&ms, ev_[0], ev_[1]));
@@ -1397,7 +1213,7 @@ void Device::dist_front_phase(const double *d_nzval, int front, int what, int bl
         const int b0 = block * OBK, b1 = std::min(b0 + OBK, (c + NB - 1) / NB);
         for (int b = b0; b < b1; b++) {
             const int kb = b * NB;
-            launch_potrf64(stream, ds_, nullptr, 1, kb, d_L_, d_info_, fa, potrf_form_);
+            launch_potrf64(stream, ds_, nullptr, 1, kb, d_L_, d_info_, fa);
             launch_trsm(stream, ds_, nullptr, 1, kb, 0, r - kb - 1, d_L_, nullptr, nullptr, fa);
             if (b + 1 < b1)
                 launch_gemm_nt(stream, ds_, nullptr, 1, kb, NB, kb + NB, b1 * NB, r - kb - NB, std::min(b1 * NB, c) - kb - NB, d_L_, fa);
@@ -1504,16 +1320,16 @@ void Device::ensure_rhs_capacity(long long nrhs) {
     }
 }
 
-// The bottom subtrees. Up to wave_max_nr_ (32) right-hand sides: one wave per (task, 16 columns), sweep_wave.hip, biggest LDS
-// class first -- measured at cfg 2 (tools/nrhs_sweep.py): 1 RHS 3.10 vs 3.97 ms per solve, 16: 3.23 vs 4.22, 32: 3.93 vs 4.39;
-// wider passes: the workgroup tasks of sweep_task.hip (64 RHS: 4.90 vs 5.58 ms -- the general op pipeline of the wave form
-// issues ~2.5x the instructions per front). GMRFX_TASK_MODE = wg / wave forces one form.
+// The bottom subtrees. Up to wave_max_nr_ (16) right-hand sides: one wave per (task, 16 columns), sweep_wave.hip, biggest LDS
+// class first; wider passes: the chunk form, four waves per (task, 16 columns), sweep_chunk.hip. Measured at cfg 2, round 5
+// (tools/nrhs_sweep.py, ms per solve, wave form / chunk form): 1 RHS 2.88 / 3.22, 16: 3.00 / 3.36, 32: 3.71 / 3.47, 64: - / 3.90.
+// GMRFX_TASK_MODE = wg / wave forces one form.
 void Device::sweep_tasks(int phase, int nr, int ldx) {
     if (nr > wave_max_nr_) {
-        // pipelined call: the forward task kernel runs beside the top of the factorisation -- ONE resident workgroup per CU
-        // (GMRFX_FUSED_TASK_LDS KB of unused dynamic LDS on top of its 72 KB), so that the panel chain's kernels find LDS
-        // (measured at cfg 2, round 4: the level under which the task kernel runs 1.40 -> 1.15 ms (0.95 alone), step 14.19 -> 14.03 ms)
-        static const int pad_kb = [] { const char *e = std::getenv("GMRFX_FUSED_TASK_LDS"); return e ? std::max(0, std::atoi(e)) : 16; }();
+        // pipelined call: the forward task kernel runs beside the top of the factorisation -- TWO resident workgroups per CU
+        // instead of four (16 KB of unused dynamic LDS on top of its 40 KB), so that the panel chain's kernels find LDS
+        // (measured at cfg 2, round 5: pad 0 / 8 / 16 / 42 KB -> step 12.59 / 12.61 / 12.38 / 12.91 ms)
+        constexpr int pad_kb = 16;
         const size_t extra = (fused_fwd_ && phase == 1) ? (size_t)pad_kb * 1024 : 0;
         ensure_dtile();
         launch_sweep_chunks(stream, ds_, phase, d_swt_, nswt_, d_swc_fwd_, d_swc_bwd_, d_swc_listf_, d_swc_listb_, d_dtile_, d_L_, d_X_,
@@ -1563,11 +1379,8 @@ void Device::forward(int nr, int ldx, int lo, int hi) {
         auto &L = swlevels_[lev];
         if (level_mark_) { launch_level_mark(stream, 1, lev); level_event(1, 1 + lev); }
         if (fused_fwd_) {
-            // GMRFX_FUSED_CUT=k (A/B): the top k levels of the forward sweep (and their dense inverses) wait for the WHOLE
-            // factorisation instead of their own level: nothing runs beside the latency-bound top of the panel chains
-            if (fused_cut_ > 0 && lev >= (int)levels_.size() - fused_cut_) HC(hipStreamWaitEvent(stream, ev_fact_, 0));
-            else if (lev > fused_gate_level_) HC(hipStreamWaitEvent(stream, ev_flevel_[lev], 0));
-            if (!inv_on_main_) invert_level(stream, lev);
+            if (lev > fused_gate_level_) HC(hipStreamWaitEvent(stream, ev_flevel_[lev], 0));
+            invert_level(stream, lev);
         } else if (lev == std::max(lo, first_multiblock_level_)) wait_inverse();
         for (int k = 0, off = 0; k < 4; off += L.ncls[k], k++)
             launch_fwd_small(stream, ds_, d_sw_levellist_ + L.first + off, L.ncls[k], kClsRows[k], d_L_, d_X_, d_W_, nr, ldx);
@@ -1899,7 +1712,6 @@ void Device::refactorize_logpdf(const double *d_nz, const double *d_X, long long
     fact_event_valid_ = true;
     inverse_pending = true;
     HC(hipMemcpyAsync(h_info_, d_info_, sizeof(int), hipMemcpyDeviceToHost, stream));
-    if (chain_used_) HC(hipMemcpyAsync(h_info_ + 1, d_chain_ + kChainErrWord, sizeof(int), hipMemcpyDeviceToHost, stream));
     factorized = true;
     selinv_valid = false;
     float tf = 0;
@@ -1907,7 +1719,6 @@ void Device::refactorize_logpdf(const double *d_nz, const double *d_X, long long
     if (nvec > 0) HC(hipStreamWaitEvent(stream, ev_qf_, 0));
     HC(hipStreamSynchronize(stream));
     info_cached_ = true;
-    check_chain_error();
     HC(hipGetLastError());
     HC(hipEventElapsedTime(&tf, ev_[0], ev_[1]));
     ms_factor = tf;

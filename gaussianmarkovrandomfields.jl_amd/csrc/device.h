@@ -231,7 +231,6 @@ public:
     bool async_phases_ = false;          // sharded phase entry points return after enqueueing (no host synchronisation, no timings)
     hipStream_t stream2 = nullptr;  // side stream: dense-inverse stages overlap the leaf levels of the forward sweep
     hipStream_t stream3 = nullptr;  // second sweep lane (solves with more than 64 right-hand sides)
-    std::vector<hipStream_t> dummy_streams_;   // GMRFX_STREAM_SKIP (A/B)
     hipEvent_t ev_fact_ = nullptr, ev_inv_ = nullptr;
 
 private:
@@ -269,34 +268,10 @@ private:
     bool syrk_xcd_ = true;          // GMRFX_SYRK_XCD=0: k_syrk_cb on a plain 3-D grid (front, tile row, tile column) instead
     FrontView *d_frec_ = nullptr, *d_frec2_ = nullptr, *d_sel_frec_ = nullptr;   // geometry records parallel to the level lists
     int *d_levellist2_ = nullptr;   // per level: the big fronts re-ordered [even positions..., odd positions...] (two-stream panel chains)
-    bool two_chains_ = true;
-    int fused_cut_ = 0;           // GMRFX_FUSED_CUT (A/B): top levels of the pipelined forward sweep that wait for the whole factorisation
-    bool inv_on_main_ = false;    // GMRFX_INV_ON_MAIN=1 (A/B): pipelined call: a level's dense inverses on the main stream behind its panels
-    // persistent panel chain (panel_chain.hip): levels with at most this many wide fronts (GMRFX_CHAIN_MAX_FRONTS; 0: never).
-    // OFF by default -- measured at cfg 2 (round 4, tools/chain_ab.py, GMRFX_CHAIN_TRACE): same bits as the launch chain, but
-    // factorisation 10.1 -> 10.9 ms (13.2 ms in its first, eight-wave form, which spilled around the inlined diagonal-block body).
-    // Inside the persistent kernel a chain step costs ~40 us against 30 us for the three launches it replaces: the diagonal block
-    // 22 us (16.9 as its own launch: write-through stores and their drain before the flag), the look-ahead tile's T 7.7 us and
-    // G 9.5 us -- a 64 x 64 x 64 product on ONE compute unit with one wave per SIMD issues an FP64 MFMA every ~138 cycles, where
-    // the launch chain spreads the same rows over a hundred workgroups.
-    static constexpr int kChainErrWord = 8 * 64, kChainMaxWgs = 256;
-    int chain_max_fronts_ = 0;
-    int potrf_form_ = 3;              // 64 x 64 diagonal blocks: 3 = 16-column steps (potrf64_blocked.h), 1 = register patches (GMRFX_POTRF=1)
-    int *d_chain_ = nullptr;
-    long long *d_chain_trace_ = nullptr;
-    int chain_base_ = 0;
-    bool chain_used_ = false;
-    void check_chain_error();
-    bool lookahead_ = false;      // GMRFX_LOOKAHEAD=1: look-ahead panel chain (potrf64.hip k_potrf64_la). OFF by default: measured at cfg 2
-                                  // (round 3) the left-looking band prologue costs 12 us + 6 us per earlier block of the outer block
-                                  // on top of the 15 us factorisation, more than the trsm + gemm launches (5 + 5 us) it takes off
-                                  // the critical path: factorisation 11.06 -> 12.99 ms. Kept (and parity-tested) as the base for a
-                                  // cheaper prologue.
-    std::vector<hipEvent_t> ev_la_p_, ev_la_t_;     // per 64-column block: diagonal chain done / bulk trsm done
     // wave tasks (sweep_wave.hip): task ids by LDS class
     static constexpr int kWaveClasses = 2;
     static constexpr int kWaveRows[kWaveClasses] = {160, 288};
-    int wave_max_nr_ = 32;        // passes of up to this many right-hand sides use the wave tasks (0: never)
+    int wave_max_nr_ = 16;        // passes of up to this many right-hand sides use the wave tasks (0: never)
     const int *d_wave_order_ = nullptr;
     int wave_first_[kWaveClasses] = {0, 0}, wave_count_[kWaveClasses] = {0, 0};
     void sweep_tasks(int phase, int nr, int ldx);
@@ -306,6 +281,7 @@ public:
     void dist_front_phase(const double *d_nzval, int front, int what, int block);
 private:
     void ensure_rdiag();
+    bool nzp_pending_ = false;                    // k_gather_values runs on the third stream and the main stream has not waited for it yet
     void ensure_dtile();
     int bwd_front_min_ = 192;                     // backward step of fronts <= 128 columns wide as one workgroup (sweep_front.hip) on levels with at least this many of them (0: never)
     Symbolic::SwChunk *d_swc_fwd_ = nullptr, *d_swc_bwd_ = nullptr;   // chunk records of the sweep tasks (forward order / backward slot programs)
@@ -322,7 +298,6 @@ private:
     int level_slots_[3] = {0, 0, 0};
     void level_event(int phase, int slot);
     bool level_mark_ = false;     // GMRFX_LEVEL_MARK=1: an empty marker kernel in front of every level (profiling aid, tools/sweep_levels.py)
-    bool small_on_side_ = true;     // GMRFX_SMALL_ON_SIDE=0: a level's small fronts before its big fronts, on one stream
     int *d_sub_first_ = nullptr, *d_sub_last_ = nullptr, *d_sel_levellist_ = nullptr;
     int nsub_cls_[3] = {0, 0, 0};
     double *d_L_ = nullptr, *d_Z_ = nullptr, *d_cb_ = nullptr, *d_nz_ = nullptr;
@@ -386,7 +361,6 @@ private:
     void host_upload_values(const double *nzval);
     hipEvent_t ev_up_ = nullptr, ev_x_ = nullptr;
     std::vector<hipEvent_t> ev_dn_;
-    std::function<void(const char *)> io_trace_cb_;     // GMRFX_IO_TRACE
     void host_io_reserve(long long count);
     void host_upload(const double *B, long long ldb, long long nrhs, double *d_dst);
     void host_download(const double *d_src, long long nrhs, double *X, long long ldx, hipStream_t after);

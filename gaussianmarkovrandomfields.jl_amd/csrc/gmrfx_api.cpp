@@ -87,7 +87,6 @@ extern "C" int32_t gmrfx_create(int64_t n, const int64_t *colptr, const int64_t 
         if (const char *e = std::getenv("GMRFX_SUBTREE_MAX")) so.subtree_max = std::atoi(e);       // 0 disables subtree tasks
         if (const char *e = std::getenv("GMRFX_SWEEP_TASK_ROWS")) so.sweep_task_rows = std::atoi(e);   // 0 disables sweep tasks
         if (const char *e = std::getenv("GMRFX_MERGE_WIDE")) so.merge_wide = std::atoi(e);   // widest child with siblings that may still be merged into its parent
-        if (const char *e = std::getenv("GMRFX_MERGE_WIDE_MAX")) so.merge_wide_max = std::atoi(e);
         if (const char *e = std::getenv("GMRFX_TOP_BY_DEPTH")) so.top_by_depth = std::atoi(e);   // top levels levelled by depth below the root (0: none)
         if (h->opts.shard_world > 1) {
             if (h->opts.shard_rank < 0 || h->opts.shard_rank >= h->opts.shard_world) throw std::invalid_argument("shard_rank out of range");

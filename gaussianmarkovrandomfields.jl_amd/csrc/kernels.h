@@ -25,9 +25,9 @@ void launch_syrk_cb_recs(hipStream_t st, const DevSym &S, const SyrkTile *recs, 
 // blocks at most 32 columns wide, factorisation only (k_trsm<0, 0>'s arithmetic on half the registers)
 void launch_trsm_narrow(hipStream_t st, const FrontView *frec, int nactive, int kb, int max_rows_below, double *L);
 void launch_trsm(hipStream_t st, const DevSym &S, const FrontView *frec, int nactive, int kb, int mode, int max_rows_below,
-                 double *L, double *Yh, const long long *yoff, const FrontArg &fa, int la = 0);
+                 double *L, double *Yh, const long long *yoff, const FrontArg &fa);
 void launch_gemm_nt(hipStream_t st, const DevSym &S, const FrontView *frec, int nactive, int k0, int K, int c0, int c1,
-                    int maxM, int maxN, double *L, const FrontArg &fa, int band = 0);
+                    int maxM, int maxN, double *L, const FrontArg &fa);
 void launch_fwd_update_recs(hipStream_t st, const DevSym &S, const FwdTile *recs, const SyrkSplit &split, int per_xcd, const double *L,
                             double *X, double *W, int nr, int ldx);
 void launch_fwd_assemble(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, double *X,
@@ -398,8 +398,6 @@ void launch_assemble_cyclic(hipStream_t st, const DevSym &S, const int *list, in
 void launch_syrk_cb_cyclic(hipStream_t st, const DevSym &S, const int *list, int trail, const double *L, double *CB, int cyc_w, int cyc_r, int cyc_b0);
 void launch_level_mark(hipStream_t st, int phase, int level);   // phase 1 = forward sweep, 2 = backward sweep, 3 = factorisation, 4 = selected inversion
 void launch_permute(hipStream_t st, const int *iperm, int n, double *Bc, long long ldb, double *X, int nr, int ldx, int dir);
-// column-major block copy by nwg workgroups (one side may be page-locked host memory: PCIe traffic inside a kernel)
-void launch_stream_copy(hipStream_t st, const double *src, long long lds, double *dst, long long ldd, long long rows, long long cols, int nwg);
 void launch_newton_update(hipStream_t st, const double *prior, double *nz, long long nnz, const long long *map, const double *h,
                           long long cnt);
 int quadform_blocks(int n);
@@ -414,9 +412,6 @@ void launch_logdet(hipStream_t st, const double *L, const long long *diagoff, co
 void launch_gather(hipStream_t st, const double *src, const long long *off, long long cnt, double *out);
 void launch_gather_diag(hipStream_t st, const double *src, const long long *diagoff, const int *perm, int n, double *out);
 
-// panel_chain.hip -- one persistent launch per 256-column outer block of a level's wide fronts (potrf / trsm / K = 64 updates)
-void launch_panel_chain(hipStream_t st, const FrontView *frec, int nfront, int J0, int stride_cap, int nwg, int base, int *flags, int *err,
-                        double *L, int *info, long long *trace = nullptr);
 
 // dense.hip -- the dense-operator leg of the Kronecker path: R = D T (row-major, D n1 x n1, T / R n1 x n2) and a transpose
 void launch_dense_apply(hipStream_t st, const double *D, const double *T, double *R, int n1, long long n2);
@@ -428,19 +423,14 @@ void launch_factor_small(hipStream_t st, const DevSym &S, const int *list, int n
 // phase 0: factor, 1: forward sweep, 2: backward sweep of whole small subtrees (one workgroup per subtree)
 void launch_subtree(hipStream_t st, const DevSym &S, int phase, const int *sub_first, const int *sub_last, int ntasks,
                     int rmax, const double *nzval, double *L, double *CB, int *info, double *X, double *W, int nr, int ldx);
-// form: 3 = 16-column steps (potrf64_blocked.h, the product path), 1 = register patches (potrf64_body.h; GMRFX_POTRF=1)
-// wmax: the widest block of the launch (<= 64): picks the workgroup shape of the 16-column-step kernel
-void launch_potrf64(hipStream_t st, const DevSym &S, const FrontView *frec, int nactive, int kb, double *L, int *info, const FrontArg &fa, int form = 3,
+// wmax: the widest block of the launch (<= 64): picks the workgroup shape (potrf64.hip)
+void launch_potrf64(hipStream_t st, const DevSym &S, const FrontView *frec, int nactive, int kb, double *L, int *info, const FrontArg &fa,
                     int wmax = 64);
-// look-ahead form: brings the band tiles (b, b-1), (b, b) up to date left-looking over columns kb0 .. kb-1, then factors (potrf64.hip)
-void launch_potrf64_la(hipStream_t st, const DevSym &S, const FrontView *frec, int nactive, int kb, int kb0, double *L, int *info,
-                       const FrontArg &fa);   // potrf64.hip
 void launch_fwd_small(hipStream_t st, const DevSym &S, const int *list, int nfronts, int rmax, const double *L,
                       double *X, double *W, int nr, int ldx);
 void launch_bwd_small(hipStream_t st, const DevSym &S, const int *list, int nfronts, int rmax, const double *L,
                       double *X, int nr, int ldx);
 
-// sweep_task.hip -- whole bottom subtrees on an LDS-resident local vector: phase 1 forward, 2 backward
 // backward step of a front of at most bwd_front_max_cols() columns as one workgroup (sweep_front.hip): x[own] = L11^-T (Yin[own] - L21' Xt[trailing])
 void launch_bwd_front(hipStream_t st, const DevSym &S, const int *list, int nfronts, const double *L, const double *Xt, const double *Yin,
                       double *Xout, int nr, int ldx);
@@ -452,8 +442,6 @@ void launch_sweep_chunks(hipStream_t st, const DevSym &S, int phase, const Sweep
                          double *X, double *W, int nr, int ldx, size_t extra_lds);
 int sweep_chunk_nc();
 int sweep_chunk_spare_row();
-void launch_sweep_tasks(hipStream_t st, const DevSym &S, int phase, const SweepTask *tasks, int ntasks,
-                        const double *L, double *X, double *W, int nr, int ldx, size_t extra_lds = 0);
 
 // sweep_wave.hip -- the same tasks, one wave per (task, 16 right-hand sides); order = task ids of one LDS class
 void launch_wave_tasks(hipStream_t st, const DevSym &S, int phase, const SweepTask *tasks, const int *order, int ntasks, int rows_cap,

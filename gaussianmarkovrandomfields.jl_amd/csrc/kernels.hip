@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void k_assemble(DevSym S, const int *__restric
 template <int MODE, int SPLIT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k_trsm(DevSym S, const FrontView *__restrict__ frec, int kb,
                                               double *__restrict__ L, double *__restrict__ Yh,
-                                              const long long *__restrict__ yoff, FrontArg fa, int la) {
+                                              const long long *__restrict__ yoff, FrontArg fa) {
     // SPLIT = 0: a workgroup owns 128 rows, each wave 32 of them (all four 16-column tiles) as 16 row PAIRS: MFMA
     // row lm of tile 0 / 1 is row 2 lm / 2 lm + 1 of the wave's 32, so one 16-byte load per lane and k-step feeds both
     // tiles and the results leave 16 bytes at a time (half the vector memory instructions, half the LDS reads and half
@@ -135,10 +135,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
     const int s = fv.s, c = fv.c, r = fv.r;
     if (kb >= c) return;
     const int w = min(NB, c - kb);
-    // la (look-ahead panel chain, potrf64.hip): the rows of the NEXT 64-column block (the sub-diagonal tile) are solved by
-    // the diagonal chain itself (k_potrf64_la) -- this launch starts below them
-    const int skip = (MODE == 0 && la) ? min(NB, max(0, c - kb - w)) : 0;
-    const int row0 = kb + w + skip + blockIdx.x * (SPLIT ? 16 : 128);
+    const int row0 = kb + w + blockIdx.x * (SPLIT ? 16 : 128);
     if (row0 >= r) return;
     const int ld = fv.ld;
     double *Pp = L + fv.pp;
@@ -319,7 +316,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k
 // CB -= L21 L21' (K = all c columns).
 template <int TW>   // MFMA tiles per wave and dimension: wave tile 16*TW squared, workgroup tile twice that
 __global__ __launch_bounds__(256) void k_gemm_nt(DevSym S, const FrontView *__restrict__ frec, int k0, int K, int c0, int c1,
-                                                 double *__restrict__ L, FrontArg fa, int band) {
+                                                 double *__restrict__ L, FrontArg fa) {
     // panel columns [c0, min(c1, c)) of the front, rows c0 .. r-1:  C -= A A'  with A = the K
     // (finished) panel columns k0 .. k0+K-1 of those rows. Two-level blocking: K = 64 updates stay
     // inside the current 256-column block, the rest of the panel is updated once per 256 columns
@@ -336,14 +333,6 @@ __global__ __launch_bounds__(256) void k_gemm_nt(DevSym S, const FrontView *__re
     const int bi = blockIdx.x, bj = blockIdx.y;
     constexpr int WT = 16 * TW, GT = 2 * WT;
     if (bj > bi || bi * GT >= M || bj * GT >= N) return;
-    // band (look-ahead panel chain): the diagonal and sub-diagonal 64 x 64 tiles of every target block column -- rows of
-    // the front's own columns, i.e. < c -- are kept up to date by the diagonal chain (k_potrf64_la); skipped here. c0 is
-    // a multiple of 64 and GT divides 64, so a tile lies in ONE 64-block per dimension.
-    // (the sub-diagonal tile of the LAST block column of the outer block lies in the next outer block -- rows >= c1 --, whose
-    //  first diagonal step has no left-looking prologue: it is updated here like any other tile)
-    const bool in_band = band && ((bi * GT) >> 6) - ((bj * GT) >> 6) < 2 && c0 + (((bi * GT) >> 6) << 6) < c1;
-    const int band_rows = in_band ? c - c0 : 0;         // rows (relative to c0) below this are not stored
-    if (in_band && bi * GT + GT <= band_rows) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i0 = bi * GT + (wave & 1) * WT, j0 = bj * GT + (wave >> 1) * WT;
     if (i0 >= M || j0 >= N || j0 > i0 + WT - 1) return;
@@ -447,7 +436,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(DevSym S, const FrontView *__re
 #pragma unroll
             for (int rr = 0; rr < 4; rr++) {
                 const int i = i0 + 2 * lm, j = j0 + 2 * (lk + 4 * rr) + b;
-                const bool v0 = i < M && j < N && i >= j && i >= band_rows, v1 = i + 1 < M && j < N && i + 1 >= j && i + 1 >= band_rows;
+                const bool v0 = i < M && j < N && i >= j, v1 = i + 1 < M && j < N && i + 1 >= j;
                 double *dst = C + i + (long long)j * ldc;
                 const double x0 = cv[b][rr].x - acc[0][b][rr], x1 = cv[b][rr].y - acc[1][b][rr];
                 if (v0 && v1) *(d2u *)dst = (d2u){x0, x1};
@@ -465,7 +454,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(DevSym S, const FrontView *__re
                 for (int rr = 0; rr < 4; rr++) {
                     const int i = i0 + a * 16 + lm;
                     const int j = j0 + b * 16 + lk + 4 * rr;
-                    if (i < M && j < N && i >= j && i >= band_rows) C[i + (long long)j * ldc] = cv[a][b][rr] - acc[a][b][rr];
+                    if (i < M && j < N && i >= j) C[i + (long long)j * ldc] = cv[a][b][rr] - acc[a][b][rr];
                 }
     }
 }
@@ -1297,44 +1286,6 @@ __global__ __launch_bounds__(256) void k_permute(const int *__restrict__ iperm, 
 }
 
 // ------------------------------------------------------------------------------------------
-// Column-major block copy by a FEW workgroups: dst[i + j * ldd] = src[i + j * lds], i < rows, j < cols. One side is page-locked
-// HOST memory (mapped into the GPU's address space): the right-hand sides of the pipelined factor + solve call travel over PCIe
-// inside this kernel instead of through the DMA engines -- one long launch of `nwg` workgroups beside the factorisation costs
-// the panel chain far less than a concurrent hipMemcpyAsync does (measured: the chain takes 18-24 ms instead of 11.7 next to a
-// 512 MB DMA upload). 16 bytes per lane, eight loads in flight per lane; rows even and both leading dimensions even -> the
-// vector path, otherwise scalar.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_stream_copy(const double *__restrict__ src, long long lds, double *__restrict__ dst, long long ldd,
-                                                     long long rows, long long cols) {
-    const long long nthreads = (long long)gridDim.x * 256, t0 = (long long)blockIdx.x * 256 + threadIdx.x;
-    const bool vec = ((rows | lds | ldd) & 1) == 0 && ((reinterpret_cast<unsigned long long>(src) | reinterpret_cast<unsigned long long>(dst)) & 15) == 0;
-    for (long long j = 0; j < cols; j++) {
-        const double *s = src + j * lds;
-        double *d = dst + j * ldd;
-        if (vec) {
-            const long long np = rows >> 1;
-            typedef double dv2 __attribute__((ext_vector_type(2)));
-            const dv2 *s2 = reinterpret_cast<const dv2 *>(s);
-            dv2 *d2 = reinterpret_cast<dv2 *>(d);
-            long long i = t0;
-            for (; i + 7 * nthreads < np; i += 8 * nthreads) {
-                dv2 v[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) v[u] = __builtin_nontemporal_load(s2 + i + u * nthreads);
-#pragma unroll
-                for (int u = 0; u < 8; u++) __builtin_nontemporal_store(v[u], d2 + i + u * nthreads);
-            }
-            for (; i < np; i += nthreads) d2[i] = s2[i];
-        } else {
-            for (long long i = t0; i < rows; i += nthreads) d[i] = s[i];
-        }
-    }
-}
-void launch_stream_copy(hipStream_t st, const double *src, long long lds, double *dst, long long ldd, long long rows, long long cols, int nwg) {
-    if (rows <= 0 || cols <= 0) return;
-    hipLaunchKernelGGL(k_stream_copy, dim3(nwg), dim3(256), 0, st, src, lds, dst, ldd, rows, cols);
-}
-
 // ------------------------------------------------------------------------------------------
 // log det Q = 2 sum_k log L_kk, fixed-order two-stage reduction (bit-reproducible)
 // ------------------------------------------------------------------------------------------
@@ -1558,9 +1509,8 @@ void launch_assemble(hipStream_t st, const DevSym &S, const int *list, const Asm
     // Columns through LDS, written once: a wave per column while four columns of a workgroup fit in 40 KB, a workgroup per column
     // for the tall columns of the top of the tree (up to 128 KB). Measured at cfg 2 (factorisation): HBM assembly above 1280 rows
     // 9.33 ms; wave-per-column up to 2048 rows 9.10; + workgroup-per-column above: 9.03; wave-per-column up to 1280, workgroup-per-column
-    // above: 8.96. (GMRFX_ASM_LDS_MAX / GMRFX_ASM_LDS_WIDE_MAX: the two row limits, 0 = off.)
-    static const int lds_cols_max = [] { const char *e = std::getenv("GMRFX_ASM_LDS_MAX"); return e ? std::atoi(e) : 1280; }();
-    static const int lds_wide_max = [] { const char *e = std::getenv("GMRFX_ASM_LDS_WIDE_MAX"); return e ? std::atoi(e) : 16384; }();
+    // above: 8.96.
+    constexpr int lds_cols_max = 1280, lds_wide_max = 16384;
     if (ldmax <= lds_cols_max && ldmax <= 2048) {
         hipLaunchKernelGGL(k_assemble_lds<0>, dim3(odd(cdiv(max_cols, ASM_CW)), nfronts), dim3(256), (size_t)4 * ldmax * sizeof(double), st,
                            S, arec, nzp, L, CB, ldmax);
@@ -1599,16 +1549,16 @@ void launch_syrk_cb_recs(hipStream_t st, const DevSym &S, const SyrkTile *recs, 
     hipLaunchKernelGGL(k_syrk_cb_rec, dim3(8 * (unsigned)per_xcd), dim3(256), 0, st, S, recs, split, L, CB);
 }
 void launch_trsm(hipStream_t st, const DevSym &S, const FrontView *frec, int nactive, int kb, int mode, int max_rows_below,
-                 double *L, double *Yh, const long long *yoff, const FrontArg &fa, int la) {
+                 double *L, double *Yh, const long long *yoff, const FrontArg &fa) {
     if (nactive <= 0 || max_rows_below <= 0) return;
     const bool split = (long long)cdiv(max_rows_below, 64) * nactive <= 128;
     const dim3 grid(odd(cdiv(max_rows_below, split ? 16 : 128)), nactive);
     if (mode == 0) {
-        if (split) hipLaunchKernelGGL((k_trsm<0, 1>), grid, dim3(256), 0, st, S, frec, kb, L, Yh, yoff, fa, la);
-        else hipLaunchKernelGGL((k_trsm<0, 0>), grid, dim3(256), 0, st, S, frec, kb, L, Yh, yoff, fa, la);
+        if (split) hipLaunchKernelGGL((k_trsm<0, 1>), grid, dim3(256), 0, st, S, frec, kb, L, Yh, yoff, fa);
+        else hipLaunchKernelGGL((k_trsm<0, 0>), grid, dim3(256), 0, st, S, frec, kb, L, Yh, yoff, fa);
     } else {
-        if (split) hipLaunchKernelGGL((k_trsm<1, 1>), grid, dim3(256), 0, st, S, frec, kb, L, Yh, yoff, fa, la);
-        else hipLaunchKernelGGL((k_trsm<1, 0>), grid, dim3(256), 0, st, S, frec, kb, L, Yh, yoff, fa, la);
+        if (split) hipLaunchKernelGGL((k_trsm<1, 1>), grid, dim3(256), 0, st, S, frec, kb, L, Yh, yoff, fa);
+        else hipLaunchKernelGGL((k_trsm<1, 0>), grid, dim3(256), 0, st, S, frec, kb, L, Yh, yoff, fa);
     }
 }
 void launch_trsm_narrow(hipStream_t st, const FrontView *frec, int nactive, int kb, int max_rows_below, double *L) {
@@ -1616,7 +1566,7 @@ void launch_trsm_narrow(hipStream_t st, const FrontView *frec, int nactive, int 
     hipLaunchKernelGGL(k_trsm_narrow, dim3(odd(cdiv(max_rows_below, 128)), nactive), dim3(256), 0, st, frec, kb, L);
 }
 void launch_gemm_nt(hipStream_t st, const DevSym &S, const FrontView *frec, int nactive, int k0, int K, int c0, int c1,
-                    int maxM, int maxN, double *L, const FrontArg &fa, int band) {
+                    int maxM, int maxN, double *L, const FrontArg &fa) {
     if (nactive <= 0 || maxM <= 0 || maxN <= 0) return;
     // 64x64 workgroup tiles, operands straight from L2 at 3-4 waves per SIMD. Measured on MI355X: the
     // sustained v_mfma_f64_16x16x4_f64 rate is 36.3 TFLOP/s (tools/micro/mfma64.hip), this kernel reaches
@@ -1625,9 +1575,9 @@ void launch_gemm_nt(hipStream_t st, const DevSym &S, const FrontView *frec, int 
     // Levels with a handful of fronts are latency bound: 32x32 workgroup tiles there (four times
     // the workgroups, a quarter of the MFMA chain per wave).
     if ((long long)cdiv(maxM, 64) * cdiv(maxN, 64) * nactive <= 256)
-        hipLaunchKernelGGL(k_gemm_nt<1>, dim3(odd(cdiv(maxM, 32)), odd(cdiv(maxN, 32)), nactive), dim3(256), 0, st, S, frec, k0, K, c0, c1, L, fa, band);
+        hipLaunchKernelGGL(k_gemm_nt<1>, dim3(odd(cdiv(maxM, 32)), odd(cdiv(maxN, 32)), nactive), dim3(256), 0, st, S, frec, k0, K, c0, c1, L, fa);
     else
-        hipLaunchKernelGGL(k_gemm_nt<2>, dim3(odd(cdiv(maxM, 64)), odd(cdiv(maxN, 64)), nactive), dim3(256), 0, st, S, frec, k0, K, c0, c1, L, fa, band);
+        hipLaunchKernelGGL(k_gemm_nt<2>, dim3(odd(cdiv(maxM, 64)), odd(cdiv(maxN, 64)), nactive), dim3(256), 0, st, S, frec, k0, K, c0, c1, L, fa);
 }
 void launch_fwd_assemble(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, double *X,
                          const double *W, int nr, int ldx) {

@@ -200,26 +200,14 @@ __global__ __launch_bounds__(256) void k_sel_diag(DevSym S, const int *__restric
 // 64x64 output tiles, 4 waves x 32x32, FP64 MFMA; operand orientations chosen so that all but
 // one operand stream (the upper half of the symmetric Z22) are contiguous along the lanes.
 // ------------------------------------------------------------------------------------------
-// WT: waves per side of the workgroup tile (32 WT squared): 2 = 64 x 64 (4 waves), 4 = 128 x 128 (16 waves) -- the waves of a workgroup
-// that share operand rows find them in the L1 of their CU, so the larger tile halves the bytes a workgroup pulls through L2 per flop
-template <int WT>
+// Workgroup tile 64 x 64 = 2 x 2 waves of 32 x 32. (Measured and removed in round 4, DESIGN.md section 3: 128 x 128 tiles of
+// sixteen waves -- 14.9 vs 13.0 ms --, whole fronts dealt to one XCD each -- 14.0-14.3 ms.)
+constexpr int WT = 2;
 __global__ __launch_bounds__(64 * WT * WT) void k_sel_dense(DevSym S, const int *__restrict__ list, int phase,
                                                    const double *__restrict__ L, double *__restrict__ Z,
                                                    const double *__restrict__ ZB, double *__restrict__ Yt,
-                                                   double *__restrict__ Z21t, const long long *__restrict__ woff, int rgx, int rgy, int nfr) {
-    // rgx > 0: ONE-dimensional grid dealt by XCD (workgroup id mod 8 = XCD): the fronts at list positions xcd, xcd + 8, ... belong to
-    // that XCD, which walks them one after the other, all tiles of a front in a row -- the operand panels of a front (Z22 of the
-    // trailing rows, Y) are then streamed by ONE L2 instead of all eight (PMC, round 4: 19-38x the minimal bytes on the plain grid,
-    // the kernel ran at the L2-miss bandwidth). Fronts are sorted by decreasing width: dealing them modulo 8 balances the XCDs.
-    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    if (rgx > 0) {
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        const int tpf = rgx * rgy;
-        bz = xcd + 8 * (slot / tpf);
-        if (bz >= nfr) return;
-        const int tt = slot % tpf;
-        bx = tt % rgx; by = tt / rgx;
-    }
+                                                   double *__restrict__ Z21t, const long long *__restrict__ woff) {
+    const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     const int s = list[bz];
     const int c = S.sfirst[s + 1] - S.sfirst[s];
     const int r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
@@ -373,22 +361,8 @@ void launch_sel_dense(hipStream_t st, const DevSym &S, const int *list, int nfro
     if (nfronts <= 0) return;
     const int M = phase == 0 ? max_trail : max_c, N = phase == 1 ? max_trail : max_c;
     if (M <= 0 || N <= 0) return;
-    // GMRFX_SEL_XCD: levels with at least this many fronts deal their tiles by XCD (default 0: never -- measured at cfg 2, round 4:
-    // selected inversion 13.0 ms on the plain grid, 14.0-14.3 ms with whole fronts per XCD from 8 / 32 / 128 fronts up: the plain grid's
-    // 19-38x re-read traffic is served by the Infinity Cache through all eight L2s at ~4.7 TB/s, one L2 per front is the narrower pipe)
-    static const int xcd_min = [] { const char *e = getenv("GMRFX_SEL_XCD"); return e ? atoi(e) : 0; }();
-    // GMRFX_SEL_WT=4: 128 x 128 workgroup tiles (16 waves) for levels whose fronts are at least 256 wide in both tile dimensions
-    static const int wt_req = [] { const char *e = getenv("GMRFX_SEL_WT"); return e ? atoi(e) : 2; }();
-    const bool big = wt_req == 4 && M >= 256 && N >= 256;
-    const int T = big ? 128 : 64;
-    const int gx = cdiv(M, T), gy = cdiv(N, T);
-    if (!big && xcd_min > 0 && nfronts >= xcd_min) {
-        const long long groups = (nfronts + 7) / 8;
-        hipLaunchKernelGGL(k_sel_dense<2>, dim3((unsigned)(groups * gx * gy * 8)), dim3(256), 0, st, S, list, phase, L, Z, ZB, Yt, Z21t, woff, gx, gy, nfronts);
-    } else if (big)
-        hipLaunchKernelGGL(k_sel_dense<4>, dim3((unsigned)(gx | 1), (unsigned)(gy | 1), nfronts), dim3(1024), 0, st, S, list, phase, L, Z, ZB, Yt, Z21t, woff, 0, 0, nfronts);
-    else
-        hipLaunchKernelGGL(k_sel_dense<2>, dim3((unsigned)(gx | 1), (unsigned)(gy | 1), nfronts), dim3(256), 0, st, S, list, phase, L, Z, ZB, Yt, Z21t, woff, 0, 0, nfronts);
+    const int gx = cdiv(M, 64), gy = cdiv(N, 64);
+    hipLaunchKernelGGL(k_sel_dense, dim3((unsigned)(gx | 1), (unsigned)(gy | 1), nfronts), dim3(256), 0, st, S, list, phase, L, Z, ZB, Yt, Z21t, woff);
 }
 
 }  // namespace gmrfx

@@ -409,13 +409,10 @@ __global__ __launch_bounds__(256) void k_pack_diag(const Chunk *__restrict__ rec
     }
 }
 
-static int chunk_cfg() {      // GMRFX_TASK_CFG: columns of the right-hand sides per workgroup / 16-column tiles per wave:
-                              // 0 (default) = 16 / 1 (4 waves, four workgroups per CU); 1 = 32 / 1 (8 waves, two per CU);
-                              // 2 = 32 / 2 (4 waves); 3 = 64 / 2 (8 waves, one per CU)
-    static const int v = [] { const char *e = std::getenv("GMRFX_TASK_CFG"); const int x = e ? std::atoi(e) : 0; return x >= 0 && x <= 3 ? x : 0; }();
-    return v;
-}
-int sweep_chunk_nc() { const int c = chunk_cfg(); return c == 0 ? 16 : c == 3 ? 64 : 32; }
+// 16 columns of the right-hand sides per workgroup, one 16-column tile per wave: 4 waves, four workgroups per compute unit.
+// (Measured at cfg 2, round 5: 32 columns / 8 waves / two workgroups per CU 0.61 / 0.67 ms forward / backward against 0.56 / 0.64;
+//  two tiles per wave, 32 or 64 columns: 0.74-0.75 / 0.86-0.87 ms.)
+int sweep_chunk_nc() { return 16; }
 
 void launch_pack_diag(hipStream_t st, const Symbolic::SwChunk *recs, int nchunks, const double *L, double *dtile) {
     if (nchunks <= 0) return;
@@ -426,18 +423,8 @@ void launch_sweep_chunks(hipStream_t st, const DevSym &S, int phase, const Sweep
                          const Symbolic::SwChunk *recs_bwd, const int *listf, const int *listb, const double *dtile, const double *L,
                          double *X, double *W, int nr, int ldx, size_t extra_lds) {
     if (ntasks <= 0) return;
-    const int cfg = chunk_cfg();
-    const int g8 = (ntasks + 7) / 8;
-    if (phase == 1) {
-        if (cfg == 0) hipLaunchKernelGGL((k_fwd_chunks<16, 1>), dim3(g8 * 32), dim3(256), extra_lds, st, tasks, ntasks, recs_fwd, listf, dtile, L, X, W, nr, ldx);
-        else if (cfg == 1) hipLaunchKernelGGL((k_fwd_chunks<32, 1>), dim3(g8 * 16), dim3(512), extra_lds, st, tasks, ntasks, recs_fwd, listf, dtile, L, X, W, nr, ldx);
-        else if (cfg == 2) hipLaunchKernelGGL((k_fwd_chunks<32, 2>), dim3(g8 * 16), dim3(256), extra_lds, st, tasks, ntasks, recs_fwd, listf, dtile, L, X, W, nr, ldx);
-        else hipLaunchKernelGGL((k_fwd_chunks<64, 2>), dim3(ntasks), dim3(512), 0, st, tasks, ntasks, recs_fwd, listf, dtile, L, X, W, nr, ldx);
-    } else {
-        if (cfg == 0) hipLaunchKernelGGL((k_bwd_chunks<16, 1, 3>), dim3(g8 * 32), dim3(256), 0, st, S, tasks, ntasks, recs_bwd, listb, dtile, L, X, nr, ldx);
-        else if (cfg == 1) hipLaunchKernelGGL((k_bwd_chunks<32, 1, 3>), dim3(g8 * 16), dim3(512), 0, st, S, tasks, ntasks, recs_bwd, listb, dtile, L, X, nr, ldx);
-        else if (cfg == 2) hipLaunchKernelGGL((k_bwd_chunks<32, 2, 4>), dim3(g8 * 16), dim3(256), 0, st, S, tasks, ntasks, recs_bwd, listb, dtile, L, X, nr, ldx);
-        else hipLaunchKernelGGL((k_bwd_chunks<64, 2, 4>), dim3(ntasks), dim3(512), 0, st, S, tasks, ntasks, recs_bwd, listb, dtile, L, X, nr, ldx);
-    }
+    const int grid = ((ntasks + 7) / 8) * 32;       // blocks b, b + 8, b + 16, b + 24 (same XCD): the four column slices of one task
+    if (phase == 1) hipLaunchKernelGGL((k_fwd_chunks<16, 1>), dim3(grid), dim3(256), extra_lds, st, tasks, ntasks, recs_fwd, listf, dtile, L, X, W, nr, ldx);
+    else hipLaunchKernelGGL((k_bwd_chunks<16, 1, 3>), dim3(grid), dim3(256), 0, st, S, tasks, ntasks, recs_bwd, listb, dtile, L, X, nr, ldx);
 }
 }  // namespace gmrfx

@@ -1,7 +1,7 @@
 // sweep_wave.hip -- SWEEP TASKS, one WAVE per (task, 16 right-hand sides): the forward / backward substitution of a whole
 // bottom subtree (Symbolic::swt_*, symbolic.h) on a local vector of 16 columns kept in LDS.
 //
-// Why this shape (round 3; it replaces the 16-wave workgroup tasks of sweep_task.hip as the default). Measured on the
+// Why this shape (round 3; the form for up to 16 right-hand sides -- wider passes take the chunk form, sweep_chunk.hip). Measured on the
 // workgroup version (tools/task_dbg.sh): the memory phases of the task kernels (panel warm-up, slice of X in, x out) take
 // 0.26 / 0.37 ms of the 0.81 / 0.89 ms; the FRONT LOOP takes 0.55 ms whatever the operands cost (compiled without any
 // operand load: unchanged), with one or with two resident workgroups per CU (unchanged): a front costs ~7900 cycles of a CU

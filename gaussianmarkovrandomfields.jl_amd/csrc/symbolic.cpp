@@ -134,14 +134,6 @@ static inline i64 panel_span(i64 ld, i64 c) { return (ld * ((c + 3) & ~i64(3)) +
 void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *user_perm,
              const SymOptions &opt, Symbolic &S) {
     auto t0 = std::chrono::steady_clock::now();
-    const bool sym_timing = std::getenv("GMRFX_SYM_TIMING") != nullptr;
-    auto tprev = t0;
-    auto tick = [&](const char *what) {
-        if (!sym_timing) return;
-        auto t = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "[gmrfx symbolic] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t - tprev).count());
-        tprev = t;
-    };
     if (n <= 0) throw std::invalid_argument("n must be positive");
     if (n >= (i64)2147483000) throw std::invalid_argument("n too large for 32-bit node indices");
     if (base != 0 && base != 1) throw std::invalid_argument("index_base must be 0 or 1");
@@ -172,7 +164,6 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
     std::vector<i32> iperm(n);
     for (i64 k = 0; k < n; k++) iperm[perm[k]] = (i32)k;
 
-    tick("ordering");
     // ---- etree + postorder (the final order is the caller's/ND order composed with an
     //      etree postorder: an equivalent reordering, same fill) -----------------------------
     std::vector<i64> up; std::vector<i32> ui, parent;
@@ -196,7 +187,6 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
     colcounts(n, up, ui, parent, cc);
     for (i64 j = 0; j < n; j++) S.nnz_l_true += cc[j];
 
-    tick("etree + postorder + colcounts");
     // ---- supernodes: maximal chains with nested structure, then relaxed amalgamation -------
     std::vector<i32> sfirst;  // start column of each supernode
     std::vector<i32> nchild(n, 0);
@@ -295,7 +285,6 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
     { std::vector<i64> w(S.childptr.begin(), S.childptr.end() - 1);
       for (i32 s = 0; s < ns; s++) if (S.sparent[s] != -1) S.children[w[S.sparent[s]]++] = s; }
 
-    tick("supernodes");
     // ---- row structures: own columns, A-rows of own columns, children's trailing rows -------
     // lower pattern by column of P A P'
     std::vector<i64> lp(n + 1, 0);
@@ -341,7 +330,6 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
         if (want != S.sparent[s]) throw std::runtime_error("internal: supernodal etree inconsistent");
     }
 
-    tick("row structures");
     // ---- relative indices child -> parent -----------------------------------------------------
     S.rel.assign(S.sum_rows, -1);
     for (i32 s = 0; s < ns; s++) {
@@ -357,7 +345,6 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
         }
     }
 
-    tick("relative indices");
     // ---- storage layout -------------------------------------------------------------------
     S.panelptr.assign(ns + 1, 0);
     S.ld.resize(ns);
@@ -390,7 +377,6 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
         for (i32 j = 0; j < c; j++) S.diagoff[S.sfirst[s] + j] = S.panelptr[s] + (i64)j * S.ld[s] + j;
     }
 
-    tick("storage layout");
     // ---- levels --------------------------------------------------------------------------
     S.level.assign(ns, 0);
     for (i32 s = 0; s < ns; s++) {
@@ -608,7 +594,6 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
         return 4;
     };
     for (i32 s = 0; s < ns; s++) S.is_small[s] = cls(s) < 4;
-    tick("levels + sharding");
     // ---- subtree tasks ---------------------------------------------------------------------
     // Supernodes are numbered in postorder, so the subtree of s is the id range [s-cnt+1, s].
     S.in_subtree.assign(ns, 0);
@@ -686,7 +671,7 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
     S.lrow.assign((size_t)S.sum_rows, -1);
     {
         const int rcap = opt.subtree_max > 0 ? 0 : std::min(288,   // (not with the legacy subtree tasks)
-                                                                               opt.sweep_task_rows >= 0 ? opt.sweep_task_rows : 288);   // 288 = TASK_ROWS of sweep_task.hip
+                                                                               opt.sweep_task_rows >= 0 ? opt.sweep_task_rows : 288);   // 288 = rows of the local vector in sweep_chunk.hip / sweep_wave.hip
         S.swt_rows = rcap;
         std::vector<i32> cnt(ns, 1), ncol(ns, 0), maxc(ns, 0), nchk(ns, 0);
         std::vector<double> work(ns, 0.0);
@@ -827,7 +812,6 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
         S.sw_level_nsmall[l] = k;
     }
 
-    tick("tasks");
     // ---- contribution-block arena with lifetime reuse ------------------------------------------
     // The level schedule fixes when a block is written and when it is last read: CB_s lives from level(s) to
     // level(parent(s)) in the factorisation; in the (top-down) selected inversion the trailing inverse block
@@ -946,7 +930,6 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
         }
     }
 
-    tick("arena + transfers");
     // ---- Q scatter map -------------------------------------------------------------------
     // Which stored triangle defines Q: if both strict triangles are present use opt.uplo,
     // otherwise whatever is stored.
@@ -1039,7 +1022,6 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
 
     S.perm.swap(perm);
     S.iperm.swap(iperm);
-    tick("Q scatter map + tiles");
     S.ms_symbolic = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 

@@ -69,6 +69,22 @@ EXPORTS = [
 ]
 
 
+def source_tree_hash() -> str:
+    """sha256 (first 16 hex digits) over the library's sources -- csrc/*.{hip,cpp,h} and include/gmrfx.h, names and
+    contents, in name order. The counter passes under profiles/ store it (tools/pmc_traffic.py, tools/cfg3_profile.py) and
+    bench.py only quotes their traffic figures for the tree it is timing."""
+    import glob, hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(_HERE, "..", "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "..", "csrc", "*.cpp")) +
+                   glob.glob(os.path.join(_HERE, "..", "csrc", "*.h")), key=os.path.basename)
+    files.append(os.path.join(_HERE, "..", "..", "include", "gmrfx.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def lib():
     """Load libgmrfx.so; fails loudly if it has not been built (no fallback of any kind)."""
     global _lib

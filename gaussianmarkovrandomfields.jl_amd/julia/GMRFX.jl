@@ -8,7 +8,8 @@
 # `solve!`, the hooks below, `deepcopy(cache)`). Keep them in sync.
 module GMRFX
 
-using LinearAlgebra, SparseArrays
+using LinearAlgebra, SparseArrays, Random
+import Distributions
 import GaussianMarkovRandomFields as G
 import GaussianMarkovRandomFields: WorkspaceBackend, refactorize!, backend_solve, compute_logdet,
     compute_selinv!, get_selinv, get_selinv_diag, backend_backward_solve, selinv_dot, selinv_extract_at,
@@ -104,9 +105,12 @@ function refactorize!(b::MI355XBackend, Q::Symmetric)
 end
 
 # workspace_solve(ws, B) on a workspace whose values were just updated (gmrf_workspace.jl:170-178, 207-215: ensure_numeric! then
-# backend_solve) as ONE pipelined call: the forward sweep follows the factorisation up the tree, the upload of B runs beside the
-# factorisation on a copy stream and X leaves in slices behind the backward sweep (csrc/device.cpp, host_upload / host_download).
-# Same bits as refactorize! + backend_solve.
+# backend_solve) as ONE pipelined call: the forward sweep follows the factorisation up the tree on a side stream. The host
+# transfers are SERIAL -- B goes up in front of the factorisation (staged through page-locked memory by host threads when
+# pageable), X comes down in slices behind the backward sweep (csrc/device.cpp, host_upload / host_download: a transfer beside
+# the factorisation slows its launch chain by more than it hides). Same bits as refactorize! + backend_solve.
+# The reference's workspace_solve ends in `b.factor \ rhs`, which throws PosDefException on a failed factor (backend.jl:178-193):
+# so does this call -- a non-positive pivot never comes back as a silent NaN solution.
 function refactorize_solve!(b::MI355XBackend, Q::Symmetric, rhs::AbstractVecOrMat)
     nz = nonzeros(parent(Q))
     B = Matrix{Float64}(reshape(rhs, b.n, :)); X = similar(B)
@@ -116,6 +120,7 @@ function refactorize_solve!(b::MI355XBackend, Q::Symmetric, rhs::AbstractVecOrMa
         b.h.ptr, nz, B, b.n, size(B, 2), X, b.n, info), b.h)
     b.selinv_cache = nothing
     b.selinv_diag_cache = nothing
+    info[] > 0 && throw(PosDefException(Int(info[])))
     return rhs isa AbstractVector ? vec(X) : X
 end
 
@@ -124,7 +129,7 @@ end
 # factorisation is a plain backend_solve. Two methods, as in the reference (one AbstractVecOrMat method would be ambiguous with its).
 function _workspace_solve(ws::GMRFWorkspace, B::AbstractVecOrMat)
     ws.numeric_valid && return backend_solve(ws.backend, B isa AbstractVector ? B : Matrix{Float64}(B))
-    X = refactorize_solve!(ws.backend, Symmetric(ws.Q), B)          # = ensure_numeric!(ws) + backend_solve(ws.backend, B)
+    X = refactorize_solve!(ws.backend, Symmetric(ws.Q), B)          # = ensure_numeric!(ws) + backend_solve(ws.backend, B); throws on a failed factor
     ws.numeric_valid = true
     ws.selinv_valid = false
     ws.logdet_valid = false
@@ -226,6 +231,27 @@ function backend_backward_solve(b::MI355XBackend, Zm::Matrix{Float64})
     X = similar(Zm)
     GC.@preserve Zm X check(ccall((:gmrfx_backward_solve, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64),
         b.h.ptr, Zm, stride(Zm, 2), size(Zm, 2), X, stride(X, 2)), b.h)
+    return X
+end
+
+# ---- rand(d, k): k samples in ONE backward sweep ------------------------------------------------------------------------------
+# The reference's `_rand!` takes one vector (src/gmrf.jl:271-281, src/workspace/workspace_gmrf.jl:275-286) and Distributions' matrix
+# method `_rand!(rng, d, X::AbstractMatrix)` loops it over the columns: rand(d, 256) is 256 single-RHS sweeps with 256 host round
+# trips. On this backend the matrix method is ONE `backend_backward_solve(b, Z::Matrix)`: randn! fills Z column by column in the
+# order the column loop would draw it, so the same rng gives the same samples (to the last bit while every column takes the same
+# kernels: tests/mirror/workspace_gmrf.py, tests/test_seam_a_and_constraints.py); the mean and the constraint correction
+# (x -= A~' (L_c \ (A x - e)), workspace_gmrf.jl:280-284) are applied to all columns at once.
+function Distributions._rand!(rng::AbstractRNG, d::G.WorkspaceGMRF{<:Any, MI355XBackend}, X::AbstractMatrix{<:Real})
+    G.ensure_loaded!(d)
+    Z = randn!(rng, Matrix{Float64}(undef, size(X, 1), size(X, 2)))
+    G.ensure_numeric!(d.workspace)
+    Y = backend_backward_solve(d.workspace.backend, Z)
+    Y .+= d.mean
+    if d.constraints !== nothing
+        ci = d.constraints
+        Y .-= ci.A_tilde_T * (ci.L_c \ (ci.matrix * Y .- ci.vector))
+    end
+    X .= Y
     return X
 end
 
@@ -354,6 +380,20 @@ G.supports_backward_solve(::MI355XCholesky) = Val{true}()
 G._selinv_diag_impl(cache, ::MI355XCholesky) = get_selinv_diag(_be(cache))
 G._selinv_impl(cache, ::MI355XCholesky) = Symmetric(get_selinv(_be(cache)))
 G._backward_solve_impl(cache, x, ::MI355XCholesky) = backend_backward_solve(_be(cache), x)
+G._backward_solve_impl(cache, Z::Matrix{Float64}, ::MI355XCholesky) = backend_backward_solve(_be(cache), Z)
+# seam-A twin of the batched sampler above (src/gmrf.jl:271-281 draws the columns one by one); any other algorithm keeps
+# Distributions' column loop
+function Distributions._rand!(rng::AbstractRNG, d::G.GMRF, X::AbstractMatrix{<:Real})
+    if d.linsolve_cache.alg isa MI355XCholesky
+        Z = randn!(rng, Matrix{Float64}(undef, size(X, 1), size(X, 2)))
+        X .= G.backward_solve(d.linsolve_cache, Z) .+ d.mean
+    else
+        for j in axes(X, 2)
+            Distributions._rand!(rng, d, view(X, :, j))
+        end
+    end
+    return X
+end
 G._logdet_cov_impl(cache, ::MI355XCholesky) = -compute_logdet(_be(cache))       # note the sign (logdet.jl:30)
 G.prepare_for_linsolve(A::SparseMatrixCSC, ::MI355XCholesky) = Symmetric(A)
 G.configure_algorithm(alg::MI355XCholesky) = alg

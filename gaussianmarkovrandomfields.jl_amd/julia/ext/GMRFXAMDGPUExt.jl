@@ -49,6 +49,7 @@ function refactorize_solve!(X::ROCMatrix{Float64}, b::MI355XBackend, d_nz::ROCVe
         (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64, Ref{Int64}),
         b.h.ptr, devptr(d_nz), devptr(B), stride(B, 2), size(B, 2), devptr(X), stride(X, 2), info), b.h)
     _invalidate!(b)
+    info[] > 0 && throw(PosDefException(Int(info[])))      # (as `b.factor \ rhs` does on a failed CHOLMOD factor: backend.jl:178-193)
     return X
 end
 

@@ -8,6 +8,7 @@ from contextlib import contextmanager
 
 import numpy as np
 import scipy.sparse as sp
+from gmrfx._lib import PosDefException
 
 from gmrfx.backend import MI355XBackend, _as_csc
 
@@ -72,6 +73,8 @@ class GMRFWorkspace:
             if self.Q.nnz != self.backend._nnz:
                 raise ValueError("the sparsity pattern must be invariant across refactorizations")
             x = self.backend.refactorize_solve(self.Q.data, b)
+            if self.backend.last_info > 0:        # `b.factor \ rhs` throws on a failed factor (backend.jl:178-193): never a silent NaN solution
+                raise PosDefException(5, f"matrix is not positive definite; Cholesky factorization failed at pivot {self.backend.last_info}")
             self.numeric_valid = True
             self.selinv_valid = False
             self.logdet_valid = False

@@ -78,6 +78,31 @@ class WorkspaceGMRF:
             X -= ci.A_tilde_T @ ci._lc_solve(ci.matrix @ X - ci.vector[:, None])
         return X
 
+    def rand_from(self, Z):
+        """The batched sampler of julia/GMRFX.jl (Distributions._rand!(rng, d::WorkspaceGMRF{<:Any, MI355XBackend}, X::AbstractMatrix))
+        on given standard-normal draws Z (n x k): ONE multi-column backward sweep, mean and constraint correction on all columns."""
+        self.ensure_loaded()
+        Z = np.asarray(Z, dtype=np.float64)
+        X = self.workspace.backward_solve(Z).reshape(Z.shape) + self.mean_[:, None]
+        if self.constraints is not None:
+            ci = self.constraints
+            X -= ci.A_tilde_T @ ci._lc_solve(ci.matrix @ X - ci.vector[:, None])
+        return X
+
+    def rand_from_column_by_column(self, Z):
+        """What the reference does with the same draws (workspace_gmrf.jl:275-286 under Distributions' column loop): one
+        single-RHS backward sweep, one mean shift and one constraint correction per sample."""
+        self.ensure_loaded()
+        Z = np.asarray(Z, dtype=np.float64)
+        X = np.empty_like(Z)
+        for j in range(Z.shape[1]):
+            x = self.workspace.backward_solve(Z[:, j].copy()) + self.mean_
+            if self.constraints is not None:
+                ci = self.constraints
+                x = x - ci.A_tilde_T @ ci._lc_solve((ci.matrix @ x - ci.vector)[:, None])[:, 0]
+            X[:, j] = x
+        return X
+
     def logpdf(self, z) -> float:
         self.ensure_loaded()
         r = np.asarray(z) - self.mean_

@@ -1099,27 +1099,6 @@ def test_sweep_task_forms_match_the_oracle(mode, nrhs, monkeypatch):
     assert np.array_equal(be.backend_solve(B), be.backend_solve(B))
 
 
-def test_lookahead_panel_chain_matches_the_oracle(monkeypatch):
-    """GMRFX_LOOKAHEAD=1 (off by default, slower at cfg 2): the diagonal chain keeps its band tiles up to date left-looking
-    (k_potrf64_la) while trsm / gemm follow one step behind on a second stream without touching them. Same factor as the
-    oracle entry by entry on fronts with several 64-column blocks, partial last blocks and more than one 256-column outer
-    block; solve and log-determinant as well."""
-    rng = np.random.default_rng(21)
-    n = 700
-    A = sp.random(n, n, density=0.25, random_state=5, format="csc")
-    Q = sp.csc_matrix(A @ A.T + n * sp.identity(n))
-    monkeypatch.setenv("GMRFX_LOOKAHEAD", "1")
-    be = gmrfx.MI355XBackend(Q)
-    monkeypatch.delenv("GMRFX_LOOKAHEAD")
-    assert be.stats()["max_cols"] > 320           # a front with more than one outer block
-    F = orc.OracleFactor(Q, be.ordering_permutation())
-    Lg, Lo = be.factor_csc(), F.L()
-    assert abs(Lg - Lo).max() <= 1e-10 * abs(Lo).max()
-    B = rng.standard_normal((n, 3))
-    assert relerr(be.backend_solve(B), F.solve(B)) < 1e-10
-    assert abs(be.compute_logdet() - F.logdet()) < 1e-11 * abs(F.logdet())
-
-
 @pytest.mark.parametrize("mesh_kind", ["2d", "3d"])
 def test_refactorize_solve_pipelined_equals_separate_calls(mesh_kind):
     """gmrfx_refactorize_solve[_dev] (workspace_solve on a workspace with new values, gmrf_workspace.jl:170-178 + 207-215; the
@@ -1185,7 +1164,8 @@ def test_refactorize_solve_pipelined_equals_separate_calls(mesh_kind):
 
 def test_refactorize_solve_host_io_paths_equal_device_call():
     """gmrfx_refactorize_solve with HOST right-hand sides (what the reference's seam hands over, backend.jl:207-209): the
-    upload runs on a copy stream beside the factorisation and the result leaves in slices (Device::host_upload / host_download).
+    transfers are serial -- B goes up on a copy stream IN FRONT of the factorisation, the result leaves in slices behind the backward
+    sweep (Device::host_upload / host_download) -- only the host-side staging is overlapped.
     Pageable arrays (staged through the handle's page-locked buffer by several host threads, more than one 32 MB slice),
     page-locked arrays (direct DMA) and a leading dimension larger than n must all give the bits of the device-resident call."""
     import torch
@@ -1292,40 +1272,6 @@ def test_dense_fronts_of_every_width_through_the_diagonal_block_kernel(n, monkey
     be.refactorize(Q)
     assert be.last_info == 0
     be.close()
-
-
-@pytest.mark.parametrize("mesh_kind", ["2d", "2d_wide", "3d"])
-def test_panel_chain_persistent_kernel_equals_launch_chain(mesh_kind, monkeypatch):
-    """The persistent panel-chain kernel (csrc/panel_chain.hip, GMRFX_CHAIN_MAX_FRONTS > 0: one launch per 256-column outer block of
-    a level's wide fronts, flags between its workgroups, look-ahead on the diagonal block; off by default, measured slower) against
-    the launch chain potrf64 -> trsm -> gemm: the factor bit for bit (fronts with partial last blocks, several fronts per launch,
-    teams with more tiles than workgroups), log-determinant and a solve; and an indefinite matrix reports the same pivot."""
-    if mesh_kind == "2d":
-        mesh = spde.grid_mesh_2d(300, 290, jitter=0.25, seed=5); Q = spde.matern_precision(mesh, 0, 0.2)
-    elif mesh_kind == "2d_wide":
-        mesh = spde.grid_mesh_2d(120, 500, jitter=0.2, seed=2); Q = spde.matern_precision(mesh, 0, 0.3)
-    else:
-        mesh = spde.grid_mesh_3d(26, 25, 24); Q = spde.matern_precision(mesh, 0, 0.4)
-    monkeypatch.setenv("GMRFX_CHAIN_MAX_FRONTS", "0")
-    monkeypatch.setenv("GMRFX_POTRF", "1")          # the persistent chain carries the register-patch diagonal block: compare with ITS launch chain
-    a = gmrfx.MI355XBackend(Q, coords=mesh.points)
-    monkeypatch.setenv("GMRFX_CHAIN_MAX_FRONTS", "32")
-    b = gmrfx.MI355XBackend(Q, coords=mesh.points)
-    assert a.last_info == 0 and b.last_info == 0
-    assert np.array_equal(a.factor_values(), b.factor_values())
-    assert a.compute_logdet() == b.compute_logdet()
-    B = np.random.default_rng(2).standard_normal((Q.shape[0], 5))
-    X = b.backend_solve(B)
-    assert np.array_equal(X, a.backend_solve(B))
-    assert np.linalg.norm(Q @ X - B) / np.linalg.norm(B) < 1e-10
-    bad = sp.csc_matrix(Q).copy(); bad.sort_indices()
-    vals = bad.data.copy()
-    col = Q.shape[0] - 3
-    k = bad.indptr[col] + int(np.searchsorted(bad.indices[bad.indptr[col]:bad.indptr[col + 1]], col))
-    vals[k] = -abs(vals[k])
-    a.refactorize_values(vals); b.refactorize_values(vals)
-    assert a.last_info == b.last_info > 0
-    a.close(); b.close()
 
 
 def test_refactorize_logpdf_one_call_equals_three_calls():

@@ -181,3 +181,22 @@ def test_workspace_solve_is_a_real_method_on_this_backend():
     assert "refactorize_solve!(ws.backend, Symmetric(ws.Q), B)" in body and "ws.numeric_valid = true" in body
     assert "ws.selinv_valid = false" in body and "ws.logdet_valid = false" in body
     assert any(c[0] == "gmrfx_refactorize_solve" for c in julia_ccalls(JL))
+
+
+def test_batched_rand_is_a_real_method_on_both_seams():
+    """rand(d, k) reaches the backend as ONE multi-column backward sweep (round 5): Distributions' matrix method `_rand!` is
+    overloaded -- as code -- for WorkspaceGMRFs on MI355XBackend (reference: one vector at a time, workspace_gmrf.jl:275-286) and for
+    GMRFs whose cache algorithm is MI355XCholesky (gmrf.jl:271-281); both go through backend_backward_solve(b, Z::Matrix), which binds
+    gmrfx_backward_solve with the matrix's column stride; a failed factor in the pipelined solve throws PosDefException."""
+    code = "\n".join(l for l in open(JL).read().splitlines() if not l.lstrip().startswith("#"))
+    m = re.search(r"function Distributions\._rand!\(rng::AbstractRNG,\s*d::G\.WorkspaceGMRF\{<:Any,\s*MI355XBackend\},\s*X::AbstractMatrix\{<:Real\}\)(.*?)\nend", code, re.S)
+    assert m, "no batched _rand! for WorkspaceGMRF on MI355XBackend"
+    body = m.group(1)
+    assert "randn!(rng" in body and "backend_backward_solve(d.workspace.backend, Z)" in body and "ci.L_c \\" in body and "d.mean" in body
+    m = re.search(r"function Distributions\._rand!\(rng::AbstractRNG,\s*d::G\.GMRF,\s*X::AbstractMatrix\{<:Real\}\)(.*?)\nend\n", code, re.S)
+    assert m and "MI355XCholesky" in m.group(1) and "G.backward_solve(d.linsolve_cache, Z)" in m.group(1)
+    assert re.search(r"G\._backward_solve_impl\(cache,\s*Z::Matrix\{Float64\},\s*::MI355XCholesky\)", code)
+    assert re.search(r"function backend_backward_solve\(b::MI355XBackend,\s*Zm::Matrix\{Float64\}\)", code)
+    assert len(re.findall(r"info\[\] > 0 && throw\(PosDefException", code)) >= 1
+    ext = "\n".join(l for l in open(JL_EXT).read().splitlines() if not l.lstrip().startswith("#"))
+    assert "info[] > 0 && throw(PosDefException" in ext

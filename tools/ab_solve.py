@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of environment switches on the cfg-2 64-RHS solve (separate call): forward / backward sweep ms per setting, each in a child process.
-    python3 tools/ab_solve.py "" "GMRFX_BWD_XCD=8" ..."""
+    python3 tools/ab_solve.py "" "GMRFX_BWD_FRONT=0" ..."""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''

@@ -130,6 +130,8 @@ def join(trace_d, fetch_d, write_d, prefix):
             stats_rows.append([ph, k, e["calls"], round(e["us"], 1), round(e["us"] / e["calls"], 1), round(100 * e["us"] / tot_us, 1),
                                round((e["fetch_x2"] + e["write"]) / 1e9, 3)])
     out["selinv"]["ms_event"] = meta["ms_selinv"]; out["rand256"]["ms_event"] = meta["ms_rand256"]
+    from gmrfx._lib import source_tree_hash
+    out["csrc_hash"] = source_tree_hash()       # the source tree these counters belong to (bench.py checks it)
     json.dump(out, open(prefix + "_pmc_traffic.json", "w"), indent=1)
     with open(prefix + "_kernel_stats.csv", "w") as fh:
         w = csv.writer(fh)

@@ -24,14 +24,13 @@ int main(){
   hipStream_t st; HC(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   hipEvent_t e0,e1; HC(hipEventCreate(&e0)); HC(hipEventCreate(&e1));
   const int reps=200; float ms;
-  for(int form : {3, 1}) {
+  for(int form : {3}) {      // (the register-patch form of rounds 1-3 is gone from the library)
   auto launch = [&](hipStream_t q, double *dst, int wv) {
     const FrontArg fa{1,0,wv,wv,n,0,0};
     if (form == 3) { if (wv <= 16) hipLaunchKernelGGL((k_potrf64_b<1,1>),dim3(1),dim3(64),0,q,S,(const FrontView*)nullptr,0,dst,dinfo,fa);
       else if (wv <= 32) hipLaunchKernelGGL((k_potrf64_b<2,2>),dim3(1),dim3(128),0,q,S,(const FrontView*)nullptr,0,dst,dinfo,fa);
       else if (wv <= 48) hipLaunchKernelGGL((k_potrf64_b<4,3>),dim3(1),dim3(256),0,q,S,(const FrontView*)nullptr,0,dst,dinfo,fa);
       else hipLaunchKernelGGL((k_potrf64_b<8,4>),dim3(1),dim3(512),0,q,S,(const FrontView*)nullptr,0,dst,dinfo,fa); }
-    else hipLaunchKernelGGL(k_potrf64,dim3(1),dim3(256),0,q,S,(const FrontView*)nullptr,0,dst,dinfo,fa);
   };
   printf("==== %s\n", form == 3 ? "k_potrf64_b (16-column steps, 512 threads)" : "k_potrf64 (register patches, 256 threads)");
   for(int wv : {64, 37, 16, 3, 61, 48}) {
@@ -40,12 +39,6 @@ int main(){
     for(int r=0;r<reps;r++){ hipMemcpyAsync(dL,dA,n*n*8,hipMemcpyDeviceToDevice,st); launch(st,dL,wv); }
     HC(hipEventRecord(e1,st)); HC(hipStreamSynchronize(st)); HC(hipEventElapsedTime(&ms,e0,e1));
     printf("k_potrf64 (w=%d) + d2d copy: %.2f us per launch\n", wv, ms*1000/reps);
-#ifdef GMRFX_CYC
-    { long long c[4][16]={{0}};
-      HC(hipMemcpyFromSymbol(c, HIP_SYMBOL(g_cyc64), sizeof(c))); long long z[64]={0}; HC(hipMemcpyToSymbol(HIP_SYMBOL(g_cyc64), z, sizeof(z)));
-      const char* nm[6]={"head","lds-read","chain","Y","update/out","barrier"};
-      for(int w2=0;w2<4;w2++){ printf(" wave %d cycles/step (incl. ~350 per mark):",w2); double tot=0; for(int k=0;k<6;k++){ double v=c[w2][k]/(double)reps/((wv+3)/4); tot+=v; printf(" %s=%.0f",nm[k],v);} printf(" total=%.0f\n",tot); } }
-#endif
 #ifdef GMRFX_CYC
     if (form == 3) { long long c[64]; HC(hipMemcpyFromSymbol(c, HIP_SYMBOL(pb::g_pb_cyc), sizeof(c)));
       printf("  diagonal wave, cycles since kernel start: loaded %lld;", c[1]-c[0]);
@@ -88,8 +81,8 @@ int main(){
       HC(hipDeviceSynchronize());
       auto t0 = std::chrono::steady_clock::now();
       for(int r=0;r<reps;r++){
-        hipLaunchKernelGGL(k_potrf64,dim3(1),dim3(256),0,st,S,(const FrontView*)nullptr,0,dL,dinfo,fa);
-        if (two) hipLaunchKernelGGL(k_potrf64,dim3(1),dim3(256),0,st2,S,(const FrontView*)nullptr,0,dL2,dinfo,fa);
+        hipLaunchKernelGGL((k_potrf64_b<8,4>),dim3(1),dim3(512),0,st,S,(const FrontView*)nullptr,0,dL,dinfo,fa);
+        if (two) hipLaunchKernelGGL((k_potrf64_b<8,4>),dim3(1),dim3(512),0,st2,S,(const FrontView*)nullptr,0,dL2,dinfo,fa);
       }
       HC(hipDeviceSynchronize());
       const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();

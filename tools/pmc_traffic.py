@@ -31,7 +31,7 @@ def last_step_start(names):
 
 def phase(n):
     if n.startswith(("k_factor", "k_assemble", "k_potrf", "k_trsm", "k_gemm_nt", "k_syrk")): return "factor"
-    if n.startswith("k_inv_stage"): return "dense_inverse"
+    if n.startswith(("k_inv_stage", "k_pack_diag", "k_rdiag")): return "dense_inverse"      # once per factorisation, on the first solve
     if n.startswith(("k_fwd", )): return "sweep_forward"
     if n.startswith(("k_bwd", )): return "sweep_backward"
     if n.startswith("k_permute"): return "permute"
@@ -61,6 +61,11 @@ def main():
                    "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads); values per bench step "
                    "(refactorise + solve).")
     res["workload"] = {"grid": grid, "nrhs": nrhs}
+    # the source tree these counters belong to: bench.py quotes the figures only while it is timing the same tree
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gaussianmarkovrandomfields.jl_amd"))
+    from gmrfx._lib import source_tree_hash
+    res["csrc_hash"] = source_tree_hash()
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps({k: v for k, v in res.items() if k not in ("per_kernel_GB_per_step", "note")}))
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Average duration of the sweep-task kernels (sweep_chunk.hip: k_fwd_chunks / k_bwd_chunks / k_pack_diag; one wave per task and
 # 16 columns: k_wave_task) in a 64-RHS solve at cfg 2, once per environment setting given ("" = defaults):
-#     tools/task_times.sh "" "GMRFX_TASK_CFG=1" ...
+#     tools/task_times.sh "" "GMRFX_TASK_MODE=wave" ...
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 mkdir -p gpurun_out
 [ $# -eq 0 ] && set -- ""
