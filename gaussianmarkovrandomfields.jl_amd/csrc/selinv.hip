@@ -356,6 +356,13 @@ void launch_sel_diag(hipStream_t st, const DevSym &S, const int *list, int nacti
     hipLaunchKernelGGL(k_sel_diag, dim3(nactive), dim3(256), 0, st, S, list, kb, L, Z, Yh, yoff);
 }
 
+// (Round 5, measured and removed: phase 1 of the big fronts -- Z21' = -Y Z22, two thirds to four fifths of the flops on the top
+//  levels -- with a 64 x 64 WAVE tile, 4 x 4 MFMA tiles per wave, every operand value re-used four times from registers (one 16-byte
+//  load per four MFMAs instead of two; rows 4 lm + a / columns 4 lm + b so that a lane's operands and results are 32 contiguous
+//  bytes), 218 VGPRs = two waves per SIMD. Correct on the first run (36 selected-inversion tests incl. cfg 3 / cfg 4 at full size);
+//  L2-miss traffic of the selected inversion 61 -> 52 GB, the phase itself 41-50 TFLOP/s -- the same as the 32 x 32 tile it replaced
+//  (levels 11-16: 4.07 ms against 3.9), selected inversion 13.0 -> 13.3 ms. The dense phases are not bound by their re-reads: they sit
+//  at the 49-55 TFLOP/s this chip gives a direct-operand FP64 MFMA product at two to three waves per SIMD.)
 void launch_sel_dense(hipStream_t st, const DevSym &S, const int *list, int nfronts, int phase, int max_c, int max_trail,
                       const double *L, double *Z, const double *ZB, double *Yt, double *Z21t, const long long *woff) {
     if (nfronts <= 0) return;

@@ -1,4 +1,8 @@
 // sweep_front.hip -- the backward step of a mid-level front as ONE workgroup and ONE launch (round 5).
+// (The same idea for the first half of the FORWARD step -- own rows assembled in LDS, y = L11^-1 b in the same launch, instead of
+//  k_fwd_assemble + k_xmul -- was built to parity and measured: 53 / 77 / 82 / 47 / 42 us on levels 5-9 of cfg 2 against 45 / 65 / 68 /
+//  37 / 33 for the two launches, whose finer workgroups (32 rows / 16 rows of a front) hide the record -> row table -> child rows
+//  chain better than one workgroup per front does. Removed.)
 //
 // The level schedule ran a big front's backward step as two launches: t = y - L21' x[trailing rows] (k_bwd_gemm_longk: a
 // workgroup per 16 or 32 own columns, every one of them gathering ALL trailing rows of x: the mid levels moved 2-3 x their
