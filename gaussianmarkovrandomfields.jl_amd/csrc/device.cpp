@@ -66,7 +66,7 @@ Device::~Device() {
     if (h_nzstage_) (void)hipHostFree(h_nzstage_);
     if (ev_up_) (void)hipEventDestroy(ev_up_);
     if (ev_x_) (void)hipEventDestroy(ev_x_);
-    for (auto &e : ev_dn_) (void)hipEventDestroy(e);
+    for (auto &e : ev_ring_) (void)hipEventDestroy(e);
     if (stream_io_) (void)hipStreamDestroy(stream_io_);
     if (h_logdet_) (void)hipHostFree(h_logdet_);
     if (h_qf_) (void)hipHostFree(h_qf_);
@@ -696,12 +696,6 @@ static bool host_ptr_is_pinned(const void *p) {
     if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
     return a.type == hipMemoryTypeHost || a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
 }
-// the address the GPU uses for a page-locked host pointer
-static double *host_ptr_device_view(const void *p) {
-    void *d = nullptr;
-    if (hipHostGetDevicePointer(&d, const_cast<void *>(p), 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    return (double *)d;
-}
 static int host_io_threads() {
     static const int nt = [] {
         const unsigned hc = std::thread::hardware_concurrency();
@@ -709,7 +703,11 @@ static int host_io_threads() {
     }();
     return nt;
 }
-static constexpr long long kIoSliceBytes = 32ll << 20;     // staging granularity
+// Pageable host memory is staged through a RING of page-locked slices that belongs to the handle: kIoRing slices of
+// kIoSliceBytes (128 MB per handle, whatever the size of the right-hand sides -- a WorkspacePool keeps one handle per thread; round 4
+// held n x nrhs doubles, 512 MB at cfg 2). Slice k uses slot k mod kIoRing once slice k - kIoRing has left it.
+static constexpr long long kIoSliceBytes = 16ll << 20;     // staging granularity
+static constexpr int kIoRing = 8;
 
 // count doubles copied by up to T host threads (used for values that must arrive before anything can start)
 static void parallel_memcpy(double *dst, const double *src, long long count) {
@@ -731,12 +729,11 @@ void Device::host_io_reserve(long long count) {
         HC(hipEventCreateWithFlags(&ev_up_, hipEventDisableTiming));
         HC(hipEventCreateWithFlags(&ev_x_, hipEventDisableTiming));
     }
+    count = std::min<long long>(count, kIoRing * (kIoSliceBytes / (long long)sizeof(double)));
     if (count <= h_stage_cap_) return;
-    if (h_stage_) { HC(hipDeviceSynchronize()); (void)hipHostFree(h_stage_); h_stage_ = nullptr; h_stage_cap_ = 0; }
+    if (h_stage_) { HC(hipStreamSynchronize(stream_io_)); (void)hipHostFree(h_stage_); h_stage_ = nullptr; h_stage_cap_ = 0; }   // (only the copy stream ever touches it)
     HC(hipHostMalloc((void **)&h_stage_, (size_t)count * sizeof(double), hipHostMallocDefault));
     h_stage_cap_ = count;
-    d_stage_view_ = host_ptr_device_view(h_stage_);
-    if (!d_stage_view_) throw std::runtime_error("page-locked staging buffer is not visible to the device");
 }
 
 // Q's values from a host array to d_nz_, ahead of the factorisation (nothing else runs yet: plain DMA)
@@ -763,11 +760,16 @@ void Device::host_upload(const double *B, long long ldb, long long nrhs, double 
         HC(hipEventRecord(ev_up_, stream_io_));
         return;
     }
-    host_io_reserve(n * nrhs);
-    // column slices of ~64 MB; slice k is staged by host thread k mod T, which then launches its copy kernel
+    // column slices; slice k is staged by host thread k mod T into ring slot k mod kIoRing (once the DMA of slice k - kIoRing has
+    // left that slot), then handed to the DMA engine
     const long long cols_per = std::max<long long>(1, kIoSliceBytes / (n * (long long)sizeof(double)));
+    const long long slot_doubles = cols_per * n;
+    host_io_reserve(std::min<long long>(n * nrhs, kIoRing * slot_doubles));
     const long long nsl = (nrhs + cols_per - 1) / cols_per;
     const int T = (int)std::min<long long>(host_io_threads(), nsl);
+    while ((int)ev_ring_.size() < kIoRing) { hipEvent_t e; HC(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ev_ring_.push_back(e); }
+    std::vector<std::atomic<int>> posted((size_t)nsl);
+    for (auto &a : posted) a.store(0);
     std::vector<std::thread> th;
     std::exception_ptr err;
     std::atomic<bool> failed{false};
@@ -777,9 +779,17 @@ void Device::host_upload(const double *B, long long ldb, long long nrhs, double 
             HC(hipSetDevice(dev));
             for (long long k = t; k < nsl && !failed.load(); k += T) {
                 const long long j0 = k * cols_per, nc = std::min(cols_per, nrhs - j0);
+                const int slot = (int)(k % kIoRing);
+                if (k >= kIoRing) {         // the slot's previous slice: its copy has been enqueued (posted), now wait until it has run
+                    while (!posted[(size_t)(k - kIoRing)].load(std::memory_order_acquire)) { if (failed.load()) return; std::this_thread::yield(); }
+                    HC(hipEventSynchronize(ev_ring_[slot]));
+                }
+                double *st = h_stage_ + slot * slot_doubles;
                 for (long long j = 0; j < nc; j++)
-                    std::memcpy(h_stage_ + (j0 + j) * n, B + (j0 + j) * ldb, (size_t)n * sizeof(double));
-                HC(hipMemcpyAsync(d_dst + j0 * n, h_stage_ + j0 * n, (size_t)(nc * n) * sizeof(double), hipMemcpyHostToDevice, stream_io_));
+                    std::memcpy(st + j * n, B + (j0 + j) * ldb, (size_t)n * sizeof(double));
+                HC(hipMemcpyAsync(d_dst + j0 * n, st, (size_t)(nc * n) * sizeof(double), hipMemcpyHostToDevice, stream_io_));
+                HC(hipEventRecord(ev_ring_[slot], stream_io_));
+                posted[(size_t)k].store(1, std::memory_order_release);
             }
         } catch (...) {
             if (!failed.exchange(true)) err = std::current_exception();
@@ -805,16 +815,16 @@ void Device::host_download(const double *d_src, long long nrhs, double *X, long 
         HC(hipStreamSynchronize(stream_io_));
         return;
     }
-    host_io_reserve(n * nrhs);
+    // slice k: device -> ring slot k mod kIoRing (once slice k - kIoRing has been copied out of it) -> the caller's array; host
+    // thread k mod T does all three steps, up to T transfers in flight
     const long long cols_per = std::max<long long>(1, (kIoSliceBytes / 2) / (n * (long long)sizeof(double)));
+    const long long slot_doubles = cols_per * n;
+    host_io_reserve(std::min<long long>(n * nrhs, kIoRing * slot_doubles));
     const long long nsl = (nrhs + cols_per - 1) / cols_per;
-    while ((long long)ev_dn_.size() < nsl) { hipEvent_t e; HC(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ev_dn_.push_back(e); }
-    for (long long k = 0; k < nsl; k++) {
-        const long long j0 = k * cols_per, nc = std::min(cols_per, nrhs - j0);
-        HC(hipMemcpyAsync(h_stage_ + j0 * n, d_src + j0 * n, (size_t)(nc * n) * sizeof(double), hipMemcpyDeviceToHost, stream_io_));
-        HC(hipEventRecord(ev_dn_[k], stream_io_));
-    }
-    const int T = (int)std::min<long long>(host_io_threads(), nsl);
+    while ((int)ev_ring_.size() < kIoRing) { hipEvent_t e; HC(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ev_ring_.push_back(e); }
+    std::vector<std::atomic<int>> done((size_t)nsl);
+    for (auto &a : done) a.store(0);
+    const int T = (int)std::min<long long>(std::min<long long>(host_io_threads(), kIoRing), nsl);
     std::vector<std::thread> th;
     std::exception_ptr err;
     std::atomic<bool> failed{false};
@@ -822,11 +832,18 @@ void Device::host_download(const double *d_src, long long nrhs, double *X, long 
     auto work = [&](int t) {
         try {
             HC(hipSetDevice(dev));
-            for (long long k = t; k < nsl; k += T) {
+            for (long long k = t; k < nsl && !failed.load(); k += T) {
                 const long long j0 = k * cols_per, nc = std::min(cols_per, nrhs - j0);
-                HC(hipEventSynchronize(ev_dn_[k]));
+                const int slot = (int)(k % kIoRing);
+                if (k >= kIoRing)
+                    while (!done[(size_t)(k - kIoRing)].load(std::memory_order_acquire)) { if (failed.load()) return; std::this_thread::yield(); }
+                double *st = h_stage_ + slot * slot_doubles;
+                HC(hipMemcpyAsync(st, d_src + j0 * n, (size_t)(nc * n) * sizeof(double), hipMemcpyDeviceToHost, stream_io_));
+                HC(hipEventRecord(ev_ring_[slot], stream_io_));
+                HC(hipEventSynchronize(ev_ring_[slot]));
                 for (long long j = 0; j < nc; j++)
-                    std::memcpy(X + (j0 + j) * ldx, h_stage_ + (j0 + j) * n, (size_t)n * sizeof(double));
+                    std::memcpy(X + (j0 + j) * ldx, st + j * n, (size_t)n * sizeof(double));
+                done[(size_t)k].store(1, std::memory_order_release);
             }
         } catch (...) {
             if (!failed.exchange(true)) err = std::current_exception();

@@ -356,11 +356,11 @@ private:
     int *d_info_ = nullptr;
     // host I/O of the pipelined factor + solve call: copy stream, page-locked staging buffer, events
     hipStream_t stream_io_ = nullptr;
-    double *h_stage_ = nullptr, *d_stage_view_ = nullptr, *h_nzstage_ = nullptr;
+    double *h_stage_ = nullptr, *h_nzstage_ = nullptr;
     long long h_stage_cap_ = 0;
     void host_upload_values(const double *nzval);
     hipEvent_t ev_up_ = nullptr, ev_x_ = nullptr;
-    std::vector<hipEvent_t> ev_dn_;
+    std::vector<hipEvent_t> ev_ring_;             // one per slot of the page-locked staging ring (host_upload / host_download)
     void host_io_reserve(long long count);
     void host_upload(const double *B, long long ldb, long long nrhs, double *d_dst);
     void host_download(const double *d_src, long long nrhs, double *X, long long ldx, hipStream_t after);

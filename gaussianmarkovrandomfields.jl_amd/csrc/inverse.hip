@@ -129,6 +129,9 @@ __global__ __launch_bounds__(64 * NW) void k_xmul(DevSym S, const int *__restric
     for (int t = 0; t < 4; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
     const int qlo = trans ? k0 : 0, qhi = trans ? c : min(c, k0 + 16);
     constexpr int KU = 4;
+    // (Round 5, measured and dropped: plain entries of the upper triangle instead of the accessor away from the tile's own diagonal
+    //  block, and the operands of batch n + 1 requested before the MFMAs of batch n -- 164 instead of ~110 VGPRs, forward / backward
+    //  sweep 2.04 / 1.60 ms against 1.94 / 1.55 on the same box.)
 #pragma unroll 1
     for (int q0 = qlo + wave * 4 * KU; q0 < qhi; q0 += NW * 4 * KU) {
         double av[KU], bv[KU][4];

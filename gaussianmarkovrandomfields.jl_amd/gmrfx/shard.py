@@ -52,6 +52,7 @@ class ShardedFactor:
         self.last_info = 0
         self._info_pending = False
         self._df_views = {}
+        self._p2p_cache = {}                      # prebuilt P2POp lists of the recurring transfer lists (see _p2p)
         # one stream orders everything: the library's kernels, torch's copies, the transfers torch.distributed enqueues
         self.be.set_stream(torch.cuda.current_stream(self.dev).cuda_stream, True, True)
         # per top level: the cross-edge transfers of the factorisation (contribution blocks) and of the forward sweep
@@ -85,10 +86,27 @@ class ShardedFactor:
         base = self.be.device_ptr(which)
         return self.torch.as_tensor(_DevView(base + 8 * int(off), int(cnt)), device=self.dev)
 
-    def _p2p(self, items):
+    def _p2p(self, items, key=None):
         """items: (src, dst, which buffer, offset, count) -- every rank passes the same list; the transfers this rank
-        takes part in are posted as one batch."""
+        takes part in are posted as one batch. `key` names a list that recurs every step (the contribution blocks / update
+        vectors of one top level, the owned rows going home): its views of the library's buffers and its P2POp objects are
+        then built ONCE and posted again as they are (round 4 rebuilt both on every call: a few hundred Python objects per
+        step on the critical path between two phases). Device path only: the gloo rehearsal stages through fresh host copies."""
         t, dist = self.torch, self.dist
+        if key is not None and not self.host_staging:
+            ops = self._p2p_cache.get(key)
+            if ops is None:
+                ops = []
+                for tag, (src, dst, which, off, cnt) in enumerate(items):
+                    if src == dst or self.rank not in (src, dst) or cnt == 0:
+                        continue
+                    v = self._view(which, off, cnt)
+                    ops.append(dist.P2POp(dist.isend, v, dst, tag=tag) if self.rank == src else dist.P2POp(dist.irecv, v, src, tag=tag))
+                self._p2p_cache[key] = ops
+            if ops:
+                for r in dist.batch_isend_irecv(ops):
+                    r.wait()            # (RCCL: the current STREAM waits, the host does not)
+            return
         ops, post = [], []
         for tag, (src, dst, which, off, cnt) in enumerate(items):
             if src == dst or self.rank not in (src, dst) or cnt == 0:
@@ -136,7 +154,7 @@ class ShardedFactor:
         be = self.be
         be.refactorize_phase_dev(d_nzval_ptr, 0)
         for k in range(self.K):
-            self._p2p(self._cb_items[k])
+            self._p2p(self._cb_items[k], key=("cb", k))
             for i in self._dist_of_level[k]:
                 if self.rank in self.df["group"][i]:
                     self._factor_distributed_front(d_nzval_ptr, i)
@@ -217,13 +235,13 @@ class ShardedFactor:
         else:
             be.solve_phase_dev(d_B, ldb, nrhs, d_X, ldx, 0)                      # transpose in + own forward
             for k in range(self.K):
-                self._p2p([(src, dst, 3, r0 * nrhs, nr * nrhs) for src, dst, r0, nr in self._w_items[k]])
+                self._p2p([(src, dst, 3, r0 * nrhs, nr * nrhs) for src, dst, r0, nr in self._w_items[k]], key=("w", k, nrhs))
                 be.solve_phase_dev(d_B, ldb, nrhs, d_X, ldx, 100 + k)            # forward, top level k
         for k in range(self.K - 1, -1, -1):
             be.solve_phase_dev(d_B, ldb, nrhs, d_X, ldx, (300 if backward_only else 200) + k)    # backward, top level k
             self._bcast_rows(self._top_blocks[k], nrhs)                          # x of that level's fronts -> everybody
         be.solve_phase_dev(d_B, ldb, nrhs, d_X, ldx, 12 if backward_only else 2)  # own backward
-        self._p2p([(o, 0, 2, r0 * nrhs, nr * nrhs) for o, r0, nr in self._sub_blocks])     # x of the owned subtrees -> rank 0
+        self._p2p([(o, 0, 2, r0 * nrhs, nr * nrhs) for o, r0, nr in self._sub_blocks], key=("home", nrhs))     # x of the owned subtrees -> rank 0
         if self.rank == 0:
             be.solve_phase_dev(d_B, ldb, nrhs, d_X, ldx, 3)                      # transpose out
 
