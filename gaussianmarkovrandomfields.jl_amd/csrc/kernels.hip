@@ -1099,7 +1099,7 @@ __global__ __launch_bounds__(256) void k_fwd_own_update(DevSym S, const int *__r
 
 // Backward update of a big front: own columns -= L21' * x_R over ALL trailing rows: a
 // workgroup owns 64 own columns x 64 right-hand sides, its waves split the trailing rows.
-template <int NA, int NW>   // NA: see k_fwd_update_longk; NW: waves per workgroup splitting K (8 only with NA = 1)
+template <int NA, int NW>   // NA: 16-column tiles of own columns per workgroup; NW: waves per workgroup splitting K
 __global__ __launch_bounds__(64 * NW) void k_bwd_gemm_longk(DevSym S, const int *__restrict__ list,
                                                           const double *__restrict__ L, const double *X, double *Xown, int nr,
                                                           int ldx, int blk, int cap) {
@@ -1209,7 +1209,13 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_gemm_longk(DevSym S, const int 
         }
     } else {
         if (NW == 4) splitk_reduce4<NA>(acc, red, wave, lane);
-        else splitk_reduce_nw<NW>(acc[0], red, wave, lane);
+        else {
+#pragma unroll
+            for (int a = 0; a < NA; a++) {
+                if (a > 0) __syncthreads();         // (the buffer of the partial tiles is reused)
+                splitk_reduce_nw<NW>(acc[a], red, wave, lane);
+            }
+        }
         // X -= acc in two passes (all loads, then all stores: one round trip instead of a chain of 8)
 #pragma unroll
         for (int t = 0; t < 4; t++) {
@@ -1602,8 +1608,14 @@ void launch_bwd_gemm(hipStream_t st, const DevSym &S, const int *list, int nfron
     if (nfronts <= 0 || max_cols <= 0) return;
     if (blk >= 0) max_cols = std::min(max_cols - blk * cap, cap);
     if (max_cols <= 0) return;
-    // the 8-wave, 16-column variant up to ~3 workgroups per CU (measured: 512-1024 beats 128 and 2048)
-    if ((long long)cdiv(max_cols, 32) * nfronts <= 768)
+    // the 8-wave variants up to ~3 workgroups per CU (measured: 512-1024 beats 128 and 2048). Every workgroup of a front gathers ALL
+    // of the front's trailing rows of x: 32 own columns per workgroup instead of 16 halves those re-reads (levels 10-13 of cfg 2
+    // moved 2.5-3 x their algorithmic bytes) on levels that still fill the chip with them (measured at cfg 2, 32 / 16 columns per
+    // workgroup: level 10 (768 workgroups of 32) 72 / 83 us, 11 (576) 79 / 88; 12 (352) 79 / 73, 13: 85 / 75, 14: 66 / 55, 15: 62 / 47)
+    const long long wg32 = (long long)cdiv(max_cols, 32) * nfronts;
+    if (wg32 <= 768 && wg32 >= 384)
+        hipLaunchKernelGGL((k_bwd_gemm_longk<2, 8>), dim3(odd(cdiv(max_cols, 32)), nfronts), dim3(512), 0, st, S, list, L, X, Xown, nr, ldx, blk, cap);
+    else if (wg32 <= 768)
         hipLaunchKernelGGL((k_bwd_gemm_longk<1, 8>), dim3(odd(cdiv(max_cols, 16)), nfronts), dim3(512), 0, st, S, list, L, X, Xown, nr, ldx, blk, cap);
     else
         hipLaunchKernelGGL((k_bwd_gemm_longk<2, 4>), dim3(odd(cdiv(max_cols, 32)), nfronts), dim3(256), 0, st, S, list, L, X, Xown, nr, ldx, blk, cap);
