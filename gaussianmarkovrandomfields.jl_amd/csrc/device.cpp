@@ -976,8 +976,11 @@ void Device::factor_levels(int lo, int hi) {
         }
         if (nf > 0 && level_max_trail(L) > 0) {
             HC(hipEventRecord(ev_syrk_[2 * nsy], stream));
-            if (syrk_xcd_) launch_syrk_cb_recs(stream, ds_, d_syrk_recs_ + L.syrk_off, L.syrk_split, L.syrk_per, d_L_, d_cb_);
+            // levels of HUGE fronts (3-D problems): the children's extend-add alone, then the product on 128 x 128 staged tiles
+            const bool huge = syrk_xcd_ && !sharded() && level_max_trail(L) >= 4096 && L.max_cols >= 1024;
+            if (syrk_xcd_) launch_syrk_cb_recs(stream, ds_, d_syrk_recs_ + L.syrk_off, L.syrk_split, L.syrk_per, d_L_, d_cb_, huge ? 1 : 0);
             else launch_syrk_cb(stream, ds_, list, nf, level_max_trail(L), d_L_, d_cb_);
+            if (huge) launch_syrk_big(stream, ds_, list, nf, level_max_trail(L), d_L_, d_cb_);
             HC(hipEventRecord(ev_syrk_[2 * nsy + 1], stream));
             nsy++;
         }

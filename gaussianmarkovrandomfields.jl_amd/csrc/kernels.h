@@ -21,7 +21,10 @@ void launch_assemble(hipStream_t st, const DevSym &S, const int *list, const Asm
                      const double *nzval, double *L, double *CB);
 void launch_syrk_cb(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_trail, const double *L, double *CB);
 // The same tiles from self-contained records, one contiguous run per XCD (workgroup id mod 8 = XCD): see k_syrk_cb_rec.
-void launch_syrk_cb_recs(hipStream_t st, const DevSym &S, const SyrkTile *recs, const SyrkSplit &split, int per_xcd, const double *L, double *CB);
+void launch_syrk_cb_recs(hipStream_t st, const DevSym &S, const SyrkTile *recs, const SyrkSplit &split, int per_xcd, const double *L, double *CB,
+                         int noprod = 0);
+// CB -= L21 L21' on 128 x 128 LDS-staged tiles (behind a gather-only pass: noprod = 1), for levels of huge fronts
+void launch_syrk_big(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_trail, const double *L, double *CB);
 // blocks at most 32 columns wide, factorisation only (k_trsm<0, 0>'s arithmetic on half the registers)
 void launch_trsm_narrow(hipStream_t st, const FrontView *frec, int nactive, int kb, int max_rows_below, double *L);
 void launch_trsm(hipStream_t st, const DevSym &S, const FrontView *frec, int nactive, int kb, int mode, int max_rows_below,

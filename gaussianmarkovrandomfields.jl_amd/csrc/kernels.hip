@@ -561,7 +561,9 @@ __global__ __launch_bounds__(256) void k_syrk_cb(DevSym S, const int *__restrict
 // are requested right behind it, and only then does anything wait. Children are still added one after the other, the k
 // order is unchanged: bit-identical to k_syrk_cb.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_syrk_cb_rec(DevSym S, const SyrkTile *__restrict__ recs, const SyrkSplit split,
-                                                     const double *__restrict__ L, double *__restrict__ CB) {
+                                                     const double *__restrict__ L, double *__restrict__ CB, int noprod) {
+    // noprod: the children's extend-add only -- the product follows as its own launch on 128 x 128 staged tiles (k_syrk_big: the
+    // huge fronts of 3-D problems)
     __shared__ double Tl[64 * 65];
     const int x = blockIdx.x & 7;
     const int t = split.start[x] + (int)(blockIdx.x >> 3);
@@ -594,7 +596,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
             bv[u][0] = xb.x; bv[u][1] = xb.y;
         }
     };
-    if (live) request(0);
+    if (live && !noprod) request(0);
     // the first two children's entries: (row la, column lb + 4 u) of the child's rows / columns inside this tile.
     // Round trips: record -> [k-batch 0 + child 0] -> child 1 -> k-batch 1 ...
     // Every vector memory instruction costs the CU's address unit ~16 cycles whatever its lanes do, and these levels
@@ -657,7 +659,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
     // compiling parts out (profiles/r04_syrk_parts.txt): gather, product and store used to follow each other, a third of a
     // mid-level tile's time each.
     // D[m_ = j][n = i] = sum_q L21[j][q] L21[i][q]: rows i on the lanes (contiguous in column-major CB)
-    if (live)
+    if (live && !noprod)
         for (int q0 = 0; q0 < c; q0 += 4 * KU) {
             if (q0 > 0) request(q0);
             mfma_batch(q0);
@@ -1550,9 +1552,16 @@ void launch_syrk_cb_cyclic(hipStream_t st, const DevSym &S, const int *list, int
     if (trail <= 0) return;
     hipLaunchKernelGGL(k_syrk_cb, dim3(odd(cdiv(trail, 64)), odd(cdiv(trail, 64)), 1), dim3(256), 0, st, S, list, L, CB, cyc_w, cyc_r, cyc_b0);
 }
-void launch_syrk_cb_recs(hipStream_t st, const DevSym &S, const SyrkTile *recs, const SyrkSplit &split, int per_xcd, const double *L, double *CB) {
+void launch_syrk_cb_recs(hipStream_t st, const DevSym &S, const SyrkTile *recs, const SyrkSplit &split, int per_xcd, const double *L, double *CB,
+                         int noprod) {
     if (per_xcd <= 0) return;
-    hipLaunchKernelGGL(k_syrk_cb_rec, dim3(8 * (unsigned)per_xcd), dim3(256), 0, st, S, recs, split, L, CB);
+    hipLaunchKernelGGL(k_syrk_cb_rec, dim3(8 * (unsigned)per_xcd), dim3(256), 0, st, S, recs, split, L, CB, noprod);
+}
+__global__ void k_syrk_big(DevSym S, const int *__restrict__ list, const double *__restrict__ L, double *__restrict__ CB);   // with k_gemm_nt_big, below
+void launch_syrk_big(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_trail, const double *L, double *CB) {
+    if (nfronts <= 0 || max_trail <= 0) return;
+    const int nt = cdiv(max_trail, 128);
+    hipLaunchKernelGGL(k_syrk_big, dim3(odd(nt), odd(nt), nfronts), dim3(512), 0, st, S, list, L, CB);
 }
 void launch_trsm(hipStream_t st, const DevSym &S, const FrontView *frec, int nactive, int kb, int mode, int max_rows_below,
                  double *L, double *Yh, const long long *yoff, const FrontArg &fa) {
@@ -1571,9 +1580,118 @@ void launch_trsm_narrow(hipStream_t st, const FrontView *frec, int nactive, int 
     if (nactive <= 0 || max_rows_below <= 0) return;
     hipLaunchKernelGGL(k_trsm_narrow, dim3(odd(cdiv(max_rows_below, 128)), nactive), dim3(256), 0, st, frec, kb, L);
 }
+// The same update for the HUGE fronts of 3-D problems (round 5): 128 x 128 workgroup tiles, operands staged through LDS -- 16 k
+// at a time, double-buffered through registers -- and shared by eight waves of 32 x 64 (tools/micro/dgemm_mfma.hip: 54 TFLOP/s on
+// an ideal shape against 47-49 for the direct-operand 64 x 64 tile above, which is what the three top levels of the 126^3 mesh
+// ran at). The transplant lost twice at cfg 2 (a quarter of the tiles, one wave per SIMD on half the chip);
+// it is only used where a launch has thousands of such tiles: K a multiple of 16, at least 4096 rows below the block.
+// Same arithmetic per entry (the k order inside an entry's sum is the same); the strict upper triangle of the diagonal tiles
+// is computed and not stored.
+// C (M x N, leading dimension ldc; lower part, i >= j) -= A[0 .. M) A[0 .. N)' over K columns of A (leading dimension lda); K any
+// (a k beyond K is staged as zero)
+__device__ __forceinline__ void gemm_nt_big_tile(const double *__restrict__ A, int lda, double *__restrict__ C, long long ldc, int M, int N, int K) {
+    constexpr int TM = 128, KB = 16;
+    __shared__ double As[2][KB][TM + 8], Bs[2][KB][TM + 8];      // +8: consecutive k rows start in different banks
+    const int bi = blockIdx.x, bj = blockIdx.y;
+    if (bj > bi || bi * TM >= M || bj * TM >= N) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lm = lane & 15, lk = lane >> 4;
+    const int m0 = bi * TM, n0 = bj * TM;
+    const int wi = (wave & 3) * 32, wj = (wave >> 2) * 64;       // wave sub-tile: 32 rows x 64 columns
+    d4 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+    // staging: 512 threads, a 128 x 16 slab = 4 doubles per thread (row tid % 128 -- clamped: rows past the edge are never
+    // stored --, k = 4 (tid / 128) ..)
+    const int lr = tid & 127, l4 = (tid >> 7) * 4;
+    const double *pa = A + min(m0 + lr, M - 1);
+    const double *pb = A + min(n0 + lr, M - 1);
+    double ra[4], rb[4];
+    auto fetch = [&](int kb) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int k = kb * KB + l4 + q;
+            const long long ko = (long long)min(k, K - 1) * lda;
+            const double mk = k < K ? 1.0 : 0.0;
+            ra[q] = pa[ko] * mk; rb[q] = pb[ko];
+        }
+    };
+    fetch(0);
+#pragma unroll
+    for (int q = 0; q < 4; q++) { As[0][l4 + q][lr] = ra[q]; Bs[0][l4 + q][lr] = rb[q]; }
+    __syncthreads();
+    const int nk = (K + KB - 1) / KB;
+    for (int kb = 0; kb < nk; kb++) {
+        const int cur = kb & 1;
+        if (kb + 1 < nk) fetch(kb + 1);
+#pragma unroll
+        for (int sidx = 0; sidx < KB / 4; sidx++) {
+            double av[2], bv[4];
+#pragma unroll
+            for (int a = 0; a < 2; a++) av[a] = As[cur][4 * sidx + lk][wi + 16 * a + lm];
+#pragma unroll
+            for (int b = 0; b < 4; b++) bv[b] = Bs[cur][4 * sidx + lk][wj + 16 * b + lm];
+            // D[m = column j][n = row i]: first operand = rows of B (columns of C), second = rows of A (the lanes walk i)
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[b], av[a], acc[a][b], 0, 0, 0);
+        }
+        if (kb + 1 < nk) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) { As[cur ^ 1][l4 + q][lr] = ra[q]; Bs[cur ^ 1][l4 + q][lr] = rb[q]; }
+        }
+        __syncthreads();
+    }
+    // C -= acc, lower part only (i >= j), all loads before all stores
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int i = m0 + wi + 16 * a + lm;
+            double cv[4];
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                const int j = n0 + wj + 16 * b + lk + 4 * rr;
+                cv[rr] = C[min(i, M - 1) + (long long)min(j, N - 1) * ldc];
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                const int j = n0 + wj + 16 * b + lk + 4 * rr;
+                if (i < M && j < N && i >= j) C[i + (long long)j * ldc] = cv[rr] - acc[a][b][rr];
+            }
+        }
+}
+__global__ __launch_bounds__(512) void k_gemm_nt_big(const FrontView *__restrict__ frec, int k0, int K, int c0, int c1,
+                                                     double *__restrict__ L, FrontArg fa) {
+    const FrontView fv = front_view(frec, blockIdx.z, fa);
+    const int c = fv.c;
+    if (c0 >= c) return;
+    double *P = L + fv.pp;
+    gemm_nt_big_tile(P + c0 + (long long)k0 * fv.ld, fv.ld, P + c0 + (long long)c0 * fv.ld, fv.ld, fv.r - c0, min(c1, c) - c0, K);
+}
+// The contribution block's product on the same tiles: CB -= L21 L21' behind a gather-only pass of k_syrk_cb_rec (noprod). At
+// cfg 4 the one-pass kernel's 64 x 64 tiles stream K = 8 000-16 000 columns of both operands per tile (8 flop per byte: it ran at
+// ~34 TFLOP/s, 3.5 of the 5.1 s); a 128 x 128 tile halves the operand bytes per flop. The extra read-modify-write of the block
+// (m^2 doubles twice) is milliseconds against seconds there.
+__global__ __launch_bounds__(512) void k_syrk_big(DevSym S, const int *__restrict__ list, const double *__restrict__ L, double *__restrict__ CB) {
+    const int s = list[blockIdx.z];
+    const int c = S.sfirst[s + 1] - S.sfirst[s];
+    const int r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
+    const int m = r - c;
+    if (m <= 0) return;
+    gemm_nt_big_tile(L + S.panelptr[s] + c, S.ld[s], CB + S.cbptr[s], m, m, m, c);
+}
+
 void launch_gemm_nt(hipStream_t st, const DevSym &S, const FrontView *frec, int nactive, int k0, int K, int c0, int c1,
                     int maxM, int maxN, double *L, const FrontArg &fa) {
     if (nactive <= 0 || maxM <= 0 || maxN <= 0) return;
+    if (K % 16 == 0 && K >= 256 && maxM >= 4096 && maxN >= 512) {
+        hipLaunchKernelGGL(k_gemm_nt_big, dim3(odd(cdiv(maxM, 128)), odd(cdiv(maxN, 128)), nactive), dim3(512), 0, st, frec, k0, K, c0, c1, L, fa);
+        return;
+    }
     // 64x64 workgroup tiles, operands straight from L2 at 3-4 waves per SIMD. Measured on MI355X: the
     // sustained v_mfma_f64_16x16x4_f64 rate is 36.3 TFLOP/s (tools/micro/mfma64.hip), this kernel reaches
     // ~27 TFLOP/s on the top-of-tree SYRKs; 128x128 tiles (register- or LDS-staged) were tried and lost

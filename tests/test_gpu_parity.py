@@ -1274,6 +1274,55 @@ def test_dense_fronts_of_every_width_through_the_diagonal_block_kernel(n, monkey
     be.close()
 
 
+def test_one_dense_front_wide_enough_for_the_staged_panel_update():
+    """Round 5 (csrc/kernels.hip, k_gemm_nt_big): fronts with at least 4096 rows below a 256-column outer block take the K = 256
+    panel update on 128 x 128 LDS-staged tiles (the top fronts of 3-D problems: cfg 4). A dense SPD matrix of 4700 unknowns is ONE
+    front of that kind (its first outer blocks qualify, the rest fall back to the direct-operand tiles): solve and log-determinant
+    against LAPACK."""
+    n = 4700
+    rng = np.random.default_rng(9)
+    G = rng.standard_normal((n, 64))
+    A = G @ G.T / 64.0 + np.diag(1.0 + rng.random(n))
+    Q = sp.csc_matrix(A)
+    be = gmrfx.MI355XBackend(Q, ordering="natural", device=0)
+    assert be.last_info == 0
+    B = rng.standard_normal((n, 3))
+    Lc = np.linalg.cholesky(A)
+    X = np.linalg.solve(Lc.T, np.linalg.solve(Lc, B))
+    assert relerr(be.backend_solve(B), X) < 1e-10
+    assert abs(be.compute_logdet() - 2.0 * np.log(np.diag(Lc)).sum()) < 1e-9 * n
+    be.close()
+
+
+def test_two_huge_fronts_take_the_two_pass_contribution_product():
+    """Round 5 (csrc/kernels.hip, k_syrk_big): on a level whose fronts have >= 1024 columns and >= 4096 rows below them the
+    contribution block is built in two passes -- the children's extend-add alone (k_syrk_cb_rec, noprod), then CB -= L21 L21' on
+    128 x 128 LDS-staged tiles. Two dense 1024-column blocks that only meet through a dense 4100-column block (4100: a ragged
+    last tile) are two such fronts under the natural ordering; solve and log-determinant against LAPACK."""
+    c, m = 1024, 4100
+    n = 2 * c + m
+    rng = np.random.default_rng(10)
+    G1 = rng.standard_normal((n, 24))
+    G2 = rng.standard_normal((n, 24))
+    G1[c:2 * c] = 0.0                           # the first block never meets the second: their coupling is exactly zero
+    G2[:c] = 0.0
+    A = (G1 @ G1.T + G2 @ G2.T) / 48.0 + np.diag(1.0 + rng.random(n))
+    assert not A[:c, c:2 * c].any()
+    Q = sp.csc_matrix(A)
+    be = gmrfx.MI355XBackend(Q, ordering="natural", device=0)
+    assert be.last_info == 0
+    sym = be.symbolic()
+    cols = np.diff(sym.super_first)
+    trail = np.diff(sym.row_ptr) - cols
+    assert np.count_nonzero((cols >= 1024) & (trail >= 4096)) == 2, (cols, trail)
+    B = rng.standard_normal((n, 2))
+    Lc = np.linalg.cholesky(A)
+    X = np.linalg.solve(Lc.T, np.linalg.solve(Lc, B))
+    assert relerr(be.backend_solve(B), X) < 1e-10
+    assert abs(be.compute_logdet() - 2.0 * np.log(np.diag(Lc)).sum()) < 1e-9 * n
+    be.close()
+
+
 def test_refactorize_logpdf_one_call_equals_three_calls():
     """gmrfx_refactorize_logpdf_dev (one evaluation of the hyper-parameter loop: factorisation, r'Qr beside it on the side stream,
     log-determinant behind it, one synchronisation) against gmrfx_refactorize_dev + gmrfx_quadform_dev + gmrfx_logdet: quadratic
