@@ -1029,6 +1029,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
     }
 }
 
+// (Measured and dropped, round 5: the same update with ONE WAVE per record, no LDS and no barrier -- the children's rows entering
+//  through the matrix pipe as k-steps against an indicator operand (-1 at the target row), sixteen independent chains per CU
+//  instead of three. Forward sweep of cfg 2: 1.96 ms with this kernel, 1.89-1.91 with the wave form on the levels of >= 2 500-6 000
+//  tiles: the mid levels already move their bytes -- panel rows, W written once and read once -- at ~4.5 TB/s; what is left is
+//  the hand-off of W itself. And its sums round differently from k_fwd_update_longk's, which the sharded rehearsal compares bit for bit.)
+
 // Blocked forward substitution inside a front wider than `cap` columns: after y_blk = X_blk b_blk, the own rows
 // below the block get  b[i] -= sum_{q in block} L[i][q] y[q].  A workgroup owns 32 rows x 64 right-hand sides,
 // its four waves split the K range (the block's columns); the partial tiles are summed through LDS.

@@ -338,6 +338,105 @@ __global__ __launch_bounds__(64 * WT * WT) void k_sel_dense(DevSym S, const int 
     }
 }
 
+// Phase 1 of the big fronts on 128 x 128 tiles staged through LDS (round 5). The 64 x 64 direct-operand tiles of k_sel_dense
+// re-read Y and Z22 once per tile: on levels 9-16 of cfg 3 the L2 missed 20-38 x the minimal bytes (profiles/r04_cfg3_selinv_levels.txt)
+// and the phase ran at 34-41 TFLOP/s where a front's operands (15 MB at level 13) no longer fit the XCD's L2. Here eight waves
+// share a 128 (k) x 128 (i) tile, the operands come in 16-deep slabs through a double-buffered LDS stage -- a quarter of the
+// operand bytes per flop -- and the symmetric Z22 is read from whichever stored side is contiguous: rows q above the tile's
+// i range as ZB[i + q m] (along the lanes), below it as ZB[q + i m] (four consecutive q per thread), across it element-wise.
+__global__ __launch_bounds__(512) void k_sel_z21_big(DevSym S, const int *__restrict__ list, double *__restrict__ Z, const double *__restrict__ ZB,
+                                                     const double *__restrict__ Yt, double *__restrict__ Z21t, const long long *__restrict__ woff) {
+    constexpr int TM = 128, KB = 16;
+    __shared__ double As[2][KB][TM + 8], Bs[2][KB][TM + 8];
+    const int s = list[blockIdx.z];
+    const int c = S.sfirst[s + 1] - S.sfirst[s];
+    const int r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
+    const int m = r - c;
+    const int k0t = blockIdx.x * TM, i0t = blockIdx.y * TM;
+    if (m <= 0 || k0t >= c || i0t >= m) return;
+    const int ld = S.ld[s];
+    double *Zp = Z + S.panelptr[s];
+    const double *ZBs = ZB + S.cbptr[s];
+    const double *Y = Yt + woff[s];
+    double *Zt = Z21t + woff[s] + (long long)m * c;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lm = lane & 15, lk = lane >> 4;
+    const int wi = (wave & 3) * 32, wj = (wave >> 2) * 64;       // wave sub-tile: 32 k's x 64 i's
+    d4 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+    const int lr = tid & 127, l4 = (tid >> 7) * 4;
+    const int ka = min(k0t + lr, c - 1);            // this thread's k (operand A: Y[k + q c]) ...
+    const int ib = min(i0t + lr, m - 1);            // ... and i (operand B: Z22[q][i]) of the staged slabs
+    double ra[4], rb[4];
+    auto fetch = [&](int qb) {
+        const int q0 = qb * KB + l4;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int q = q0 + u, qc = min(q, m - 1);
+            ra[u] = Y[ka + (long long)qc * c] * (q < m ? 1.0 : 0.0);
+        }
+        if (q0 + 3 < i0t) {                      // above the tile's rows: ZB[i + q m], contiguous along the threads
+#pragma unroll
+            for (int u = 0; u < 4; u++) rb[u] = ZBs[ib + (long long)(q0 + u) * m];
+        } else if (q0 >= i0t + TM && q0 + 3 < m) {         // below: ZB[q + i m], four consecutive q
+#pragma unroll
+            for (int u = 0; u < 4; u++) rb[u] = ZBs[(q0 + u) + (long long)ib * m];
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int qc = min(q0 + u, m - 1);
+                rb[u] = ZBs[max(ib, qc) + (long long)min(ib, qc) * m];
+            }
+        }
+    };
+    fetch(0);
+#pragma unroll
+    for (int u = 0; u < 4; u++) { As[0][l4 + u][lr] = ra[u]; Bs[0][l4 + u][lr] = rb[u]; }
+    __syncthreads();
+    const int nq = (m + KB - 1) / KB;
+    for (int qb = 0; qb < nq; qb++) {
+        const int cur = qb & 1;
+        if (qb + 1 < nq) fetch(qb + 1);
+#pragma unroll
+        for (int sidx = 0; sidx < KB / 4; sidx++) {
+            double av[2], bv[4];
+#pragma unroll
+            for (int a = 0; a < 2; a++) av[a] = As[cur][4 * sidx + lk][wi + 16 * a + lm];
+#pragma unroll
+            for (int b = 0; b < 4; b++) bv[b] = Bs[cur][4 * sidx + lk][wj + 16 * b + lm];
+            // D[i][k]: first operand = the i's (register index walks them), second = the k's (the lanes walk them)
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[b], av[a], acc[a][b], 0, 0, 0);
+        }
+        if (qb + 1 < nq) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) { As[cur ^ 1][l4 + u][lr] = ra[u]; Bs[cur ^ 1][l4 + u][lr] = rb[u]; }
+        }
+        __syncthreads();
+    }
+    // Z21[i][k] = -acc: into the panel of Z (rows c + i) and, transposed, behind Yt for phase 2
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int k = k0t + wi + 16 * a + lm;
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                const int i = i0t + wj + 16 * b + lk + 4 * rr;
+                if (k < c && i < m) {
+                    const double v = -acc[a][b][rr];
+                    Zp[(c + i) + (long long)k * ld] = v;
+                    Zt[k + (long long)i * c] = v;
+                }
+            }
+        }
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 void launch_sel_gather(hipStream_t st, const SelRec *recs, const DevSym &S, const int *list, int nfronts, int max_trail,
@@ -368,6 +467,14 @@ void launch_sel_dense(hipStream_t st, const DevSym &S, const int *list, int nfro
     if (nfronts <= 0) return;
     const int M = phase == 0 ? max_trail : max_c, N = phase == 1 ? max_trail : max_c;
     if (M <= 0 || N <= 0) return;
+    // Fronts of 3-D problems only (>= 1024 columns over >= 1024 rows): a 72^3-node 3-D SPDE went from 273 to 250 ms with it; on the 2-D
+    // cfg 3, whose widest levels are 2-4 fronts of 1000 columns, the 128 x 128 tiles are too few to fill 256 CUs (13.9 -> 14.5 ms with
+    // a 128-column threshold) -- tools/ab_selinv.py.
+    if (phase == 1 && max_c >= 1024 && max_trail >= 1024) {
+        hipLaunchKernelGGL(k_sel_z21_big, dim3((unsigned)(cdiv(max_c, 128) | 1), (unsigned)(cdiv(max_trail, 128) | 1), nfronts), dim3(512), 0, st,
+                           S, list, Z, ZB, Yt, Z21t, woff);
+        return;
+    }
     const int gx = cdiv(M, 64), gy = cdiv(N, 64);
     hipLaunchKernelGGL(k_sel_dense, dim3((unsigned)(gx | 1), (unsigned)(gy | 1), nfronts), dim3(256), 0, st, S, list, phase, L, Z, ZB, Yt, Z21t, woff);
 }

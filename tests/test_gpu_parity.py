@@ -1320,6 +1320,10 @@ def test_two_huge_fronts_take_the_two_pass_contribution_product():
     X = np.linalg.solve(Lc.T, np.linalg.solve(Lc, B))
     assert relerr(be.backend_solve(B), X) < 1e-10
     assert abs(be.compute_logdet() - 2.0 * np.log(np.diag(Lc)).sum()) < 1e-9 * n
+    # the selected inversion of the same fronts (csrc/selinv.hip, k_sel_z21_big: Z21 on 128 x 128 staged tiles): diagonal of A^-1
+    be.compute_selinv()
+    Li = np.linalg.solve(Lc, np.eye(n))
+    assert relerr(be.get_selinv_diag(), np.einsum("ij,ij->j", Li, Li)) < 1e-8
     be.close()
 
 
