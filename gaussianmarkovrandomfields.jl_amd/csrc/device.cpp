@@ -1418,10 +1418,18 @@ void Device::forward(int nr, int ldx, int lo, int hi) {
             if (j + 1 < nbk) launch_fwd_own_update(stream, ds_, list, L.active[(size_t)(j + 1) * inv_cap_ / NB], L.max_cols, d_L_, d_X2_, d_X_, nr, ldx, j, inv_cap_);
         }
         // levels with many tiles: record-driven, per-XCD runs; the handful-of-fronts levels keep the 16-row latency variant
-        if (syrk_xcd_ && (long long)((level_max_trail(L) + 31) / 32) * nf > 128)
-            launch_fwd_update_recs(stream, ds_, d_fwd_recs_ + L.fwd_off, L.fwd_split, L.fwd_per, d_L_, d_X2_, d_W_, nr, ldx);
-        else
-            launch_fwd_update(stream, ds_, list, nf, level_max_trail(L), d_L_, d_X2_, d_W_, nr, ldx);
+        // Passes of at most 16 right-hand sides: the fronts up to kFwdWaveCols columns wide go one WAVE per 32-row tile (no LDS, no
+        // barrier: k_fwd_update_wave), chosen per FRONT so that a front's sums do not depend on the list it comes in
+        constexpr int kFwdWaveCols = 512;
+        const int cmin = syrk_xcd_ && nr <= 16 ? kFwdWaveCols : 0;
+        const int nwider = (size_t)(kFwdWaveCols / NB + 1) < L.active.size() ? L.active[kFwdWaveCols / NB] : 0;      // fronts wider than that
+        if (cmin > 0 && nwider < nf) launch_fwd_update_wave(stream, ds_, d_fwd_recs_ + L.fwd_off, L.fwd_split, L.fwd_per, d_L_, d_X2_, d_W_, nr, ldx, cmin);
+        if (L.max_cols > cmin) {
+            if (syrk_xcd_ && (long long)((level_max_trail(L) + 31) / 32) * nf > 128)
+                launch_fwd_update_recs(stream, ds_, d_fwd_recs_ + L.fwd_off, L.fwd_split, L.fwd_per, d_L_, d_X2_, d_W_, nr, ldx, cmin);
+            else
+                launch_fwd_update(stream, ds_, list, nf, level_max_trail(L), d_L_, d_X2_, d_W_, nr, ldx, cmin);
+        }
     }
     if (level_mark_) level_event(1, 1 + hi);
 }

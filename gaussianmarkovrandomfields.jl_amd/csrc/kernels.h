@@ -31,12 +31,15 @@ void launch_trsm(hipStream_t st, const DevSym &S, const FrontView *frec, int nac
                  double *L, double *Yh, const long long *yoff, const FrontArg &fa);
 void launch_gemm_nt(hipStream_t st, const DevSym &S, const FrontView *frec, int nactive, int k0, int K, int c0, int c1,
                     int maxM, int maxN, double *L, const FrontArg &fa);
+// cmin: fronts of at most cmin columns are skipped (passes of <= 16 right-hand sides: launch_fwd_update_wave has them, cmax = cmin)
 void launch_fwd_update_recs(hipStream_t st, const DevSym &S, const FwdTile *recs, const SyrkSplit &split, int per_xcd, const double *L,
-                            double *X, double *W, int nr, int ldx);
+                            double *X, double *W, int nr, int ldx, int cmin = 0);
+void launch_fwd_update_wave(hipStream_t st, const DevSym &S, const FwdTile *recs, const SyrkSplit &split, int per_xcd, const double *L,
+                            double *X, double *W, int nr, int ldx, int cmax);
 void launch_fwd_assemble(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, double *X,
                          const double *W, int nr, int ldx);
 void launch_fwd_update(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_trail, const double *L,
-                       double *X, double *W, int nr, int ldx);
+                       double *X, double *W, int nr, int ldx, int cmin = 0);
 #ifdef __HIPCC__
 typedef double gmrfx_d4 __attribute__((ext_vector_type(4)));
 // X[k][q] of the dense inverse X = L11^-1 of a big front (0 above the diagonal): strict lower part

@@ -771,12 +771,13 @@ template <int NA>   // 16-row tiles per workgroup: 2 normally, 1 for levels with
                     // workgroups, half the MFMA chain of each: one CU only sustains ~0.14 TFLOP/s of FP64 MFMA)
 __global__ __launch_bounds__(256) void k_fwd_update_longk(DevSym S, const int *__restrict__ list,
                                                          const double *__restrict__ L, double *__restrict__ X,
-                                                         double *__restrict__ W, int nr, int ldx) {
+                                                         double *__restrict__ W, int nr, int ldx, int cmin) {
     __shared__ double red[3 * 16 * 64];
     constexpr int RT = 16 * NA;
     __shared__ double Tl[RT * 64];   // children's contributions to this tile of W_s
     const int s = list[blockIdx.y];
     const int c = S.sfirst[s + 1] - S.sfirst[s];
+    if (c <= cmin) return;           // (narrow passes: k_fwd_update_wave has these fronts)
     const int r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
     const int i0 = c + blockIdx.x * RT;
     if (i0 >= r) return;
@@ -916,13 +917,14 @@ __global__ __launch_bounds__(256) void k_fwd_update_longk(DevSym S, const int *_
 // k_fwd_update_longk<2>.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k_fwd_update_rec(DevSym S, const FwdTile *__restrict__ recs, const SyrkSplit split,
                                                         const double *__restrict__ L, const double *__restrict__ X,
-                                                        double *__restrict__ W, int nr, int ldx) {
+                                                        double *__restrict__ W, int nr, int ldx, int cmin) {
     __shared__ double red[3 * 16 * 64];
     __shared__ double Tl[32 * 64];   // children's contributions to this tile of W_s
     const int xcd = blockIdx.x & 7;
     const int tix = split.start[xcd] + (int)(blockIdx.x >> 3);
     if (tix >= split.start[xcd + 1]) return;
     const FwdTile T = recs[tix];
+    if (T.c <= cmin) return;
     const int c = T.c, r = T.r, ld = T.ld, i0 = T.i0;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int lm = lane & 15, lk = lane >> 4;
@@ -1034,6 +1036,92 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 //  instead of three. Forward sweep of cfg 2: 1.96 ms with this kernel, 1.89-1.91 with the wave form on the levels of >= 2 500-6 000
 //  tiles: the mid levels already move their bytes -- panel rows, W written once and read once -- at ~4.5 TB/s; what is left is
 //  the hand-off of W itself. And its sums round differently from k_fwd_update_longk's, which the sharded rehearsal compares bit for bit.)
+
+// Passes of at most 16 right-hand sides (the single solve, the Newton step): the update of fronts up to `cmax` columns wide with
+// ONE WAVE per record, no LDS and no barrier. The 64-column kernels above spend a 1-column pass on the same chain of round trips
+// with a barrier between any two of them, three workgroups per CU: 0.71 of the 2.84 ms of a single-RHS solve of cfg 2 went there.
+// Here a wave owns the 32 rows x 16 right-hand sides of a record for the whole K range, and the children's update vectors enter
+// THROUGH THE MATRIX PIPE: a child row that lands on tile row i is one more k-step whose first operand is the indicator (-1 at
+// row i, 0 elsewhere) and whose second operand is the child's row -- the accumulator ends as L21 y - (children), every child row
+// added exactly once (a product with 0 adds an exact 0), children in edge order, rows in order: reproducible, and the same for a
+// front whatever the level list it comes in (sharded or not). Eight independent chains per SIMD.
+// Wider fronts (the top of the tree: K in the hundreds to thousands over a handful of tiles) keep the split-K kernels (cmin).
+__global__ __launch_bounds__(64) void k_fwd_update_wave(DevSym S, const FwdTile *__restrict__ recs, const SyrkSplit split,
+                                                        const double *__restrict__ L, const double *__restrict__ X,
+                                                        double *__restrict__ W, int nr, int ldx, int cmax) {
+    const int xcd = blockIdx.x & 7;
+    const int tix = split.start[xcd] + (int)(blockIdx.x >> 3);
+    if (tix >= split.start[xcd + 1]) return;
+    const FwdTile T = recs[tix];
+    const int c = T.c, r = T.r, ld = T.ld, i0 = T.i0;
+    if (c > cmax) return;
+    const int lane = threadIdx.x;
+    const int lm = lane & 15, lk = lane >> 4;
+    const double *P = L + T.pp;
+    const double *Yb = X + T.xoff * ldx;
+    double *Ws = W + T.woff * ldx;
+    const double *pa = P + min(i0 + 2 * lm, r - 1);       // rows in pairs: MFMA row lm of row tile 0 / 1 = tile row 2 lm / 2 lm + 1
+    const int jl = min(lm, nr - 1);
+    constexpr int KU = 8;
+    d4 acc[2] = {(d4){0.0, 0.0, 0.0, 0.0}, (d4){0.0, 0.0, 0.0, 0.0}};
+    for (int k0 = 0; k0 < c; k0 += 4 * KU) {
+        double av[KU][2], bv[KU];
+#pragma unroll
+        for (int u = 0; u < KU; u++) {
+            const int kk = k0 + 4 * u + lk;
+            const int kc = min(kk, c - 1);
+            const double mk = kk < c ? 1.0 : 0.0;
+            const d2u x = *(const d2u *)(pa + (long long)kc * ld);
+            av[u][0] = x.x * mk; av[u][1] = x.y * mk;
+            bv[u] = Yb[(long long)kc * ldx + jl];
+        }
+#pragma unroll
+        for (int u = 0; u < KU; u++)
+            if (k0 + 4 * u < c) {
+                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][0], bv[u], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][1], bv[u], acc[1], 0, 0, 0);
+            }
+    }
+    const int myrow = i0 + 2 * lm;
+    auto child = [&](const int *__restrict__ reld, const double *__restrict__ Wd, int a0, int a1) {
+        for (int b0 = a0; b0 < a1; b0 += 4 * KU) {
+            double sv[KU][2], wv[KU];
+#pragma unroll
+            for (int u = 0; u < KU; u++) {
+                const int row = b0 + 4 * u + lk;
+                const int rc = min(row, a1 - 1);
+                const int d = reld[rc] - myrow;
+                const bool ok = row < a1;
+                sv[u][0] = (ok && d == 0) ? -1.0 : 0.0;
+                sv[u][1] = (ok && d == 1) ? -1.0 : 0.0;
+                wv[u] = Wd[(long long)rc * ldx + jl];
+            }
+#pragma unroll
+            for (int u = 0; u < KU; u++)
+                if (b0 + 4 * u < a1) {
+                    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(sv[u][0], wv[u], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(sv[u][1], wv[u], acc[1], 0, 0, 0);
+                }
+        }
+    };
+    if (T.nch > 0) child(S.rel + T.reloff[0], W + T.cwoff[0] * ldx, T.a0[0], T.a1[0]);
+    if (T.nch > 1) child(S.rel + T.reloff[1], W + T.cwoff[1] * ldx, T.a0[1], T.a1[1]);
+    for (long long cb = T.ch0 + 2; cb < T.ch0 + T.nch; cb++) {      // further children: the long way
+        const EdgeRec er = S.edge[cb];
+        const int a0 = S.etile[er.tptr + T.tile], a1 = S.etile[er.tptr + T.tile + 1];
+        child(S.rel + er.reloff, W + er.woff * ldx, a0, a1);
+    }
+    // W = -(acc): lane (lm, lk), register rr of row tile a = row i0 + 2 (lk + 4 rr) + a, right-hand side lm
+    if (lm < nr) {
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                const int i = i0 + 2 * (lk + 4 * rr) + a;
+                if (i < r) Ws[(long long)(i - c) * ldx + lm] = -acc[a][rr];
+            }
+    }
+}
 
 // Blocked forward substitution inside a front wider than `cap` columns: after y_blk = X_blk b_blk, the own rows
 // below the block get  b[i] -= sum_{q in block} L[i][q] y[q].  A workgroup owns 32 rows x 64 right-hand sides,
@@ -1296,6 +1384,29 @@ __global__ __launch_bounds__(256) void k_permute(const int *__restrict__ iperm, 
             for (int u = 0; u < 16; u++)
                 if (b + 4 * u < nr) Bc[i + (long long)(b + 4 * u) * ldb] = T[a * 65 + b + 4 * u];
         }
+    }
+}
+// The same for passes of at most 8 right-hand sides (the single solve): a thread per ORIGINAL row -- the caller side coalesced, the
+// solver side 8 nr-byte pieces. The 64 x 64 transpose above spends 60 + 41 us on a 1-column pass of 10^6 rows (15 625 workgroups
+// of which one column in 64 carries data); this one 8 + 8.
+__global__ __launch_bounds__(256) void k_permute_narrow(const int *__restrict__ iperm, int n, double *__restrict__ Bc,
+                                                        long long ldb, double *__restrict__ X, int nr, int ldx, int dir) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long long row = iperm ? iperm[i] : i;
+    double v[8];
+    if (dir == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = Bc[i + (long long)min(j, nr - 1) * ldb];
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (j < nr) X[row * ldx + j] = v[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = X[row * ldx + min(j, nr - 1)];
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (j < nr) Bc[i + (long long)j * ldb] = v[j];
     }
 }
 
@@ -1715,17 +1826,22 @@ void launch_fwd_assemble(hipStream_t st, const DevSym &S, const int *list, int n
     hipLaunchKernelGGL(k_fwd_assemble, dim3(odd(cdiv(max_cols, FWD_RB)), nfronts), dim3(256), 0, st, S, list, X, W, nr, ldx);
 }
 void launch_fwd_update(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_trail, const double *L,
-                       double *X, double *W, int nr, int ldx) {
+                       double *X, double *W, int nr, int ldx, int cmin) {
     if (nfronts <= 0 || max_trail <= 0) return;
     if ((long long)cdiv(max_trail, 32) * nfronts <= 128)
-        hipLaunchKernelGGL(k_fwd_update_longk<1>, dim3(odd(cdiv(max_trail, 16)), nfronts), dim3(256), 0, st, S, list, L, X, W, nr, ldx);
+        hipLaunchKernelGGL(k_fwd_update_longk<1>, dim3(odd(cdiv(max_trail, 16)), nfronts), dim3(256), 0, st, S, list, L, X, W, nr, ldx, cmin);
     else
-        hipLaunchKernelGGL(k_fwd_update_longk<2>, dim3(odd(cdiv(max_trail, 32)), nfronts), dim3(256), 0, st, S, list, L, X, W, nr, ldx);
+        hipLaunchKernelGGL(k_fwd_update_longk<2>, dim3(odd(cdiv(max_trail, 32)), nfronts), dim3(256), 0, st, S, list, L, X, W, nr, ldx, cmin);
 }
 void launch_fwd_update_recs(hipStream_t st, const DevSym &S, const FwdTile *recs, const SyrkSplit &split, int per_xcd, const double *L,
-                            double *X, double *W, int nr, int ldx) {
+                            double *X, double *W, int nr, int ldx, int cmin) {
     if (per_xcd <= 0) return;
-    hipLaunchKernelGGL(k_fwd_update_rec, dim3(8 * (unsigned)per_xcd), dim3(256), 0, st, S, recs, split, L, X, W, nr, ldx);
+    hipLaunchKernelGGL(k_fwd_update_rec, dim3(8 * (unsigned)per_xcd), dim3(256), 0, st, S, recs, split, L, X, W, nr, ldx, cmin);
+}
+void launch_fwd_update_wave(hipStream_t st, const DevSym &S, const FwdTile *recs, const SyrkSplit &split, int per_xcd, const double *L,
+                            double *X, double *W, int nr, int ldx, int cmax) {
+    if (per_xcd <= 0) return;
+    hipLaunchKernelGGL(k_fwd_update_wave, dim3(8 * (unsigned)per_xcd), dim3(64), 0, st, S, recs, split, L, X, W, nr, ldx, cmax);
 }
 void launch_bwd_gemm(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, const double *L,
                      const double *X, double *Xown, int nr, int ldx, int blk, int cap) {
@@ -1757,7 +1873,8 @@ void launch_level_mark(hipStream_t st, int phase, int level) {
     hipLaunchKernelGGL(k_level_mark, dim3(level + 2), dim3(64 * phase), 0, st);      // level -1 = the sweep tasks / subtrees
 }
 void launch_permute(hipStream_t st, const int *perm, int n, double *Bc, long long ldb, double *X, int nr, int ldx, int dir) {
-    hipLaunchKernelGGL(k_permute, dim3(cdiv(n, 64)), dim3(256), 0, st, perm, n, Bc, ldb, X, nr, ldx, dir);
+    if (nr <= 8) hipLaunchKernelGGL(k_permute_narrow, dim3(cdiv(n, 256)), dim3(256), 0, st, perm, n, Bc, ldb, X, nr, ldx, dir);
+    else hipLaunchKernelGGL(k_permute, dim3(cdiv(n, 64)), dim3(256), 0, st, perm, n, Bc, ldb, X, nr, ldx, dir);
 }
 // nz[map[k]] = prior[map[k]] - h[k] on top of nz = prior: the Newton-loop update of the reference
 // (_update_hessian!, src/workspace/gaussian_approximation.jl:103-129) with Q kept on the device.

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of environment switches on the cfg-2 64-RHS solve (separate call): forward / backward sweep ms per setting, each in a child process.
+"""A/B of environment switches on the cfg-2 solve (separate call; 64 right-hand sides, AB_NRHS=k in the environment: k): forward / backward sweep ms per setting, each in a child process.
     python3 tools/ab_solve.py "" "GMRFX_BWD_FRONT=0" ..."""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,12 +15,13 @@ n = Q.shape[0]
 dev = torch.device("cuda", 0)
 be = gmrfx.MI355XBackend(Q, coords=mesh.points, device=0, factorize=False)
 d_nz = torch.from_numpy(np.ascontiguousarray(Q.data)).to(dev)
-d_B = torch.randn((64, n), generator=torch.Generator().manual_seed(1), dtype=torch.float64).to(dev)
+NR = int(os.environ.get("AB_NRHS", "64"))
+d_B = torch.randn((NR, n), generator=torch.Generator().manual_seed(1), dtype=torch.float64).to(dev)
 d_X = torch.empty_like(d_B)
 be.refactorize_dev(d_nz.data_ptr())
 f, b = [], []
 for k in range(12):
-    be.solve_dev(d_B.data_ptr(), n, 64, d_X.data_ptr(), n)
+    be.solve_dev(d_B.data_ptr(), n, NR, d_X.data_ptr(), n)
     st = be.stats()
     if k >= 2: f.append(st["ms_solve_fwd"]); b.append(st["ms_solve_bwd"])
 print(json.dumps({"fwd": float(np.median(f)), "bwd": float(np.median(b))}))

@@ -19,11 +19,11 @@ multifrontal schedule adds on top: listed separately as `handoff`.
 import csv, glob, json, os, sys
 sys.path.insert(0, "gaussianmarkovrandomfields.jl_amd")
 OUT = "gpurun_out/sweep_levels.json"
-NRHS = 64
+NRHS = int(os.environ.get("SWL_NRHS", "64"))      # SWL_NRHS=1: the single right-hand side solve (with SWL_NOMARK=1: no marker kernels)
 
 
 def run():
-    os.environ["GMRFX_LEVEL_MARK"] = "1"
+    if not os.environ.get("SWL_NOMARK"): os.environ["GMRFX_LEVEL_MARK"] = "1"
     import numpy as np, torch, gmrfx
     from gmrfx import spde
     grid = int(os.environ.get("SWL_GRID", "1000"))
