@@ -413,12 +413,13 @@ void Device::upload(const Symbolic &S) {
             L.nsmall = lnsmall[l];
             for (int k = 0; k < 4; k++) L.ncls[k] = lncls[(size_t)l * 4 + k];
             L.max_rows = L.max_cols = 0;
-            int max_trail = 0;
+            int max_trail = 0, min_trail = INT_MAX;
             for (int k = L.nsmall; k < L.count; k++) {
                 i32 s = llist[L.first + k];
                 L.max_rows = std::max(L.max_rows, S.nrows(s));
                 L.max_cols = std::max(L.max_cols, S.ncols(s));
                 max_trail = std::max(max_trail, S.nrows(s) - S.ncols(s));
+                if (S.nrows(s) > S.ncols(s)) min_trail = std::min(min_trail, S.nrows(s) - S.ncols(s));
                 const double cc = S.ncols(s), mm = S.nrows(s) - S.ncols(s);
                 if (count_flops) syrk_flops += cc * mm * (mm + 1);   // lower triangle of the contribution block: 2 c flops per entry
             }
@@ -439,6 +440,7 @@ void Device::upload(const Symbolic &S) {
                 }
                 L.wider[q] = cnt;
             }
+            L.min_trail = min_trail == INT_MAX ? 0 : min_trail;
             L.active.push_back(max_trail);  // stash: last element = max trailing rows of the level
         }
     };
@@ -1420,7 +1422,7 @@ void Device::forward(int nr, int ldx, int lo, int hi) {
         // levels with many tiles: record-driven, per-XCD runs; the handful-of-fronts levels keep the 16-row latency variant
         // Passes of at most 16 right-hand sides: the fronts up to kFwdWaveCols columns wide go one WAVE per 32-row tile (no LDS, no
         // barrier: k_fwd_update_wave), chosen per FRONT so that a front's sums do not depend on the list it comes in
-        constexpr int kFwdWaveCols = 512;
+        constexpr int kFwdWaveCols = 512;       // (measured at cfg 2, 1 RHS, forward ms: 256: 1.188, 512: 1.133, 1024: 1.184)
         const int cmin = syrk_xcd_ && nr <= 16 ? kFwdWaveCols : 0;
         const int nwider = (size_t)(kFwdWaveCols / NB + 1) < L.active.size() ? L.active[kFwdWaveCols / NB] : 0;      // fronts wider than that
         if (cmin > 0 && nwider < nf) launch_fwd_update_wave(stream, ds_, d_fwd_recs_ + L.fwd_off, L.fwd_split, L.fwd_per, d_L_, d_X2_, d_W_, nr, ldx, cmin);
@@ -1450,7 +1452,11 @@ void Device::backward(int nr, int ldx, bool y_in_x2, int hi, int lo) {
         // one launch (sweep_front.hip); in place when y sits in X (own rows are read and written by their front alone)
         // Only on levels with enough such fronts to fill the chip: a workgroup walks its front's trailing rows batch after batch,
         // and a level of a hundred fronts with 700 trailing rows each is faster as many small workgroups (the two launches).
-        if (bwd_front_min_ > 0) {
+        // Passes of at most 16 right-hand sides: t = y - L21' x one WAVE per 16 own columns for the fronts with at most kBwdWaveRows
+        // trailing rows (k_bwd_wave), the split-K kernels for the others, x = L11^-T t as everywhere
+        constexpr int kBwdWaveRows = 768;       // (measured at cfg 2, 1 RHS, backward ms: 512: 1.190, 768: 1.177, 1100: 1.181, 1600: 1.213, all: 1.257)
+        const bool narrow = nr <= 16;
+        if (bwd_front_min_ > 0 && !narrow) {
             // (a front needs its WHOLE inverse for this: at most min(128, inv_cap_) columns)
             const size_t kq = (size_t)std::min(bwd_front_max_cols(), inv_cap_) / NB;
             const int nwide = kq + 1 < L.active.size() ? L.active[kq] : 0;   // fronts with more than kq NB columns (the last entry of `active` is the stash of level_max_trail)
@@ -1461,8 +1467,11 @@ void Device::backward(int nr, int ldx, bool y_in_x2, int hi, int lo) {
             }
         }
         const int nbk = std::max(1, (L.max_cols + inv_cap_ - 1) / inv_cap_);
+        double *const Xt = y_in_x2 ? d_X2_ : d_X_;
+        const int mmin = narrow ? kBwdWaveRows : 0;
+        if (narrow && level_max_trail(L) > 0 && L.min_trail <= kBwdWaveRows) launch_bwd_wave(stream, ds_, list, nf, L.max_cols, d_L_, d_X_, Xt, nr, ldx, kBwdWaveRows);
         if (y_in_x2) {
-            if (level_max_trail(L) > 0) launch_bwd_gemm(stream, ds_, list, nf, L.max_cols, d_L_, d_X_, d_X2_, nr, ldx);
+            if (level_max_trail(L) > mmin) launch_bwd_gemm(stream, ds_, list, nf, L.max_cols, d_L_, d_X_, d_X2_, nr, ldx, -1, 1 << 30, mmin);
             // fronts wider than inv_cap_: from the last block up, t_j -= L[own rows below, block j]' x, x_j = X_jj' t_j
             for (int j = nbk - 1; j >= 0; j--) {
                 const int na = nbk == 1 ? nf : L.active[std::min<size_t>((size_t)j * inv_cap_ / NB, L.active.size() - 2)];
@@ -1470,7 +1479,7 @@ void Device::backward(int nr, int ldx, bool y_in_x2, int hi, int lo) {
                 launch_xmul(stream, ds_, list, na, L.max_cols, 1, d_L_, d_X2_, d_X_, nr, ldx, j, inv_cap_);
             }
         } else {
-            if (level_max_trail(L) > 0) launch_bwd_gemm(stream, ds_, list, nf, L.max_cols, d_L_, d_X_, d_X_, nr, ldx);
+            if (level_max_trail(L) > mmin) launch_bwd_gemm(stream, ds_, list, nf, L.max_cols, d_L_, d_X_, d_X_, nr, ldx, -1, 1 << 30, mmin);
             for (int j = nbk - 1; j >= 0; j--) {
                 const int na = nbk == 1 ? nf : L.active[std::min<size_t>((size_t)j * inv_cap_ / NB, L.active.size() - 2)];
                 if (j + 1 < nbk) launch_bwd_gemm(stream, ds_, list, L.active[(size_t)(j + 1) * inv_cap_ / NB], L.max_cols, d_L_, d_X_, d_X_, nr, ldx, j, inv_cap_);

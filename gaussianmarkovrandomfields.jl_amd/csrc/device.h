@@ -137,6 +137,7 @@ struct LevelInfo {
     int ncls[4];      // of which r <= 48 / 64 / 96 / 128 (in this order)
     int max_rows;     // over big fronts
     int max_cols;     // over big fronts (they are sorted by decreasing column count)
+    int min_trail = 0; // fewest trailing rows of a big front with any (0: none has)
     std::vector<int> active;  // active[k] = number of big fronts with ncols > k*NB
     int wider[3] = {0, 0, 0}; // big fronts with more than 48 / 32 / 16 columns (first 64-column block: the diagonal-block kernel's shapes)
     // contribution-block SYRK: the level's 64 x 64 tiles in the order they are handed out, cut into one run per XCD

@@ -394,7 +394,11 @@ void launch_copy_own(hipStream_t st, const DevSym &S, const int *list, int nfron
                      double *Xdst, int nr, int ldx, int blk = 0, int cap = 1 << 30);
 // X: rows of the ancestors (already final x, read only); Xown: the fronts' own rows, updated in place
 void launch_bwd_gemm(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, const double *L,
-                     const double *X, double *Xown, int nr, int ldx, int blk = -1, int cap = 1 << 30);
+                     const double *X, double *Xown, int nr, int ldx, int blk = -1, int cap = 1 << 30, int mmin = 0);
+// passes of at most 16 right-hand sides: the fronts with at most mmax trailing rows, one wave per 16 own columns (launch_bwd_gemm with
+// mmin = mmax has the others)
+void launch_bwd_wave(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, const double *L, const double *X, double *Xown,
+                     int nr, int ldx, int mmax);
 // blocked substitution inside fronts wider than `cap` columns (forward): own rows below block blk -= L[.., block] y_blk
 void launch_fwd_own_update(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, const double *L,
                            const double *Y, double *X, int nr, int ldx, int blk, int cap);

@@ -1193,12 +1193,72 @@ __global__ __launch_bounds__(256) void k_fwd_own_update(DevSym S, const int *__r
     }
 }
 
+// Passes of at most 16 right-hand sides: t = y - L21' x[trailing rows] of a front with at most `mmax` trailing rows, ONE WAVE per
+// 16 own columns for the whole K range -- no LDS, no barrier, a quarter of the registers of the 64-column kernels: eight chains
+// per SIMD (k_fwd_update_wave is the forward twin). Operands in pairs along K as in k_bwd_gemm_longk: a lane loads rows q, q + 1
+// of its column and of the row list, q = batch + 8 h + 2 lk, and feeds k-steps 2 h and 2 h + 1 with them. The row indices of
+// batch k + 1 are requested with the operands of batch k. Fronts with more trailing rows keep the split-K kernels (mmin).
+__global__ __launch_bounds__(64) void k_bwd_wave(DevSym S, const int *__restrict__ list, const double *__restrict__ L, const double *X,
+                                                 double *Xown, int nr, int ldx, int mmax) {
+    const int s = list[blockIdx.y];
+    const int c = S.sfirst[s + 1] - S.sfirst[s];
+    const int r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
+    const int i0 = blockIdx.x * 16;
+    if (i0 >= c || r <= c || r - c > mmax) return;
+    const int lane = threadIdx.x;
+    const int lm = lane & 15, lk = lane >> 4;
+    const int ld = S.ld[s];
+    const int first = S.sfirst[s];
+    const double *pa = L + S.panelptr[s] + (long long)min(i0 + lm, c - 1) * ld;
+    const int *rows = S.rows + S.rowptr[s];
+    const int jl = min(lm, nr - 1);
+    d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+    constexpr int NH = 4;                   // pairs per lane and batch: 8 k-steps = 32 rows
+    long long xr[2 * NH], xn[2 * NH];
+    auto request_rows = [&](int kb) {
+#pragma unroll
+        for (int h = 0; h < NH; h++) {
+            const int q = kb + 8 * h + 2 * lk;
+            const i2u v = *(const i2u *)(rows + min(q, r - 1));
+            xn[2 * h] = v.x;
+            xn[2 * h + 1] = q + 1 < r ? v.y : v.x;          // past the list: any valid row (its product is masked)
+        }
+    };
+    request_rows(c);
+    for (int k0 = c; k0 < r; k0 += 8 * NH) {
+        double av[2 * NH], bv[2 * NH];
+#pragma unroll
+        for (int u = 0; u < 2 * NH; u++) xr[u] = xn[u];
+        request_rows(k0 + 8 * NH);
+#pragma unroll
+        for (int h = 0; h < NH; h++) {
+            const int q = k0 + 8 * h + 2 * lk;
+            const d2u v = *(const d2u *)(pa + min(q, r - 1));
+            av[2 * h] = v.x * (q < r ? 1.0 : 0.0); av[2 * h + 1] = v.y * (q + 1 < r ? 1.0 : 0.0);
+        }
+#pragma unroll
+        for (int u = 0; u < 2 * NH; u++) bv[u] = X[xr[u] * ldx + jl];
+#pragma unroll
+        for (int u = 0; u < 2 * NH; u++)
+            if (k0 + 8 * (u >> 1) < r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+    }
+    // t[col][rhs]: register rr of lane (lm, lk) = own column i0 + lk + 4 rr, right-hand side lm (all loads, then all stores)
+    double xv[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) xv[rr] = Xown[(long long)(first + min(i0 + lk + 4 * rr, c - 1)) * ldx + jl];
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {
+        const int col = i0 + lk + 4 * rr;
+        if (col < c && lm < nr) Xown[(long long)(first + col) * ldx + lm] = xv[rr] - acc[rr];
+    }
+}
+
 // Backward update of a big front: own columns -= L21' * x_R over ALL trailing rows: a
 // workgroup owns 64 own columns x 64 right-hand sides, its waves split the trailing rows.
 template <int NA, int NW>   // NA: 16-column tiles of own columns per workgroup; NW: waves per workgroup splitting K
 __global__ __launch_bounds__(64 * NW) void k_bwd_gemm_longk(DevSym S, const int *__restrict__ list,
                                                           const double *__restrict__ L, const double *X, double *Xown, int nr,
-                                                          int ldx, int blk, int cap) {
+                                                          int ldx, int blk, int cap, int mmin) {
     // blk < 0: all own columns, K = the trailing rows [c, r). blk >= 0 (blocked substitution inside a front wider
     // than `cap` columns): own columns of block blk only, K = the OWN rows below the block, [(blk + 1) cap, c)
     // -- the same product with other bounds (rows[] lists the own columns first, so x of own rows is found the
@@ -1212,6 +1272,7 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_gemm_longk(DevSym S, const int 
     const int r = blk < 0 ? rfull : cfull;                             // K ends at row r
     const int i0 = col0 + blockIdx.x * 16 * NA;
     if (i0 >= c || r <= c) return;
+    if (blk < 0 && r - c <= mmin) return;       // (narrow passes: k_bwd_wave has the fronts with at most mmin trailing rows)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int lm = lane & 15, lk = lane >> 4;
     const int ld = S.ld[s];
@@ -1844,7 +1905,7 @@ void launch_fwd_update_wave(hipStream_t st, const DevSym &S, const FwdTile *recs
     hipLaunchKernelGGL(k_fwd_update_wave, dim3(8 * (unsigned)per_xcd), dim3(64), 0, st, S, recs, split, L, X, W, nr, ldx, cmax);
 }
 void launch_bwd_gemm(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, const double *L,
-                     const double *X, double *Xown, int nr, int ldx, int blk, int cap) {
+                     const double *X, double *Xown, int nr, int ldx, int blk, int cap, int mmin) {
     if (nfronts <= 0 || max_cols <= 0) return;
     if (blk >= 0) max_cols = std::min(max_cols - blk * cap, cap);
     if (max_cols <= 0) return;
@@ -1854,11 +1915,16 @@ void launch_bwd_gemm(hipStream_t st, const DevSym &S, const int *list, int nfron
     // workgroup: level 10 (768 workgroups of 32) 72 / 83 us, 11 (576) 79 / 88; 12 (352) 79 / 73, 13: 85 / 75, 14: 66 / 55, 15: 62 / 47)
     const long long wg32 = (long long)cdiv(max_cols, 32) * nfronts;
     if (wg32 <= 768 && wg32 >= 384)
-        hipLaunchKernelGGL((k_bwd_gemm_longk<2, 8>), dim3(odd(cdiv(max_cols, 32)), nfronts), dim3(512), 0, st, S, list, L, X, Xown, nr, ldx, blk, cap);
+        hipLaunchKernelGGL((k_bwd_gemm_longk<2, 8>), dim3(odd(cdiv(max_cols, 32)), nfronts), dim3(512), 0, st, S, list, L, X, Xown, nr, ldx, blk, cap, mmin);
     else if (wg32 <= 768)
-        hipLaunchKernelGGL((k_bwd_gemm_longk<1, 8>), dim3(odd(cdiv(max_cols, 16)), nfronts), dim3(512), 0, st, S, list, L, X, Xown, nr, ldx, blk, cap);
+        hipLaunchKernelGGL((k_bwd_gemm_longk<1, 8>), dim3(odd(cdiv(max_cols, 16)), nfronts), dim3(512), 0, st, S, list, L, X, Xown, nr, ldx, blk, cap, mmin);
     else
-        hipLaunchKernelGGL((k_bwd_gemm_longk<2, 4>), dim3(odd(cdiv(max_cols, 32)), nfronts), dim3(256), 0, st, S, list, L, X, Xown, nr, ldx, blk, cap);
+        hipLaunchKernelGGL((k_bwd_gemm_longk<2, 4>), dim3(odd(cdiv(max_cols, 32)), nfronts), dim3(256), 0, st, S, list, L, X, Xown, nr, ldx, blk, cap, mmin);
+}
+void launch_bwd_wave(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, const double *L, const double *X, double *Xown,
+                     int nr, int ldx, int mmax) {
+    if (nfronts <= 0 || max_cols <= 0) return;
+    hipLaunchKernelGGL(k_bwd_wave, dim3(odd(cdiv(max_cols, 16)), nfronts), dim3(64), 0, st, S, list, L, X, Xown, nr, ldx, mmax);
 }
 void launch_fwd_own_update(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, const double *L,
                            const double *Y, double *X, int nr, int ldx, int blk, int cap) {

@@ -238,8 +238,8 @@ end
 # The reference's `_rand!` takes one vector (src/gmrf.jl:271-281, src/workspace/workspace_gmrf.jl:275-286) and Distributions' matrix
 # method `_rand!(rng, d, X::AbstractMatrix)` loops it over the columns: rand(d, 256) is 256 single-RHS sweeps with 256 host round
 # trips. On this backend the matrix method is ONE `backend_backward_solve(b, Z::Matrix)`: randn! fills Z column by column in the
-# order the column loop would draw it, so the same rng gives the same samples (to the last bit while every column takes the same
-# kernels: tests/mirror/workspace_gmrf.py, tests/test_seam_a_and_constraints.py); the mean and the constraint correction
+# order the column loop would draw it, so the same rng gives the same samples (to 1e-12: a wide pass and a one-column pass take kernels
+# that add the same terms in different orders: tests/mirror/workspace_gmrf.py, tests/test_seam_a_and_constraints.py); the mean and the constraint correction
 # (x -= A~' (L_c \ (A x - e)), workspace_gmrf.jl:280-284) are applied to all columns at once.
 function Distributions._rand!(rng::AbstractRNG, d::G.WorkspaceGMRF{<:Any, MI355XBackend}, X::AbstractMatrix{<:Real})
     G.ensure_loaded!(d)
