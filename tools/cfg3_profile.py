@@ -6,7 +6,7 @@
     rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/c3_trace -- python3 tools/cfg3_profile.py run
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/c3_fetch -- python3 tools/cfg3_profile.py run
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/c3_write -- python3 tools/cfg3_profile.py run
-    python3 tools/cfg3_profile.py join gpurun_out/c3_trace gpurun_out/c3_fetch gpurun_out/c3_write profiles/r04_cfg3
+    python3 tools/cfg3_profile.py join gpurun_out/c3_trace gpurun_out/c3_fetch gpurun_out/c3_write profiles/r05_cfg3
 
 `run` factorises, then does the selected inversion and the 256-sample backward solve twice; `join` cuts the LAST of each out of
 the traces (phases: everything between the last factorisation kernel and the next k_permute = selected inversion; from there to
