@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Randomised parity sweep on the GPU: many small/medium SPD patterns of different shapes against dense
-LAPACK identities (solve, logdet, selinv diag, backward-solve covariance identity). usage: fuzz_gpu.py [ncases] [seed]"""
+LAPACK identities (solve, logdet, selinv diag, backward-solve covariance identity). usage: fuzz_gpu.py [ncases] [seed]
+`fuzz_gpu.py big [ncases] [seed]`: 2-D / 3-D meshes of 2e4-2e5 nodes instead (level kernels, sweep tasks, narrow and wide passes) --
+no dense reference at that size: normwise backward errors of solves with 1 / 3 / 16 / 33 / 64 / 70 right-hand sides, the backward-solve identity
+s'Qs = z'z, and every pass width against the 64-column pass of the same columns (1e-10)."""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gaussianmarkovrandomfields.jl_amd"))
 import numpy as np, scipy.sparse as sp
@@ -9,6 +12,8 @@ import gmrfx
 from gmrfx import spde
 from mirror import GMRFWorkspace
 
+big = len(sys.argv) > 1 and sys.argv[1] == "big"
+if big: sys.argv.pop(1)
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 
@@ -41,6 +46,39 @@ def rand_case(i):
 
 worst = 0.0
 t0 = time.time()
+if big:
+    for i in range(ncases):
+        if i % 3 == 2:
+            a = int(rng.integers(20, 44)); m = spde.grid_mesh_3d(a, a + int(rng.integers(0, 6)), a); name = f"matern3d {a}^3"
+            Q = spde.matern_precision(m, 0, float(rng.uniform(0.3, 0.8)))
+        else:
+            a, b = int(rng.integers(140, 460)), int(rng.integers(140, 460))
+            m = spde.grid_mesh_2d(a, b, jitter=float(rng.uniform(0, 0.3)), seed=int(rng.integers(1 << 30))); name = f"matern2d {a}x{b}"
+            sm, rg = int(rng.integers(0, 2)), float(rng.uniform(0.1, 0.6))
+            name += f" s{sm} r{rg:.2f}"
+            Q = spde.matern_precision(m, sm, rg)
+        Q = sp.csc_matrix(Q); n = Q.shape[0]
+        be = gmrfx.MI355XBackend(Q, coords=m.points)
+        B = rng.standard_normal((n, 70))
+        X64 = be.backend_solve(B[:, :64])
+        qn = abs(Q).sum(axis=0).max()            # ||Q||_1: residuals are judged as NORMWISE BACKWARD ERRORS (alpha = 3 precisions on
+        bwerr = lambda X, Bk: np.linalg.norm(Q @ X - Bk) / (qn * np.linalg.norm(X) + np.linalg.norm(Bk))   # 400^2 nodes have cond ~ 1e9)
+        errs = [bwerr(X64, B[:, :64])]
+        for k in (1, 3, 16, 33, 70):
+            Xk = be.backend_solve(B[:, :k])
+            errs.append(bwerr(Xk, B[:, :k]))
+            kk = min(k, 64)
+            errs.append(np.abs(Xk[:, :kk] - X64[:, :kk]).max() / np.abs(X64).max())
+        z = rng.standard_normal((n, 5))
+        S5 = be.backend_backward_solve(z)
+        errs.append(np.abs(np.einsum("ij,ij->j", S5, Q @ S5) / np.einsum("ij,ij->j", z, z) - 1.0).max())
+        s1 = be.backend_backward_solve(z[:, 0])
+        errs.append(np.abs(np.ravel(s1) - S5[:, 0]).max() / np.abs(S5).max())
+        err = max(errs); worst = max(worst, err)
+        print(f"{i:3d} {name:32s} n={n:7d} worst {err:.2e}" + ("" if err < 1e-10 else "   <-- FAIL " + " ".join(f"{e:.1e}" for e in errs)), flush=True)
+        be.close()
+    print(f"worst {worst:.2e} over {ncases} big cases in {time.time() - t0:.1f}s")
+    sys.exit(0 if worst < 1e-10 else 1)
 for i in range(ncases):
     name, Q, kw = rand_case(i)
     Q = sp.csc_matrix(Q); n = Q.shape[0]
