@@ -131,7 +131,9 @@ __global__ __launch_bounds__(64 * NW) void k_xmul(DevSym S, const int *__restric
     constexpr int KU = 4;
     // (Round 5, measured and dropped: plain entries of the upper triangle instead of the accessor away from the tile's own diagonal
     //  block, and the operands of batch n + 1 requested before the MFMAs of batch n -- 164 instead of ~110 VGPRs, forward / backward
-    //  sweep 2.04 / 1.60 ms against 1.94 / 1.55 on the same box.)
+    //  sweep 2.04 / 1.60 ms against 1.94 / 1.55 on the same box. And for passes of at most 16 right-hand sides: one wave per 16-row
+    //  tile over the whole K range instead of the split-K workgroup, as the update kernels of such passes do -- 1-RHS solve 2.37 ->
+    //  2.51 ms: here the K range is a chain of up to eight dependent batches, which four or eight waves shorten.)
 #pragma unroll 1
     for (int q0 = qlo + wave * 4 * KU; q0 < qhi; q0 += NW * 4 * KU) {
         double av[KU], bv[KU][4];
