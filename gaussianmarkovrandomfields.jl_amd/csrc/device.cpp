@@ -347,6 +347,7 @@ void Device::upload(const Symbolic &S) {
                 wave_count_[k] = (int)ord.size() - wave_first_[k];
             }
             if ((int)ord.size() != nswt_) throw std::runtime_error("internal: a sweep task exceeds the largest wave-task class");
+            for (int t = 0; t < nswt_; t++) ord.push_back(t);       // ... and all of them, heaviest first (passes of at most 4 columns: one launch)
             const int *op; up(op, ord); d_wave_order_ = op;
         }
         HC(hipStreamSynchronize(stream));
@@ -1359,6 +1360,11 @@ void Device::sweep_tasks(int phase, int nr, int ldx) {
         return;
     }
     ensure_rdiag();
+    if (nr <= 4) {      // the local vector of such a pass is 9 KB at most whatever the class: one launch, no tail of the big class before the small one starts
+        launch_wave_tasks(stream, ds_, phase, d_swt_, d_wave_order_ + nswt_, nswt_, kWaveRows[kWaveClasses - 1], d_L_, d_rdiag_, d_rdiag_ + S_->n, d_X_,
+                          d_W_, nr, ldx);
+        return;
+    }
     for (int k = kWaveClasses - 1; k >= 0; k--)
         launch_wave_tasks(stream, ds_, phase, d_swt_, d_wave_order_ + wave_first_[k], wave_count_[k], kWaveRows[k], d_L_, d_rdiag_,
                           d_rdiag_ + S_->n, d_X_, d_W_, nr, ldx);

@@ -165,9 +165,16 @@ __device__ __forceinline__ void wissue(WBuf &b, const WOp &op, const WSrc &src, 
 
 // compute op `b.op` on the local vector V (16 columns, row-major; row `trash` is scratch) and finalise its job when it is
 // the last op. Xt: the task's rows of the right-hand sides, this lane's column (global), row 0 = local row 0.
+// CS = columns the local vector STORES (2, 4, 8 or 16: passes of one or two right-hand sides keep 4.6 KB of it instead of 37 KB, so
+// 16 waves of a CU are resident instead of 4 -- the task kernels of a 1-RHS solve took 0.31 + 0.08 ms per direction in 4.5 rounds of
+// one wave per SIMD; 0.22 + 0.07 now, at the four waves per SIMD their 119-128 VGPRs allow. Forcing five -- 96 VGPRs, 46-63 spilled --
+// is slower: 1-RHS solve 2.11 -> 2.66 ms). Lanes of the columns beyond CS read a stored column again and never write.
+template <int CS>
 __device__ __forceinline__ void wconsume(const WBuf &b, d4 &acc0, d4 &acc1, double *V, double *__restrict__ Xt, const int ldx,
                                          const int trash, const int lm, const int lk, const bool colok) {
     const WOp &op = b.op;
+    const int lc = lm & (CS - 1);
+    const bool wok = lm < CS;
     if (op.first) { acc0 = (d4){0.0, 0.0, 0.0, 0.0}; acc1 = (d4){0.0, 0.0, 0.0, 0.0}; }
     double bv[4];
     {
@@ -175,7 +182,7 @@ __device__ __forceinline__ void wconsume(const WBuf &b, d4 &acc0, d4 &acc1, doub
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int row = op.kind == 2 ? max(b.l[u], 0) : min(base + 4 * u, top);
-            bv[u] = V[row * 16 + lm];
+            bv[u] = V[row * CS + lc];
         }
     }
     acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(b.a[0], bv[0], acc0, 0, 0, 0);
@@ -191,17 +198,21 @@ __device__ __forceinline__ void wconsume(const WBuf &b, d4 &acc0, d4 &acc1, doub
     for (int rr = 0; rr < 4; rr++) {
         const int k = op.m0 + lk + 4 * rr;
         const int row = op.kind == 1 ? b.l[rr] : op.o + k;
-        dst[rr] = (k < lim ? row : trash) * 16 + lm;
+        dst[rr] = (k < lim ? row : trash) * CS + lc;
     }
     if (op.kind == 1 || op.kind == 2) {
         double old[4];
 #pragma unroll
         for (int rr = 0; rr < 4; rr++) old[rr] = V[dst[rr]];
+        if (wok) {
 #pragma unroll
-        for (int rr = 0; rr < 4; rr++) V[dst[rr]] = old[rr] - acc[rr];
+            for (int rr = 0; rr < 4; rr++) V[dst[rr]] = old[rr] - acc[rr];
+        }
     } else {
+        if (wok) {
 #pragma unroll
-        for (int rr = 0; rr < 4; rr++) V[dst[rr]] = acc[rr];
+            for (int rr = 0; rr < 4; rr++) V[dst[rr]] = acc[rr];
+        }
         if (op.kind == 0) {             // y goes straight to HBM
 #pragma unroll
             for (int rr = 0; rr < 4; rr++) {
@@ -248,12 +259,12 @@ __device__ __forceinline__ double wprologue(const DevSym &S, const SweepTask &T,
     return (s0 + s1) + (s2 + s3) + (double)is;
 }
 
-template <bool FWD> __global__ __launch_bounds__(64)
+template <bool FWD, int CS> __global__ __launch_bounds__(64)
 void k_wave_task(DevSym S, const SweepTask *__restrict__ tasks, const int *__restrict__ order, int ntasks, int CT,
                  WSrc src, double *__restrict__ X, double *__restrict__ W, int nr_all, int ldx, int rows_cap) {
     extern __shared__ double wsh[];
-    double *V = wsh;                                             // (rows_cap + 1) x 16: the last row is scratch
-    WMeta *meta = (WMeta *)(wsh + (size_t)(rows_cap + 1) * 16);  // WT_MAXF
+    double *V = wsh;                                             // (rows_cap + 1) x CS: the last row is scratch
+    WMeta *meta = (WMeta *)(wsh + (size_t)(rows_cap + 1) * CS);  // WT_MAXF
     const double *__restrict__ L = src.L;
     int ti, tile;
     if (!wtask_of_block(ntasks, CT, ti, tile)) return;
@@ -262,6 +273,8 @@ void k_wave_task(DevSym S, const SweepTask *__restrict__ tasks, const int *__res
     const int nrl = min(nr_all - cbase, 16);
     const int lane = threadIdx.x, lm = lane & 15, lk = lane >> 4;
     const bool colok = lm < nrl;
+    const bool wok = lm < CS;
+    const int lc = lm & (CS - 1);
     const int jc = cbase + min(lm, nrl - 1);
     const int col0 = T.col0, NT = T.nt, nf = T.s1 - T.s0 + 1, mroot = T.mroot;
     // ---- the task's slice of the right-hand sides: NT contiguous rows (4 rows per load instruction, 8 in flight) ----
@@ -272,10 +285,10 @@ void k_wave_task(DevSym S, const SweepTask *__restrict__ tasks, const int *__res
 #pragma unroll
             for (int u = 0; u < 8; u++) v[u] = Xs[(long long)min(i0 + 4 * u, NT - 1) * ldx];
 #pragma unroll
-            for (int u = 0; u < 8; u++) if (i0 + 4 * u < NT) V[(i0 + 4 * u) * 16 + lm] = colok ? v[u] : 0.0;
+            for (int u = 0; u < 8; u++) if (i0 + 4 * u < NT && wok) V[(i0 + 4 * u) * CS + lc] = colok ? v[u] : 0.0;
         }
         if (FWD) {
-            for (int i = NT + lk; i < NT + mroot; i += 4) V[i * 16 + lm] = 0.0;
+            if (wok) for (int i = NT + lk; i < NT + mroot; i += 4) V[i * CS + lc] = 0.0;
         } else {        // x of the root's trailing rows (ancestors of the subtree: final)
             const int *rows = S.rows + T.rroot;
             for (int i0 = lk; i0 < mroot; i0 += 32) {
@@ -286,7 +299,7 @@ void k_wave_task(DevSym S, const SweepTask *__restrict__ tasks, const int *__res
 #pragma unroll
                 for (int u = 0; u < 8; u++) v[u] = X[(long long)ri[u] * ldx + jc];
 #pragma unroll
-                for (int u = 0; u < 8; u++) if (i0 + 4 * u < mroot) V[(NT + i0 + 4 * u) * 16 + lm] = colok ? v[u] : 0.0;
+                for (int u = 0; u < 8; u++) if (i0 + 4 * u < mroot && wok) V[(NT + i0 + 4 * u) * CS + lc] = colok ? v[u] : 0.0;
             }
         }
     }
@@ -304,25 +317,25 @@ void k_wave_task(DevSym S, const SweepTask *__restrict__ tasks, const int *__res
     static_assert(WT_D == 4, "the pipeline below rotates four operand sets");
     while (b0.op.kind >= 0) {
         wissue(b3, gen.next(), src, col0, lm, lk);
-        wconsume(b0, acc0, acc1, V, Xt, ldx, rows_cap, lm, lk, colok);
+        wconsume<CS>(b0, acc0, acc1, V, Xt, ldx, rows_cap, lm, lk, colok);
         if (b1.op.kind < 0) break;
         wissue(b0, gen.next(), src, col0, lm, lk);
-        wconsume(b1, acc0, acc1, V, Xt, ldx, rows_cap, lm, lk, colok);
+        wconsume<CS>(b1, acc0, acc1, V, Xt, ldx, rows_cap, lm, lk, colok);
         if (b2.op.kind < 0) break;
         wissue(b1, gen.next(), src, col0, lm, lk);
-        wconsume(b2, acc0, acc1, V, Xt, ldx, rows_cap, lm, lk, colok);
+        wconsume<CS>(b2, acc0, acc1, V, Xt, ldx, rows_cap, lm, lk, colok);
         if (b3.op.kind < 0) break;
         wissue(b2, gen.next(), src, col0, lm, lk);
-        wconsume(b3, acc0, acc1, V, Xt, ldx, rows_cap, lm, lk, colok);
+        wconsume<CS>(b3, acc0, acc1, V, Xt, ldx, rows_cap, lm, lk, colok);
     }
     // ---- write-out ---------------------------------------------------------------------------------------------------
     if (FWD) {          // the root's update vector W (y went to X job by job)
         if (colok) {
             double *Wr = W + T.woff * ldx + cbase + lm;
-            for (int i = lk; i < mroot; i += 4) Wr[(long long)i * ldx] = V[(NT + i) * 16 + lm];
+            for (int i = lk; i < mroot; i += 4) Wr[(long long)i * ldx] = V[(NT + i) * CS + lc];
         }
     } else if (colok) {
-        for (int i = lk; i < NT; i += 4) Xt[(long long)i * ldx] = V[i * 16 + lm];
+        for (int i = lk; i < NT; i += 4) Xt[(long long)i * ldx] = V[i * CS + lc];
     }
     if (sink == 1.2345678e-300) X[(long long)col0 * ldx] = sink;      // keeps the warm-up loads alive; never true
 }
@@ -342,10 +355,20 @@ void launch_wave_tasks(hipStream_t st, const DevSym &S, int phase, const SweepTa
     if (ntasks <= 0) return;
     const int CT = (nr + 15) / 16;
     const int grid = ((ntasks + 7) / 8) * 8 * CT;
-    const size_t lds = (size_t)(rows_cap + 1) * 16 * sizeof(double) + WT_MAXF * sizeof(WMeta);
     const WSrc src{L, rdiag, zero, S.lrow};
-    if (phase == 1) hipLaunchKernelGGL(k_wave_task<true>, dim3(grid), dim3(64), lds, st, S, tasks, order, ntasks, CT, src, X, W, nr, ldx, rows_cap);
-    else hipLaunchKernelGGL(k_wave_task<false>, dim3(grid), dim3(64), lds, st, S, tasks, order, ntasks, CT, src, X, W, nr, ldx, rows_cap);
+    // columns the local vector stores: the width of the pass rounded up to 2, 4, 8 or 16
+    const int cs = nr <= 2 ? 2 : nr <= 4 ? 4 : nr <= 8 ? 8 : 16;
+    const size_t lds = (size_t)(rows_cap + 1) * cs * sizeof(double) + WT_MAXF * sizeof(WMeta);
+#define GMRFX_WAVE_TASK(CS_)                                                                                                                       \
+    do {                                                                                                                                           \
+        if (phase == 1) hipLaunchKernelGGL((k_wave_task<true, CS_>), dim3(grid), dim3(64), lds, st, S, tasks, order, ntasks, CT, src, X, W, nr, ldx, rows_cap); \
+        else hipLaunchKernelGGL((k_wave_task<false, CS_>), dim3(grid), dim3(64), lds, st, S, tasks, order, ntasks, CT, src, X, W, nr, ldx, rows_cap);          \
+    } while (0)
+    if (cs == 2) GMRFX_WAVE_TASK(2);
+    else if (cs == 4) GMRFX_WAVE_TASK(4);
+    else if (cs == 8) GMRFX_WAVE_TASK(8);
+    else GMRFX_WAVE_TASK(16);
+#undef GMRFX_WAVE_TASK
 }
 
 }  // namespace gmrfx
