@@ -203,7 +203,9 @@ __global__ __launch_bounds__(256) void k_sel_diag(DevSym S, const int *__restric
 // Workgroup tile 64 x 64 = 2 x 2 waves of 32 x 32. (Measured and removed in round 4, DESIGN.md section 3: 128 x 128 tiles of
 // sixteen waves -- 14.9 vs 13.0 ms --, whole fronts dealt to one XCD each -- 14.0-14.3 ms. Round 5, the same deal only on levels with
 // at least 8 / 16 / 32 / 64 / 256 / 1024 fronts, where it is balanced: 14.8 / 14.6 / 14.2 / 14.5 / 14.4 / 14.1 against 13.2 ms on the same box --
-// a front's operand slabs are served faster by eight L2s than by one, at every level of the tree.)
+// a front's operand slabs are served faster by eight L2s than by one, at every level of the tree. Also round 5: one kernel per phase
+// (phase 1 then needs 76 + 32 registers and runs four waves per SIMD instead of three): 13.3 -> 14.9-15.0 ms; two / one workgroups per
+// CU (unused dynamic LDS): 14.8 / 20.4 ms. Three waves per SIMD of this tile shape is the optimum.)
 constexpr int WT = 2;
 __global__ __launch_bounds__(64 * WT * WT) void k_sel_dense(DevSym S, const int *__restrict__ list, int phase,
                                                    const double *__restrict__ L, double *__restrict__ Z,
