@@ -173,6 +173,56 @@ __global__ __launch_bounds__(64 * NW) void k_xmul(DevSym S, const int *__restric
         }
 }
 
+// The same product for passes of at most 16 right-hand sides: ONE right-hand-side tile instead of four (a quarter of the MFMAs and of
+// the partial tiles, 2 KB of LDS per wave instead of 8: twice the resident workgroups), the K range still split over the waves of
+// the workgroup -- a one-wave form was measured slower (note above): partial sums in wave order, like the 64-column kernel.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_xmul_narrow(DevSym S, const int *__restrict__ list, int trans, const double *__restrict__ L,
+                                                         const double *__restrict__ Xin, double *__restrict__ Xout, int nr, int ldx, int blk, int cap) {
+    const int s = list[blockIdx.y];
+    const int cfull = S.sfirst[s + 1] - S.sfirst[s];
+    const int col0 = blk * cap;
+    const int c = min(cap, cfull - col0);
+    __shared__ double red[NW * 4 * 64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int k0 = blockIdx.x * 16;
+    if (k0 >= c) return;
+    const int ld = S.ld[s];
+    const int first = S.sfirst[s] + col0;
+    const double *P = L + S.panelptr[s] + col0 + (long long)col0 * ld;
+    const int lm = lane & 15, lk = lane >> 4;
+    const double *Bb = Xin + (long long)first * ldx + min(lm, nr - 1);
+    d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+    const int qlo = trans ? k0 : 0, qhi = trans ? c : min(c, k0 + 16);
+    constexpr int KU = 4;
+#pragma unroll 1
+    for (int q0 = qlo + wave * 4 * KU; q0 < qhi; q0 += NW * 4 * KU) {
+        double av[KU], bv[KU];
+#pragma unroll
+        for (int u = 0; u < KU; u++) {
+            const int q = q0 + 4 * u + lk;
+            av[u] = trans ? xinv_elem(P, ld, c, q, k0 + lm) : xinv_elem(P, ld, c, k0 + lm, q);
+            bv[u] = Bb[(long long)min(q, c - 1) * ldx];
+        }
+#pragma unroll
+        for (int u = 0; u < KU; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) red[(wave * 4 + rr) * 64 + lane] = acc[rr];
+    __syncthreads();
+    if (wave == 0 && lm < nr) {
+        double *Yb = Xout + (long long)first * ldx + lm;
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+            double sum = red[rr * 64 + lane];
+#pragma unroll
+            for (int w = 1; w < NW; w++) sum += red[(w * 4 + rr) * 64 + lane];
+            const int k = k0 + lk + 4 * rr;
+            if (k < c) Yb[(long long)k * ldx] = sum;
+        }
+    }
+}
+
 // Xdst[own rows of the listed fronts] = Xsrc[same rows]
 __global__ __launch_bounds__(256) void k_copy_own(DevSym S, const int *__restrict__ list,
                                                   const double *__restrict__ Xsrc, double *__restrict__ Xdst, int nr,
@@ -206,6 +256,13 @@ void launch_xmul(hipStream_t st, const DevSym &S, const int *list, int nfronts, 
     if (nfronts <= 0 || max_c <= 0) return;
     max_c = std::min(max_c - blk * cap, cap);      // width of block `blk` of the widest front
     if (max_c <= 0) return;
+    if (nr <= 16) {
+        if ((long long)cdiv(max_c, 16) * nfronts <= 256)
+            hipLaunchKernelGGL(k_xmul_narrow<8>, dim3((unsigned)(cdiv(max_c, 16) | 1), nfronts), dim3(512), 0, st, S, list, trans, L, Xin, Xout, nr, ldx, blk, cap);
+        else
+            hipLaunchKernelGGL(k_xmul_narrow<4>, dim3((unsigned)(cdiv(max_c, 16) | 1), nfronts), dim3(256), 0, st, S, list, trans, L, Xin, Xout, nr, ldx, blk, cap);
+        return;
+    }
     if ((long long)cdiv(max_c, 16) * nfronts <= 256)
         hipLaunchKernelGGL(k_xmul<8>, dim3((unsigned)(cdiv(max_c, 16) | 1), nfronts), dim3(512), 0, st, S, list, trans, L, Xin, Xout, nr, ldx, blk, cap);
     else
