@@ -1429,10 +1429,12 @@ void Device::forward(int nr, int ldx, int lo, int hi) {
         // levels with many tiles: record-driven, per-XCD runs; the handful-of-fronts levels keep the 16-row latency variant
         // Passes of at most 16 right-hand sides: the fronts up to kFwdWaveCols columns wide go one WAVE per 32-row tile (no LDS, no
         // barrier: k_fwd_update_wave), chosen per FRONT so that a front's sums do not depend on the list it comes in
-        constexpr int kFwdWaveCols = 512;       // (measured at cfg 2, 1 RHS, forward ms: 256: 1.188, 512: 1.133, 1024: 1.184)
+        constexpr int kFwdWaveCols = 1024;      // (measured at cfg 2, 1 RHS, forward ms, with four waves sharing the K range of a front wider than 128
+                                                //  columns: 256: 0.933, 512: 0.841, 1024: 0.832, 2048: 0.836)
         const int cmin = syrk_xcd_ && nr <= 16 ? kFwdWaveCols : 0;
         const int nwider = (size_t)(kFwdWaveCols / NB + 1) < L.active.size() ? L.active[kFwdWaveCols / NB] : 0;      // fronts wider than that
-        if (cmin > 0 && nwider < nf) launch_fwd_update_wave(stream, ds_, d_fwd_recs_ + L.fwd_off, L.fwd_split, L.fwd_per, d_L_, d_X2_, d_W_, nr, ldx, cmin);
+        if (cmin > 0 && nwider < nf) launch_fwd_update_wave(stream, ds_, d_fwd_recs_ + L.fwd_off, L.fwd_split, L.fwd_per, d_L_, d_X2_, d_W_, nr, ldx, cmin,
+                                                              L.max_cols > launch_wave_split_cols());
         if (L.max_cols > cmin) {
             if (syrk_xcd_ && (long long)((level_max_trail(L) + 31) / 32) * nf > 128)
                 launch_fwd_update_recs(stream, ds_, d_fwd_recs_ + L.fwd_off, L.fwd_split, L.fwd_per, d_L_, d_X2_, d_W_, nr, ldx, cmin);
@@ -1461,7 +1463,8 @@ void Device::backward(int nr, int ldx, bool y_in_x2, int hi, int lo) {
         // and a level of a hundred fronts with 700 trailing rows each is faster as many small workgroups (the two launches).
         // Passes of at most 16 right-hand sides: t = y - L21' x one WAVE per 16 own columns for the fronts with at most kBwdWaveRows
         // trailing rows (k_bwd_wave), the split-K kernels for the others, x = L11^-T t as everywhere
-        constexpr int kBwdWaveRows = 768;       // (measured at cfg 2, 1 RHS, backward ms: 512: 1.190, 768: 1.177, 1100: 1.181, 1600: 1.213, all: 1.257)
+        constexpr int kBwdWaveRows = 4096;      // (every front of a 2-D problem; measured at cfg 2, 1 RHS, backward ms, with four waves sharing the K range of a front of more than 256
+                                                //  rows: 768: 0.848, 1100: 0.824, 1600: 0.814, every front: 0.792; one wave per tile only: 768 was the optimum, 1.177)
         const bool narrow = nr <= 16;
         if (bwd_front_min_ > 0 && !narrow) {
             // (a front needs its WHOLE inverse for this: at most min(128, inv_cap_) columns)
@@ -1476,7 +1479,8 @@ void Device::backward(int nr, int ldx, bool y_in_x2, int hi, int lo) {
         const int nbk = std::max(1, (L.max_cols + inv_cap_ - 1) / inv_cap_);
         double *const Xt = y_in_x2 ? d_X2_ : d_X_;
         const int mmin = narrow ? kBwdWaveRows : 0;
-        if (narrow && level_max_trail(L) > 0 && L.min_trail <= kBwdWaveRows) launch_bwd_wave(stream, ds_, list, nf, L.max_cols, d_L_, d_X_, Xt, nr, ldx, kBwdWaveRows);
+        if (narrow && level_max_trail(L) > 0 && L.min_trail <= kBwdWaveRows) launch_bwd_wave(stream, ds_, list, nf, L.max_cols, d_L_, d_X_, Xt, nr, ldx, kBwdWaveRows,
+                                                                                                  level_max_trail(L) > launch_wave_split_rows());
         if (y_in_x2) {
             if (level_max_trail(L) > mmin) launch_bwd_gemm(stream, ds_, list, nf, L.max_cols, d_L_, d_X_, d_X2_, nr, ldx, -1, 1 << 30, mmin);
             // fronts wider than inv_cap_: from the last block up, t_j -= L[own rows below, block j]' x, x_j = X_jj' t_j

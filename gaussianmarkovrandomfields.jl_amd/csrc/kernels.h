@@ -35,7 +35,7 @@ void launch_gemm_nt(hipStream_t st, const DevSym &S, const FrontView *frec, int 
 void launch_fwd_update_recs(hipStream_t st, const DevSym &S, const FwdTile *recs, const SyrkSplit &split, int per_xcd, const double *L,
                             double *X, double *W, int nr, int ldx, int cmin = 0);
 void launch_fwd_update_wave(hipStream_t st, const DevSym &S, const FwdTile *recs, const SyrkSplit &split, int per_xcd, const double *L,
-                            double *X, double *W, int nr, int ldx, int cmax);
+                            double *X, double *W, int nr, int ldx, int cmax, bool split_k);      // split_k: the level has fronts wider than launch_wave_split_cols()
 void launch_fwd_assemble(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, double *X,
                          const double *W, int nr, int ldx);
 void launch_fwd_update(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_trail, const double *L,
@@ -398,7 +398,9 @@ void launch_bwd_gemm(hipStream_t st, const DevSym &S, const int *list, int nfron
 // passes of at most 16 right-hand sides: the fronts with at most mmax trailing rows, one wave per 16 own columns (launch_bwd_gemm with
 // mmin = mmax has the others)
 void launch_bwd_wave(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, const double *L, const double *X, double *Xown,
-                     int nr, int ldx, int mmax);
+                     int nr, int ldx, int mmax, bool split_k);       // split_k: the level has fronts with more than launch_wave_split_rows() trailing rows
+int launch_wave_split_cols();
+int launch_wave_split_rows();
 // blocked substitution inside fronts wider than `cap` columns (forward): own rows below block blk -= L[.., block] y_blk
 void launch_fwd_own_update(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, const double *L,
                            const double *Y, double *X, int nr, int ldx, int blk, int cap);

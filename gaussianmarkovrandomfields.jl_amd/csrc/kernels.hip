@@ -1046,16 +1046,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void k
 // added exactly once (a product with 0 adds an exact 0), children in edge order, rows in order: reproducible, and the same for a
 // front whatever the level list it comes in (sharded or not). Eight independent chains per SIMD.
 // Wider fronts (the top of the tree: K in the hundreds to thousands over a handful of tiles) keep the split-K kernels (cmin).
-__global__ __launch_bounds__(64) void k_fwd_update_wave(DevSym S, const FwdTile *__restrict__ recs, const SyrkSplit split,
+// NW = 4 (levels with fronts wider than kWaveSplitCols columns): the K range of such a front's tile is split over four waves -- a
+// chain of up to 16 dependent batches otherwise --, their partial tiles summed in wave order through 8 KB of LDS; narrower fronts of
+// the same launch are still done by wave 0 alone (the rule depends on the front's width only: its sums do not depend on the launch).
+constexpr int kWaveSplitCols = 128;
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_fwd_update_wave(DevSym S, const FwdTile *__restrict__ recs, const SyrkSplit split,
                                                         const double *__restrict__ L, const double *__restrict__ X,
                                                         double *__restrict__ W, int nr, int ldx, int cmax) {
+    __shared__ double red[NW > 1 ? NW * 8 * 64 : 1];
     const int xcd = blockIdx.x & 7;
     const int tix = split.start[xcd] + (int)(blockIdx.x >> 3);
     if (tix >= split.start[xcd + 1]) return;
     const FwdTile T = recs[tix];
     const int c = T.c, r = T.r, ld = T.ld, i0 = T.i0;
     if (c > cmax) return;
-    const int lane = threadIdx.x;
+    const int wave = NW > 1 ? (int)(threadIdx.x >> 6) : 0;
+    const int kw = (NW > 1 && c > kWaveSplitCols) ? NW : 1;       // waves that share this tile's K range
+    if (wave >= kw) return;
+    const int lane = threadIdx.x & 63;
     const int lm = lane & 15, lk = lane >> 4;
     const double *P = L + T.pp;
     const double *Yb = X + T.xoff * ldx;
@@ -1064,7 +1073,7 @@ __global__ __launch_bounds__(64) void k_fwd_update_wave(DevSym S, const FwdTile 
     const int jl = min(lm, nr - 1);
     constexpr int KU = 8;
     d4 acc[2] = {(d4){0.0, 0.0, 0.0, 0.0}, (d4){0.0, 0.0, 0.0, 0.0}};
-    for (int k0 = 0; k0 < c; k0 += 4 * KU) {
+    for (int k0 = wave * 4 * KU; k0 < c; k0 += kw * 4 * KU) {
         double av[KU][2], bv[KU];
 #pragma unroll
         for (int u = 0; u < KU; u++) {
@@ -1104,12 +1113,32 @@ __global__ __launch_bounds__(64) void k_fwd_update_wave(DevSym S, const FwdTile 
                 }
         }
     };
-    if (T.nch > 0) child(S.rel + T.reloff[0], W + T.cwoff[0] * ldx, T.a0[0], T.a1[0]);
-    if (T.nch > 1) child(S.rel + T.reloff[1], W + T.cwoff[1] * ldx, T.a0[1], T.a1[1]);
-    for (long long cb = T.ch0 + 2; cb < T.ch0 + T.nch; cb++) {      // further children: the long way
-        const EdgeRec er = S.edge[cb];
-        const int a0 = S.etile[er.tptr + T.tile], a1 = S.etile[er.tptr + T.tile + 1];
-        child(S.rel + er.reloff, W + er.woff * ldx, a0, a1);
+    if (wave == 0) {
+        if (T.nch > 0) child(S.rel + T.reloff[0], W + T.cwoff[0] * ldx, T.a0[0], T.a1[0]);
+        if (T.nch > 1) child(S.rel + T.reloff[1], W + T.cwoff[1] * ldx, T.a0[1], T.a1[1]);
+        for (long long cb = T.ch0 + 2; cb < T.ch0 + T.nch; cb++) {      // further children: the long way
+            const EdgeRec er = S.edge[cb];
+            const int a0 = S.etile[er.tptr + T.tile], a1 = S.etile[er.tptr + T.tile + 1];
+            child(S.rel + er.reloff, W + er.woff * ldx, a0, a1);
+        }
+    }
+    if constexpr (NW > 1) {
+        if (kw > 1) {       // (all NW waves of the workgroup are here: none has left)
+            if (wave > 0) {
+#pragma unroll
+                for (int a = 0; a < 2; a++)
+#pragma unroll
+                    for (int rr = 0; rr < 4; rr++) red[(wave * 8 + a * 4 + rr) * 64 + lane] = acc[a][rr];
+            }
+            __syncthreads();
+            if (wave > 0) return;
+#pragma unroll
+            for (int w = 1; w < NW; w++)
+#pragma unroll
+                for (int a = 0; a < 2; a++)
+#pragma unroll
+                    for (int rr = 0; rr < 4; rr++) acc[a][rr] += red[(w * 8 + a * 4 + rr) * 64 + lane];
+        }
     }
     // W = -(acc): lane (lm, lk), register rr of row tile a = row i0 + 2 (lk + 4 rr) + a, right-hand side lm
     if (lm < nr) {
@@ -1198,14 +1227,22 @@ __global__ __launch_bounds__(256) void k_fwd_own_update(DevSym S, const int *__r
 // per SIMD (k_fwd_update_wave is the forward twin). Operands in pairs along K as in k_bwd_gemm_longk: a lane loads rows q, q + 1
 // of its column and of the row list, q = batch + 8 h + 2 lk, and feeds k-steps 2 h and 2 h + 1 with them. The row indices of
 // batch k + 1 are requested with the operands of batch k. Fronts with more trailing rows keep the split-K kernels (mmin).
-__global__ __launch_bounds__(64) void k_bwd_wave(DevSym S, const int *__restrict__ list, const double *__restrict__ L, const double *X,
+// NW = 4 (levels with fronts of more than kWaveSplitRows trailing rows): four waves share such a front's K range, partial tiles
+// summed in wave order through LDS; fronts with fewer rows are still done by wave 0 alone (the rule depends on the front only).
+constexpr int kWaveSplitRows = 256;
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_bwd_wave(DevSym S, const int *__restrict__ list, const double *__restrict__ L, const double *X,
                                                  double *Xown, int nr, int ldx, int mmax) {
+    __shared__ double red[NW > 1 ? NW * 4 * 64 : 1];
     const int s = list[blockIdx.y];
     const int c = S.sfirst[s + 1] - S.sfirst[s];
     const int r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
     const int i0 = blockIdx.x * 16;
     if (i0 >= c || r <= c || r - c > mmax) return;
-    const int lane = threadIdx.x;
+    const int wave = NW > 1 ? (int)(threadIdx.x >> 6) : 0;
+    const int kw = (NW > 1 && r - c > kWaveSplitRows) ? NW : 1;
+    if (wave >= kw) return;
+    const int lane = threadIdx.x & 63;
     const int lm = lane & 15, lk = lane >> 4;
     const int ld = S.ld[s];
     const int first = S.sfirst[s];
@@ -1224,12 +1261,12 @@ __global__ __launch_bounds__(64) void k_bwd_wave(DevSym S, const int *__restrict
             xn[2 * h + 1] = q + 1 < r ? v.y : v.x;          // past the list: any valid row (its product is masked)
         }
     };
-    request_rows(c);
-    for (int k0 = c; k0 < r; k0 += 8 * NH) {
+    request_rows(c + wave * 8 * NH);
+    for (int k0 = c + wave * 8 * NH; k0 < r; k0 += kw * 8 * NH) {
         double av[2 * NH], bv[2 * NH];
 #pragma unroll
         for (int u = 0; u < 2 * NH; u++) xr[u] = xn[u];
-        request_rows(k0 + 8 * NH);
+        request_rows(k0 + kw * 8 * NH);
 #pragma unroll
         for (int h = 0; h < NH; h++) {
             const int q = k0 + 8 * h + 2 * lk;
@@ -1241,6 +1278,20 @@ __global__ __launch_bounds__(64) void k_bwd_wave(DevSym S, const int *__restrict
 #pragma unroll
         for (int u = 0; u < 2 * NH; u++)
             if (k0 + 8 * (u >> 1) < r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+    }
+    if constexpr (NW > 1) {
+        if (kw > 1) {
+            if (wave > 0) {
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) red[(wave * 4 + rr) * 64 + lane] = acc[rr];
+            }
+            __syncthreads();
+            if (wave > 0) return;
+#pragma unroll
+            for (int w = 1; w < NW; w++)
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) acc[rr] += red[(w * 4 + rr) * 64 + lane];
+        }
     }
     // t[col][rhs]: register rr of lane (lm, lk) = own column i0 + lk + 4 rr, right-hand side lm (all loads, then all stores)
     double xv[4];
@@ -1899,10 +1950,13 @@ void launch_fwd_update_recs(hipStream_t st, const DevSym &S, const FwdTile *recs
     if (per_xcd <= 0) return;
     hipLaunchKernelGGL(k_fwd_update_rec, dim3(8 * (unsigned)per_xcd), dim3(256), 0, st, S, recs, split, L, X, W, nr, ldx, cmin);
 }
+int launch_wave_split_cols() { return kWaveSplitCols; }
+int launch_wave_split_rows() { return kWaveSplitRows; }
 void launch_fwd_update_wave(hipStream_t st, const DevSym &S, const FwdTile *recs, const SyrkSplit &split, int per_xcd, const double *L,
-                            double *X, double *W, int nr, int ldx, int cmax) {
+                            double *X, double *W, int nr, int ldx, int cmax, bool split_k) {
     if (per_xcd <= 0) return;
-    hipLaunchKernelGGL(k_fwd_update_wave, dim3(8 * (unsigned)per_xcd), dim3(64), 0, st, S, recs, split, L, X, W, nr, ldx, cmax);
+    if (split_k) hipLaunchKernelGGL(k_fwd_update_wave<4>, dim3(8 * (unsigned)per_xcd), dim3(256), 0, st, S, recs, split, L, X, W, nr, ldx, cmax);
+    else hipLaunchKernelGGL(k_fwd_update_wave<1>, dim3(8 * (unsigned)per_xcd), dim3(64), 0, st, S, recs, split, L, X, W, nr, ldx, cmax);
 }
 void launch_bwd_gemm(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, const double *L,
                      const double *X, double *Xown, int nr, int ldx, int blk, int cap, int mmin) {
@@ -1922,9 +1976,10 @@ void launch_bwd_gemm(hipStream_t st, const DevSym &S, const int *list, int nfron
         hipLaunchKernelGGL((k_bwd_gemm_longk<2, 4>), dim3(odd(cdiv(max_cols, 32)), nfronts), dim3(256), 0, st, S, list, L, X, Xown, nr, ldx, blk, cap, mmin);
 }
 void launch_bwd_wave(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, const double *L, const double *X, double *Xown,
-                     int nr, int ldx, int mmax) {
+                     int nr, int ldx, int mmax, bool split_k) {
     if (nfronts <= 0 || max_cols <= 0) return;
-    hipLaunchKernelGGL(k_bwd_wave, dim3(odd(cdiv(max_cols, 16)), nfronts), dim3(64), 0, st, S, list, L, X, Xown, nr, ldx, mmax);
+    if (split_k) hipLaunchKernelGGL(k_bwd_wave<4>, dim3(odd(cdiv(max_cols, 16)), nfronts), dim3(256), 0, st, S, list, L, X, Xown, nr, ldx, mmax);
+    else hipLaunchKernelGGL(k_bwd_wave<1>, dim3(odd(cdiv(max_cols, 16)), nfronts), dim3(64), 0, st, S, list, L, X, Xown, nr, ldx, mmax);
 }
 void launch_fwd_own_update(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, const double *L,
                            const double *Y, double *X, int nr, int ldx, int blk, int cap) {
