@@ -1346,7 +1346,7 @@ void Device::ensure_rhs_capacity(long long nrhs) {
 // The bottom subtrees. Up to wave_max_nr_ (16) right-hand sides: one wave per (task, 16 columns), sweep_wave.hip, biggest LDS
 // class first; wider passes: the chunk form, four waves per (task, 16 columns), sweep_chunk.hip. Measured at cfg 2, round 5
 // (tools/nrhs_sweep.py, ms per solve, wave form / chunk form): 1 RHS 2.88 / 3.22, 16: 3.00 / 3.36, 32: 3.71 / 3.47, 64: - / 3.90 at the
-// time of the choice; with the narrow level kernels and the local vector as wide as the pass: 1 RHS 2.02, 16: 2.61.
+// time of the choice; with the narrow level kernels and the local vector as wide as the pass: 1 RHS 1.65, 16: 2.28.
 // GMRFX_TASK_MODE = wg / wave forces one form.
 void Device::sweep_tasks(int phase, int nr, int ldx) {
     if (nr > wave_max_nr_) {
