@@ -474,6 +474,14 @@ def main():
             be.backward_solve_dev(d_Z.data_ptr() + 8 * n * j, n, 1, d_S.data_ptr() + 8 * n * j, n)
         torch.cuda.synchronize()
         extras["ms_rand256_single_calls"] = 1e3 * (time.perf_counter() - t1) * 256.0 / 16.0
+        # one right-hand side and sixteen through the separate solve call (HIP-event time of the call, median of 5, inverses built):
+        # what `mean` / a Newton step's solve / a narrow rand cost (the passes of at most 16 columns have kernels of their own)
+        for k in (1, 16):
+            ts = []
+            for _ in range(6):
+                be.solve_dev(d_Z.data_ptr(), n, k, d_S.data_ptr(), n)
+                ts.append(be.stats()["ms_solve"])
+            extras[f"ms_solve_{k}rhs"] = float(np.median(ts[1:]))
         sy = be.symbolic()
         cc = np.diff(sy.super_first).astype(np.float64)
         mm = np.diff(sy.row_ptr).astype(np.float64) - cc
