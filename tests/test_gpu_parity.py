@@ -1099,6 +1099,36 @@ def test_sweep_task_forms_match_the_oracle(mode, nrhs, monkeypatch):
     assert np.array_equal(be.backend_solve(B), be.backend_solve(B))
 
 
+def test_narrow_passes_match_the_oracle_for_every_width():
+    """Round 5: passes of at most 16 right-hand sides have kernels of their own on every level of the tree -- the bottom tasks with a
+    local vector of 2 / 4 / 8 / 16 stored columns (sweep_wave.hip), one launch of all tasks up to 4 columns; the level fronts through
+    k_fwd_update_wave / k_bwd_wave (one wave per tile, four waves sharing the K range of fronts wider than 128 columns / with more
+    than 256 trailing rows), k_xmul_narrow, k_permute_narrow (up to 8 columns). Solve and backward solve VALUE BY VALUE against the
+    oracle for every width class and its edges, on a mesh whose top fronts have several hundred columns and trailing rows; then the
+    same columns through ONE 64-column pass (other kernels, other summation orders) to 1e-12."""
+    mesh = spde.grid_mesh_2d(230, 210, jitter=0.25, seed=19)
+    Q = sp.csc_matrix(spde.matern_precision(mesh, 0, 0.2))
+    n = Q.shape[0]
+    be = gmrfx.MI355XBackend(Q, coords=mesh.points)
+    sym = be.symbolic()
+    cols = np.diff(sym.super_first)
+    trail = np.diff(sym.row_ptr) - cols
+    assert cols.max() > 128 and trail.max() > 256          # the four-wave forms of both update kernels are exercised
+    F = orc.OracleFactor(Q, be.ordering_permutation())
+    B = np.random.default_rng(77).standard_normal((n, 17))
+    Xo, So = F.solve(B), F.backward_solve(B)
+    X64 = be.backend_solve(np.hstack([B, B, B, B[:, :13]]))[:, :17]
+    for k in (1, 2, 3, 4, 5, 8, 9, 15, 16, 17):
+        Bk = B[:, 0] if k == 1 else B[:, :k]
+        X = be.backend_solve(Bk).reshape(n, -1)
+        assert relerr(X, Xo[:, :k]) < 1e-10, k
+        assert relerr(X, X64[:, :k]) < 1e-12, k
+        S = be.backend_backward_solve(Bk).reshape(n, -1)
+        assert relerr(S, So[:, :k]) < 1e-10, k
+        assert np.array_equal(X, be.backend_solve(Bk).reshape(n, -1)), k      # bit-reproducible
+    be.close()
+
+
 @pytest.mark.parametrize("mesh_kind", ["2d", "3d"])
 def test_refactorize_solve_pipelined_equals_separate_calls(mesh_kind):
     """gmrfx_refactorize_solve[_dev] (workspace_solve on a workspace with new values, gmrf_workspace.jl:170-178 + 207-215; the
