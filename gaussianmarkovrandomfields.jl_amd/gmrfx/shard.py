@@ -216,19 +216,41 @@ class ShardedFactor:
         be.dist_front_phase(d_nzval_ptr, s, 3)                      # my blocks of the contribution block
 
     # ---- solve --------------------------------------------------------------------------------------
-    def solve_dev(self, d_B: int, ldb: int, nrhs: int, d_X: int, ldx: int) -> None:
-        """Q X = B with the factor sharded over the ranks; B (full, column-major n x nrhs) on every rank,
-        X (full) is produced on rank 0. Any number of right-hand sides: passes of up to 64 columns."""
+    def solve_dev(self, d_B: int, ldb: int, nrhs: int, d_X: int, ldx: int, gather: bool = True) -> None:
+        """Q X = B with the factor sharded over the ranks; B (full, column-major n x nrhs) on every rank. gather = True: X (full) is
+        produced on rank 0 -- every rank sends the rows of its subtrees home, 7/8 of n x nrhs doubles into ONE rank's links at world
+        8. gather = False: X stays DISTRIBUTED -- every rank writes its own d_X, of which the rows `valid_rows()` names are final
+        (its subtrees' and every top front's, which are broadcast anyway): no transfer at all behind the backward sweep; a caller
+        that wants all of X on one rank gathers those rows itself, later or never (a mean / a sample that is reduced further
+        stays where it is). Any number of right-hand sides: passes of up to 64 columns."""
         for j0 in range(0, int(nrhs), 64):
-            self._solve_pass(d_B + 8 * j0 * ldb, ldb, min(64, nrhs - j0), d_X + 8 * j0 * ldx, ldx, backward_only=False)
+            self._solve_pass(d_B + 8 * j0 * ldb, ldb, min(64, nrhs - j0), d_X + 8 * j0 * ldx, ldx, backward_only=False, gather=gather)
 
-    def backward_solve_dev(self, d_Z: int, ldz: int, nrhs: int, d_X: int, ldx: int) -> None:
+    def backward_solve_dev(self, d_Z: int, ldz: int, nrhs: int, d_X: int, ldx: int, gather: bool = True) -> None:
         """X = P' L^-T Z (`F.UP \\ z`, src/workspace/backend.jl:281-284: the sampling path) with the factor sharded over the
-        ranks; Z (full, column-major n x nrhs, in ELIMINATION order as CHOLMOD takes it) on every rank, X on rank 0."""
+        ranks; Z (full, column-major n x nrhs, in ELIMINATION order as CHOLMOD takes it) on every rank, X on rank 0 (gather = False:
+        distributed, see solve_dev)."""
         for j0 in range(0, int(nrhs), 64):
-            self._solve_pass(d_Z + 8 * j0 * ldz, ldz, min(64, nrhs - j0), d_X + 8 * j0 * ldx, ldx, backward_only=True)
+            self._solve_pass(d_Z + 8 * j0 * ldz, ldz, min(64, nrhs - j0), d_X + 8 * j0 * ldx, ldx, backward_only=True, gather=gather)
 
-    def _solve_pass(self, d_B: int, ldb: int, nrhs: int, d_X: int, ldx: int, backward_only: bool) -> None:
+    def valid_rows(self) -> np.ndarray:
+        """Boolean mask over the n rows of X in the CALLER's (original) ordering: the rows that are final on THIS rank after a
+        solve with gather = False -- the columns of its own subtrees and of every top front. The masks of all ranks cover every row;
+        the top fronts' rows are valid everywhere."""
+        n = self.be.n
+        elim = np.zeros(n, bool)
+        for o, r0, nr in self._sub_blocks:
+            if o == self.rank:
+                elim[r0:r0 + nr] = True
+        for blocks in self._top_blocks:
+            for _, r0, nr in blocks:
+                elim[r0:r0 + nr] = True
+        perm = np.asarray(self.be.ordering_permutation())      # perm[k] = original index of elimination position k
+        out = np.zeros(n, bool)
+        out[perm] = elim
+        return out
+
+    def _solve_pass(self, d_B: int, ldb: int, nrhs: int, d_X: int, ldx: int, backward_only: bool, gather: bool = True) -> None:
         be = self.be
         if backward_only:
             be.solve_phase_dev(d_B, ldb, nrhs, d_X, ldx, 10)                     # z as is
@@ -241,6 +263,9 @@ class ShardedFactor:
             be.solve_phase_dev(d_B, ldb, nrhs, d_X, ldx, (300 if backward_only else 200) + k)    # backward, top level k
             self._bcast_rows(self._top_blocks[k], nrhs)                          # x of that level's fronts -> everybody
         be.solve_phase_dev(d_B, ldb, nrhs, d_X, ldx, 12 if backward_only else 2)  # own backward
+        if not gather:
+            be.solve_phase_dev(d_B, ldb, nrhs, d_X, ldx, 3)                      # transpose out what this rank holds (valid_rows())
+            return
         self._p2p([(o, 0, 2, r0 * nrhs, nr * nrhs) for o, r0, nr in self._sub_blocks], key=("home", nrhs))     # x of the owned subtrees -> rank 0
         if self.rank == 0:
             be.solve_phase_dev(d_B, ldb, nrhs, d_X, ldx, 3)                      # transpose out

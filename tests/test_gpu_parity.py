@@ -624,6 +624,25 @@ def _shard_gpu_worker(rank, world, port, q, case="2d"):
             if not resid < 1e-10:
                 same = False
                 why.append(f"residual {resid:.3e}")
+        # X left DISTRIBUTED (gather = False: no transfer behind the backward sweep): every rank's valid rows equal the unsharded solution,
+        # and the ranks' masks cover every row (the top fronts' rows on all of them)
+        d_Xd = torch.full_like(d_B, float("nan"))
+        torch.cuda.synchronize()
+        sf.solve_dev(d_B.data_ptr(), Q.shape[0], nrhs, d_Xd.data_ptr(), Q.shape[0], gather=False)
+        d_Xall = torch.zeros_like(d_B)
+        torch.cuda.synchronize()
+        ref.solve_dev(d_B.data_ptr(), Q.shape[0], nrhs, d_Xall.data_ptr(), Q.shape[0])
+        torch.cuda.synchronize()
+        vr = sf.valid_rows()
+        vmask = torch.from_numpy(vr).to(dev)
+        if not same_t(d_Xd[:, vmask], d_Xall[:, vmask]):
+            same = False
+            why.append(f"distributed solve: the valid rows of rank {rank} differ from the unsharded solution by {float((d_Xd[:, vmask] - d_Xall[:, vmask]).abs().max()):.3e}")
+        cover = torch.from_numpy(vr.astype(np.int64))
+        dist.all_reduce(cover)
+        if int(cover.min()) < 1 or int(vr.sum()) >= Q.shape[0]:
+            same = False
+            why.append(f"valid_rows: coverage min {int(cover.min())}, rank {rank} claims {int(vr.sum())} of {Q.shape[0]} rows")
         # backward-only solve (F.UP \\ z, the sampling path) and more than 64 columns (two passes), sharded: same bits as unsharded
         nb = 70 if world == 2 else 5
         Zh = torch.randn((nb, Q.shape[0]), generator=torch.Generator().manual_seed(4), dtype=torch.float64)
