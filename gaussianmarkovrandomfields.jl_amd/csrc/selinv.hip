@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void k_sel_gather(const SelRec *__restrict__ r
         bb[jj] = b;
         src[jj] = (b < cp) ? Zp + (long long)b * ldp : ZBp + (long long)(b - cp) * mp - cp;
     }
-    for (int i = j0 + threadIdx.x; i < m; i += 256) {
+    for (int i = j0 + threadIdx.x; i < m; i += blockDim.x) {
         const int a = rel[i];
         double v[16];
 #pragma unroll
@@ -206,7 +206,10 @@ __global__ __launch_bounds__(256) void k_sel_diag(DevSym S, const int *__restric
 // a front's operand slabs are served faster by eight L2s than by one, at every level of the tree. Also round 5: one kernel per phase
 // (phase 1 then needs 76 + 32 registers and runs four waves per SIMD instead of three): 13.3 -> 14.9-15.0 ms; two / one workgroups per
 // CU (unused dynamic LDS): 14.8 / 20.4 ms. Three waves per SIMD of this tile shape is the optimum.)
-constexpr int WT = 2;
+// WT = 1 (one wave, a 32 x 32 tile) on levels whose fronts have at most 64 columns: with the 64 x 64 tile half of the four waves of such a
+// front's workgroups find no column (with the narrower k_sel_gather workgroups of the same levels: selected inversion of cfg 3 13.3-13.5 ->
+// 13.1 ms on the same box).
+template <int WT>
 __global__ __launch_bounds__(64 * WT * WT) void k_sel_dense(DevSym S, const int *__restrict__ list, int phase,
                                                    const double *__restrict__ L, double *__restrict__ Z,
                                                    const double *__restrict__ ZB, double *__restrict__ Yt,
@@ -446,7 +449,10 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 void launch_sel_gather(hipStream_t st, const SelRec *recs, const DevSym &S, const int *list, int nfronts, int max_trail,
                        const double *Z, double *ZB) {
     if (nfronts <= 0 || max_trail <= 0) return;
-    hipLaunchKernelGGL(k_sel_gather, dim3((unsigned)(cdiv(max_trail, 16) | 1), nfronts), dim3(256), 0, st, recs, S, list, Z, ZB);
+    // (a thread per row of a 16-column strip: levels whose fronts have at most 64 / 128 trailing rows get one / two waves per strip
+    //  instead of four, three of which would find no row)
+    const unsigned nthr = max_trail <= 64 ? 64 : max_trail <= 128 ? 128 : 256;
+    hipLaunchKernelGGL(k_sel_gather, dim3((unsigned)(cdiv(max_trail, 16) | 1), nfronts), dim3(nthr), 0, st, recs, S, list, Z, ZB);
 }
 void launch_sel_symm(hipStream_t st, const DevSym &S, const int *list, int nactive, int kb, int max_rows_below,
                      double *Z, const double *ZB, const double *Yh, const long long *yoff) {
@@ -479,8 +485,13 @@ void launch_sel_dense(hipStream_t st, const DevSym &S, const int *list, int nfro
                            S, list, Z, ZB, Yt, Z21t, woff);
         return;
     }
+    if (max_c <= 64) {
+        const int gx = cdiv(M, 32), gy = cdiv(N, 32);
+        hipLaunchKernelGGL(k_sel_dense<1>, dim3((unsigned)(gx | 1), (unsigned)(gy | 1), nfronts), dim3(64), 0, st, S, list, phase, L, Z, ZB, Yt, Z21t, woff);
+        return;
+    }
     const int gx = cdiv(M, 64), gy = cdiv(N, 64);
-    hipLaunchKernelGGL(k_sel_dense, dim3((unsigned)(gx | 1), (unsigned)(gy | 1), nfronts), dim3(256), 0, st, S, list, phase, L, Z, ZB, Yt, Z21t, woff);
+    hipLaunchKernelGGL(k_sel_dense<2>, dim3((unsigned)(gx | 1), (unsigned)(gy | 1), nfronts), dim3(256), 0, st, S, list, phase, L, Z, ZB, Yt, Z21t, woff);
 }
 
 }  // namespace gmrfx
