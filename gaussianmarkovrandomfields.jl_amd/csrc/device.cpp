@@ -726,13 +726,39 @@ static void parallel_memcpy(double *dst, const double *src, long long count) {
     for (auto &x : th) x.join();
 }
 
+// How a column-major n x nrhs host array is cut into slices of at most `slice_bytes` for the staging ring: whole columns while a
+// column fits a slice (cols_per of them), otherwise ppc row pieces per column of rows_per rows each -- a slot never holds more than
+// slice_bytes / 8 doubles whatever n is (round 5 clamped the RING but not the slot: from n > 2^21 on, slots 6 / 7 lay behind the
+// page-locked buffer). Pure arithmetic, exported as gmrfx_host_io_plan and walked on the CPU (tests/test_cabi.py, tools/sanitize_host.cpp).
+HostIoPlan host_io_plan(long long n, long long nrhs, long long slice_bytes) {
+    HostIoPlan p;
+    const long long slice_doubles = std::max<long long>(1, slice_bytes / (long long)sizeof(double));
+    n = std::max<long long>(n, 1);
+    if (n <= slice_doubles) {
+        p.cols_per = slice_doubles / n; p.ppc = 1; p.rows_per = n;
+        p.slot_doubles = p.cols_per * n;
+        p.nsl = (nrhs + p.cols_per - 1) / p.cols_per;
+    } else {
+        p.cols_per = 1; p.ppc = (n + slice_doubles - 1) / slice_doubles; p.rows_per = (n + p.ppc - 1) / p.ppc;
+        p.slot_doubles = p.rows_per;
+        p.nsl = nrhs * p.ppc;
+    }
+    p.reserve = std::min<long long>(p.nsl, kIoRing) * p.slot_doubles;
+    return p;
+}
+HostIoPlan host_io_plan_dir(long long n, long long nrhs, int download) { return host_io_plan(n, nrhs, download ? kIoSliceBytes / 2 : kIoSliceBytes); }
+// slice k of the plan: columns [j0, j0 + nc) x rows [r0, r0 + nr)
+static inline void host_io_slice(const HostIoPlan &p, long long k, long long n, long long nrhs, long long &j0, long long &nc, long long &r0, long long &nr) {
+    if (p.ppc == 1) { j0 = k * p.cols_per; nc = std::min(p.cols_per, nrhs - j0); r0 = 0; nr = n; }
+    else { j0 = k / p.ppc; nc = 1; r0 = (k % p.ppc) * p.rows_per; nr = std::max<long long>(0, std::min(p.rows_per, n - r0)); }
+}
+
 void Device::host_io_reserve(long long count) {
     if (!stream_io_) {
         HC(hipStreamCreateWithFlags(&stream_io_, hipStreamNonBlocking));
         HC(hipEventCreateWithFlags(&ev_up_, hipEventDisableTiming));
         HC(hipEventCreateWithFlags(&ev_x_, hipEventDisableTiming));
     }
-    count = std::min<long long>(count, kIoRing * (kIoSliceBytes / (long long)sizeof(double)));
     if (count <= h_stage_cap_) return;
     if (h_stage_) { HC(hipStreamSynchronize(stream_io_)); (void)hipHostFree(h_stage_); h_stage_ = nullptr; h_stage_cap_ = 0; }   // (only the copy stream ever touches it)
     HC(hipHostMalloc((void **)&h_stage_, (size_t)count * sizeof(double), hipHostMallocDefault));
@@ -765,10 +791,9 @@ void Device::host_upload(const double *B, long long ldb, long long nrhs, double 
     }
     // column slices; slice k is staged by host thread k mod T into ring slot k mod kIoRing (once the DMA of slice k - kIoRing has
     // left that slot), then handed to the DMA engine
-    const long long cols_per = std::max<long long>(1, kIoSliceBytes / (n * (long long)sizeof(double)));
-    const long long slot_doubles = cols_per * n;
-    host_io_reserve(std::min<long long>(n * nrhs, kIoRing * slot_doubles));
-    const long long nsl = (nrhs + cols_per - 1) / cols_per;
+    const HostIoPlan pl = host_io_plan(n, nrhs, kIoSliceBytes);
+    const long long slot_doubles = pl.slot_doubles, nsl = pl.nsl;
+    host_io_reserve(pl.reserve);
     const int T = (int)std::min<long long>(host_io_threads(), nsl);
     while ((int)ev_ring_.size() < kIoRing) { hipEvent_t e; HC(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ev_ring_.push_back(e); }
     std::vector<std::atomic<int>> posted((size_t)nsl);
@@ -781,16 +806,18 @@ void Device::host_upload(const double *B, long long ldb, long long nrhs, double 
         try {
             HC(hipSetDevice(dev));
             for (long long k = t; k < nsl && !failed.load(); k += T) {
-                const long long j0 = k * cols_per, nc = std::min(cols_per, nrhs - j0);
+                long long j0, nc, r0, nr;
+                host_io_slice(pl, k, n, nrhs, j0, nc, r0, nr);
                 const int slot = (int)(k % kIoRing);
+                if ((slot + 1) * slot_doubles > h_stage_cap_ || nc * nr > slot_doubles) throw std::runtime_error("host_upload: slice leaves the staging ring");
                 if (k >= kIoRing) {         // the slot's previous slice: its copy has been enqueued (posted), now wait until it has run
                     while (!posted[(size_t)(k - kIoRing)].load(std::memory_order_acquire)) { if (failed.load()) return; std::this_thread::yield(); }
                     HC(hipEventSynchronize(ev_ring_[slot]));
                 }
                 double *st = h_stage_ + slot * slot_doubles;
                 for (long long j = 0; j < nc; j++)
-                    std::memcpy(st + j * n, B + (j0 + j) * ldb, (size_t)n * sizeof(double));
-                HC(hipMemcpyAsync(d_dst + j0 * n, st, (size_t)(nc * n) * sizeof(double), hipMemcpyHostToDevice, stream_io_));
+                    std::memcpy(st + j * nr, B + (j0 + j) * ldb + r0, (size_t)nr * sizeof(double));
+                if (nc * nr > 0) HC(hipMemcpyAsync(d_dst + j0 * n + r0, st, (size_t)(nc * nr) * sizeof(double), hipMemcpyHostToDevice, stream_io_));
                 HC(hipEventRecord(ev_ring_[slot], stream_io_));
                 posted[(size_t)k].store(1, std::memory_order_release);
             }
@@ -820,10 +847,9 @@ void Device::host_download(const double *d_src, long long nrhs, double *X, long 
     }
     // slice k: device -> ring slot k mod kIoRing (once slice k - kIoRing has been copied out of it) -> the caller's array; host
     // thread k mod T does all three steps, up to T transfers in flight
-    const long long cols_per = std::max<long long>(1, (kIoSliceBytes / 2) / (n * (long long)sizeof(double)));
-    const long long slot_doubles = cols_per * n;
-    host_io_reserve(std::min<long long>(n * nrhs, kIoRing * slot_doubles));
-    const long long nsl = (nrhs + cols_per - 1) / cols_per;
+    const HostIoPlan pl = host_io_plan(n, nrhs, kIoSliceBytes / 2);
+    const long long slot_doubles = pl.slot_doubles, nsl = pl.nsl;
+    host_io_reserve(pl.reserve);
     while ((int)ev_ring_.size() < kIoRing) { hipEvent_t e; HC(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ev_ring_.push_back(e); }
     std::vector<std::atomic<int>> done((size_t)nsl);
     for (auto &a : done) a.store(0);
@@ -836,16 +862,18 @@ void Device::host_download(const double *d_src, long long nrhs, double *X, long 
         try {
             HC(hipSetDevice(dev));
             for (long long k = t; k < nsl && !failed.load(); k += T) {
-                const long long j0 = k * cols_per, nc = std::min(cols_per, nrhs - j0);
+                long long j0, nc, r0, nr;
+                host_io_slice(pl, k, n, nrhs, j0, nc, r0, nr);
                 const int slot = (int)(k % kIoRing);
+                if ((slot + 1) * slot_doubles > h_stage_cap_ || nc * nr > slot_doubles) throw std::runtime_error("host_download: slice leaves the staging ring");
                 if (k >= kIoRing)
                     while (!done[(size_t)(k - kIoRing)].load(std::memory_order_acquire)) { if (failed.load()) return; std::this_thread::yield(); }
                 double *st = h_stage_ + slot * slot_doubles;
-                HC(hipMemcpyAsync(st, d_src + j0 * n, (size_t)(nc * n) * sizeof(double), hipMemcpyDeviceToHost, stream_io_));
+                if (nc * nr > 0) HC(hipMemcpyAsync(st, d_src + j0 * n + r0, (size_t)(nc * nr) * sizeof(double), hipMemcpyDeviceToHost, stream_io_));
                 HC(hipEventRecord(ev_ring_[slot], stream_io_));
                 HC(hipEventSynchronize(ev_ring_[slot]));
                 for (long long j = 0; j < nc; j++)
-                    std::memcpy(X + (j0 + j) * ldx, st + j * n, (size_t)n * sizeof(double));
+                    std::memcpy(X + (j0 + j) * ldx + r0, st + j * nr, (size_t)nr * sizeof(double));
                 done[(size_t)k].store(1, std::memory_order_release);
             }
         } catch (...) {
@@ -1485,15 +1513,16 @@ void Device::backward(int nr, int ldx, bool y_in_x2, int hi, int lo) {
             if (level_max_trail(L) > mmin) launch_bwd_gemm(stream, ds_, list, nf, L.max_cols, d_L_, d_X_, d_X2_, nr, ldx, -1, 1 << 30, mmin);
             // fronts wider than inv_cap_: from the last block up, t_j -= L[own rows below, block j]' x, x_j = X_jj' t_j
             for (int j = nbk - 1; j >= 0; j--) {
-                const int na = nbk == 1 ? nf : L.active[std::min<size_t>((size_t)j * inv_cap_ / NB, L.active.size() - 2)];
-                if (j + 1 < nbk) launch_bwd_gemm(stream, ds_, list, L.active[(size_t)(j + 1) * inv_cap_ / NB], L.max_cols, d_L_, d_X_, d_X2_, nr, ldx, j, inv_cap_);
+                // (nf: k_bwd_front may have taken the narrow tail of the list above -- block 0's count is "every big front" otherwise)
+                const int na = nbk == 1 ? nf : std::min(nf, L.active[std::min<size_t>((size_t)j * inv_cap_ / NB, L.active.size() - 2)]);
+                if (j + 1 < nbk) launch_bwd_gemm(stream, ds_, list, std::min(nf, L.active[(size_t)(j + 1) * inv_cap_ / NB]), L.max_cols, d_L_, d_X_, d_X2_, nr, ldx, j, inv_cap_);
                 launch_xmul(stream, ds_, list, na, L.max_cols, 1, d_L_, d_X2_, d_X_, nr, ldx, j, inv_cap_);
             }
         } else {
             if (level_max_trail(L) > mmin) launch_bwd_gemm(stream, ds_, list, nf, L.max_cols, d_L_, d_X_, d_X_, nr, ldx, -1, 1 << 30, mmin);
             for (int j = nbk - 1; j >= 0; j--) {
-                const int na = nbk == 1 ? nf : L.active[std::min<size_t>((size_t)j * inv_cap_ / NB, L.active.size() - 2)];
-                if (j + 1 < nbk) launch_bwd_gemm(stream, ds_, list, L.active[(size_t)(j + 1) * inv_cap_ / NB], L.max_cols, d_L_, d_X_, d_X_, nr, ldx, j, inv_cap_);
+                const int na = nbk == 1 ? nf : std::min(nf, L.active[std::min<size_t>((size_t)j * inv_cap_ / NB, L.active.size() - 2)]);
+                if (j + 1 < nbk) launch_bwd_gemm(stream, ds_, list, std::min(nf, L.active[(size_t)(j + 1) * inv_cap_ / NB]), L.max_cols, d_L_, d_X_, d_X_, nr, ldx, j, inv_cap_);
                 launch_xmul(stream, ds_, list, na, L.max_cols, 1, d_L_, d_X_, d_X2_, nr, ldx, j, inv_cap_);
                 // x_j has to be back in X before the block above reads it
                 launch_copy_own(stream, ds_, list, na, L.max_cols, d_X2_, d_X_, nr, ldx, j, inv_cap_);

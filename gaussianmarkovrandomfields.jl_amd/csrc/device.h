@@ -380,4 +380,9 @@ private:
 
 void hip_check(hipError_t e, const char *what);
 
+// slicing of a column-major n x nrhs host array for the page-locked staging ring (device.cpp: host_upload / host_download)
+struct HostIoPlan { long long cols_per = 1, ppc = 1, rows_per = 0, slot_doubles = 0, nsl = 0, reserve = 0; };
+HostIoPlan host_io_plan(long long n, long long nrhs, long long slice_bytes);
+HostIoPlan host_io_plan_dir(long long n, long long nrhs, int download);
+
 }  // namespace gmrfx

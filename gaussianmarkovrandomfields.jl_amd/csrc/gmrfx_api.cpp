@@ -268,6 +268,14 @@ extern "C" int32_t gmrfx_level_times(gmrfx_handle *h, int32_t which, double *ms,
         return GMRFX_OK;
     });
 }
+// The slicing of host_upload (download = 0) / host_download (1) for an n x nrhs array: plan = {columns per slice, row pieces per
+// column, rows per piece, doubles per ring slot, slices, doubles reserved}. No handle, no device: arithmetic only.
+extern "C" int32_t gmrfx_host_io_plan(int64_t n, int64_t nrhs, int32_t download, int64_t *plan) {
+    if (!plan || n < 0 || nrhs < 0) return GMRFX_ERR_INVALID_ARG;
+    const gmrfx::HostIoPlan p = gmrfx::host_io_plan_dir(n, nrhs, download);
+    plan[0] = p.cols_per; plan[1] = p.ppc; plan[2] = p.rows_per; plan[3] = p.slot_doubles; plan[4] = p.nsl; plan[5] = p.reserve;
+    return GMRFX_OK;
+}
 extern "C" int32_t gmrfx_set_stream(gmrfx_handle *h, void *hip_stream, int32_t use_external, int32_t async_phases) {
     return guarded(h, [&]() -> int32_t {
         if (int32_t e = need_device(h, false)) return e;

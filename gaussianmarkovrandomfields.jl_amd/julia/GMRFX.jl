@@ -309,7 +309,10 @@ end
 
 # KL (Vecchia) sparse approximate Cholesky on the GPU (src/kl_cholesky/kl_cholesky.jl:32-55): same contract as the
 # reference method, for a dense Float64 covariance. One task per column: its row indices in descending order.
-function G.sparse_approximate_cholesky!(Θ::Matrix{Float64}, L::SparseMatrixCSC{Float64, Int}; device::Integer = -1)
+# Selected by a trailing `MI355XBackend` argument, like `GMRFWorkspace(Q, MI355XBackend)`: a method on (Matrix{Float64},
+# SparseMatrixCSC{Float64, Int}) alone would REPLACE the reference's own for those types (piracy) and take its AD-transparent
+# generic path away from every caller that merely loads the plug-in.
+function G.sparse_approximate_cholesky!(Θ::Matrix{Float64}, L::SparseMatrixCSC{Float64, Int}, ::Type{MI355XBackend}; device::Integer = -1)
     n = size(L, 2)
     rows = similar(L.rowval)
     for k in 1:n
@@ -381,17 +384,20 @@ G._selinv_diag_impl(cache, ::MI355XCholesky) = get_selinv_diag(_be(cache))
 G._selinv_impl(cache, ::MI355XCholesky) = Symmetric(get_selinv(_be(cache)))
 G._backward_solve_impl(cache, x, ::MI355XCholesky) = backend_backward_solve(_be(cache), x)
 G._backward_solve_impl(cache, Z::Matrix{Float64}, ::MI355XCholesky) = backend_backward_solve(_be(cache), Z)
-# seam-A twin of the batched sampler above (src/gmrf.jl:271-281 draws the columns one by one); any other algorithm keeps
-# Distributions' column loop
-function Distributions._rand!(rng::AbstractRNG, d::G.GMRF, X::AbstractMatrix{<:Real})
-    if d.linsolve_cache.alg isa MI355XCholesky
-        Z = randn!(rng, Matrix{Float64}(undef, size(X, 1), size(X, 2)))
-        X .= G.backward_solve(d.linsolve_cache, Z) .+ d.mean
-    else
-        for j in axes(X, 2)
-            Distributions._rand!(rng, d, view(X, :, j))
-        end
-    end
+# seam-A twin of the batched sampler above (src/gmrf.jl:271-281 draws the columns one by one). Restricted BY DISPATCH to GMRFs whose
+# LinearSolve cache carries this plug-in's algorithm: `GMRF` has its cache type as its sixth parameter (src/gmrf.jl:144-156) and
+# `LinearSolve.LinearCache{TA, Tb, Tu, Tp, Talg, ...}` its algorithm type as its fifth (LinearSolve 2 and 3, the compat range of
+# the reference's Project.toml; checked when the module loads). Every other GMRF keeps Distributions' own matrix method -- the
+# plug-in owns a type in the signature (`MI355XCholesky`), so this is no piracy on Distributions / GaussianMarkovRandomFields.
+let body = Base.unwrap_unionall(LinearSolve.LinearCache)
+    body.parameters[5] === fieldtype(body, :alg) ||
+        error("GMRFX: LinearSolve.LinearCache no longer has its algorithm as fifth type parameter; adjust MI355XLinearCache")
+end
+const MI355XLinearCache = LinearSolve.LinearCache{<:Any, <:Any, <:Any, <:Any, MI355XCholesky}
+const MI355XGMRF = G.GMRF{<:Any, <:Any, <:Any, <:Any, <:Any, <:MI355XLinearCache}
+function Distributions._rand!(rng::AbstractRNG, d::MI355XGMRF, X::AbstractMatrix{<:Real})
+    Z = randn!(rng, Matrix{Float64}(undef, size(X, 1), size(X, 2)))
+    X .= G.backward_solve(d.linsolve_cache, Z) .+ d.mean
     return X
 end
 G._logdet_cov_impl(cache, ::MI355XCholesky) = -compute_logdet(_be(cache))       # note the sign (logdet.jl:30)

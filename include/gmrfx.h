@@ -228,6 +228,15 @@ int32_t gmrfx_shard_rows(const gmrfx_handle *h, int32_t kind, int64_t *nblocks, 
                          int64_t *level);
 int32_t gmrfx_logdet_partial(gmrfx_handle *h, double *out);
 
+/* How the HOST entry points (gmrfx_solve, gmrfx_refactorize_solve, ... with pageable B / X: what `workspace_solve(ws, B::Matrix)`
+ * hands over, src/workspace/gmrf_workspace.jl:207-215) cut a column-major n x nrhs array into slices for the handle's
+ * page-locked staging ring of 8 slots (download = 0: B in, 1: X out). plan[0] columns per slice, [1] row pieces per column
+ * (> 1 once a column exceeds a slice), [2] rows per piece, [3] doubles per ring slot, [4] slices, [5] doubles reserved
+ * (= min(slices, 8) x slot). Slice k covers columns [k plan[0], ...) when plan[1] == 1, else column k / plan[1], rows
+ * [(k mod plan[1]) plan[2], ...). Arithmetic only (no handle, no device) -- exported so that the invariant "every slice fits
+ * its slot, the slices tile the array" is checked on the CPU for sizes no test box holds. */
+int32_t gmrfx_host_io_plan(int64_t n, int64_t nrhs, int32_t download, int64_t *plan /* 6 */);
+
 /* Q X = B. Replaces `F \ b` / `F \ B`: src/workspace/backend.jl:191-209. */
 int32_t gmrfx_solve(gmrfx_handle *h, const double *B, int64_t ldb, int64_t nrhs, double *X, int64_t ldx);
 int32_t gmrfx_solve_dev(gmrfx_handle *h, const double *d_B, int64_t ldb, int64_t nrhs, double *d_X, int64_t ldx);

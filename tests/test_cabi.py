@@ -75,3 +75,32 @@ def test_kl_cholesky_validates_and_fails_loudly_without_a_gpu():
     if not torch.cuda.is_available():
         with pytest.raises(gmrfx.GmrfxError):
             klchol.sparse_approximate_cholesky_inplace(np.eye(3), sp.csc_matrix(np.tril(np.ones((3, 3)))))
+
+
+@pytest.mark.parametrize("download", [0, 1])
+def test_host_io_slices_fit_their_ring_slot_and_tile_the_array(download):
+    # the staging ring of the host entry points (device.cpp host_upload / host_download): every slice must fit its slot of the
+    # page-locked buffer whatever n is -- round 5 sized the slot by n once a column exceeded a slice (n > 2^21: a 1500 x 1500 grid,
+    # a 130^3 mesh) but clamped the ring to 128 MB, so slots 6 / 7 lay behind the allocation. Arithmetic only: no device needed.
+    L = _lib.lib()
+    ring = 8
+    for n, nrhs in [(1, 1), (9, 3), (10 ** 6, 64), (2 ** 21, 64), (2 ** 21 + 1, 64), (2_250_000, 8), (2_197_000, 70), (10 ** 7, 5),
+                    (3 * 2 ** 21 + 5, 9), (2 ** 20 + 3, 1), (123_457, 300)]:
+        plan = np.zeros(6, np.int64)
+        assert L.gmrfx_host_io_plan(n, nrhs, download, _lib.ptr(plan)) == 0
+        cols_per, ppc, rows_per, slot, nsl, reserve = plan.tolist()
+        slice_doubles = (16 << 20) // 8 // (2 if download else 1)
+        assert slot <= max(slice_doubles, 1) and reserve == min(nsl, ring) * slot and reserve <= ring * slice_doubles
+        covered = 0
+        for k in range(nsl):
+            if ppc == 1:
+                j0 = k * cols_per
+                nc, r0, nr = min(cols_per, nrhs - j0), 0, n
+            else:
+                j0, nc = k // ppc, 1
+                r0 = (k % ppc) * rows_per
+                nr = max(0, min(rows_per, n - r0))
+            assert 0 <= j0 and j0 + nc <= nrhs and 0 <= r0 and r0 + nr <= n and nc >= 1
+            assert nc * nr <= slot and ((k % ring) + 1) * slot <= reserve
+            covered += nc * nr
+        assert covered == n * nrhs

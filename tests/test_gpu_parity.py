@@ -1050,6 +1050,34 @@ def test_backward_step_one_workgroup_per_front_equals_two_launches(name, monkeyp
     assert np.array_equal(one.backend_solve(B), one.backend_solve(B))       # bit-reproducible
 
 
+@pytest.mark.parametrize("cap", ["64", "128"])
+def test_one_workgroup_backward_step_beside_blocked_substitution(cap, monkeypatch):
+    """A level that has BOTH fronts wider than the inverse cap (blocked substitution, block 0's list = 'every big front') and a
+    narrow tail k_bwd_front has already finished: the blocked loop must not run over that tail again (round-5 advisor finding:
+    na = L.active[0] ignored the fronts taken off the list -- x overwritten with L11^-T of the already final x). Passes wider than
+    16 columns, y in the second buffer (solve) and in place (backward-only), against the oracle."""
+    monkeypatch.setenv("GMRFX_BWD_FRONT", "1")
+    monkeypatch.setenv("GMRFX_INV_CAP", cap)
+    rng = np.random.default_rng(100 + int(cap))
+    m3 = spde.grid_mesh_3d(13, 12, 11)
+    # block-diagonal: one dense 330-column front beside thirty dense 100-column fronts (too many rows for the fused small-front
+    # kernels, too wide for the sweep tasks, narrow enough for k_bwd_front at cap 128) -- wide and narrow on one level
+    wide = np.cov(rng.standard_normal((330, 900))) + np.eye(330)
+    blocks = [wide] + [np.cov(rng.standard_normal((100, 300))) + np.eye(100) for _ in range(30)]
+    cases = [(sp.csc_matrix(sp.block_diag(blocks)), {}),
+             (sp.csc_matrix(spde.matern_precision(spde.grid_mesh_2d(70, 66, jitter=0.2), 0, 0.3)), {}),
+             (sp.csc_matrix(spde.matern_precision(m3, 0, 0.5)), {"coords": m3.points})]
+    for Q, kw in cases:
+        be = gmrfx.MI355XBackend(Q, **kw)
+        F = orc.OracleFactor(Q, be.ordering_permutation())
+        n = Q.shape[0]
+        for nrhs in (17, 64, 70):
+            B = rng.standard_normal((n, nrhs))
+            assert relerr(be.backend_solve(B), F.solve(B)) < 1e-10
+            assert relerr(be.backend_backward_solve(B), F.backward_solve(B)) < 1e-10
+        be.close()
+
+
 @pytest.mark.parametrize("name", ["matern64_coords", "cfg1_alpha3_65x65", "matern3d_10", "rand400"])
 def test_tile_records_and_plain_grid_give_the_same_bits(name, monkeypatch):
     """The record-driven kernels (contribution-block SYRK and forward update: one self-contained record per tile, handed

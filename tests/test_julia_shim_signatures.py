@@ -193,10 +193,84 @@ def test_batched_rand_is_a_real_method_on_both_seams():
     assert m, "no batched _rand! for WorkspaceGMRF on MI355XBackend"
     body = m.group(1)
     assert "randn!(rng" in body and "backend_backward_solve(d.workspace.backend, Z)" in body and "ci.L_c \\" in body and "d.mean" in body
-    m = re.search(r"function Distributions\._rand!\(rng::AbstractRNG,\s*d::G\.GMRF,\s*X::AbstractMatrix\{<:Real\}\)(.*?)\nend\n", code, re.S)
-    assert m and "MI355XCholesky" in m.group(1) and "G.backward_solve(d.linsolve_cache, Z)" in m.group(1)
+    # (round 6: restricted by dispatch to GMRFs whose cache carries MI355XCholesky -- no method on a bare G.GMRF any more)
+    m = re.search(r"function Distributions\._rand!\(rng::AbstractRNG,\s*d::MI355XGMRF,\s*X::AbstractMatrix\{<:Real\}\)(.*?)\nend\n", code, re.S)
+    assert m and "G.backward_solve(d.linsolve_cache, Z)" in m.group(1) and "randn!(rng" in m.group(1) and "d.mean" in m.group(1)
     assert re.search(r"G\._backward_solve_impl\(cache,\s*Z::Matrix\{Float64\},\s*::MI355XCholesky\)", code)
     assert re.search(r"function backend_backward_solve\(b::MI355XBackend,\s*Zm::Matrix\{Float64\}\)", code)
     assert len(re.findall(r"info\[\] > 0 && throw\(PosDefException", code)) >= 1
     ext = "\n".join(l for l in open(JL_EXT).read().splitlines() if not l.lstrip().startswith("#"))
     assert "info[] > 0 && throw(PosDefException" in ext
+
+
+# ---- round 6: no type piracy, and every foreign name the shim extends exists ------------------------------------------------
+OWNED = ("MI355XBackend", "MI355XCholesky", "MI355XCacheval", "MI355XGMRF", "MI355XLinearCache", "Handle", "Opts")
+FOREIGN = ("G", "Distributions", "LinearSolve", "SciMLBase", "Base", "LinearAlgebra", "SparseArrays")
+
+
+def foreign_method_definitions(path):
+    """every `function M.f(sig...)` / `M.f(sig...) = ...` with M a foreign module, as (module, name, signature text, line)"""
+    code = "\n".join("" if l.lstrip().startswith("#") else l for l in open(path).read().splitlines())
+    out = []
+    for m in re.finditer(r"^(?:function\s+)?((?:%s))\.([\w!]+)\(" % "|".join(FOREIGN), code, flags=re.M):
+        start = m.end() - 1
+        end = _balanced(code, start)
+        rest = code[end:end + 40].lstrip()
+        is_def = m.group(0).startswith("function") or rest.startswith("=") and not rest.startswith("==") or rest.startswith("where")
+        if not is_def:
+            continue
+        out.append((m.group(1), m.group(2), code[start + 1:end - 1], f"{os.path.basename(path)}:{code.count(chr(10), 0, m.start()) + 1}"))
+    return out
+
+
+def test_no_type_piracy_every_foreign_method_carries_an_owned_type():
+    """A method added to a function of ANOTHER package must dispatch on a type this plug-in owns, otherwise loading the plug-in
+    changes behaviour for callers that never asked for it (round-5 findings: `Distributions._rand!(rng, d::G.GMRF, X)` replaced the
+    matrix sampler of every GMRF; `G.sparse_approximate_cholesky!(::Matrix{Float64}, ::SparseMatrixCSC{Float64, Int})` replaced the
+    reference's own method). Aliases count through their definition: MI355XGMRF must bottom out in MI355XCholesky."""
+    defs = foreign_method_definitions(JL) + foreign_method_definitions(JL_EXT)
+    assert len(defs) >= 15
+    for mod, name, sig, line in defs:
+        assert any(re.search(r"\b%s\b" % t, sig) for t in OWNED + ("ROCArray", "ROCVector", "ROCMatrix")) or \
+            (os.path.basename(JL_EXT) in line and "MI355X" in sig), f"{line}: {mod}.{name}({sig}) dispatches on foreign types only (type piracy)"
+    src = open(JL).read()
+    m = re.search(r"const MI355XLinearCache = (.*)", src)
+    assert m and "MI355XCholesky" in m.group(1) and "LinearSolve.LinearCache{" in m.group(1)
+    # the algorithm is the FIFTH parameter of LinearCache{TA, Tb, Tu, Tp, Talg, ...}: four wildcards in front of it
+    assert m.group(1).split("LinearSolve.LinearCache{")[1].split("MI355XCholesky")[0].count("<:Any") == 4
+    m = re.search(r"const MI355XGMRF = (.*)", src)
+    # GMRF{T, VMean, VInfo, PrecisionMap, QSqrt, Cache, RBMCStrat} (reference src/gmrf.jl:144-156): the cache is the SIXTH
+    assert m and "G.GMRF{" in m.group(1) and m.group(1).split("G.GMRF{")[1].split("<:MI355XLinearCache")[0].count("<:Any") == 5
+    assert "body.parameters[5] === fieldtype(body, :alg)" in src, "the load-time guard for LinearCache's parameter order is gone"
+    code = "\n".join(l for l in src.splitlines() if not l.lstrip().startswith("#"))
+    assert not re.search(r"_rand!\(rng::AbstractRNG,\s*d::G\.GMRF\s*,", code), "the unrestricted GMRF sampler is back"
+
+
+REF = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src")), reason="the reference tree is not on this box (GPU boxes)")
+def test_every_reference_name_the_shim_extends_or_calls_exists_in_the_reference():
+    """grep-level: every `G.name` the shim touches (methods it adds, functions it calls, types it dispatches on) is defined in
+    /root/reference/src or ext -- a renamed hook would otherwise only surface when somebody loads the plug-in under Julia"""
+    ref = ""
+    for base in ("src", "ext"):
+        for dp, _, fs in os.walk(os.path.join(REF, base)):
+            for f in fs:
+                if f.endswith(".jl"):
+                    ref += open(os.path.join(dp, f), errors="replace").read() + "\n"
+    names = set()
+    for path in (JL, JL_EXT):
+        code = "\n".join("" if l.lstrip().startswith("#") else l for l in open(path).read().splitlines())
+        names |= set(re.findall(r"\bG\.([A-Za-z_][\w!]*)", code))
+    assert len(names) >= 15
+    for nm in sorted(names):
+        e = re.escape(nm)
+        defined = re.search(r"(?:^|\n)\s*(?:function|struct|mutable struct|abstract type|const|macro)\s+(?:\w+\.)?%s(?![\w!])" % e, ref) or \
+            re.search(r"(?:^|\n)\s*(?:\w+\.)?%s\([^\n]*\)\s*(?:where[^\n=]*)?=" % e, ref) or \
+            re.search(r"(?:^|\n)\s*(?:@kwdef\s+)?(?:mutable\s+)?struct\s+%s(?![\w!])" % e, ref)
+        assert defined, f"G.{nm} is used by the shim but not defined anywhere under {REF}/src or ext"
+    # the GMRF struct still has its cache as sixth type parameter
+    m = re.search(r"struct GMRF\{(.*?)\}\s*<:", ref, re.S)
+    params = [p.strip().split("<:")[0].strip() for p in _split_top(m.group(1).replace("\n", " "))]
+    assert params[5] == "Cache" and len(params) == 7, params
