@@ -34,6 +34,87 @@ FP64_MFMA_MEASURED_TF = 75.7   # sustained v_mfma_f64_16x16x4_f64 with >= 2 issu
                                # 128x128-tile DGEMM reaches 54 (tools/micro/dgemm_mfma.hip)
 
 
+LAUNCH_FLOOR_US = 2.0      # what ONE dependent launch costs on the GPU side whatever it does: 0.9 us launch-to-launch boundary (a chain
+                           # of dependent kernels that each spin 5 / 10 us costs 5.89 / 10.88 us per launch, stream or graph alike) +
+                           # the ~1 us cold start of a one-round-trip kernel (tools/micro/launch_floor.hip, profiles/r04_barrier_lat.txt)
+COPY_PEAK_GUIDE_GBS = 6290.0   # MI355X_MICROARCH.md: achievable HBM copy rate; the live figure of this box is measured below
+
+
+def measure_copy_peak(dev, nbytes=1 << 30):
+    """Device-to-device copy rate of this box, read + write bytes over HIP-event time (the sweep's roofline is quoted
+    against peak AND against what a plain copy reaches here)."""
+    import torch
+    a = torch.empty(nbytes // 8, dtype=torch.float64, device=dev).normal_()
+    b = torch.empty_like(a)
+    for _ in range(2):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(5):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    del a, b
+    return 2.0 * nbytes / (ms * 1e-3) / 1e9
+
+
+def sweep_model_bound(be, nrhs, copy_gbs, floor_us=LAUNCH_FLOOR_US, small_rows=64):
+    """A defensible CEILING for the multifrontal triangular sweeps as they are scheduled here -- the number that belongs next to the
+    70 %-of-HBM-peak target of the north star. For the sweep-task launch and for every tree level, forward and backward:
+        (algorithmic bytes + the W / x hand-off the level moves through HBM) / copy peak  +  launches x per-launch floor.
+    Algorithmic bytes of a front: panel 8 r c, row list 4 r, own rows of X read and written 16 c nrhs. Hand-off: the
+    update vector of a front, 8 nrhs (r - c) bytes, is written once by the front and read once by its parent's level in the forward
+    sweep (fronts INSIDE a sweep task hand off in LDS: only task roots write); in the backward sweep a front gathers its r - c trailing
+    rows of x. Launches per level as device.cpp enqueues them: forward = one per non-empty small-front class + assemble, triangular
+    product, update for the big fronts; backward = small classes + one launch (k_bwd_front) or two. The bound concedes the hand-off
+    (a supernodal sweep WITHOUT per-front update vectors would not move it) and the level-by-level launch structure; what is left
+    between it and the measured time is the kernels'."""
+    import numpy as np
+    sy = be.symbolic()
+    c = np.diff(sy.super_first).astype(np.float64)
+    r = np.diff(sy.row_ptr).astype(np.float64)
+    m = r - c
+    lev = np.asarray(sy.level)
+    par = np.asarray(sy.super_parent)
+    _, tf, tl, _ = be.sweep_tasks()
+    in_task = np.zeros(len(c), bool)
+    for a, b in zip(tf, tl):
+        in_task[a:b + 1] = True
+    roots = np.zeros(len(c), bool)
+    roots[np.asarray(tl, dtype=np.int64)] = True
+    alg = 8 * r * c + 4 * r + 16 * c * nrhs
+    hand = 8.0 * nrhs * m
+    small = (c <= 64) & (r <= small_rows)
+    cls48 = small & (r <= 48)
+    fwd_b = bwd_b = 0.0
+    fwd_l = bwd_l = 0
+    rows = []
+    if in_task.any():
+        fb = float(alg[in_task].sum() + hand[roots].sum())          # task roots write their update vector
+        bb = float(alg[in_task].sum() + hand[roots].sum())          # ... and gather their trailing x
+        fwd_b += fb; bwd_b += bb; fwd_l += 1; bwd_l += 1
+        rows.append({"level": -1, "fronts": int(in_task.sum()), "fwd_bytes": fb, "bwd_bytes": bb, "fwd_launches": 1, "bwd_launches": 1})
+    for lv in range(int(lev.max()) + 1):
+        sel = (~in_task) & (lev == lv)
+        if not sel.any():
+            continue
+        kid = np.isin(par, np.nonzero(sel)[0]) & (par >= 0) & (~in_task | roots)
+        fb = float(alg[sel].sum() + hand[sel].sum() + hand[kid].sum())
+        bb = float(alg[sel].sum() + hand[sel].sum())
+        ncls = int((sel & cls48).any()) + int((sel & small & ~cls48).any())
+        big = sel & ~small
+        fl = ncls + (3 if big.any() else 0)
+        bl = ncls + (0 if not big.any() else (1 if (c[big] <= 128).all() else 2))
+        fwd_b += fb; bwd_b += bb; fwd_l += fl; bwd_l += bl
+        rows.append({"level": lv, "fronts": int(sel.sum()), "fwd_bytes": fb, "bwd_bytes": bb, "fwd_launches": fl, "bwd_launches": bl})
+    ms = lambda by, nl: by / (copy_gbs * 1e9) * 1e3 + nl * floor_us * 1e-3
+    return {"fwd_ms": ms(fwd_b, fwd_l), "bwd_ms": ms(bwd_b, bwd_l), "fwd_bytes": fwd_b, "bwd_bytes": bwd_b, "fwd_launches": fwd_l,
+            "bwd_launches": bwd_l, "handoff_bytes_fwd": float(fwd_b - alg.sum()), "handoff_bytes_bwd": float(bwd_b - alg.sum()),
+            "levels": rows}
+
+
 def cholmod_reference(Q, perm, Bn, workdir):
     """The reference's own CPU path (Julia + CHOLMOD) when a `julia` binary exists on this box: bench/cholmod_baseline.jl
     on the same Q / permutation / right-hand sides. Returns its JSON object, or a note that it is unavailable."""
@@ -146,27 +227,44 @@ def bench_sharded(args, Q, mesh, dist, rank, world, local_rank, steps=None, warm
     d_X = torch.zeros_like(d_B)
     torch.cuda.synchronize()     # torch's fill runs on torch's stream; the library's streams do not wait for it
     sf = shard.ShardedFactor(Q, dist, device=local_rank, coords=mesh.points)
+    # B is ROW-SHARDED: a rank only holds the rows it reads (shard.needed_rows(): its subtrees' and its own top fronts'; the masks
+    # partition the rows), the rest of its buffer is zeroed -- nothing of B is replicated over the ranks
+    need = torch.from_numpy(sf.needed_rows()).to(dev)
+    d_B[:, ~need] = 0.0
+    torch.cuda.synchronize()
 
-    def step():
+    def step(gather):
         sf.refactorize_dev(d_nz.data_ptr(), check=False)                   # (the pivot report rides with logdet's host round trip)
-        # X stays DISTRIBUTED in the timed step (every rank's valid rows of its own d_X: shard.valid_rows()): the reference's callers reduce
-        # X further (mean, variances, samples) and never need it on one rank; the gather -- 7/8 of n x nrhs doubles into rank 0's links --
-        # is done ONCE behind the timed region for the residual check (--gather-x puts it back into every step)
-        sf.solve_dev(d_B.data_ptr(), n, args.nrhs, d_X.data_ptr(), n, gather=bool(getattr(args, "gather_x", False)))
+        sf.solve_dev(d_B.data_ptr(), n, args.nrhs, d_X.data_ptr(), n, gather=gather)
         sf.logdet()                                                         # all-reduce of the ranks' partial sums (config 2: "+ logdet")
         return sf.last_info
 
+    def timed(gather, k):
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            inf = step(gather)
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if args.rehearse else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t, inf
+
+    # HEADLINE = the step that does the single-GPU step's work: refactorise + solve with ALL of X delivered on rank 0 + logdet
+    # (round 5 timed the distributed-X form only: less work than the N = 1 line and than earlier rounds -- advisor finding). The
+    # distributed-X form (every rank keeps the rows shard.valid_rows() names; the reference's callers reduce X further) is timed
+    # right behind it and reported beside it, never as `value`. --gather-x is kept for compatibility (it is the default now).
     for _ in range(warmup):
-        step()
-    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        info = step()
-    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if args.rehearse else dev)
-    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        step(True)
+    el, info = timed(True, steps)
+    for _ in range(min(warmup, 2)):
+        step(False)
+    el_dist, _ = timed(False, steps)
     sf.solve_dev(d_B.data_ptr(), n, args.nrhs, d_X.data_ptr(), n, gather=True)      # (untimed: all of X on rank 0 for the check)
     torch.cuda.synchronize()
+    # how many ranks the collective library really spans: a device all-reduce of ones (RCCL unless --rehearse)
+    ones = torch.ones(1, dtype=torch.float64, device="cpu" if args.rehearse else dev)
+    dist.all_reduce(ones)
+    rccl_ranks = int(round(float(ones.item())))
     ld = sf.logdet()
     st = sf.be.stats()
     mem = torch.tensor([st["bytes_device_total"], st["bytes_factor"]], dtype=torch.float64, device="cpu" if args.rehearse else dev)
@@ -191,7 +289,10 @@ def bench_sharded(args, Q, mesh, dist, rank, world, local_rank, steps=None, warm
                "plan": {"top_fronts": plan["top_fronts"], "cross_rank_edges": sf.info["n_edges"], "top_levels": sf.K, **bounds},
                "per_rank_hbm_bytes": {"max_total": float(mem_max[0]), "max_factor_panels": float(mem_max[1]), "sum_factor_panels": float(mem_sum[1])},
                "exchange": "gloo + host staging (rehearsal)" if args.rehearse else "RCCL point-to-point (batch_isend_irecv) + broadcast + all-reduce over xGMI, stream-ordered (no host synchronisation between phases)",
-               "x": "gathered on rank 0 in every step" if getattr(args, "gather_x", False) else "left distributed in the timed steps (shard.valid_rows() per rank); gathered once, untimed, for the check",
+               "x": "gathered on rank 0 in every timed step (the headline: the same work as the N = 1 line)",
+               "ms_per_step_x_distributed": 1e3 * float(el_dist.item()) / steps, "value_x_distributed": n / (float(el_dist.item()) / steps),
+               "b": "row-sharded: every rank holds the rows shard.needed_rows() names, zeros elsewhere",
+               "rccl_ranks": rccl_ranks, "collective_backend": dist.get_backend(), "world_size": dist.get_world_size(),
                "check": {"logdet": ld, "rel_residual": resid, "info": info}}
     dist.barrier()
     sf.close()
@@ -223,7 +324,9 @@ def bench_cfg4_sharded(args, dist, rank, world, local_rank):
         return {"status": f"skipped: a rank's part ({need / 1e9:.0f} GB predicted on rank {rank}) does not fit its GPU ({free / 1e9:.0f} GB free)"} if rank == 0 else None
     level_ms = None
     try:
-        with open(os.path.join(ROOT, "profiles", f"r03_level_ms_cfg4_{G}cubed.json")) as fh:
+        import glob
+        cand = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_level_ms_cfg4_{G}cubed.json")))     # newest round last
+        with open(cand[-1]) as fh:
             level_ms = json.load(fh)                   # measured on one GPU (tools/level_times.py cfg4): the unsharded problem
     except Exception:                                  # needs 226 GB and cannot sit next to the sharded one
         level_ms = None
@@ -563,10 +666,18 @@ def main():
         med = lambda v: float(np.median(v))
         mf, ms_, mfw, mbw = med(t_factor), med(t_solve), med(t_fwd), med(t_bwd)
         # algorithmic bytes of one triangular sweep: 8 nnz(L) + 4 sum_s r_s + 2*8*n*nrhs
+        # (round 6: the TRUE nnz(L) -- amalgamation zeros and panel padding are this implementation's bytes, not the algorithm's; the
+        #  figure on the stored entries, which rounds 1-5 quoted, stays beside it as frac_on_stored_entries)
         nnzl = st["nnz_l_stored"]
-        bytes_sweep = 8.0 * nnzl + 4.0 * st["sum_rows"] + 16.0 * n * args.nrhs
+        bytes_sweep = 8.0 * st["nnz_l"] + 4.0 * st["sum_rows"] + 16.0 * n * args.nrhs
+        bytes_sweep_stored = 8.0 * nnzl + 4.0 * st["sum_rows"] + 16.0 * n * args.nrhs
         sweep_ms = 0.5 * (mfw + mbw)
         sweep_gbs = bytes_sweep / (sweep_ms * 1e-3) / 1e9
+        copy_gbs = measure_copy_peak(dev)
+        try:
+            smb = sweep_model_bound(be, args.nrhs, copy_gbs)
+        except Exception as ex:        # (the bound is a report, never a reason to lose the line)
+            smb = {"error": repr(ex)}
         factor_tf = st["factor_flops"] / (mf * 1e-3) / 1e12
         # HBM traffic from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
         # runs, gfx950 FETCH_SIZE x2 correction): only valid for the workload they were collected on
@@ -617,7 +728,25 @@ def main():
                       "frac": sweep_gbs / HBM_PEAK_GBS,
                       "traffic": 0.5 * (pmc["sweep_forward"]["total_bytes"] + pmc["sweep_backward"]["total_bytes"]) if pmc else None,
                       "kernel": "triangular sweep (mean of forward and backward, all launches)", "ms": sweep_ms, "bytes": bytes_sweep,
-                      "note": "traffic: " + pmc_note}
+                      "frac_on_stored_entries": bytes_sweep_stored / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      "copy_peak_measured": copy_gbs, "frac_of_copy_peak": sweep_gbs / copy_gbs,
+                      "note": "bytes = 8 nnz(L) [true fill] + 4 sum r_s + 16 n nrhs (SURVEY 8d); traffic: " + pmc_note}
+        if "error" not in smb:
+            roof_sweep.update({
+                "model_bound_ms": {"fwd": smb["fwd_ms"], "bwd": smb["bwd_ms"], "mean": 0.5 * (smb["fwd_ms"] + smb["bwd_ms"])},
+                "frac_of_model_bound": 0.5 * (smb["fwd_ms"] + smb["bwd_ms"]) / sweep_ms,
+                "frac_of_model_bound_fwd": smb["fwd_ms"] / mfw, "frac_of_model_bound_bwd": smb["bwd_ms"] / mbw,
+                "model_bound": {"copy_peak_gbs": copy_gbs, "launch_floor_us": LAUNCH_FLOOR_US, "fwd_launches": smb["fwd_launches"],
+                                "bwd_launches": smb["bwd_launches"], "fwd_bytes": smb["fwd_bytes"], "bwd_bytes": smb["bwd_bytes"],
+                                "handoff_bytes_fwd": smb["handoff_bytes_fwd"], "handoff_bytes_bwd": smb["handoff_bytes_bwd"],
+                                # what the schedule itself forfeits of the 70 % target: the algorithmic bytes over the bound's time
+                                "ceiling_frac_of_hbm_peak": bytes_sweep / (0.5 * (smb["fwd_ms"] + smb["bwd_ms"]) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "note": "sum over the task launch and every level of (algorithmic + hand-off bytes) / measured copy peak "
+                                        "+ launches x floor (bench.py sweep_model_bound); ceiling_frac = the roofline fraction a sweep "
+                                        "running AT this bound would show"}})
+        else:
+            roof_sweep["model_bound_ms"] = None
+            roof_sweep["model_bound_error"] = smb["error"]
         if roof_sweep["traffic"]:
             # the bytes the sweeps really move (PMC), W / x hand-off between the levels included, against the same peak
             roof_sweep["frac_of_peak_with_measured_traffic"] = roof_sweep["traffic"] / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS

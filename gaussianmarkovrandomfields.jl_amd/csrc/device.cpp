@@ -170,7 +170,7 @@ void Device::upload(const Symbolic &S) {
                 t.zp = (long long)S.panelptr[p]; t.zbp = (long long)S.zbptr[p];
                 t.cp = S.ncols(p); t.mp = S.nrows(p) - S.ncols(p); t.ldp = (int)S.ld[p];
             }
-            t.foreign = (S.shard_world > 1 && p >= 0 && S.owner[p] != S.shard_rank) ? 1 : 0;   // (= DevSym::foreign_parent)
+            t.foreign = (S.shard_plan && p >= 0 && S.owner[p] != S.shard_rank) ? 1 : 0;   // (= DevSym::foreign_parent)
             sr[(size_t)s] = t;
         }
         const SelRec *sp; up(sp, sr); d_selrec_ = sp;
@@ -254,7 +254,7 @@ void Device::upload(const Symbolic &S) {
     tmp64 = conv<long long>(S.diagoff); up(lp, tmp64); ds_.diagoff = lp; HC(hipStreamSynchronize(stream));
     up(ip, S.perm); ds_.perm = ip;
     up(ip, S.iperm); d_iperm_ = ip;
-    if (S.shard_world > 1) {
+    if (S.shard_plan) {
         std::vector<unsigned char> own(S.n, 0);
         for (i32 s = 0; s < ns; s++) {
             const bool mine = S.owner[s] == S.shard_rank;
@@ -453,7 +453,7 @@ void Device::upload(const Symbolic &S) {
     {
         std::vector<int> il;
         for (i32 s = 0; s < ns; s++) {
-            const bool mine = S.shard_world <= 1 || S.owner[s] == S.shard_rank;
+            const bool mine = !S.shard_plan || S.owner[s] == S.shard_rank;
             if (S.ncols(s) > NB && mine) il.push_back(s);     // sharded handles only hold the panels they factored
         }
         std::sort(il.begin(), il.end(), [&](int a, int b) { return S.ncols(a) != S.ncols(b) ? S.ncols(a) > S.ncols(b) : a < b; });
@@ -1208,7 +1208,7 @@ void Device::refactorize(const double *nzval, bool on_device) {
 
 void Device::refactorize_phase(const double *d_nzval, int phase) {
     HC(hipSetDevice(device));
-    if (!sharded()) throw std::invalid_argument("gmrfx_refactorize_phase needs a handle created with shard_world > 1");
+    if (!sharded()) throw std::invalid_argument("gmrfx_refactorize_phase needs a sharded handle (shard_world > 1, or shard_min_top > 0)");
     const int nl = (int)levels_.size();
     const int split = std::min<int>(S_->shard_level, nl);
     info_cached_ = false;
@@ -1564,7 +1564,7 @@ int Device::level_times(int phase, double *out, int cap) {
 
 void Device::solve_phase(const double *d_B, long long ldb, long long nrhs, double *d_Xout, long long ldx_out, int phase) {
     HC(hipSetDevice(device));
-    if (!sharded()) throw std::invalid_argument("gmrfx_solve_phase needs a handle created with shard_world > 1");
+    if (!sharded()) throw std::invalid_argument("gmrfx_solve_phase needs a sharded handle (shard_world > 1, or shard_min_top > 0)");
     if (nrhs <= 0 || nrhs > 64) throw std::invalid_argument("sharded solves take 1..64 right-hand sides per call");
     const int nr = (int)nrhs, ldx = nr, nl = (int)levels_.size();
     const int split = std::min<int>(S_->shard_level, nl);
@@ -1902,7 +1902,7 @@ void Device::selinv_compute() {
 
 void Device::selinv_phase(int what, int hi, int lo) {
     HC(hipSetDevice(device));
-    if (!sharded()) throw std::invalid_argument("gmrfx_selinv_phase needs a handle created with shard_world > 1");
+    if (!sharded()) throw std::invalid_argument("gmrfx_selinv_phase needs a sharded handle (shard_world > 1, or shard_min_top > 0)");
     const int nl = (int)levels_.size();
     if (what != 0 && !selinv_begun_)       // (phases 1-3 launch kernels on the workspaces phase 0 allocates)
         throw std::invalid_argument("selinv phase 1, 2 or 3 before phase 0 (begin) since the last refactorisation");

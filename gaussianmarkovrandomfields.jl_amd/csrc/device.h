@@ -187,7 +187,7 @@ public:
     void ensure_rhs(long long nrhs) { ensure_rhs_capacity(nrhs); }
     double *cb_arena() { return d_cb_; }
     double *factor_panels() { return d_L_; }
-    bool sharded() const { return S_ && S_->shard_world > 1; }
+    bool sharded() const { return S_ && S_->shard_plan; }
     // B: column-major n x nrhs (original ordering); mode 0: full solve, 1: backward only (P' L^-T Z)
     void solve(const double *B, long long ldb, long long nrhs, double *X, long long ldx, bool on_device, int mode);
     double logdet();

@@ -88,7 +88,8 @@ extern "C" int32_t gmrfx_create(int64_t n, const int64_t *colptr, const int64_t 
         if (const char *e = std::getenv("GMRFX_SWEEP_TASK_ROWS")) so.sweep_task_rows = std::atoi(e);   // 0 disables sweep tasks
         if (const char *e = std::getenv("GMRFX_MERGE_WIDE")) so.merge_wide = std::atoi(e);   // widest child with siblings that may still be merged into its parent
         if (const char *e = std::getenv("GMRFX_TOP_BY_DEPTH")) so.top_by_depth = std::atoi(e);   // top levels levelled by depth below the root (0: none)
-        if (h->opts.shard_world > 1) {
+        if (h->opts.shard_world > 1 || (h->opts.shard_world == 1 && h->opts.shard_min_top > 0)) {
+            so.shard_min_top = std::max(0, h->opts.shard_min_top);
             if (h->opts.shard_rank < 0 || h->opts.shard_rank >= h->opts.shard_world) throw std::invalid_argument("shard_rank out of range");
             so.shard_rank = h->opts.shard_rank;
             so.shard_world = h->opts.shard_world;
@@ -505,7 +506,7 @@ static void build_zpattern(gmrfx_handle *h) {
             for (i32 i = j; i < r; i++) {
                 const i32 a = S.perm[rows[i]];
                 // a sharded handle holds the panels of its own fronts only: every other entry reads the zeroed slack word
-                const i64 off = (S.shard_world <= 1 || S.owner[s] == S.shard_rank) ? S.panelptr[s] + (i64)j * S.ld[s] + i : S.panelptr[S.nsuper];
+                const i64 off = (!S.shard_plan || S.owner[s] == S.shard_rank) ? S.panelptr[s] + (i64)j * S.ld[s] + i : S.panelptr[S.nsuper];
                 ent[w[b]++] = {a, off};
                 if (i != j) ent[w[a]++] = {b, off};
             }
@@ -576,7 +577,7 @@ static inline long long z_offset(const Symbolic &S, i64 i, i64 j) {
     const i32 r = S.nrows(s);
     const i32 *it = std::lower_bound(rows, rows + r, a);
     if (it == rows + r || *it != a) return -1;
-    if (S.shard_world > 1 && S.owner[s] != S.shard_rank) return (long long)S.panelptr[S.nsuper];      // another rank's panel: the zeroed slack word
+    if (S.shard_plan && S.owner[s] != S.shard_rank) return (long long)S.panelptr[S.nsuper];      // another rank's panel: the zeroed slack word
     return (long long)(S.panelptr[s] + (i64)(b - S.sfirst[s]) * S.ld[s] + (it - rows));
 }
 
@@ -906,7 +907,7 @@ extern "C" int32_t gmrfx_symbolic_get(const gmrfx_handle *h, int64_t *super_firs
         for (size_t k = 0; k < S.qdst.size(); k++) q_dst[k] = S.qdst[k];
         // a sharded handle stores the panels of its own fronts only: the entries of Q that go into another rank's panel
         // have no destination here (-1)
-        if (S.shard_world > 1)
+        if (S.shard_plan)
             for (i32 s = 0; s < ns; s++)
                 if (!S.stored_here(s))      // (every member of its group stores the panel of a distributed front)
                     for (i64 k = S.qptr[s]; k < S.qptr[s + 1]; k++) q_dst[k] = -1;

@@ -406,7 +406,8 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
     S.owner.assign(ns, 0);
     S.is_top.assign(ns, 0);
     S.shard_level = S.nlevels;
-    if (S.shard_world > 1) {
+    S.shard_plan = S.shard_world > 1 || opt.shard_min_top > 0;
+    if (S.shard_plan) {
         const int W = S.shard_world;
         // weight of a front ~ its factorisation flops; of a subtree = sum over its fronts (postorder ids)
         std::vector<double> wsub(ns, 0.0), wown(ns, 0.0);
@@ -448,6 +449,7 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
             }
             return best;
         };
+        int nsplit = 0;
         for (int it = 0; it < 256; it++) {
             const double cost = makespan(asg) + top_chain();
             i32 best = -1;
@@ -460,7 +462,8 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
             top[best] = 1;
             std::vector<i32> asg2;
             const double cost2 = makespan(asg2) + top_chain();
-            if ((int)T0.size() >= W && cost2 >= 0.98 * cost) { T = T0; top[best] = 0; break; }     // no longer pays
+            if ((int)T0.size() >= W && cost2 >= 0.98 * cost && nsplit >= opt.shard_min_top) { T = T0; top[best] = 0; break; }     // no longer pays
+            nsplit++;
         }
         makespan(asg);
         // owner: subtree root's rank for everything below it (postorder: parents after children)
@@ -524,7 +527,7 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
     }
     // distributed top fronts (symbolic.h): wide top fronts whose group has more than one rank
     S.dist_fronts.clear(); S.dist_index.assign(ns, -1); S.dist_gptr.assign(1, 0); S.dist_grank.clear();
-    if (S.shard_world > 1) {
+    if (S.shard_plan) {
         const int min_cols = opt.dist_min_cols >= 0 ? opt.dist_min_cols : 4096;
         std::vector<std::vector<i32>> grp(ns);          // ranks below (and at) every top front
         for (i32 s = 0; s < ns; s++) {
@@ -547,7 +550,7 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
         }
     }
     // does this rank execute front s?  (a distributed front: owner[s] runs its sweeps / selected inversion)
-    auto mine = [&](i32 s) { return S.shard_world == 1 || S.owner[s] == S.shard_rank; };
+    auto mine = [&](i32 s) { return !S.shard_plan || S.owner[s] == S.shard_rank; };
 
     // ---- per-rank storage of a sharded factorisation (round 3) ---------------------------------------------------------
     // A rank only holds what it works on: the PANELS of its own fronts (panels never cross ranks; every other front gets a
@@ -562,7 +565,7 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
         S.cross_child[s] = 1;           // are read by several: all of them live in the exchange region
         for (i64 q = S.childptr[s]; q < S.childptr[s + 1]; q++) S.cross_child[S.children[q]] = 1;
     }
-    if (S.shard_world > 1) {
+    if (S.shard_plan) {
         i64 off = 0;
         for (i32 s = 0; s < ns; s++) {
             S.panelptr[s] = off;
@@ -576,7 +579,7 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
     S.wptr.assign(ns + 1, 0);
     {
         i64 w = 0;
-        if (S.shard_world > 1) {
+        if (S.shard_plan) {
             for (i32 s = 0; s < ns; s++) if (S.cross_child[s]) { S.wptr[s] = w; w += S.nrows(s) - S.ncols(s); }
             for (i32 s = 0; s < ns; s++) if (!S.cross_child[s] && mine(s)) { S.wptr[s] = w; w += S.nrows(s) - S.ncols(s); }
         } else {
@@ -859,8 +862,8 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
         // sharded: the blocks of the cross-edge children sit in an exchange region at the start of the arena (same offsets
         // on every rank, no reuse: a handful of blocks); behind it this rank's own fronts share slots by lifetime
         i64 xtop = 0;
-        auto in_arena = [&](i32 s) { return S.shard_world == 1 || (mine(s) && !S.cross_child[s]); };
-        if (S.shard_world > 1)
+        auto in_arena = [&](i32 s) { return !S.shard_plan || (mine(s) && !S.cross_child[s]); };
+        if (S.shard_plan)
             for (i32 s = 0; s < ns; s++) {
                 S.cbptr[s] = S.zbptr[s] = 0;
                 if (S.cross_child[s]) { S.cbptr[s] = S.zbptr[s] = xtop; xtop += bsz(s); }
@@ -905,7 +908,7 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
     // column k of child d (its k-th trailing row) lands in row/column rel[k] of the parent p: a panel column (< c_p) or a column
     // of p's own contribution block. It is HELD by cb_owner(d, k / 256) and NEEDED by the owner of that parent block.
     S.xf_child.clear(); S.xf_src.clear(); S.xf_dst.clear(); S.xf_level.clear(); S.xf_col0.clear(); S.xf_off.clear(); S.xf_cnt.clear();
-    if (S.shard_world > 1) {
+    if (S.shard_plan) {
         std::vector<std::array<i64, 7>> xf;
         for (i32 d = 0; d < ns; d++) {
             const i32 p = S.sparent[d];

@@ -28,6 +28,9 @@ struct SymOptions {
     int sweep_task_rows = -1;  // LDS rows of a sweep task's local vector (Symbolic::swt_*); -1 = default, 0 = no sweep tasks
     // multi-GPU sharding of ONE factorisation along the supernodal tree (see Symbolic::owner)
     int shard_rank = 0, shard_world = 1;
+    int shard_min_top = 0;         // force at least this many fronts into the TOP of the sharded plan; with shard_world == 1 a value > 0 makes the
+                                   // handle a sharded handle of ONE rank (phase entry points, top levels, exchange lists -- all of them empty or
+                                   // self-addressed): the protocol's device path on a single GPU (tests/test_rccl_world1.py)
     int dist_min_cols = -1;        // sharded handles: a top front is factored by its whole group when it has at least this many columns
                                    // (Symbolic::dist_fronts); -1 = default (4096), 0 = never
 };
@@ -135,7 +138,8 @@ struct Symbolic {
     // phase with the cross-rank edges of that level exchanged in between.
     std::vector<i32> owner;       // nsuper
     std::vector<uint8_t> is_top;  // nsuper
-    i32 shard_rank = 0, shard_world = 1, shard_level = 0;   // shard_level = nlevels when world == 1
+    i32 shard_rank = 0, shard_world = 1, shard_level = 0;   // shard_level = nlevels when there is no plan
+    bool shard_plan = false;      // a sharded plan exists: shard_world > 1, or one rank with a forced top (SymOptions::shard_min_top)
     std::vector<i32> shard_edges; // children d with owner[d] != owner[parent(d)], ordered by (level of the parent, d)
     // DISTRIBUTED TOP FRONTS (round 3). The dense fronts at the top of a 3-D problem hold most of the flops (cfg 4: the top
     // three levels are 2.7 of 5.3 s; the root alone 47 628 columns) and each sat on ONE rank. A top front with at least
@@ -168,7 +172,7 @@ struct Symbolic {
     // rank holding panel block b / contribution-block column block q of front s
     i32 panel_owner(i32 s, i32 b) const { return is_dist(s) ? group_rank(s, b % group_size(s)) : owner[s]; }
     i32 cb_owner(i32 s, i32 q) const { return is_dist(s) ? group_rank(s, (panel_blocks(s) + q) % group_size(s)) : owner[s]; }
-    bool stored_here(i32 s) const { return shard_world == 1 || owner[s] == shard_rank || (is_dist(s) && group_pos(s, shard_rank) >= 0); }
+    bool stored_here(i32 s) const { return !shard_plan || owner[s] == shard_rank || (is_dist(s) && group_pos(s, shard_rank) >= 0); }
     std::vector<i32> shard_sub_root, shard_sub_col0;   // ALL assigned subtrees: root supernode, first column (columns [col0, sfirst[root+1]) are theirs)
     // the caller's pattern (0-based) and which stored triangle defines Q: kept for the quadratic form
     // x'Qx (sqmahal / logpdf), which runs on the caller's CSC values, not on the factor

@@ -20,6 +20,7 @@ class GmrfxOpts(C.Structure):
         ("symbolic_only", C.c_int32), ("check_posdef", C.c_int32), ("nd_leaf", C.c_int32),
         ("relax_cols", C.c_int32), ("relax_zeros", C.c_double), ("coord_dim", C.c_int32),
         ("reserved0", C.c_int32), ("coords", C.c_void_p), ("shard_rank", C.c_int32), ("shard_world", C.c_int32),
+        ("shard_min_top", C.c_int32), ("reserved1", C.c_int32),
     ]
 
 

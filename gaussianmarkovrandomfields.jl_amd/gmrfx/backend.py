@@ -52,7 +52,7 @@ class MI355XBackend:
 
     def __init__(self, Q, ordering=None, coords=None, device: int = -1, symbolic_only: bool = False,
                  check_posdef: bool = False, uplo: str = "U", nd_leaf: int = 0, relax_cols: int = 0,
-                 relax_zeros: float = 0.0, factorize: bool = True, shard_rank: int = 0, shard_world: int = 1):
+                 relax_zeros: float = 0.0, factorize: bool = True, shard_rank: int = 0, shard_world: int = 1, shard_min_top: int = 0):
         Q = _as_csc(Q)
         self.n = Q.shape[0]
         self._colptr = np.ascontiguousarray(Q.indptr, dtype=np.int64)
@@ -70,6 +70,7 @@ class MI355XBackend:
         opts.relax_zeros = relax_zeros
         opts.shard_rank = shard_rank
         opts.shard_world = shard_world
+        opts.shard_min_top = shard_min_top      # > 0 with shard_world == 1: a sharded handle of ONE rank (include/gmrfx.h)
         self.shard_rank, self.shard_world = shard_rank, shard_world
         from .ordering import ordering_permutation as _resolve
         perm = _resolve(Q, ordering, coords)
@@ -90,7 +91,7 @@ class MI355XBackend:
         self._selinv_cache = None
         self._selinv_diag_cache = None
         self.last_info = 0
-        if factorize and not symbolic_only and shard_world <= 1:
+        if factorize and not symbolic_only and shard_world <= 1 and shard_min_top <= 0:
             self.refactorize_values(Q.data)
 
     # -- lifetime ------------------------------------------------------------------------

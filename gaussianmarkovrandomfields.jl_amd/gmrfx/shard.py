@@ -217,7 +217,8 @@ class ShardedFactor:
 
     # ---- solve --------------------------------------------------------------------------------------
     def solve_dev(self, d_B: int, ldb: int, nrhs: int, d_X: int, ldx: int, gather: bool = True) -> None:
-        """Q X = B with the factor sharded over the ranks; B (full, column-major n x nrhs) on every rank. gather = True: X (full) is
+        """Q X = B with the factor sharded over the ranks; B column-major n x nrhs, of which this rank reads the rows `needed_rows()`
+        only (its subtrees' and its own top fronts': B may be row-sharded, the rest left unset). gather = True: X (full) is
         produced on rank 0 -- every rank sends the rows of its subtrees home, 7/8 of n x nrhs doubles into ONE rank's links at world
         8. gather = False: X stays DISTRIBUTED -- every rank writes its own d_X, of which the rows `valid_rows()` names are final
         (its subtrees' and every top front's, which are broadcast anyway): no transfer at all behind the backward sweep; a caller
@@ -246,6 +247,33 @@ class ShardedFactor:
             for _, r0, nr in blocks:
                 elim[r0:r0 + nr] = True
         perm = np.asarray(self.be.ordering_permutation())      # perm[k] = original index of elimination position k
+        out = np.zeros(n, bool)
+        out[perm] = elim
+        return out
+
+    def needed_rows(self) -> np.ndarray:
+        """Boolean mask over the n rows of B (solve_dev: the CALLER's ordering; backward_solve_dev takes Z in elimination order:
+        use `needed_rows(elimination=True)`): the rows THIS rank reads -- the columns of its own subtrees and of the top fronts it
+        OWNS. Nothing else of B is ever read here: a caller may leave every other row unset (B row-sharded over the ranks, never
+        replicated; the masks of all ranks partition the rows). Tested with NaN in the other rows (one-GPU rehearsals)."""
+        return self._row_mask(owned_top_only=True, elimination=False)
+
+    def needed_rows_elimination(self) -> np.ndarray:
+        return self._row_mask(owned_top_only=True, elimination=True)
+
+    def _row_mask(self, owned_top_only: bool, elimination: bool) -> np.ndarray:
+        n = self.be.n
+        elim = np.zeros(n, bool)
+        for o, r0, nr in self._sub_blocks:
+            if o == self.rank:
+                elim[r0:r0 + nr] = True
+        for blocks in self._top_blocks:
+            for o, r0, nr in blocks:
+                if not owned_top_only or o == self.rank:
+                    elim[r0:r0 + nr] = True
+        if elimination:
+            return elim
+        perm = np.asarray(self.be.ordering_permutation())
         out = np.zeros(n, bool)
         out[perm] = elim
         return out

@@ -32,6 +32,8 @@ Base.@kwdef struct Opts            # mirrors gmrfx_opts
     coords::Ptr{Float64} = C_NULL
     shard_rank::Int32 = 0          # one factorisation sharded over several GPUs (include/gmrfx.h); 0 / 1 = unsharded
     shard_world::Int32 = 1
+    shard_min_top::Int32 = 0       # > 0: at least this many top fronts; with shard_world == 1 a sharded handle of one rank (testing)
+    reserved1::Int32 = 0
 end
 
 mutable struct Handle

@@ -69,6 +69,12 @@ typedef struct gmrfx_opts {
      * group whose subtrees it joins (the least loaded owner of its children). See the
      * gmrfx_shard_* entry points. shard_world <= 1: unsharded (default). */
     int32_t shard_rank, shard_world;
+    /* Force at least this many fronts into the top of the sharded plan (0 = the cost model decides). With shard_world == 1 a
+     * value > 0 makes the handle a SHARDED handle of one rank: the phase entry points, the top levels and the (empty or
+     * self-addressed) exchange lists of the protocol below run on a single GPU -- how tests/test_rccl_world1.py executes the
+     * RCCL device path of gmrfx/shard.py on the one-GPU boxes of the test pool. */
+    int32_t shard_min_top;
+    int32_t reserved1;
 } gmrfx_opts;
 
 typedef struct gmrfx_stats {

@@ -643,6 +643,24 @@ def _shard_gpu_worker(rank, world, port, q, case="2d"):
         if int(cover.min()) < 1 or int(vr.sum()) >= Q.shape[0]:
             same = False
             why.append(f"valid_rows: coverage min {int(cover.min())}, rank {rank} claims {int(vr.sum())} of {Q.shape[0]} rows")
+        # B ROW-SHARDED (round 6): a rank reads only the rows needed_rows() names -- its subtrees' and its own top fronts'. Everything
+        # else of B is set to garbage here (1e30: a real dependence on it would wreck the answer; a clamped / masked read multiplies it
+        # by zero); the masks of the ranks partition the rows. Same bits as with the full B.
+        need = sf.needed_rows()
+        part = torch.from_numpy(need.astype(np.int64))
+        dist.all_reduce(part)
+        if int(part.min()) != 1 or int(part.max()) != 1:
+            same = False
+            why.append(f"needed_rows: the ranks' masks do not partition the rows (min {int(part.min())}, max {int(part.max())})")
+        d_Bp = d_B.clone()
+        d_Bp[:, torch.from_numpy(~need).to(dev)] = 1e30
+        d_Xp = torch.full_like(d_B, float("nan"))
+        torch.cuda.synchronize()
+        sf.solve_dev(d_Bp.data_ptr(), Q.shape[0], nrhs, d_Xp.data_ptr(), Q.shape[0], gather=False)
+        torch.cuda.synchronize()
+        if not torch.equal(d_Xp[:, vmask], d_Xd[:, vmask]):
+            same = False
+            why.append(f"row-sharded B: the valid rows of rank {rank} differ from the full-B solve by {float((d_Xp[:, vmask] - d_Xd[:, vmask]).abs().max()):.3e}")
         # backward-only solve (F.UP \\ z, the sampling path) and more than 64 columns (two passes), sharded: same bits as unsharded
         nb = 70 if world == 2 else 5
         Zh = torch.randn((nb, Q.shape[0]), generator=torch.Generator().manual_seed(4), dtype=torch.float64)
