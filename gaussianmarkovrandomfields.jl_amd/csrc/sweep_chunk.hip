@@ -96,6 +96,56 @@ template <int OFF> __device__ __forceinline__ void gl_i4(i4v &dst, const void *s
 __device__ __forceinline__ double lds_ld(const char *Vb, int off) { return *(const double *)(Vb + off); }
 __device__ __forceinline__ void lds_st(char *Vb, int off, double v) { *(double *)(Vb + off) = v; }
 
+// ---- cycle stamps (tools/chunk_cycles.py; compiled out of the library: `make cyc` builds libgmrfx_cyc.so with -DGMRFX_CYC) ----
+// Where a chunk's time goes, per row-tile slot (wave role) of the two task kernels: s_memtime stamps around (0) the prologue,
+// (1) the ISSUE of the next chunk's operand request, (2) the WAIT until this chunk's operands -- requested one chunk ago -- have
+// arrived (an explicit s_waitcnt vmcnt(K), K = the loads this wave has just issued for the next chunk: vector memory returns in
+// order), (3) y = D^-1 b (forward) / the k-tile loop t = y - L' x with its in-loop requests (backward), (4) the apply + LDS
+// read-modify-write (forward) / x = D^-T t + LDS store (backward), (5) BARRIER wait, (6) the epilogue; [7] = chunk records
+// passed, [8] = of which this slot had work. Summed over all waves of a launch with one atomic per wave and category.
+#ifdef GMRFX_CYC
+__device__ unsigned long long g_ch_cyc[2][4][10];
+#define CY_DECL long long cy_t_ = clock64(), cy_n_; unsigned long long cy_a_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define CY_MARK(k) do { __builtin_amdgcn_sched_barrier(0); cy_n_ = clock64(); cy_a_[k] += (unsigned long long)(cy_n_ - cy_t_); cy_t_ = cy_n_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define CY_COUNT(k, v) do { cy_a_[k] += (unsigned long long)(v); } while (0)
+#define CY_FLUSH(kern, role) do { if ((threadIdx.x & 63) == 0) { for (int q_ = 0; q_ < 10; q_++) atomicAdd(&g_ch_cyc[kern][role][q_], cy_a_[q_]); } } while (0)
+// wait until all but the youngest k vector-memory operations of this wave have returned
+__device__ __forceinline__ void cy_wait_vm(int k) {
+    switch (k) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+#define CY_WAIT_VM(k) cy_wait_vm(k)
+#else
+#define CY_DECL
+#define CY_MARK(k)
+#define CY_COUNT(k, v)
+#define CY_FLUSH(kern, role)
+#define CY_WAIT_VM(k)
+#endif
+// ---- knock-out variants (`make var` -> libgmrfx_var.so, -DGMRFX_VAR; tools/chunk_variants.py) -------------------------------
+// The same kernels with one part switched off by a run-time flag word (WRONG results, timing only): bit 0 = no operand requests
+// beyond a task's first chunk (what is left is the LDS / MFMA / barrier chain), bit 1 = no arithmetic (requests and barriers only:
+// what this access pattern streams at), bit 2 = no barriers, bit 4 = histogram of the SIMD every row-tile slot's wave runs on
+// (HW_ID; one atomic per wave). The flag word is a kernel-uniform scalar; the product build has none of this.
+#ifdef GMRFX_VAR
+__device__ int g_ch_var;
+__device__ unsigned long long g_ch_simd[2][4][4];
+#define VAR_DECL const int var_ = __builtin_amdgcn_readfirstlane(g_ch_var)
+#define VAR_ON(bit) ((var_ >> (bit)) & 1)
+#define VAR_SIMD(kern, role) do { if (VAR_ON(4) && (threadIdx.x & 63) == 0) { unsigned hw_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_)); \
+                                  atomicAdd(&g_ch_simd[kern][role][(hw_ >> 4) & 3], 1ull); } } while (0)
+#else
+#define VAR_DECL
+#define VAR_ON(bit) 0
+#define VAR_SIMD(kern, role)
+#endif
+
 // Records into LDS, the task's slice of X into the local vector. (Round 2's warm-up of the task's panels into L2 is gone: with
 // every operand requested a chunk ahead it cost 30-40 us per sweep.)
 template <int NC, int NTHR> __device__ __forceinline__ void chunk_prologue(const SweepTask &T, const Chunk *__restrict__ recs, int nrec, Chunk *meta,
@@ -138,9 +188,12 @@ void k_fwd_chunks(const SweepTask *__restrict__ tasks, int ntasks, const Chunk *
     const SweepTask T = tasks[tsk];
     const int col0 = T.col0, NT = T.nt, nch = T.nch, mroot = T.mroot;
     const int tid = threadIdx.x;
+    CY_DECL;
+    VAR_DECL;
     chunk_prologue<NC, NTHR>(T, recs + T.c0, nch, meta, L, X, V, nr, ldx);
     for (int i = NT * NC + tid; i < CH_ROWS * NC; i += NTHR) V[i] = 0.0;
     __syncthreads();
+    CY_MARK(0);
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int w = wv / CT, th = wv % CT;                // row-tile slot, column group (scalars)
     const int lane = tid & 63, lm = lane & 15, lk = lane >> 4;
@@ -150,13 +203,13 @@ void k_fwd_chunks(const SweepTask *__restrict__ tasks, int ntasks, const Chunk *
     char *Vb = (char *)V;
     FBuf A, B;
     UChunk mA, mB;       // the records travel with the buffers: read from LDS once per chunk
-    auto request = [&](int f, FBuf &x, UChunk &m) {
+    auto request = [&](int f, FBuf &x, UChunk &m) -> int {        // (returns the vector loads issued: used by the cycle stamps only)
         m = uniform_chunk(meta, f);
         const int npair = (m.nt + 31) >> 5;
-        if (!(w == 0 || w < npair)) return;
+        if (!(w == 0 || w < npair)) return 0;
         const double *dp = dtile + (long long)m.id * 256;
         gl_f64<0>(x.dt[0], dp, lane * 8); gl_f64<512>(x.dt[1], dp, lane * 8); gl_f64<1024>(x.dt[2], dp, lane * 8); gl_f64<1536>(x.dt[3], dp, lane * 8);
-        if (w >= npair) return;
+        if (w >= npair) return 4;
         const double *base = L + m.pa + 32 * w;
         const unsigned vo = (unsigned)(2 * lm + lk * m.ld) * 8u;
         const long long st = 4LL * m.ld;
@@ -164,12 +217,22 @@ void k_fwd_chunks(const SweepTask *__restrict__ tasks, int ntasks, const Chunk *
         const int *lp = listf + m.lr + 32 * w;
         gl_i4<0>(x.l[0], lp, lk * 32);
         gl_i4<16>(x.l[1], lp, lk * 32);
+        return 10;
     };
     request(0, A, mA);
+#ifdef GMRFX_VAR
+    if (VAR_ON(0)) B = A;          // (no later requests: the second buffer keeps valid row lists)
+#endif
     auto chunk = [&](const int f, FBuf &cur, const UChunk &m, FBuf &nxt, UChunk &mn) {
-        if (f + 1 < nch) request(f + 1, nxt, mn);
+        [[maybe_unused]] int issued = 0;
+        if (f + 1 < nch) { if (!VAR_ON(0)) issued = request(f + 1, nxt, mn); else mn = uniform_chunk(meta, f + 1); }
+        CY_MARK(1);
+        CY_WAIT_VM(issued);
+        CY_MARK(2);
+        CY_COUNT(7, 1);
         const int npair = (m.nt + 31) >> 5;
-        if (w == 0 || w < npair) {
+        if ((w == 0 || w < npair) && !VAR_ON(1)) {
+            CY_COUNT(8, 1);
             const int ku = (m.cc + 3) >> 2;
             const int rowb = m.o + lk;
             const int bb = rowb * NC * 8, sw = NC >= 32 ? (rowb & 1) << 7 : 0;
@@ -183,6 +246,7 @@ void k_fwd_chunks(const SweepTask *__restrict__ tasks, int ntasks, const Chunk *
                     for (int t = 0; t < TPW; t++)
                         y[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.dt[u], lds_ld(Vb, bb + u * 4 * NC * 8 + (clb[t] ^ sw)), y[t], 0, 0, 0);
                 }
+            CY_MARK(3);
             // y straight to X (the local vector keeps b: the other slots may still be reading it for their own copy of y,
             // and a chunk with more than 128 target rows comes as several records that each recompute y)
             if (w == 0) {
@@ -223,8 +287,10 @@ void k_fwd_chunks(const SweepTask *__restrict__ tasks, int ntasks, const Chunk *
                 }
             };
             if (w < npair) apply(cur.a, cur.l[0], cur.l[1]);
+            CY_MARK(4);
         }
-        __syncthreads();
+        if (!VAR_ON(2)) __syncthreads();
+        CY_MARK(5);
     };
     {
         int f = 0;
@@ -240,6 +306,9 @@ void k_fwd_chunks(const SweepTask *__restrict__ tasks, int ntasks, const Chunk *
             for (int i = g; i < mroot; i += G) Wr[(long long)i * ldx + j] = V[vbyte<NC>(NT + i, j) >> 3];
         }
     }
+    CY_MARK(6);
+    CY_FLUSH(0, w);
+    VAR_SIMD(0, w);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -261,6 +330,8 @@ void k_bwd_chunks(DevSym S, const SweepTask *__restrict__ tasks, int ntasks, con
     const SweepTask T = tasks[tsk];
     const int col0 = T.col0, NT = T.nt, mroot = T.mroot;
     const int tid = threadIdx.x;
+    CY_DECL;
+    VAR_DECL;
     chunk_prologue<NC, NTHR>(T, recs + T.b0, T.nbw, meta, L, X, V, nr, ldx);
     {   // x of the root's trailing rows (ancestors of the subtree: final), zeros behind them
         constexpr int GR = NTHR / NC;
@@ -281,6 +352,7 @@ void k_bwd_chunks(DevSym S, const SweepTask *__restrict__ tasks, int ntasks, con
         for (int i = (NT + mroot) * NC + tid; i < CH_ROWS * NC; i += NTHR) V[i] = 0.0;
     }
     __syncthreads();
+    CY_MARK(0);
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int w = wv / CT, th = wv % CT;
     const int lane = tid & 63, lm = lane & 15, lk = lane >> 4;
@@ -294,7 +366,7 @@ void k_bwd_chunks(DevSym S, const SweepTask *__restrict__ tasks, int ntasks, con
     const int endbar = w == 0 ? T.sbar[0] : w == 1 ? T.sbar[1] : w == 2 ? T.sbar[2] : T.sbar[3];
     BBuf<G> A, B;
     UChunk mA, mB;
-    auto request = [&](int f, BBuf<G> &x, UChunk &m) {
+    auto request = [&](int f, BBuf<G> &x, UChunk &m) -> int {      // (returns the vector loads issued: used by the cycle stamps only)
         m = uniform_chunk(meta, f);
         const double *dp = dtile + (long long)m.id * 256;
         const unsigned vd = (unsigned)(16 * lm + lk) * 8u;
@@ -310,6 +382,7 @@ void k_bwd_chunks(DevSym S, const SweepTask *__restrict__ tasks, int ntasks, con
                 gl_d2<64>(x.a[g][1], base + 16 * g, vo);
                 gl_i4<0>(x.l[g], lp + 16 * g, lk * 16);
             }
+        return 4 + 3 * (nk < G ? nk : G);
     };
     auto tile = [&](d4 (&acc)[TPW], const gmrfx_d2u &a0, const gmrfx_d2u &a1, const i4v &l) {
 #pragma unroll
@@ -322,9 +395,16 @@ void k_bwd_chunks(DevSym S, const SweepTask *__restrict__ tasks, int ntasks, con
         }
     };
     auto chunk = [&](const int f, const bool last, BBuf<G> &cur, const UChunk &m, BBuf<G> &nxt, UChunk &mn) {
-        if (!last) request(f + 1, nxt, mn);
-        for (int b = 0; b < m.nbar; b++) __syncthreads();
-        const int nk = (m.nt + 15) >> 4;
+        [[maybe_unused]] int issued = 0;
+        if (!last) { if (!VAR_ON(0)) issued = request(f + 1, nxt, mn); else mn = uniform_chunk(meta, f + 1); }
+        CY_MARK(1);
+        if (!VAR_ON(2)) for (int b = 0; b < m.nbar; b++) __syncthreads();
+        CY_MARK(5);
+        CY_WAIT_VM(issued);
+        CY_MARK(2);
+        CY_COUNT(7, 1);
+        CY_COUNT(8, 1);
+        const int nk = VAR_ON(1) ? 0 : (m.nt + 15) >> 4;
         d4 acc[TPW];
 #pragma unroll
         for (int t = 0; t < TPW; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
@@ -349,7 +429,8 @@ void k_bwd_chunks(DevSym S, const SweepTask *__restrict__ tasks, int ntasks, con
                 }
             }
         }
-        const int ku = (m.cc + 3) >> 2;
+        CY_MARK(3);
+        const int ku = VAR_ON(1) ? 0 : (m.cc + 3) >> 2;
         const int rowb = m.o + lk;
         const int bb = rowb * NC * 8, sw = NC >= 32 ? (rowb & 1) << 7 : 0;
         d4 x[TPW];
@@ -368,21 +449,29 @@ void k_bwd_chunks(DevSym S, const SweepTask *__restrict__ tasks, int ntasks, con
         for (int t = 0; t < TPW; t++)
 #pragma unroll
             for (int rr = 0; rr < 4; rr++)
-                if (lk + 4 * rr < m.cc) lds_st(Vb, bb + rr * 4 * NC * 8 + (clb[t] ^ sw), x[t][rr]);
+                if (lk + 4 * rr < m.cc && !VAR_ON(1)) lds_st(Vb, bb + rr * 4 * NC * 8 + (clb[t] ^ sw), x[t][rr]);
+        CY_MARK(4);
     };
     if (cnt > 0) request(i0, A, mA);
+#ifdef GMRFX_VAR
+    if (VAR_ON(0)) B = A;
+#endif
     {
         int k = 0;
         for (; k + 1 < cnt; k += 2) { chunk(i0 + k, false, A, mA, B, mB); chunk(i0 + k + 1, k + 2 >= cnt, B, mB, A, mA); }
         if (k < cnt) chunk(i0 + k, true, A, mA, B, mB);
     }
-    for (int b = 0; b < endbar; b++) __syncthreads();
+    if (!VAR_ON(2)) for (int b = 0; b < endbar; b++) __syncthreads();
+    CY_MARK(5);
     {
         constexpr int GR = NTHR / NC;
         const int j = tid % NC, g = tid / NC;
         if (j < nr)
             for (int i = g; i < NT; i += GR) X[(long long)(col0 + i) * ldx + j] = V[vbyte<NC>(i, j) >> 3];
     }
+    CY_MARK(6);
+    CY_FLUSH(1, w);
+    VAR_SIMD(1, w);
 }
 
 // The inverse of every chunk's diagonal block in MFMA A-operand order: element (lm, 4 u + lk) of D^-1 at [u][lane]
@@ -413,6 +502,31 @@ __global__ __launch_bounds__(256) void k_pack_diag(const Chunk *__restrict__ rec
 // (Measured at cfg 2, round 5: 32 columns / 8 waves / two workgroups per CU 0.61 / 0.67 ms forward / backward against 0.56 / 0.64;
 //  two tiles per wave, 32 or 64 columns: 0.74-0.75 / 0.86-0.87 ms.)
 int sweep_chunk_nc() { return 16; }
+
+#ifdef GMRFX_CYC
+// tools/chunk_cycles.py: [kernel 0 = forward, 1 = backward][slot 0..3][category 0..9] (see the CY_ macros above); reset != 0 zeroes the counters
+extern "C" int gmrfx_debug_chunk_cycles(unsigned long long *out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ch_cyc), sizeof(g_ch_cyc)) != hipSuccess) return 1;
+    if (reset) {
+        static const unsigned long long zero[2][4][10] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_ch_cyc), zero, sizeof(zero)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
+
+#ifdef GMRFX_VAR
+// tools/chunk_variants.py: set the knock-out flag word; read (and clear) the SIMD histogram [kernel][slot][simd]
+extern "C" int gmrfx_debug_chunk_variant(int flags, unsigned long long *simd_out) {
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_ch_var), &flags, sizeof(int)) != hipSuccess) return 1;
+    if (simd_out) {
+        static const unsigned long long zero[2][4][4] = {};
+        if (hipMemcpyFromSymbol(simd_out, HIP_SYMBOL(g_ch_simd), sizeof(g_ch_simd)) != hipSuccess) return 1;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_ch_simd), zero, sizeof(zero)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
 
 void launch_pack_diag(hipStream_t st, const Symbolic::SwChunk *recs, int nchunks, const double *L, double *dtile) {
     if (nchunks <= 0) return;
