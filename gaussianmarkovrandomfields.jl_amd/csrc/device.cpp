@@ -1121,8 +1121,10 @@ void Device::refactorize_solve(const double *nzval, bool nz_on_device, const dou
     HC(hipMemcpyAsync(h_info_, d_info_, sizeof(int), hipMemcpyDeviceToHost, stream));
     factorized = true;
     selinv_valid = false;
-    // ---- first pass of up to 64 columns: forward sweep on the side stream, behind the level events
-    const int nr = (int)std::min<long long>(64, nrhs), ldx = nr;
+    // ---- first pass (pass_width(): up to 64 columns, 16 for 17 .. 32 right-hand sides -- the widths solve() uses, so that the two
+    // forms of the step give the same bits): forward sweep on the side stream, behind the level events
+    const int PW = pass_width(nrhs);
+    const int nr = (int)std::min<long long>(PW, nrhs), ldx = nr;
     hipEvent_t *ev = ev_lane_[0];
     {
         const hipStream_t main_stream = stream;
@@ -1148,8 +1150,8 @@ void Device::refactorize_solve(const double *nzval, bool nz_on_device, const dou
     launch_permute(stream, d_iperm_, (int)n, dXo, ldout, d_X_, nr, ldx, 1);
     HC(hipEventRecord(ev[4], stream));
     // ---- further passes: the factor is complete, plain sweeps on the main stream
-    for (long long j0 = 64; j0 < nrhs; j0 += 64) {
-        const int nr2 = (int)std::min<long long>(64, nrhs - j0);
+    for (long long j0 = PW; j0 < nrhs; j0 += PW) {
+        const int nr2 = (int)std::min<long long>(PW, nrhs - j0);
         launch_permute(stream, d_iperm_, (int)n, const_cast<double *>(dB) + j0 * ldin, ldin, d_X_, nr2, nr2, 0);
         forward(nr2, nr2, 0, nl);
         backward(nr2, nr2, true, nl, 0);
@@ -1364,7 +1366,7 @@ void Device::ensure_rhs_capacity(long long nrhs) {
         d_W_ = dalloc<double>((size_t)std::max<long long>(sum_trail_, 1) * 64);
         rhs_cap_ = 64;
     }
-    if (nrhs > 64 && !d_Xb_ && !sharded()) {
+    if (pass_width(nrhs) < nrhs && !d_Xb_ && !sharded()) {
         d_Xb_ = dalloc<double>((size_t)S_->n * 64);
         d_X2b_ = dalloc<double>((size_t)S_->n * 64);
         d_Wb_ = dalloc<double>((size_t)std::max<long long>(sum_trail_, 1) * 64);
@@ -1459,7 +1461,7 @@ void Device::forward(int nr, int ldx, int lo, int hi) {
         // barrier: k_fwd_update_wave), chosen per FRONT so that a front's sums do not depend on the list it comes in
         constexpr int kFwdWaveCols = 1024;      // (measured at cfg 2, 1 RHS, forward ms, with four waves sharing the K range of a front wider than 128
                                                 //  columns: 256: 0.933, 512: 0.841, 1024: 0.832, 2048: 0.836)
-        const int cmin = syrk_xcd_ && nr <= 16 ? kFwdWaveCols : 0;
+        const int cmin = syrk_xcd_ && nr <= narrow_pass_max() ? kFwdWaveCols : 0;
         const int nwider = (size_t)(kFwdWaveCols / NB + 1) < L.active.size() ? L.active[kFwdWaveCols / NB] : 0;      // fronts wider than that
         if (cmin > 0 && nwider < nf) launch_fwd_update_wave(stream, ds_, d_fwd_recs_ + L.fwd_off, L.fwd_split, L.fwd_per, d_L_, d_X2_, d_W_, nr, ldx, cmin,
                                                               L.max_cols > launch_wave_split_cols());
@@ -1493,7 +1495,7 @@ void Device::backward(int nr, int ldx, bool y_in_x2, int hi, int lo) {
         // trailing rows (k_bwd_wave), the split-K kernels for the others, x = L11^-T t as everywhere
         constexpr int kBwdWaveRows = 4096;      // (every front of a 2-D problem; measured at cfg 2, 1 RHS, backward ms, with four waves sharing the K range of a front of more than 256
                                                 //  rows: 768: 0.848, 1100: 0.824, 1600: 0.814, every front: 0.792; one wave per tile only: 768 was the optimum, 1.177)
-        const bool narrow = nr <= 16;
+        const bool narrow = nr <= narrow_pass_max_bwd();
         if (bwd_front_min_ > 0 && !narrow) {
             // (a front needs its WHOLE inverse for this: at most min(128, inv_cap_) columns)
             const size_t kq = (size_t)std::min(bwd_front_max_cols(), inv_cap_) / NB;
@@ -1633,7 +1635,9 @@ void Device::solve(const double *B, long long ldb, long long nrhs, double *X, lo
     // 64-column passes, alternating between the two lanes when there is more than one pass. forward() / backward()
     // enqueue on the members `stream`, d_X_, d_X2_, d_W_: a lane is selected by swapping them in for the duration
     // of the (asynchronous) enqueue.
-    const bool two = nrhs > 64 && d_Xb_ != nullptr;
+    // passes of pass_width() = 64 columns, alternating between the two lanes when there is more than one pass
+    const int PW = pass_width(nrhs);
+    const bool two = nrhs > PW && d_Xb_ != nullptr;
     struct LaneState { hipStream_t st; double *X, *X2, *W; };
     LaneState lanes[2] = {{stream, d_X_, d_X2_, d_W_}, {stream3, d_Xb_, d_X2b_, d_Wb_}};
     if (two) {
@@ -1661,8 +1665,8 @@ void Device::solve(const double *B, long long ldb, long long nrhs, double *X, lo
     } restore{*this, main_stream, X0, X20, W0};
     HC(hipEventRecord(ev_[0], stream));
     int pass = 0;
-    for (long long j0 = 0; j0 < nrhs; j0 += 64, pass++) {
-        const int nr = (int)std::min<long long>(64, nrhs - j0);
+    for (long long j0 = 0; j0 < nrhs; j0 += PW, pass++) {
+        const int nr = (int)std::min<long long>(PW, nrhs - j0);
         const int ldx = nr;
         const int ln = two ? (pass & 1) : 0;
         collect(ln);                         // the lane's previous pass has finished: its buffers are free

@@ -185,6 +185,12 @@ public:
     double *rhs_x() { return d_X_; }
     double *rhs_w() { return d_W_; }
     void ensure_rhs(long long nrhs) { ensure_rhs_capacity(nrhs); }
+    // columns per sweep pass for a solve of nrhs right-hand sides: ONE rule for solve() and the pipelined call, so that both give
+    // the same bits for the same nrhs. 64 throughout. (Round 6, measured and dropped: 17 .. 32 right-hand sides as TWO 16-column
+    // passes side by side on the two lanes -- 17 / 24 / 32 columns 3.01 / 3.35 / 3.71 ms against 3.40 / 3.4 / 3.44 as one pass: two
+    // latency-bound passes do not overlap on this runtime (twice the launches through one command processor), the second lane only
+    // pays from 65 columns on. What such passes get instead: the narrow level kernels on two right-hand-side tiles, narrow_pass_max().)
+    static int pass_width(long long) { return 64; }
     double *cb_arena() { return d_cb_; }
     double *factor_panels() { return d_L_; }
     bool sharded() const { return S_ && S_->shard_plan; }

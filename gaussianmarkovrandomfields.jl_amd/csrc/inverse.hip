@@ -179,6 +179,7 @@ __global__ __launch_bounds__(64 * NW) void k_xmul(DevSym S, const int *__restric
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void k_xmul_narrow(DevSym S, const int *__restrict__ list, int trans, const double *__restrict__ L,
                                                          const double *__restrict__ Xin, double *__restrict__ Xout, int nr, int ldx, int blk, int cap) {
+    { const int jt = 16 * blockIdx.z; Xin += jt; Xout += jt; nr = min(nr - jt, 16); }       // (round 6) blockIdx.z = 16-column tile of the right-hand sides
     const int s = list[blockIdx.y];
     const int cfull = S.sfirst[s + 1] - S.sfirst[s];
     const int col0 = blk * cap;
@@ -256,11 +257,12 @@ void launch_xmul(hipStream_t st, const DevSym &S, const int *list, int nfronts, 
     if (nfronts <= 0 || max_c <= 0) return;
     max_c = std::min(max_c - blk * cap, cap);      // width of block `blk` of the widest front
     if (max_c <= 0) return;
-    if (nr <= 16) {
+    if (nr <= (trans ? narrow_pass_max_bwd() : narrow_pass_max())) {          // one right-hand-side tile per workgroup, ceil(nr / 16) tiles in grid z
+        const unsigned jt = (unsigned)cdiv(nr, 16);
         if ((long long)cdiv(max_c, 16) * nfronts <= 256)
-            hipLaunchKernelGGL(k_xmul_narrow<8>, dim3((unsigned)(cdiv(max_c, 16) | 1), nfronts), dim3(512), 0, st, S, list, trans, L, Xin, Xout, nr, ldx, blk, cap);
+            hipLaunchKernelGGL(k_xmul_narrow<8>, dim3((unsigned)(cdiv(max_c, 16) | 1), nfronts, jt), dim3(512), 0, st, S, list, trans, L, Xin, Xout, nr, ldx, blk, cap);
         else
-            hipLaunchKernelGGL(k_xmul_narrow<4>, dim3((unsigned)(cdiv(max_c, 16) | 1), nfronts), dim3(256), 0, st, S, list, trans, L, Xin, Xout, nr, ldx, blk, cap);
+            hipLaunchKernelGGL(k_xmul_narrow<4>, dim3((unsigned)(cdiv(max_c, 16) | 1), nfronts, jt), dim3(256), 0, st, S, list, trans, L, Xin, Xout, nr, ldx, blk, cap);
         return;
     }
     if ((long long)cdiv(max_c, 16) * nfronts <= 256)

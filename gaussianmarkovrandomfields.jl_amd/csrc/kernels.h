@@ -400,6 +400,10 @@ void launch_bwd_gemm(hipStream_t st, const DevSym &S, const int *list, int nfron
 void launch_bwd_wave(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, const double *L, const double *X, double *Xown,
                      int nr, int ldx, int mmax, bool split_k);       // split_k: the level has fronts with more than launch_wave_split_rows() trailing rows
 int launch_wave_split_cols();
+// widest pass (right-hand sides) that takes the narrow level kernels -- one wave / one right-hand-side tile per workgroup, grid z (y
+// for k_fwd_update_wave) = ceil(nr / 16) tiles: k_fwd_update_wave, k_bwd_wave, k_xmul_narrow
+int narrow_pass_max();
+int narrow_pass_max_bwd();
 int launch_wave_split_rows();
 // blocked substitution inside fronts wider than `cap` columns (forward): own rows below block blk -= L[.., block] y_blk
 void launch_fwd_own_update(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, const double *L,

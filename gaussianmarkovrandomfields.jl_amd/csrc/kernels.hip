@@ -1055,6 +1055,8 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_update_wave(DevSym S, const Fwd
                                                         const double *__restrict__ L, const double *__restrict__ X,
                                                         double *__restrict__ W, int nr, int ldx, int cmax) {
     __shared__ double red[NW > 1 ? NW * 8 * 64 : 1];
+    // (round 6) blockIdx.y = 16-column tile of the right-hand sides: a pass of 17 .. 32 columns runs these kernels on two tiles
+    { const int jt = 16 * blockIdx.y; X += jt; W += jt; nr = min(nr - jt, 16); }
     const int xcd = blockIdx.x & 7;
     const int tix = split.start[xcd] + (int)(blockIdx.x >> 3);
     if (tix >= split.start[xcd + 1]) return;
@@ -1234,6 +1236,7 @@ template <int NW>
 __global__ __launch_bounds__(64 * NW) void k_bwd_wave(DevSym S, const int *__restrict__ list, const double *__restrict__ L, const double *X,
                                                  double *Xown, int nr, int ldx, int mmax) {
     __shared__ double red[NW > 1 ? NW * 4 * 64 : 1];
+    { const int jt = 16 * blockIdx.z; X += jt; Xown += jt; nr = min(nr - jt, 16); }       // (round 6) blockIdx.z = 16-column tile of the right-hand sides
     const int s = list[blockIdx.y];
     const int c = S.sfirst[s + 1] - S.sfirst[s];
     const int r = (int)(S.rowptr[s + 1] - S.rowptr[s]);
@@ -1950,13 +1953,21 @@ void launch_fwd_update_recs(hipStream_t st, const DevSym &S, const FwdTile *recs
     if (per_xcd <= 0) return;
     hipLaunchKernelGGL(k_fwd_update_rec, dim3(8 * (unsigned)per_xcd), dim3(256), 0, st, S, recs, split, L, X, W, nr, ldx, cmin);
 }
+// Passes of up to 32 right-hand sides take the narrow FORWARD kernels (k_fwd_update_wave, k_xmul_narrow) on two right-hand-side tiles
+// (round 6; measured at cfg 2, tools/nrhs_sweep.py: 17 / 24 / 32 columns 3.22 / 3.29 / 3.35 -> 2.98 / 3.05 / 3.09 ms; the same on three
+// or four tiles loses: 48 columns 3.54 -> 3.85 ms). The BACKWARD kernels of such passes stay the 64-column ones -- k_bwd_front /
+// k_bwd_gemm_longk beat k_bwd_wave on two tiles (backward 1.39 vs 1.42-1.47 ms) --, and so do the bottom tasks (chunk form on two column
+// slices: 2.98 ms at 17 columns against 3.37 with one wave per task and tile).
+int narrow_pass_max() { return 32; }
+int narrow_pass_max_bwd() { return 16; }
 int launch_wave_split_cols() { return kWaveSplitCols; }
 int launch_wave_split_rows() { return kWaveSplitRows; }
 void launch_fwd_update_wave(hipStream_t st, const DevSym &S, const FwdTile *recs, const SyrkSplit &split, int per_xcd, const double *L,
                             double *X, double *W, int nr, int ldx, int cmax, bool split_k) {
     if (per_xcd <= 0) return;
-    if (split_k) hipLaunchKernelGGL(k_fwd_update_wave<4>, dim3(8 * (unsigned)per_xcd), dim3(256), 0, st, S, recs, split, L, X, W, nr, ldx, cmax);
-    else hipLaunchKernelGGL(k_fwd_update_wave<1>, dim3(8 * (unsigned)per_xcd), dim3(64), 0, st, S, recs, split, L, X, W, nr, ldx, cmax);
+    const unsigned jt = (unsigned)cdiv(nr, 16);
+    if (split_k) hipLaunchKernelGGL(k_fwd_update_wave<4>, dim3(8 * (unsigned)per_xcd, jt), dim3(256), 0, st, S, recs, split, L, X, W, nr, ldx, cmax);
+    else hipLaunchKernelGGL(k_fwd_update_wave<1>, dim3(8 * (unsigned)per_xcd, jt), dim3(64), 0, st, S, recs, split, L, X, W, nr, ldx, cmax);
 }
 void launch_bwd_gemm(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, const double *L,
                      const double *X, double *Xown, int nr, int ldx, int blk, int cap, int mmin) {
@@ -1978,8 +1989,9 @@ void launch_bwd_gemm(hipStream_t st, const DevSym &S, const int *list, int nfron
 void launch_bwd_wave(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, const double *L, const double *X, double *Xown,
                      int nr, int ldx, int mmax, bool split_k) {
     if (nfronts <= 0 || max_cols <= 0) return;
-    if (split_k) hipLaunchKernelGGL(k_bwd_wave<4>, dim3(odd(cdiv(max_cols, 16)), nfronts), dim3(256), 0, st, S, list, L, X, Xown, nr, ldx, mmax);
-    else hipLaunchKernelGGL(k_bwd_wave<1>, dim3(odd(cdiv(max_cols, 16)), nfronts), dim3(64), 0, st, S, list, L, X, Xown, nr, ldx, mmax);
+    const unsigned jt = (unsigned)cdiv(nr, 16);
+    if (split_k) hipLaunchKernelGGL(k_bwd_wave<4>, dim3(odd(cdiv(max_cols, 16)), nfronts, jt), dim3(256), 0, st, S, list, L, X, Xown, nr, ldx, mmax);
+    else hipLaunchKernelGGL(k_bwd_wave<1>, dim3(odd(cdiv(max_cols, 16)), nfronts, jt), dim3(64), 0, st, S, list, L, X, Xown, nr, ldx, mmax);
 }
 void launch_fwd_own_update(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_cols, const double *L,
                            const double *Y, double *X, int nr, int ldx, int blk, int cap) {

@@ -148,22 +148,65 @@ __device__ unsigned long long g_ch_simd[2][4][4];
 
 // Records into LDS, the task's slice of X into the local vector. (Round 2's warm-up of the task's panels into L2 is gone: with
 // every operand requested a chunk ahead it cost 30-40 us per sweep.)
-template <int NC, int NTHR> __device__ __forceinline__ void chunk_prologue(const SweepTask &T, const Chunk *__restrict__ recs, int nrec, Chunk *meta,
-                                                                              const double *__restrict__ L, const double *__restrict__ X,
-                                                                              double *V, int nr, int ldx) {
+// Round 6: ALL loads of the prologue are in flight at once. The knock-out timings (profiles/r06_chunk_variants_start.txt) put
+// prologue + epilogue at 0.22 of the forward task kernel's 0.62 ms and at 0.36 of the backward one's 0.63: the local vector was
+// filled 64 rows per loop iteration, each iteration an exposed memory round trip (up to five for the own rows, and in the backward
+// kernel up to five more PAIRS -- row index, then x -- for the root's trailing rows) in a workgroup that lives ~22 us. Now: the
+// index loads of the trailing rows first, the own rows' loads behind them, the gathered rows as soon as the indices are back, the
+// LDS stores last; iterations beyond the task's rows are skipped by a uniform branch. ROOT = the backward kernel (local rows
+// NT .. NT + mroot - 1 = x of the root's trailing rows, rows[] = their positions); the forward kernel zeroes them itself.
+template <int NC, int NTHR, bool ROOT> __device__ __forceinline__ void chunk_prologue(const SweepTask &T, const Chunk *__restrict__ recs, int nrec, Chunk *meta,
+                                                                                         const int *__restrict__ rows, const double *__restrict__ X,
+                                                                                         double *V, int nr, int ldx) {
     const int tid = threadIdx.x;
-    for (int i = tid; i < 2 * nrec; i += NTHR) ((int4 *)meta)[i] = ((const int4 *)recs)[i];
-    constexpr int G = NTHR / NC;
+    constexpr int G = NTHR / NC;                       // row groups: a pass of the loops below covers 4 G rows
+    constexpr int NIT = (CH_ROWS - 1 + 4 * G - 1) / (4 * G);
     const int j = tid % NC, g = tid / NC;
     const int jc = min(j, nr - 1);
     const double jm = j < nr ? 1.0 : 0.0;
-    const int NT = T.nt, col0 = T.col0;
-    for (int i0 = g; i0 < NT; i0 += 4 * G) {
-        double v[4];
+    const int NT = T.nt, col0 = T.col0, mroot = ROOT ? T.mroot : 0;
+    int ri[NIT][4];
+    double v[NIT][4], vr[NIT][4];
+    if (ROOT) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) v[u] = X[(long long)(col0 + min(i0 + G * u, NT - 1)) * ldx + jc];
+        for (int it = 0; it < NIT; it++)
+            if (it * 4 * G < mroot) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) if (i0 + G * u < NT) V[vbyte<NC>(i0 + G * u, j) >> 3] = v[u] * jm;
+                for (int u = 0; u < 4; u++) ri[it][u] = rows[min(g + (4 * it + u) * G, mroot - 1)];
+            }
+    }
+    int4 mrec[(2 * CH_MAXC + NTHR - 1) / NTHR];
+#pragma unroll
+    for (int q = 0; q < (2 * CH_MAXC + NTHR - 1) / NTHR; q++) mrec[q] = ((const int4 *)recs)[min(tid + q * NTHR, 2 * nrec - 1)];
+#pragma unroll
+    for (int it = 0; it < NIT; it++)
+        if (it * 4 * G < NT) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[it][u] = X[(long long)(col0 + min(g + (4 * it + u) * G, NT - 1)) * ldx + jc];
+        }
+    if (ROOT) {
+#pragma unroll
+        for (int it = 0; it < NIT; it++)
+            if (it * 4 * G < mroot) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) vr[it][u] = X[(long long)ri[it][u] * ldx + jc];
+            }
+    }
+#pragma unroll
+    for (int q = 0; q < (2 * CH_MAXC + NTHR - 1) / NTHR; q++) if (tid + q * NTHR < 2 * nrec) ((int4 *)meta)[tid + q * NTHR] = mrec[q];
+#pragma unroll
+    for (int it = 0; it < NIT; it++)
+        if (it * 4 * G < NT) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int i = g + (4 * it + u) * G; if (i < NT) V[vbyte<NC>(i, j) >> 3] = v[it][u] * jm; }
+        }
+    if (ROOT) {
+#pragma unroll
+        for (int it = 0; it < NIT; it++)
+            if (it * 4 * G < mroot) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const int i = g + (4 * it + u) * G; if (i < mroot) V[vbyte<NC>(NT + i, j) >> 3] = vr[it][u] * jm; }
+            }
     }
 }
 
@@ -190,7 +233,7 @@ void k_fwd_chunks(const SweepTask *__restrict__ tasks, int ntasks, const Chunk *
     const int tid = threadIdx.x;
     CY_DECL;
     VAR_DECL;
-    chunk_prologue<NC, NTHR>(T, recs + T.c0, nch, meta, L, X, V, nr, ldx);
+    chunk_prologue<NC, NTHR, false>(T, recs + T.c0, nch, meta, nullptr, X, V, nr, ldx);
     for (int i = NT * NC + tid; i < CH_ROWS * NC; i += NTHR) V[i] = 0.0;
     __syncthreads();
     CY_MARK(0);
@@ -332,25 +375,9 @@ void k_bwd_chunks(DevSym S, const SweepTask *__restrict__ tasks, int ntasks, con
     const int tid = threadIdx.x;
     CY_DECL;
     VAR_DECL;
-    chunk_prologue<NC, NTHR>(T, recs + T.b0, T.nbw, meta, L, X, V, nr, ldx);
-    {   // x of the root's trailing rows (ancestors of the subtree: final), zeros behind them
-        constexpr int GR = NTHR / NC;
-        const int j = tid % NC, g = tid / NC;
-        const int jc = min(j, nr - 1);
-        const double jm = j < nr ? 1.0 : 0.0;
-        const int *rows = S.rows + T.rroot;
-        for (int i0 = g; i0 < mroot; i0 += 4 * GR) {
-            int ri[4];
-            double v[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) ri[u] = rows[min(i0 + GR * u, mroot - 1)];
-#pragma unroll
-            for (int u = 0; u < 4; u++) v[u] = X[(long long)ri[u] * ldx + jc];
-#pragma unroll
-            for (int u = 0; u < 4; u++) if (i0 + GR * u < mroot) V[vbyte<NC>(NT + i0 + GR * u, j) >> 3] = v[u] * jm;
-        }
-        for (int i = (NT + mroot) * NC + tid; i < CH_ROWS * NC; i += NTHR) V[i] = 0.0;
-    }
+    // own rows (y of the subtree) and x of the root's trailing rows (ancestors of the subtree: final), zeros behind them
+    chunk_prologue<NC, NTHR, true>(T, recs + T.b0, T.nbw, meta, S.rows + T.rroot, X, V, nr, ldx);
+    for (int i = (NT + mroot) * NC + tid; i < CH_ROWS * NC; i += NTHR) V[i] = 0.0;
     __syncthreads();
     CY_MARK(0);
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -1180,10 +1180,12 @@ def test_narrow_passes_match_the_oracle_for_every_width():
     trail = np.diff(sym.row_ptr) - cols
     assert cols.max() > 128 and trail.max() > 256          # the four-wave forms of both update kernels are exercised
     F = orc.OracleFactor(Q, be.ordering_permutation())
-    B = np.random.default_rng(77).standard_normal((n, 17))
+    # (round 6: passes of 17 .. 32 columns run the narrow FORWARD kernels on two right-hand-side tiles, grid y / z = the tile; 33 is
+    #  the first width on the 64-column kernels throughout)
+    B = np.random.default_rng(77).standard_normal((n, 33))
     Xo, So = F.solve(B), F.backward_solve(B)
-    X64 = be.backend_solve(np.hstack([B, B, B, B[:, :13]]))[:, :17]
-    for k in (1, 2, 3, 4, 5, 8, 9, 15, 16, 17):
+    X64 = be.backend_solve(np.hstack([B, B[:, :31]]))[:, :33]
+    for k in (1, 2, 3, 4, 5, 8, 9, 15, 16, 17, 18, 24, 31, 32, 33):
         Bk = B[:, 0] if k == 1 else B[:, :k]
         X = be.backend_solve(Bk).reshape(n, -1)
         assert relerr(X, Xo[:, :k]) < 1e-10, k

@@ -11,7 +11,7 @@ mesh = spde.grid_mesh_2d(grid, grid, jitter=0.25, seed=0)
 Q = spde.matern_precision(mesh, smoothness=0, range_=0.2)
 n = Q.shape[0]
 be = gmrfx.MI355XBackend(Q, coords=mesh.points)
-for nr in (1, 2, 4, 8, 16, 32, 64, 128, 256):
+for nr in [int(x) for x in os.environ.get("NRHS_LIST", "1,2,4,8,16,17,24,32,33,48,64,128,256").split(",")]:
     B = torch.randn((nr, n), dtype=torch.float64, device="cuda"); X = torch.empty_like(B)
     torch.cuda.synchronize()
     for rep in range(3):
