@@ -305,9 +305,11 @@ extern "C" int32_t gmrfx_shard_edges(const gmrfx_handle *h, int64_t *child, int6
         const i32 d = S.shard_edges[k], p = S.sparent[d];
         const int64_t m = S.nrows(d) - S.ncols(d);
         child[k] = d; src[k] = S.owner[d]; dst[k] = S.owner[p]; level[k] = S.level[p];
-        cb_offset[k] = S.cbptr[d]; cb_count[k] = m * m;
+        // offsets in THIS rank's arena (round 6: per-rank layouts); -1 when this rank is neither end of the edge
+        const bool end = S.owner[d] == S.shard_rank || S.owner[p] == S.shard_rank;
+        cb_offset[k] = end ? S.cbptr[d] : -1; cb_count[k] = m * m;
         w_row0[k] = wptr[d]; w_nrows[k] = m;
-        if (zb_offset) zb_offset[k] = S.zbptr[d];
+        if (zb_offset) zb_offset[k] = end ? S.zbptr[d] : -1;
         if (child_level) child_level[k] = S.level[d];
     }
     return GMRFX_OK;

@@ -820,8 +820,8 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
     // level(parent(s)) in the factorisation; in the (top-down) selected inversion the trailing inverse block
     // of s lives from level(s) down to the lowest level of its children. Slots are handed out first-fit level
     // by level (the blocks a level reads are only released after the level's own blocks have their slots, so
-    // nothing a level writes aliases anything it reads). Offsets are computed over ALL fronts, so every rank of
-    // a sharded factorisation sees the same layout. Subtree tasks run fronts out of level order: linear layout.
+    // nothing a level writes aliases anything it reads). A sharded handle has its own layout per rank (below).
+    // Subtree tasks run fronts out of level order: linear layout.
     S.zbptr = S.cbptr;
     if (!(opt.subtree_max > 0)) {
         struct Arena {      // best fit, coalescing free list (offset-ordered map + size-ordered index)
@@ -859,46 +859,99 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
             }
         };
         auto bsz = [&](i32 s) { const i64 m = S.nrows(s) - S.ncols(s); return ((m * m) + 15) & ~i64(15); };
-        // sharded: the blocks of the cross-edge children sit in an exchange region at the start of the arena (same offsets
-        // on every rank, no reuse: a handful of blocks); behind it this rank's own fronts share slots by lifetime
-        i64 xtop = 0;
-        auto in_arena = [&](i32 s) { return !S.shard_plan || (mine(s) && !S.cross_child[s]); };
-        if (S.shard_plan)
-            for (i32 s = 0; s < ns; s++) {
-                S.cbptr[s] = S.zbptr[s] = 0;
-                if (S.cross_child[s]) { S.cbptr[s] = S.zbptr[s] = xtop; xtop += bsz(s); }
+        i64 peak = 0;
+        if (!S.shard_plan) {
+            std::vector<std::vector<i32>> bylevel(S.nlevels);
+            for (i32 s = 0; s < ns; s++) bylevel[S.level[s]].push_back(s);
+            {   // factorisation: bottom-up
+                Arena A;
+                for (i32 l = 0; l < S.nlevels; l++) {
+                    for (i32 s : bylevel[l]) if (bsz(s) > 0) S.cbptr[s] = A.alloc(bsz(s));
+                    peak = std::max(peak, A.top);
+                    for (i32 s : bylevel[l])
+                        for (i64 q = S.childptr[s]; q < S.childptr[s + 1]; q++) {
+                            const i32 d = S.children[q];
+                            if (bsz(d) > 0) A.release(S.cbptr[d], bsz(d));
+                        }
+                }
             }
-        std::vector<std::vector<i32>> bylevel(S.nlevels);
-        for (i32 s = 0; s < ns; s++) if (in_arena(s)) bylevel[S.level[s]].push_back(s);
-        i64 peak = xtop;
-        {   // factorisation: bottom-up
-            Arena A;
-            A.top = xtop;
-            for (i32 l = 0; l < S.nlevels; l++) {
-                for (i32 s : bylevel[l]) if (bsz(s) > 0) S.cbptr[s] = A.alloc(bsz(s));
-                peak = std::max(peak, A.top);
-                for (i32 s : bylevel[l])
-                    for (i64 q = S.childptr[s]; q < S.childptr[s + 1]; q++) {
-                        const i32 d = S.children[q];
-                        if (bsz(d) > 0 && in_arena(d)) A.release(S.cbptr[d], bsz(d));
+            {   // selected inversion: top-down
+                Arena A;
+                std::vector<i32> minchild(ns, -1);
+                for (i32 s = 0; s < ns; s++) {
+                    i32 mc = S.level[s];                                   // no children: released after its own level
+                    for (i64 q = S.childptr[s]; q < S.childptr[s + 1]; q++) mc = std::min(mc, S.level[S.children[q]]);
+                    minchild[s] = mc;
+                }
+                std::vector<std::vector<i32>> dies(S.nlevels);
+                for (i32 s = 0; s < ns; s++) dies[minchild[s]].push_back(s);
+                for (i32 l = S.nlevels - 1; l >= 0; l--) {
+                    for (i32 s : bylevel[l]) if (bsz(s) > 0) S.zbptr[s] = A.alloc(bsz(s));
+                    peak = std::max(peak, A.top);
+                    for (i32 s : dies[l]) if (bsz(s) > 0) A.release(S.zbptr[s], bsz(s));
+                }
+            }
+        } else {
+            // SHARDED (round 6): a PER-RANK layout. Rounds 3-5 put the blocks of every cross-edge child -- and of every distributed
+            // front and its children -- into an exchange region laid out identically on every rank, without reuse ("a handful of
+            // blocks"): at cfg 4 / world 8 that region is 75 GB of 14 blocks on EVERY rank, 90 of the 120-129 GB a rank needs. A
+            // transfer does not need equal offsets on its two ends (each rank builds its views from its own tables:
+            // gmrfx_shard_transfers / gmrfx_shard_edges report THIS rank's offsets), so every rank now gives slots only to the
+            // blocks it touches, all of them by lifetime:
+            //   factorisation  CB_s is PRODUCED here (this rank executes s, or is a member of the group of the distributed front
+            //                  s: its own column blocks) -> born at level(s); or only RECEIVED here (whole, or the column ranges
+            //                  that fall into this rank's blocks of a distributed parent) -> born when level(parent) starts: the
+            //                  receive is posted behind this rank's phases of the level below, stream-ordered; everything dies
+            //                  behind level(parent) (a sender's wait() orders its later kernels behind the send).
+            //   selected inv.  the trailing inverse block of s lives on owner[s] from level(s) down to its lowest child, and on
+            //                  the owner of a parent on another rank from the gather (gmrfx_selinv_phase(1, level(s))) to the
+            //                  end of that level (sent away).
+            // A block keeps the full (r - c)^2 layout wherever it lives (kernels address columns globally); only the slots move.
+            const i32 me = S.shard_rank;
+            auto in_group = [&](i32 s) { return S.is_dist(s) && S.group_pos(s, me) >= 0; };
+            auto produce = [&](i32 s) { return mine(s) || in_group(s); };
+            auto receive = [&](i32 s) { const i32 p = S.sparent[s]; return p >= 0 && (S.is_dist(p) ? in_group(p) : S.owner[p] == me); };
+            for (i32 s = 0; s < ns; s++) S.cbptr[s] = S.zbptr[s] = 0;
+            std::vector<std::vector<i32>> born(S.nlevels), arrive(S.nlevels), consumed(S.nlevels);
+            for (i32 s = 0; s < ns; s++) {
+                if (bsz(s) <= 0) continue;
+                const i32 p = S.sparent[s];
+                const bool pr = produce(s), rc = receive(s);
+                if (pr) born[S.level[s]].push_back(s);
+                else if (rc) arrive[S.level[p]].push_back(s);
+                if ((pr || rc) && p >= 0) consumed[S.level[p]].push_back(s);
+            }
+            {   // factorisation: bottom-up
+                Arena A;
+                for (i32 l = 0; l < S.nlevels; l++) {
+                    for (i32 s : arrive[l]) S.cbptr[s] = A.alloc(bsz(s));
+                    for (i32 s : born[l]) S.cbptr[s] = A.alloc(bsz(s));
+                    peak = std::max(peak, A.top);
+                    for (i32 s : consumed[l]) A.release(S.cbptr[s], bsz(s));
+                }
+            }
+            {   // selected inversion: top-down (a distributed front is inverted by its owner alone)
+                Arena A;
+                std::vector<std::vector<i32>> zborn(S.nlevels), zsent(S.nlevels), zdies(S.nlevels);
+                for (i32 s = 0; s < ns; s++) {
+                    if (bsz(s) <= 0) continue;
+                    const i32 p = S.sparent[s];
+                    if (mine(s)) {
+                        i32 mc = S.level[s];
+                        for (i64 q = S.childptr[s]; q < S.childptr[s + 1]; q++) mc = std::min(mc, S.level[S.children[q]]);
+                        zborn[S.level[s]].push_back(s);
+                        zdies[mc].push_back(s);
+                    } else if (p >= 0 && S.owner[p] == me) {
+                        zborn[S.level[s]].push_back(s);
+                        zsent[S.level[s]].push_back(s);
                     }
-            }
-        }
-        {   // selected inversion: top-down
-            Arena A;
-            A.top = xtop;
-            std::vector<i32> minchild(ns, -1);
-            for (i32 s = 0; s < ns; s++) {
-                i32 mc = S.level[s];                                   // no children: released after its own level
-                for (i64 q = S.childptr[s]; q < S.childptr[s + 1]; q++) mc = std::min(mc, S.level[S.children[q]]);
-                minchild[s] = mc;
-            }
-            std::vector<std::vector<i32>> dies(S.nlevels);
-            for (i32 s = 0; s < ns; s++) if (in_arena(s)) dies[minchild[s]].push_back(s);
-            for (i32 l = S.nlevels - 1; l >= 0; l--) {
-                for (i32 s : bylevel[l]) if (bsz(s) > 0) S.zbptr[s] = A.alloc(bsz(s));
-                peak = std::max(peak, A.top);
-                for (i32 s : dies[l]) if (bsz(s) > 0) A.release(S.zbptr[s], bsz(s));
+                }
+                for (i32 l = S.nlevels - 1; l >= 0; l--) {
+                    for (i32 s : zborn[l]) S.zbptr[s] = A.alloc(bsz(s));
+                    peak = std::max(peak, A.top);
+                    for (i32 s : zsent[l]) A.release(S.zbptr[s], bsz(s));
+                    for (i32 s : zdies[l]) A.release(S.zbptr[s], bsz(s));
+                }
             }
         }
         S.cb_arena = std::max<i64>(peak, 16);
@@ -922,7 +975,9 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
                 const i32 src = S.cb_owner(d, k / 256), dst = need(k);
                 i32 k1 = k + 1;
                 while (k1 < md && S.cb_owner(d, k1 / 256) == src && need(k1) == dst) k1++;
-                if (src != dst) xf.push_back({(i64)S.level[p], (i64)d, (i64)src, (i64)dst, S.cbptr[d] + (i64)k * md, (i64)(k1 - k) * md, (i64)k});
+                if (src != dst)       // (offset: in THIS rank's arena; -1 when this rank is neither end)
+                    xf.push_back({(i64)S.level[p], (i64)d, (i64)src, (i64)dst, (src == S.shard_rank || dst == S.shard_rank) ? S.cbptr[d] + (i64)k * md : (i64)-1,
+                                  (i64)(k1 - k) * md, (i64)k});
                 k = k1;
             }
         }

@@ -164,8 +164,10 @@ int32_t gmrfx_refactorize_update_solve_dev(gmrfx_handle *h, const double *d_hval
  * rank of the group whose subtrees it joins -- independent top fronts run on different GPUs, and data crosses ranks
  * only along the tree edges whose two ends have different owners (gmrfx_shard_edges: child, src, dst, level of the
  * parent, the contribution block's place in the arena gmrfx_device_ptr(h, 0), the update vector's rows in
- * gmrfx_device_ptr(h, 3)). All ranks share one layout of the arena / X / W buffers, so a block is sent to the same
- * offset it came from. K = nlevels - shard_level top levels.
+ * gmrfx_device_ptr(h, 3)). X / W rows are laid out identically on all ranks; the contribution-block ARENA has its own
+ * layout on every rank (round 6: a rank only gives slots -- shared by lifetime -- to the blocks it produces or receives),
+ * so cb_offset / zb_offset / gmrfx_shard_transfers' offset are THIS rank's offsets (-1 when the rank is neither end):
+ * the sender builds its view from its own handle's table, the receiver from its own. K = nlevels - shard_level top levels.
  *   refactorisation  gmrfx_refactorize_phase(h, nzval, 0)      the subtrees this rank owns
  *                    for k = 0 .. K-1:  [contribution blocks of the edges with level = shard_level + k: src -> dst]
  *                                       gmrfx_refactorize_phase(h, nzval, 1 + k)   this rank's fronts of top level k
@@ -213,8 +215,9 @@ int32_t gmrfx_set_stream(gmrfx_handle *h, void *hip_stream, int32_t use_external
  *   gmrfx_shard_dist_fronts: counts[0] fronts, [1] group entries, [2] transfers, [3] world; per front (nullable): supernode,
  *     columns, rows, panel offset in gmrfx_device_ptr(h, 1), panel leading dimension, tree level; gptr / grank: its group.
  *   gmrfx_shard_transfers: every contribution-block transfer of the factorisation, ordered by the parent's level: `count`
- *     doubles (whole columns of `child`'s block) at `offset` of gmrfx_device_ptr(h, 0) go src -> dst before level `level` is
- *     assembled (col0: the first of these columns). Replaces the cb_offset / cb_count columns of gmrfx_shard_edges for the factorisation.
+ *     doubles (whole columns of `child`'s block) at `offset` of THIS rank's gmrfx_device_ptr(h, 0) (-1 when this rank is neither
+ *     src nor dst; the two ends have different offsets) go src -> dst before level `level` is assembled (col0: the first of
+ *     these columns). Replaces the cb_offset / cb_count columns of gmrfx_shard_edges for the factorisation.
  *   gmrfx_dist_front_phase(h, d_nzval, front, what, block): 0 = assemble this rank's panel blocks; 1 = factor panel block
  *     `block` (its owner; a no-op elsewhere) [then broadcast columns 256 block .. of the panel inside the group]; 2 = apply
  *     block `block` to this rank's later panel blocks (4 = to block + 1 only, 5 = to the later blocks except block + 1: the
