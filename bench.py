@@ -105,7 +105,9 @@ def sweep_model_bound(be, nrhs, copy_gbs, floor_us=LAUNCH_FLOOR_US, small_rows=6
         bb = float(alg[sel].sum() + hand[sel].sum())
         ncls = int((sel & cls48).any()) + int((sel & small & ~cls48).any())
         big = sel & ~small
-        fl = ncls + (3 if big.any() else 0)
+        # (round 6: k_fwd_front takes the fronts of at most 128 columns of a level that has at least 384 of them: one launch)
+        ff = big & (c <= 128)
+        fl = ncls + ((1 + (3 if (big & ~ff).any() else 0)) if ff.sum() >= 384 else (3 if big.any() else 0))
         bl = ncls + (0 if not big.any() else (1 if (c[big] <= 128).all() else 2))
         fwd_b += fb; bwd_b += bb; fwd_l += fl; bwd_l += bl
         rows.append({"level": lv, "fronts": int(sel.sum()), "fwd_bytes": fb, "bwd_bytes": bb, "fwd_launches": fl, "bwd_launches": bl})

@@ -365,6 +365,7 @@ void Device::upload(const Symbolic &S) {
             const int *l2p; up(l2p, l2); d_levellist2_ = const_cast<int *>(l2p);
             if (const char *e = std::getenv("GMRFX_LEVEL_MARK")) level_mark_ = std::atoi(e) != 0;
             if (const char *e = std::getenv("GMRFX_BWD_FRONT")) bwd_front_min_ = std::atoi(e);    // fronts a level needs for the one-workgroup backward step (0: never)
+            if (const char *e = std::getenv("GMRFX_FWD_FRONT")) fwd_front_min_ = std::atoi(e);    // ... and for the one-workgroup forward step
         }
         const int *a; up(a, S.sub_first); d_sub_first_ = const_cast<int *>(a);
         const int *b; up(b, S.sub_last); d_sub_last_ = const_cast<int *>(b);
@@ -1444,7 +1445,21 @@ void Device::forward(int nr, int ldx, int lo, int hi) {
         for (int k = 0, off = 0; k < 4; off += L.ncls[k], k++)
             launch_fwd_small(stream, ds_, d_sw_levellist_ + L.first + off, L.ncls[k], kClsRows[k], d_L_, d_X_, d_W_, nr, ldx);
         const int *list = d_sw_levellist_ + L.first + L.nsmall;
-        const int nf = L.count - L.nsmall;
+        int nf = L.count - L.nsmall;
+        // fronts of at most 128 columns (the tail of the list: sorted by decreasing width): the WHOLE step -- own rows assembled,
+        // y = L11^-1 b, W = children - L21 y -- as one workgroup and one launch (k_fwd_front, sweep_front.hip), on levels with enough
+        // of them to fill the chip and for passes wider than the narrow kernels take; wider fronts keep the three launches below
+        int cmin_front = 0;
+        if (fwd_front_min_ > 0 && nr > narrow_pass_max()) {
+            const size_t kq = (size_t)std::min(bwd_front_max_cols(), inv_cap_) / NB;       // (a front needs its WHOLE inverse for this)
+            const int nwide = kq + 1 < L.active.size() ? L.active[kq] : 0;
+            if (nf - nwide >= fwd_front_min_) {
+                launch_fwd_front(stream, ds_, list + nwide, nf - nwide, d_L_, d_X_, d_X2_, d_W_, nr, ldx);
+                nf = nwide;
+                cmin_front = (int)kq * NB;       // the record-driven update below skips the fronts taken here (its records cover the level)
+                if (nf == 0) continue;
+            }
+        }
         launch_fwd_assemble(stream, ds_, list, nf, L.max_cols, d_X_, d_W_, nr, ldx);   // own rows only
         // y = L11^-1 b as one triangular product per front (dense inverse, inverse.hip), then the
         // trailing update W -= L21 y with K = all columns of the front
@@ -1452,18 +1467,20 @@ void Device::forward(int nr, int ldx, int lo, int hi) {
         // fronts wider than inv_cap_: block by block (y_j = X_jj b_j, then the own rows below -= L[.., block j] y_j)
         const int nbk = std::max(1, (L.max_cols + inv_cap_ - 1) / inv_cap_);
         for (int j = 0; j < nbk; j++) {
-            const int na = nbk == 1 ? nf : L.active[std::min<size_t>((size_t)j * inv_cap_ / NB, L.active.size() - 2)];
+            // (nf: k_fwd_front may have taken the narrow tail of the list above -- block 0's count is "every big front" otherwise)
+            const int na = nbk == 1 ? nf : std::min(nf, L.active[std::min<size_t>((size_t)j * inv_cap_ / NB, L.active.size() - 2)]);
             launch_xmul(stream, ds_, list, na, L.max_cols, 0, d_L_, d_X_, d_X2_, nr, ldx, j, inv_cap_);
-            if (j + 1 < nbk) launch_fwd_own_update(stream, ds_, list, L.active[(size_t)(j + 1) * inv_cap_ / NB], L.max_cols, d_L_, d_X2_, d_X_, nr, ldx, j, inv_cap_);
+            if (j + 1 < nbk) launch_fwd_own_update(stream, ds_, list, std::min(nf, L.active[(size_t)(j + 1) * inv_cap_ / NB]), L.max_cols, d_L_, d_X2_, d_X_, nr, ldx, j, inv_cap_);
         }
         // levels with many tiles: record-driven, per-XCD runs; the handful-of-fronts levels keep the 16-row latency variant
         // Passes of at most 16 right-hand sides: the fronts up to kFwdWaveCols columns wide go one WAVE per 32-row tile (no LDS, no
         // barrier: k_fwd_update_wave), chosen per FRONT so that a front's sums do not depend on the list it comes in
         constexpr int kFwdWaveCols = 1024;      // (measured at cfg 2, 1 RHS, forward ms, with four waves sharing the K range of a front wider than 128
                                                 //  columns: 256: 0.933, 512: 0.841, 1024: 0.832, 2048: 0.836)
-        const int cmin = syrk_xcd_ && nr <= narrow_pass_max() ? kFwdWaveCols : 0;
+        const int cwave = syrk_xcd_ && nr <= narrow_pass_max() ? kFwdWaveCols : 0;
+        const int cmin = std::max(cwave, cmin_front);          // fronts up to this width are not the split-K kernels' (wave kernel / k_fwd_front)
         const int nwider = (size_t)(kFwdWaveCols / NB + 1) < L.active.size() ? L.active[kFwdWaveCols / NB] : 0;      // fronts wider than that
-        if (cmin > 0 && nwider < nf) launch_fwd_update_wave(stream, ds_, d_fwd_recs_ + L.fwd_off, L.fwd_split, L.fwd_per, d_L_, d_X2_, d_W_, nr, ldx, cmin,
+        if (cwave > 0 && nwider < nf) launch_fwd_update_wave(stream, ds_, d_fwd_recs_ + L.fwd_off, L.fwd_split, L.fwd_per, d_L_, d_X2_, d_W_, nr, ldx, cwave,
                                                               L.max_cols > launch_wave_split_cols());
         if (L.max_cols > cmin) {
             if (syrk_xcd_ && (long long)((level_max_trail(L) + 31) / 32) * nf > 128)

@@ -290,6 +290,9 @@ private:
     void ensure_rdiag();
     bool nzp_pending_ = false;                    // k_gather_values runs on the third stream and the main stream has not waited for it yet
     void ensure_dtile();
+    int fwd_front_min_ = 384;                     // the forward twin (k_fwd_front): levels with at least this many such fronts (measured at cfg 2, round 6, one workgroup per
+                                                  // front against the three launches, us: level 5 (1472 fronts) 103 / 128, 6 (2271) 167 / 211, 7 (1034) 159 / 207, 8 (513) 103 / 131,
+                                                  // 9 (256, 236 of them eligible) 103 + 58 / 113: a level needs about two workgroups per compute unit)
     int bwd_front_min_ = 192;                     // backward step of fronts <= 128 columns wide as one workgroup (sweep_front.hip) on levels with at least this many of them (0: never)
     Symbolic::SwChunk *d_swc_fwd_ = nullptr, *d_swc_bwd_ = nullptr;   // chunk records of the sweep tasks (forward order / backward slot programs)
     int *d_swc_listf_ = nullptr, *d_swc_listb_ = nullptr;               // their target rows as LDS byte offsets, in the lane order of the two kernels

@@ -451,6 +451,9 @@ void launch_bwd_small(hipStream_t st, const DevSym &S, const int *list, int nfro
 void launch_bwd_front(hipStream_t st, const DevSym &S, const int *list, int nfronts, const double *L, const double *Xt, const double *Yin,
                       double *Xout, int nr, int ldx);
 int bwd_front_max_cols();
+// the forward twin: the whole forward step of such a front (own rows assembled, Y[own] = L11^-1 b, W = children - L21 y) as one workgroup
+void launch_fwd_front(hipStream_t st, const DevSym &S, const int *list, int nfronts, const double *L, const double *X, double *Y, double *W,
+                      int nr, int ldx);
 // chunk form of the sweep tasks (sweep_chunk.hip)
 void launch_pack_diag(hipStream_t st, const Symbolic::SwChunk *recs, int nchunks, const double *L, double *dtile);
 void launch_sweep_chunks(hipStream_t st, const DevSym &S, int phase, const SweepTask *tasks, int ntasks, const Symbolic::SwChunk *recs_fwd,

@@ -189,4 +189,226 @@ void launch_bwd_front(hipStream_t st, const DevSym &S, const int *list, int nfro
     if (nfronts <= 0) return;
     hipLaunchKernelGGL(k_bwd_front, dim3(nfronts), dim3(512), 0, st, S, list, L, Xt, Yin, Xout, nr, ldx);
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// The FORWARD twin (round 6): the whole forward step of a front of at most 128 columns -- own rows assembled from X and the
+// children's update vectors, y = L11^-1 b, W = (children) - L21 y -- as ONE workgroup of eight waves and ONE launch instead of three
+// (k_fwd_assemble -> k_xmul -> k_fwd_update_rec), for passes wider than the narrow kernels take. Round 5 fused only the first two
+// steps and lost (header of this file): the update is two thirds of a mid level's forward time (levels 5-9 of cfg 2: 550 of 790 us)
+// and the three launches moved their bytes at 2.7-2.95 TB/s where k_bwd_front moves the same levels at 3.6-4.0.
+//  * phase A: b = X[own rows] + the children's rows that land on them (per-edge table DevSym::erow, children in edge order: the
+//    same sums in the same order as k_fwd_assemble), 16 rows per thread, into LDS (row stride 72 doubles);
+//  * phase B: y = L11^-1 b, a wave per 16 rows (NTL right-hand-side tiles each: the dealing of k_bwd_front), the inverse from the
+//    panel's upper triangle -- element (i, k), k < i, sits at row k of column i --, the diagonal tile masked; y goes to Y (the second
+//    right-hand-side buffer, where the backward sweep expects it) and, behind a barrier, over b in LDS (rows up to the next
+//    multiple of 16 zeroed: phase C's k-steps run over them);
+//  * phase C: a wave owns a 32-row tile of the trailing rows for the whole K range and all four right-hand-side tiles, operand rows
+//    in pairs (16-byte loads), y from LDS; the children's update vectors enter THROUGH THE MATRIX PIPE like in k_fwd_update_wave
+//    (a child row that lands on tile row i is one more k-step against the indicator -1 at row i: exact, fixed order, no LDS tile,
+//    no barrier), tile ranges from the per-edge table DevSym::etile; W is written once.
+// Same sums in a fixed order per front: bit-reproducible, and the same for a front whatever list it comes in.
+constexpr int FF_TS = 72;
+
+template <int NTL> __device__ __forceinline__ void fwd_front_body(double *sh, const DevSym &S, const int s, const double *__restrict__ L,
+                                                                  const double *X, double *Y, double *W, int nr, int ldx) {
+    const int first = S.sfirst[s];
+    const int c = S.sfirst[s + 1] - first;
+    const long long rp = S.rowptr[s];
+    const int r = (int)(S.rowptr[s + 1] - rp);
+    const int ld = S.ld[s];
+    const double *P = L + S.panelptr[s];
+    const int m = r - c;
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, lm = lane & 15, lk = lane >> 4;
+    const long long ch0 = S.childptr[s], ch1 = S.childptr[s + 1];
+    const int ctop = (c + 15) & ~15;
+    // ---- phase A ----
+    {
+        const int j = lane, jc = min(j, nr - 1);
+        const double jm = j < nr ? 1.0 : 0.0;
+        constexpr int NU = BF_MAXC / 8;                 // rows w + 8 u of the front
+        double x[NU];
+#pragma unroll
+        for (int u = 0; u < NU; u++) x[u] = (8 * u < c) ? X[(long long)(first + min(w + 8 * u, c - 1)) * ldx + jc] : 0.0;
+        for (long long ch = ch0; ch < ch1; ch++) {
+            const EdgeRec er = S.edge[ch];
+            if (er.nown <= 0) continue;                 // no row of this child lands on an own column
+            const int *er_row = S.erow + er.eoff;
+            const double *Wd = W + er.woff * ldx;
+            int jr[NU];
+#pragma unroll
+            for (int u = 0; u < NU; u++) jr[u] = (8 * u < c) ? er_row[min(w + 8 * u, c - 1)] : -1;      // wave-uniform
+            double v[NU];
+#pragma unroll
+            for (int u = 0; u < NU; u++) v[u] = jr[u] >= 0 ? Wd[(long long)jr[u] * ldx + jc] : 0.0;
+#pragma unroll
+            for (int u = 0; u < NU; u++) x[u] += v[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NU; u++) {
+            const int i = w + 8 * u;
+            if (i < ctop) sh[i * FF_TS + j] = i < c ? x[u] * jm : 0.0;
+        }
+    }
+    __syncthreads();
+    // ---- phase B: y = L11^-1 b ----
+    constexpr int WPT = 4 / NTL;
+    const int ct = w / WPT, t0 = (w % WPT) * NTL;
+    const bool active = ct * 16 < c;
+    d4 y[NTL];
+#pragma unroll
+    for (int t = 0; t < NTL; t++) y[t] = (d4){0.0, 0.0, 0.0, 0.0};
+    if (active) {
+        const int i0 = ct * 16;
+        const int ic = min(i0 + lm, c - 1);
+        const double *pc = P + (long long)ic * ld;          // column i of the panel: rows k < i hold L11^-1[i][k]
+        double an[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) an[u] = pc[min(4 * u + lk, c - 1)];
+#pragma unroll 1
+        for (int k0 = 0; k0 < i0; k0 += 16) {
+            double av[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) av[u] = an[u];
+#pragma unroll
+            for (int u = 0; u < 4; u++) an[u] = pc[min(k0 + 16 + 4 * u + lk, c - 1)];       // (the next tile's, requested before this tile's MFMAs)
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const double *br = sh + (k0 + 4 * u + lk) * FF_TS + 16 * t0 + lm;
+#pragma unroll
+                for (int t = 0; t < NTL; t++) y[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], br[16 * t], y[t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {                        // diagonal tile: k <= i
+            const int k = i0 + 4 * u + lk, kc = min(k, c - 1);
+            const double v = P[min(ic, kc) + (long long)max(ic, kc) * ld];
+            double a = (k < c && i0 + lm < c && k < i0 + lm) ? v : 0.0;
+            if (k == i0 + lm && k < c) a = 1.0 / v;
+            const double *br = sh + k * FF_TS + 16 * t0 + lm;
+#pragma unroll
+            for (int t = 0; t < NTL; t++) y[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, br[16 * t], y[t], 0, 0, 0);
+        }
+    }
+    __syncthreads();                                         // every wave has read the b it needs
+    if (active) {
+        double *Yo = Y + (long long)first * ldx;
+#pragma unroll
+        for (int t = 0; t < NTL; t++)
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                const int i = ct * 16 + lk + 4 * rr, j = 16 * (t0 + t) + lm;
+                const bool ok = i < c && j < nr;
+                sh[i * FF_TS + j] = ok ? y[t][rr] : 0.0;
+                if (ok) Yo[(long long)i * ldx + j] = y[t][rr];
+            }
+    }
+    __syncthreads();
+    // ---- phase C: W = (children) - L21 y, a wave per 32-row tile ----
+    if (m <= 0) return;
+    const int nt32 = (m + 31) >> 5;
+    double *Ws = W + S.wptr[s] * ldx;
+    int jl[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) jl[t] = min(16 * t + lm, nr - 1);
+    for (int T = w; T < nt32; T += 8) {
+        const int i0 = 32 * T;
+        d4 acc[2][4];
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) acc[a][t] = (d4){0.0, 0.0, 0.0, 0.0};
+        // (a pair that starts at the last trailing row reads one double behind the column: the next column's first entry or the
+        //  padding behind the panel; its row is never stored)
+        const double *pa = P + c + min(i0 + 2 * lm, m - 1);
+        constexpr int KU = 2;
+        // (the panel operand of batch n + 1 is requested before the MFMAs of batch n: a batch's 16 MFMAs take about one memory
+        //  round trip of a wave's time, and with two waves per SIMD nobody else hides it)
+        d2u an[KU];
+#pragma unroll
+        for (int u = 0; u < KU; u++) an[u] = *(const d2u *)(pa + (long long)min(4 * u + lk, c - 1) * ld);
+#pragma unroll 1
+        for (int k0 = 0; k0 < c; k0 += 4 * KU) {
+            double av[KU][2], bv[KU][4];
+#pragma unroll
+            for (int u = 0; u < KU; u++) { av[u][0] = an[u].x; av[u][1] = an[u].y; }
+#pragma unroll
+            for (int u = 0; u < KU; u++) an[u] = *(const d2u *)(pa + (long long)min(k0 + 4 * KU + 4 * u + lk, c - 1) * ld);
+#pragma unroll
+            for (int u = 0; u < KU; u++) {
+                const int kk = k0 + 4 * u + lk;             // (rows c .. ctop - 1 of y are zero in LDS; the panel column is clamped)
+                const double *br = sh + kk * FF_TS + lm;
+#pragma unroll
+                for (int t = 0; t < 4; t++) bv[u][t] = br[16 * t];
+            }
+#pragma unroll
+            for (int u = 0; u < KU; u++)
+                if (k0 + 4 * u < c) {
+#pragma unroll
+                    for (int a = 0; a < 2; a++)
+#pragma unroll
+                        for (int t = 0; t < 4; t++) acc[a][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][a], bv[u][t], acc[a][t], 0, 0, 0);
+                }
+        }
+        // children: rows [a0, a1) of a child land in this tile; four of them per k-step against the indicator operand
+        const int myrow = c + i0 + 2 * lm;
+        for (long long ch = ch0; ch < ch1; ch++) {
+            const EdgeRec er = S.edge[ch];
+            const int a0 = S.etile[er.tptr + T], a1 = S.etile[er.tptr + T + 1];
+            const int *reld = S.rel + er.reloff;
+            const double *Wd = W + er.woff * ldx;
+#pragma unroll 1
+            for (int b0 = a0; b0 < a1; b0 += 4 * KU) {
+                double sv[KU][2], wv[KU][4];
+#pragma unroll
+                for (int u = 0; u < KU; u++) {
+                    const int row = b0 + 4 * u + lk;
+                    const int rc = min(row, a1 - 1);
+                    const int d = reld[rc] - myrow;
+                    const bool ok = row < a1;
+                    sv[u][0] = (ok && d == 0) ? -1.0 : 0.0;
+                    sv[u][1] = (ok && d == 1) ? -1.0 : 0.0;
+#pragma unroll
+                    for (int t = 0; t < 4; t++) wv[u][t] = Wd[(long long)rc * ldx + jl[t]];
+                }
+#pragma unroll
+                for (int u = 0; u < KU; u++)
+                    if (b0 + 4 * u < a1) {
+#pragma unroll
+                        for (int a = 0; a < 2; a++)
+#pragma unroll
+                            for (int t = 0; t < 4; t++) acc[a][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(sv[u][a], wv[u][t], acc[a][t], 0, 0, 0);
+                    }
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                const int i = i0 + 2 * (lk + 4 * rr) + a;
+                if (i < m) {
+#pragma unroll
+                    for (int t = 0; t < 4; t++)
+                        if (16 * t + lm < nr) Ws[(long long)i * ldx + 16 * t + lm] = -acc[a][t][rr];
+                }
+            }
+    }
+}
+
+__global__ __launch_bounds__(512) void k_fwd_front(DevSym S, const int *__restrict__ list, const double *__restrict__ L, const double *X, double *Y,
+                                                   double *W, int nr, int ldx) {
+    __shared__ double sh[BF_MAXC * FF_TS];            // 72 KB: b, then y (c x 72)
+    const int s = list[blockIdx.x];
+    const int nct = (S.sfirst[s + 1] - S.sfirst[s] + 15) >> 4;
+    if (nct > 4) fwd_front_body<4>(sh, S, s, L, X, Y, W, nr, ldx);
+    else if (nct > 2) fwd_front_body<2>(sh, S, s, L, X, Y, W, nr, ldx);
+    else fwd_front_body<1>(sh, S, s, L, X, Y, W, nr, ldx);
+}
+
+void launch_fwd_front(hipStream_t st, const DevSym &S, const int *list, int nfronts, const double *L, const double *X, double *Y, double *W,
+                      int nr, int ldx) {
+    if (nfronts <= 0) return;
+    hipLaunchKernelGGL(k_fwd_front, dim3(nfronts), dim3(512), 0, st, S, list, L, X, Y, W, nr, ldx);
+}
 }  // namespace gmrfx

@@ -1068,6 +1068,34 @@ def test_backward_step_one_workgroup_per_front_equals_two_launches(name, monkeyp
     assert np.array_equal(one.backend_solve(B), one.backend_solve(B))       # bit-reproducible
 
 
+@pytest.mark.parametrize("name", ["matern64_coords", "cfg1_alpha3_65x65", "matern3d_10", "rand400", "tall_fronts", "dense70"])
+def test_forward_step_one_workgroup_per_front_equals_three_launches(name, monkeypatch):
+    """Round 6 (csrc/sweep_front.hip, k_fwd_front): the WHOLE forward step of a front of at most 128 columns as one workgroup -- own rows
+    assembled from X and the children's update vectors, y = L11^-1 b, W = children - L21 y with the children's rows entering through the
+    matrix pipe -- against the three launches it replaces (GMRFX_FWD_FRONT=0) and against the oracle: solves of 33 .. 70 right-hand
+    sides (narrower passes keep the narrow kernels), ragged blocks, bit-reproducible. By default only levels with at least 192 such
+    fronts take it (the 10^6-node problems of the full-size tests); GMRFX_FWD_FRONT=1 sends every eligible front of these cases."""
+    Q, kw = next((sp.csc_matrix(q), k) for n, q, k in CASES if n == name)
+    n = Q.shape[0]
+    rng = np.random.default_rng(12)
+    monkeypatch.setenv("GMRFX_FWD_FRONT", "1")
+    one = gmrfx.MI355XBackend(Q, **kw)
+    monkeypatch.setenv("GMRFX_FWD_FRONT", "0")
+    three = gmrfx.MI355XBackend(Q, ordering=one.ordering_permutation())
+    monkeypatch.delenv("GMRFX_FWD_FRONT")
+    F = orc.OracleFactor(Q, one.ordering_permutation())
+    for nrhs in (33, 40, 64, 70, 1, 17):
+        B = rng.standard_normal((n, nrhs))
+        assert relerr(one.backend_solve(B), F.solve(B)) < 1e-10
+        assert relerr(one.backend_solve(B), three.backend_solve(B)) < 1e-11
+    assert np.array_equal(one.backend_solve(B), one.backend_solve(B))       # bit-reproducible
+    B = rng.standard_normal((n, 64))
+    assert np.array_equal(one.backend_solve(B), one.backend_solve(B))
+    # the pipelined call takes the same kernels: same bits as the two calls
+    X1 = one.refactorize_solve(Q.data, B)
+    assert np.array_equal(X1, one.backend_solve(B))
+
+
 @pytest.mark.parametrize("cap", ["64", "128"])
 def test_one_workgroup_backward_step_beside_blocked_substitution(cap, monkeypatch):
     """A level that has BOTH fronts wider than the inverse cap (blocked substitution, block 0's list = 'every big front') and a
@@ -1075,6 +1103,7 @@ def test_one_workgroup_backward_step_beside_blocked_substitution(cap, monkeypatc
     na = L.active[0] ignored the fronts taken off the list -- x overwritten with L11^-T of the already final x). Passes wider than
     16 columns, y in the second buffer (solve) and in place (backward-only), against the oracle."""
     monkeypatch.setenv("GMRFX_BWD_FRONT", "1")
+    monkeypatch.setenv("GMRFX_FWD_FRONT", "1")          # (round 6: the forward twin has the same list arithmetic)
     monkeypatch.setenv("GMRFX_INV_CAP", cap)
     rng = np.random.default_rng(100 + int(cap))
     m3 = spde.grid_mesh_3d(13, 12, 11)
