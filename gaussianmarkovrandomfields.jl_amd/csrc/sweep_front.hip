@@ -20,6 +20,12 @@
 //  * t = y - acc goes to LDS (over the stage), and the same wave forms x = L11^-T t for its 16 rows from the inverse the
 //    factorisation left in the panel's upper triangle -- plain loads away from the diagonal tile -- and writes x once.
 // Same sums in a fixed order: bit-reproducible. Fronts wider than 128 columns keep the two-launch path.
+// (Round 6, measured and dropped: the first half alone -- t = y - L21' x -- for WIDER fronts as one workgroup per 128-column slice, so
+//  that a front's trailing rows of x are gathered once per 128 own columns instead of once per 16 or 32 (k_bwd_gemm_longk; levels 10-12
+//  of cfg 2 move 2.5-3 x their algorithmic bytes). Built to parity (seven cases against the oracle and the split-K kernel); backward
+//  sweep of cfg 2: 1.451 ms without it, 1.446 on levels with >= 192 slices, 1.502 with >= 96 (levels 10-12), 2.008 with >= 32 (levels
+//  10-15): a slice walks 60-90 barrier-paced 16-row batches one after the other where the split-K kernel puts eight waves on the K
+//  range -- those levels are latency-bound per front, not traffic-bound. Removed.)
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
