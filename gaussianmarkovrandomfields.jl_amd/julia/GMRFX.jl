@@ -65,7 +65,7 @@ resolve_ordering(Q, ordering::AbstractVector{<:Integer}) = Vector{Int}(ordering)
 resolve_ordering(Q, ordering) = Vector{Int}(G.ordering_permutation(Q, ordering))
 
 function create(Q::SparseMatrixCSC{Float64, Int}; ordering = nothing, coords = nothing, device = -1,
-        check_posdef = false)
+        check_posdef = false, shard_rank = 0, shard_world = 1, shard_min_top = 0)
     n = size(Q, 1)
     perm = resolve_ordering(Q, ordering)
     perm === nothing || isperm(perm) && length(perm) == n || throw(ArgumentError("ordering is not a permutation of 1:$n"))
@@ -73,6 +73,7 @@ function create(Q::SparseMatrixCSC{Float64, Int}; ordering = nothing, coords = n
     out = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve Q perm C begin
         o = Opts(struct_size = sizeof(Opts), device = device, check_posdef = check_posdef,
+            shard_rank = shard_rank, shard_world = shard_world, shard_min_top = shard_min_top,
             ordering = ordering === :natural ? 1 : 0,
             coord_dim = C === nothing ? 0 : size(C, 1), coords = C === nothing ? C_NULL : pointer(C))
         check(ccall((:gmrfx_create, LIB), Int32,
@@ -342,6 +343,73 @@ function Base.deepcopy_internal(b::MI355XBackend, stackdict::IdDict)   # deepcop
     return c
 end
 
+# ---------------------------------------------------------------------------------- one factorisation over several GPUs
+# The native driver of the sharded protocol (libgmrfx_rccl.so, include/gmrfx_rccl.h: RCCL point-to-point / broadcast / all-reduce
+# between the phases of libgmrfx.so), one Julia process (Distributed.jl worker / MPI rank) per GPU:
+#     id = rank == 0 ? rccl_unique_id() : <the 128 bytes from rank 0, by whatever the host uses: Distributed, MPI, a file>
+#     sf = ShardedMI355X(Q, world, rank, id; coords)          # same Q on every rank
+#     refactorize!(sf, d_nz); solve!(d_X, sf, d_B); logdet(sf) # ROCArray operands: julia/ext/GMRFXAMDGPUExt.jl
+# The reference has nothing to replace here (CHOLMOD has one address space: src/workspace/backend.jl:165-209); this is what the
+# exchange of Schur-complement blocks stands in for.
+const LIB_RCCL = get(ENV, "GMRFX_RCCL_LIB", joinpath(@__DIR__, "..", "libgmrfx_rccl.so"))
+
+function rccl_unique_id()
+    id = Vector{UInt8}(undef, 128)
+    code = ccall((:gmrfx_rccl_unique_id, LIB_RCCL), Int32, (Ptr{Cvoid},), id)
+    code == 0 || error("gmrfx_rccl_unique_id failed ($code)")
+    return id
+end
+
+mutable struct ShardedMI355X
+    h::Handle
+    drv::Ptr{Cvoid}
+    n::Int
+    world::Int
+    rank::Int
+end
+
+function ShardedMI355X(Q::SparseMatrixCSC{Float64, Int}, world::Integer, rank::Integer, id::Vector{UInt8};
+        ordering = nothing, coords = nothing, device = -1, shard_min_top = 0)
+    length(id) == 128 || throw(ArgumentError("the communicator id has 128 bytes"))
+    h = create(Q; ordering, coords, device, shard_rank = rank, shard_world = world, shard_min_top)
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    code = GC.@preserve id ccall((:gmrfx_rccl_create, LIB_RCCL), Int32, (Ptr{Cvoid}, Int32, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Ptr{Cvoid}}),
+        h.ptr, world, rank, id, C_NULL, out)
+    code == 0 || error("gmrfx_rccl_create failed ($code)")
+    sf = ShardedMI355X(h, out[], size(Q, 1), world, rank)
+    finalizer(x -> (x.drv == C_NULL || ccall((:gmrfx_rccl_destroy, LIB_RCCL), Cvoid, (Ptr{Cvoid},), x.drv); x.drv = C_NULL), sf)
+    return sf
+end
+
+function check_rccl(code::Int32, sf::ShardedMI355X)
+    code == 0 && return nothing
+    error("gmrfx_rccl ($code): " * unsafe_string(ccall((:gmrfx_rccl_last_error, LIB_RCCL), Cstring, (Ptr{Cvoid},), sf.drv)))
+end
+
+# log det Q over all ranks + the pivot report (PosDefException like refactorize! under check_posdef)
+function LinearAlgebra.logdet(sf::ShardedMI355X)
+    ld = Ref{Float64}(0.0); info = Ref{Int64}(0)
+    check_rccl(ccall((:gmrfx_rccl_logdet, LIB_RCCL), Int32, (Ptr{Cvoid}, Ref{Float64}, Ref{Int64}), sf.drv, ld, info), sf)
+    info[] > 0 && throw(PosDefException(Int(info[])))
+    return ld[]
+end
+
+# diag(Q^-1) on every rank (the sharded Takahashi recursion + an all-reduce)
+function selinv_diag(sf::ShardedMI355X)
+    out = Vector{Float64}(undef, sf.n)
+    check_rccl(ccall((:gmrfx_rccl_selinv_diag, LIB_RCCL), Int32, (Ptr{Cvoid}, Ptr{Float64}), sf.drv, out), sf)
+    return out
+end
+
+# the rows of B this rank reads in solve! (the ranks' masks partition 1:n: B may be row-sharded)
+function needed_rows(sf::ShardedMI355X)
+    mask = Vector{UInt8}(undef, sf.n)
+    check_rccl(ccall((:gmrfx_rccl_needed_rows, LIB_RCCL), Int32, (Ptr{Cvoid}, Ptr{UInt8}), sf.drv, mask), sf)
+    return mask .!= 0
+end
+
+function solve! end       # ROCArray methods: julia/ext/GMRFXAMDGPUExt.jl
+
 # ---------------------------------------------------------------------------------- seam A
 # LinearSolve algorithm; GMRF-side hooks exactly as the Pardiso extension (ext/GaussianMarkovRandomFieldsPardiso.jl:10-80).
 import LinearSolve, SciMLBase
@@ -410,5 +478,5 @@ G.configure_algorithm(alg::MI355XCholesky) = alg
 G.algorithm_applicable(::MI355XCholesky, ::Union{SparseMatrixCSC, Symmetric{<:Any, <:SparseMatrixCSC}}) = Val{true}()
 G.algorithm_applicable(::MI355XCholesky, ::AbstractMatrix) = Val{false}()
 
-export MI355XBackend, MI355XCholesky, MI355XCacheval, ordering_permutation
+export MI355XBackend, MI355XCholesky, MI355XCacheval, ordering_permutation, ShardedMI355X, rccl_unique_id
 end # module

@@ -20,6 +20,7 @@ using AMDGPU
 using LinearAlgebra
 import GMRFX
 import GMRFX: MI355XBackend, LIB, check, refactorize_solve!, backend_solve!, backend_backward_solve!, logpdf_terms
+import GMRFX: ShardedMI355X, LIB_RCCL, check_rccl, solve!
 import GaussianMarkovRandomFields: refactorize!
 
 devptr(A::ROCArray{Float64}) = reinterpret(Ptr{Float64}, pointer(A))
@@ -84,6 +85,32 @@ function logpdf_terms(b::MI355XBackend, d_nz::ROCVector{Float64}, X::ROCMatrix{F
         b.h.ptr, devptr(d_nz), devptr(X), stride(X, 2), size(X, 2), mu, quad, ld, info), b.h)
     _invalidate!(b)
     return quad, ld[]
+end
+
+
+# ---- one factorisation over several GPUs: the native RCCL driver (libgmrfx_rccl.so) with operands resident in HBM ----
+function refactorize!(sf::ShardedMI355X, d_nz::ROCVector{Float64})
+    AMDGPU.synchronize()
+    GC.@preserve d_nz check_rccl(ccall((:gmrfx_rccl_refactorize, LIB_RCCL), Int32, (Ptr{Cvoid}, Ptr{Float64}), sf.drv, devptr(d_nz)), sf)
+    return sf
+end
+
+# Q X = B over all ranks; gather = true: all of X on rank 0, false: every rank keeps the rows it owns (+ every top front's)
+function solve!(X::ROCMatrix{Float64}, sf::ShardedMI355X, B::ROCMatrix{Float64}; gather::Bool = true)
+    size(B, 1) == sf.n && size(X) == size(B) || throw(DimensionMismatch("B / X must be n x k"))
+    AMDGPU.synchronize()
+    GC.@preserve B X check_rccl(ccall((:gmrfx_rccl_solve, LIB_RCCL), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64, Int32),
+        sf.drv, devptr(B), stride(B, 2), size(B, 2), devptr(X), stride(X, 2), gather ? 1 : 0), sf)
+    return X
+end
+
+# X = P' L^-T Z over all ranks (samples: Z in elimination order, as CHOLMOD's F.UP \ z takes it)
+function backend_backward_solve!(X::ROCMatrix{Float64}, sf::ShardedMI355X, Z::ROCMatrix{Float64}; gather::Bool = true)
+    size(Z, 1) == sf.n && size(X) == size(Z) || throw(DimensionMismatch("Z / X must be n x k"))
+    AMDGPU.synchronize()
+    GC.@preserve Z X check_rccl(ccall((:gmrfx_rccl_backward_solve, LIB_RCCL), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64, Int32),
+        sf.drv, devptr(Z), stride(Z, 2), size(Z, 2), devptr(X), stride(X, 2), gather ? 1 : 0), sf)
+    return X
 end
 
 end # module

@@ -16,6 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 JL = os.path.join(ROOT, "gaussianmarkovrandomfields.jl_amd", "julia", "GMRFX.jl")
 JL_EXT = os.path.join(ROOT, "gaussianmarkovrandomfields.jl_amd", "julia", "ext", "GMRFXAMDGPUExt.jl")      # ROCArray methods (*_dev entry points)
 HDR = os.path.join(ROOT, "include", "gmrfx.h")
+HDR_RCCL = os.path.join(ROOT, "include", "gmrfx_rccl.h")       # the native RCCL driver (libgmrfx_rccl.so), bound through LIB_RCCL
 sys.path.insert(0, os.path.join(ROOT, "gaussianmarkovrandomfields.jl_amd"))
 
 # Julia ccall type -> canonical C type (const and parameter names stripped, pointers as "T*")
@@ -23,7 +24,7 @@ JL2C = {
     "Int32": "int32_t", "Int64": "int64_t", "Float64": "double", "Cvoid": "void", "Cstring": "char*",
     "Ptr{Cvoid}": "HANDLE*", "Ptr{Float64}": "double*", "Ptr{Int64}": "int64_t*", "Ptr{Int32}": "int32_t*",
     "Ref{Int64}": "int64_t*", "Ref{Int32}": "int32_t*", "Ref{Float64}": "double*", "Ref{Opts}": "gmrfx_opts*",
-    "Ref{Ptr{Cvoid}}": "HANDLE**", "Ptr{Ptr{Cvoid}}": "HANDLE**",
+    "Ref{Ptr{Cvoid}}": "HANDLE**", "Ptr{Ptr{Cvoid}}": "HANDLE**", "Ptr{UInt8}": "uint8_t*",
 }
 
 
@@ -63,7 +64,9 @@ def julia_ccalls(path=None):
         return julia_ccalls(JL) + julia_ccalls(JL_EXT)
     src = open(path).read()
     calls = []
-    for m in re.finditer(r"ccall\(\(:(gmrfx_\w+),\s*LIB\)\s*,", src):
+    for m in re.finditer(r"ccall\(\(:(gmrfx_\w+),\s*LIB(?:_RCCL)?\)\s*,", src):
+        if ("LIB_RCCL" in m.group(0)) != m.group(1).startswith("gmrfx_rccl_"):
+            raise AssertionError(f"{m.group(1)} is bound through the wrong library constant")
         end = _balanced(src, m.start() + len("ccall"))
         inner = src[m.end():end - 1]
         parts = _split_top(inner)
@@ -76,7 +79,7 @@ def julia_ccalls(path=None):
 
 
 def header_prototypes():
-    h = open(HDR).read()
+    h = open(HDR).read() + "\n" + open(HDR_RCCL).read()
     h = re.sub(r"/\*.*?\*/", " ", h, flags=re.S)
     h = re.sub(r"//[^\n]*", " ", h)
     protos = {}
@@ -97,7 +100,7 @@ def canon(decl, is_ret=False):
     d = d.replace("*", " ")
     toks = d.split()
     base = toks[0] if (is_ret or len(toks) == 1) else " ".join(toks[:-1])       # drop the parameter name
-    base = {"gmrfx_handle": "HANDLE", "long long": "int64_t", "int": "int32_t", "char": "char"}.get(base, base)
+    base = {"gmrfx_handle": "HANDLE", "gmrfx_rccl": "HANDLE", "long long": "int64_t", "int": "int32_t", "char": "char"}.get(base, base)
     return base + "*" * stars
 
 
@@ -115,7 +118,7 @@ def test_every_ccall_matches_its_prototype():
             assert jt in JL2C, f"{line}: {name} argument {k}: unknown Julia type {jt}"
             want = JL2C[jt]
             # a `const gmrfx_handle *` and a `gmrfx_handle *` are the same pointer; void* scratch / device pointers too
-            ok = want == ct or (want == "HANDLE*" and ct in ("void*",))
+            ok = want == ct or (want == "HANDLE*" and ct in ("void*",)) or (want == "double*" and ct == "double*")
             assert ok, f"{line}: {name} argument {k}: header has {ct}, the shim passes {jt}"
 
 
@@ -204,7 +207,7 @@ def test_batched_rand_is_a_real_method_on_both_seams():
 
 
 # ---- round 6: no type piracy, and every foreign name the shim extends exists ------------------------------------------------
-OWNED = ("MI355XBackend", "MI355XCholesky", "MI355XCacheval", "MI355XGMRF", "MI355XLinearCache", "Handle", "Opts")
+OWNED = ("MI355XBackend", "MI355XCholesky", "MI355XCacheval", "MI355XGMRF", "MI355XLinearCache", "Handle", "Opts", "ShardedMI355X")
 FOREIGN = ("G", "Distributions", "LinearSolve", "SciMLBase", "Base", "LinearAlgebra", "SparseArrays")
 
 
@@ -274,3 +277,16 @@ def test_every_reference_name_the_shim_extends_or_calls_exists_in_the_reference(
     m = re.search(r"struct GMRF\{(.*?)\}\s*<:", ref, re.S)
     params = [p.strip().split("<:")[0].strip() for p in _split_top(m.group(1).replace("\n", " "))]
     assert params[5] == "Cache" and len(params) == 7, params
+
+
+def test_native_rccl_driver_is_bound_in_the_shim():
+    """INTEGRATION.md section 6 as code: the sharded protocol is reachable from the Julia host through libgmrfx_rccl.so (LIB_RCCL) --
+    communicator id, driver creation with the shard options passed to gmrfx_create, refactorise / solve / sample with ROCArray
+    operands (extension), log-determinant, selected-inverse diagonal, the row mask of a row-sharded B."""
+    names = {c[0] for c in julia_ccalls()}
+    for need in ("gmrfx_rccl_unique_id", "gmrfx_rccl_create", "gmrfx_rccl_destroy", "gmrfx_rccl_last_error", "gmrfx_rccl_refactorize",
+                 "gmrfx_rccl_solve", "gmrfx_rccl_backward_solve", "gmrfx_rccl_logdet", "gmrfx_rccl_selinv_diag", "gmrfx_rccl_needed_rows"):
+        assert need in names, need
+    src = open(JL).read()
+    assert "shard_rank = shard_rank, shard_world = shard_world, shard_min_top = shard_min_top" in src
+    assert re.search(r"mutable struct ShardedMI355X", src) and "const LIB_RCCL" in src

@@ -62,3 +62,36 @@ def test_rccl_path_runs_on_a_one_rank_group():
     assert res["residual"] < 1e-10 and res["selinv_diag_maxrel"] < 1e-10
     assert all(res["collectives_on_views_identity"].values()), res
     assert res["self_p2p_bytes_equal"], res
+
+
+PKG = os.path.join(os.path.dirname(HERE), "gaussianmarkovrandomfields.jl_amd")
+
+
+def test_native_rccl_driver_library_exports_its_header():
+    """libgmrfx_rccl.so (csrc/rccl_driver.cpp: the sharded protocol over RCCL without Python, include/gmrfx_rccl.h) is built by
+    __graft_entry__.build() and exports every symbol its header declares; it links libgmrfx.so through the public C ABI only."""
+    import ctypes
+    import re
+    lib = os.path.join(PKG, "libgmrfx_rccl.so")
+    assert os.path.exists(lib), "libgmrfx_rccl.so has not been built (make -C gaussianmarkovrandomfields.jl_amd rccl)"
+    hdr = open(os.path.join(os.path.dirname(HERE), "include", "gmrfx_rccl.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    syms = sorted(set(re.findall(r"\b(gmrfx_rccl_[a-z_0-9]+)\s*\(", hdr)))
+    assert len(syms) >= 9
+    out = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True).stdout
+    for s in syms:
+        assert re.search(r"\bT %s\b" % s, out), f"{s} declared in include/gmrfx_rccl.h but not exported"
+    # the driver sits ABOVE the C ABI: it may not reach into the library's internals
+    und = subprocess.run(["nm", "-D", "--undefined-only", lib], capture_output=True, text=True).stdout
+    internal = [l for l in und.splitlines() if "gmrfx" in l and not re.search(r"\bU gmrfx_[a-z_0-9]+$", l.strip())]
+    assert not internal, internal
+
+
+@pytest.mark.gpu
+def test_native_rccl_driver_on_a_one_rank_communicator():
+    """tools/rccl_driver_test.cpp: no Python in the process -- a sharded handle of one rank through gmrfx_rccl_refactorize / _solve /
+    _backward_solve / _logdet / _selinv_diag on a one-rank RCCL communicator against an unsharded handle (bit for bit / 1e-12)."""
+    exe = os.path.join(PKG, "rccl_driver_test")
+    assert os.path.exists(exe), "rccl_driver_test has not been built (make -C gaussianmarkovrandomfields.jl_amd rccl)"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0 and "rccl_driver_test: ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
