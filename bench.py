@@ -690,13 +690,13 @@ def main():
         tree_hash = source_tree_hash()
         pmc, pmc_note = None, "no counter pass for this workload under profiles/"
         try:
-            with open(os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")) as fh:
                 pj = json.load(fh)
             if pj["workload"] == {"grid": args.grid, "nrhs": args.nrhs}:
                 if pj.get("csrc_hash") == tree_hash:
-                    pmc, pmc_note = pj, f"profiles/r05_pmc_traffic.json, collected on source tree {tree_hash} = the tree being timed"
+                    pmc, pmc_note = pj, f"profiles/r06_pmc_traffic.json, collected on source tree {tree_hash} = the tree being timed"
                 else:
-                    pmc_note = (f"null: profiles/r05_pmc_traffic.json belongs to source tree {pj.get('csrc_hash')}, the tree being timed is "
+                    pmc_note = (f"null: profiles/r06_pmc_traffic.json belongs to source tree {pj.get('csrc_hash')}, the tree being timed is "
                                 f"{tree_hash} (re-run tools/final_profile.sh)")
         except Exception:
             pmc = None
@@ -755,13 +755,13 @@ def main():
         roof_cfg3 = {}
         pmc3, pmc3_note = None, "no counter pass for this workload under profiles/"
         try:
-            with open(os.path.join(ROOT, "profiles", "r05_cfg3_pmc_traffic.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r06_cfg3_pmc_traffic.json")) as fh:
                 p3 = json.load(fh)
             if p3["workload"]["grid"] == args.grid:
                 if p3.get("csrc_hash") == tree_hash:
-                    pmc3, pmc3_note = p3, f"profiles/r05_cfg3_pmc_traffic.json, collected on source tree {tree_hash} = the tree being timed"
+                    pmc3, pmc3_note = p3, f"profiles/r06_cfg3_pmc_traffic.json, collected on source tree {tree_hash} = the tree being timed"
                 else:
-                    pmc3_note = f"null: profiles/r05_cfg3_pmc_traffic.json belongs to source tree {p3.get('csrc_hash')}, the tree being timed is {tree_hash}"
+                    pmc3_note = f"null: profiles/r06_cfg3_pmc_traffic.json belongs to source tree {p3.get('csrc_hash')}, the tree being timed is {tree_hash}"
         except Exception:
             pmc3 = None
         if cfg3 is not None:

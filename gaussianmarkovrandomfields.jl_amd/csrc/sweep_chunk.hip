@@ -19,8 +19,9 @@
 //  * No clamps, no masks: the analysis pads every target-row list to a multiple of 32 with a spare row of the local vector
 //    (row CH_SPARE: results of padding rows land there in the forward sweep; it stays zero in the backward sweep, where it
 //    meets the operand rows read past the panel), panels are followed by zero columns up to a multiple of 4 and by >= 16
-//    zero doubles (symbolic.cpp: panel_span), and the inverse diagonal blocks come PACKED in MFMA operand order with zeros
-//    outside the block (k_pack_diag, once per factorisation: 2 KB per chunk).
+//    zero doubles (symbolic.cpp: panel_span -- reads past those reach the next panel's first entries: mapped, finite, and
+//    multiplied into discarded rows only, see there), and the inverse diagonal blocks come PACKED in MFMA operand order with
+//    zeros outside the block (k_pack_diag, once per factorisation: 2 KB per chunk).
 //  * Addresses are one scalar base + one lane offset per chunk: target rows arrive as ready-made LDS byte offsets (one
 //    v_xor per row adds the lane's column), operand rows in 16-byte pairs (MFMA row lm of tile 0 / 1 = rows 2 lm / 2 lm + 1
 //    of a 32-row pair: the assignment of matrix rows to MFMA rows is free as long as the row list follows it).

@@ -126,9 +126,13 @@ void colcounts(i64 n, const std::vector<i64> &up, const std::vector<i32> &ui,
 
 // Doubles a panel of c columns with leading dimension ld occupies in the factor storage: its columns are padded with zero
 // columns to a multiple of 4 (one FP64-MFMA k-step) and followed by at least 16 zero doubles, rounded to 128 bytes. The
-// padding is never written (the buffer is zeroed once): the chunk kernels of the sweep tasks (sweep_chunk.hip) read whole
-// k-steps and whole 16-row tiles without clamps, and what they read beyond a panel's entries is either the same panel's
-// next column or these zeros.
+// padding is never written (the buffer is zeroed once). The chunk kernels of the sweep tasks (sweep_chunk.hip) read whole
+// k-steps and whole 32-row pairs without clamps. What they read beyond a panel's entries is the same panel's next column,
+// this padding -- or, in a panel's last padded column and behind a ragged last chunk (up to ~31 doubles resp. 15 columns
+// further), the FIRST ENTRIES OF THE NEXT PANEL: always mapped memory (the storage ends in 16 x 320 doubles of slack), always
+// finite while the neighbouring panels are (they are zero before their first factorisation and hold the previous factor's
+// finite values while a pipelined call re-factors them), and only ever multiplied into rows that are discarded: the spare row
+// of the local vector (forward) resp. the operand rows that meet its zeros (backward). Not "zeros", as rounds 5's comment said.
 static inline i64 panel_span(i64 ld, i64 c) { return (ld * ((c + 3) & ~i64(3)) + 16 + 15) & ~i64(15); }
 
 void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *user_perm,

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Flop and TIME bounds of the sharding plan at 2 / 4 / 8 ranks for cfg 2 and cfg 4, from the per-level times measured on one
-GPU (tools/level_times.py -> profiles/r05_level_ms_<cfg>.json; GMRFX_PROFILE_ROUND picks another round's files). Host only (symbolic-only handles).
+GPU (tools/level_times.py -> profiles/r06_level_ms_<cfg>.json; GMRFX_PROFILE_ROUND picks another round's files). Host only (symbolic-only handles).
 
     python3 tools/shard_bounds.py [cfg2|cfg4] ...   -> prints a table and one JSON object per configuration"""
 import json, os, sys
@@ -16,7 +16,7 @@ def run(cfg):
         mesh = spde.grid_mesh_3d(126, 126, 126); Q = spde.matern_precision(mesh, 0, 0.4); name = "cfg4_126cubed"
     else:
         mesh = spde.grid_mesh_2d(1000, 1000, jitter=0.25, seed=0); Q = spde.matern_precision(mesh, 0, 0.2); name = "cfg2_1000"
-    lv = json.load(open(os.path.join(ROOT, "profiles", f"{os.environ.get('GMRFX_PROFILE_ROUND', 'r05')}_level_ms_{name}.json")))
+    lv = json.load(open(os.path.join(ROOT, "profiles", f"{os.environ.get('GMRFX_PROFILE_ROUND', 'r06')}_level_ms_{name}.json")))
     res = {"workload": name, "one_gpu_ms": {"factor": sum(lv["factor"]), "fwd": sum(lv["fwd"]), "bwd": sum(lv["bwd"])}, "ranks": {}}
     step = np.asarray(lv["factor"]) + np.asarray(lv["fwd"]) + np.asarray(lv["bwd"])
     print(f"== {name}: one GPU factor {sum(lv['factor']):.2f} ms + sweeps {sum(lv['fwd']) + sum(lv['bwd']):.2f} ms")
