@@ -926,12 +926,49 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
                 if ((pr || rc) && p >= 0) consumed[S.level[p]].push_back(s);
             }
             {   // factorisation: bottom-up
-                Arena A;
+                // The handful of blocks that live into the TOP phase (consumed at a level >= shard_level: the contribution blocks of
+                // this rank's subtree roots, of the distributed fronts it is a member of, and what it receives) are 4-8 GB each at
+                // cfg 4, and the online best-fit allocator left 7 GB of holes between them (rank 1 at world 8: 31.2 GB of arena for
+                // 24.3 GB live). They are laid out OFFLINE instead -- largest first, each at the lowest offset free of every
+                // already placed block whose lifetime [birth level, consumption level] meets its own -- with the blocks born in
+                // the subtree phase stacked at the bottom; the subtree phase's own blocks keep the online allocator, above that
+                // stack (they are all dead when the first top level starts, so the other top blocks may lie over them).
+                const i32 L0 = S.shard_level;
+                struct TB { i32 s; i64 sz; i32 t0, t1; i64 off; };
+                std::vector<TB> top;
+                std::vector<uint8_t> is_topblk(ns, 0);
                 for (i32 l = 0; l < S.nlevels; l++) {
-                    for (i32 s : arrive[l]) S.cbptr[s] = A.alloc(bsz(s));
-                    for (i32 s : born[l]) S.cbptr[s] = A.alloc(bsz(s));
+                    for (i32 s : arrive[l]) { const i32 p = S.sparent[s]; if (S.level[p] >= L0) { top.push_back({s, bsz(s), S.level[p], S.level[p], -1}); is_topblk[s] = 1; } }
+                    for (i32 s : born[l]) { const i32 p = S.sparent[s]; if (p >= 0 && S.level[p] >= L0) { top.push_back({s, bsz(s), l, S.level[p], -1}); is_topblk[s] = 1; } }
+                }
+                std::stable_sort(top.begin(), top.end(), [&](const TB &a, const TB &b) {
+                    const bool ea = a.t0 < L0, eb = b.t0 < L0;          // born in the subtree phase: first, at the bottom
+                    if (ea != eb) return ea;
+                    return a.sz != b.sz ? a.sz > b.sz : a.s < b.s;
+                });
+                i64 bottom = 0, toppeak = 0;
+                for (size_t k = 0; k < top.size(); k++) {
+                    TB &b = top[k];
+                    if (b.t0 < L0) { b.off = bottom; bottom += b.sz; }
+                    else {
+                        std::vector<std::pair<i64, i64>> busy;
+                        for (size_t q = 0; q < k; q++) if (top[q].t0 <= b.t1 && b.t0 <= top[q].t1) busy.emplace_back(top[q].off, top[q].off + top[q].sz);
+                        std::sort(busy.begin(), busy.end());
+                        i64 at = 0;
+                        for (auto &iv : busy) { if (iv.first - at >= b.sz) break; at = std::max(at, iv.second); }
+                        b.off = at;
+                    }
+                    S.cbptr[b.s] = b.off;
+                    toppeak = std::max(toppeak, b.off + b.sz);
+                }
+                Arena A;
+                A.top = bottom;
+                peak = std::max(peak, toppeak);
+                for (i32 l = 0; l < S.nlevels; l++) {
+                    for (i32 s : arrive[l]) if (!is_topblk[s]) S.cbptr[s] = A.alloc(bsz(s));
+                    for (i32 s : born[l]) if (!is_topblk[s]) S.cbptr[s] = A.alloc(bsz(s));
                     peak = std::max(peak, A.top);
-                    for (i32 s : consumed[l]) A.release(S.cbptr[s], bsz(s));
+                    for (i32 s : consumed[l]) if (!is_topblk[s]) A.release(S.cbptr[s], bsz(s));
                 }
             }
             {   // selected inversion: top-down (a distributed front is inverted by its owner alone)
