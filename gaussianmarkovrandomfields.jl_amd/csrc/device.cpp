@@ -1253,6 +1253,17 @@ void Device::dist_front_phase(const double *d_nzval, int front, int what, int bl
     const int c = S_->ncols(R), r = S_->nrows(R);
     const int nob = S_->panel_blocks(R);
     const FrontArg fa{1, (int)R, c, r, (int)S_->ld[R], (int)S_->sfirst[R], (long long)S_->panelptr[R]};
+    // Block-cyclic STORAGE (Symbolic::compact_here: a front without trailing rows on a member that is not its owner): this rank holds
+    // its own blocks one behind the other + a window of two received blocks. The kernels keep addressing columns globally: block b is
+    // handed to them under the pseudo panel base that puts its columns where they are stored, and the K operand of a panel update
+    // (the block column just received, or an own one) under a base of its own (FrontArg::ppa).
+    const bool compact = S_->compact_here(R);
+    const long long ldR = S_->ld[R], ppl = S_->panelptr[R];
+    auto blk_pp = [&](int b) -> long long { return compact ? ppl - 256LL * (b - b / g) * ldR : ppl; };
+    auto a_pp = [&](int b) -> long long {
+        if (!compact) return kNoPpa;
+        return b % g == me ? blk_pp(b) : ppl + S_->compact_window(R, b & 1) - 256LL * b * ldR;
+    };
     if (!d_dist_list_) {
         d_dist_list_ = dalloc<int>(S_->dist_fronts.size());
         HC(hipMemcpyAsync(d_dist_list_, S_->dist_fronts.data(), S_->dist_fronts.size() * sizeof(int), hipMemcpyHostToDevice, stream));
@@ -1260,17 +1271,19 @@ void Device::dist_front_phase(const double *d_nzval, int front, int what, int bl
     const int *list = d_dist_list_ + S_->dist_index[R];
     if (what == 0) {
         if (!d_nzval) throw std::invalid_argument("d_nzval is null");
-        launch_assemble_cyclic(stream, ds_, list, c, d_nzval, d_L_, d_cb_, g, me);
+        launch_assemble_cyclic(stream, ds_, list, c, d_nzval, d_L_, d_cb_, g, me, compact);
     } else if (what == 1) {
         if (block < 0 || block >= nob) throw std::invalid_argument("distributed front: block out of range");
         if (block % g != me) return;
+        FrontArg fb = fa;
+        fb.pp = blk_pp(block);
         const int b0 = block * OBK, b1 = std::min(b0 + OBK, (c + NB - 1) / NB);
         for (int b = b0; b < b1; b++) {
             const int kb = b * NB;
-            launch_potrf64(stream, ds_, nullptr, 1, kb, d_L_, d_info_, fa);
-            launch_trsm(stream, ds_, nullptr, 1, kb, 0, r - kb - 1, d_L_, nullptr, nullptr, fa);
+            launch_potrf64(stream, ds_, nullptr, 1, kb, d_L_, d_info_, fb);
+            launch_trsm(stream, ds_, nullptr, 1, kb, 0, r - kb - 1, d_L_, nullptr, nullptr, fb);
             if (b + 1 < b1)
-                launch_gemm_nt(stream, ds_, nullptr, 1, kb, NB, kb + NB, b1 * NB, r - kb - NB, std::min(b1 * NB, c) - kb - NB, d_L_, fa);
+                launch_gemm_nt(stream, ds_, nullptr, 1, kb, NB, kb + NB, b1 * NB, r - kb - NB, std::min(b1 * NB, c) - kb - NB, d_L_, fb);
         }
     } else if (what == 2 || what == 4 || what == 5) {
         // 2: block -> all my later blocks; 4: -> block + 1 only (look-ahead: its owner factors and broadcasts it next, while
@@ -1281,7 +1294,10 @@ void Device::dist_front_phase(const double *d_nzval, int front, int what, int bl
         for (int j = jlo; j < jhi; j++) {
             if (j % g != me) continue;
             const int c0 = j * 256;
-            launch_gemm_nt(stream, ds_, nullptr, 1, k0, K, c0, c0 + 256, r - c0, std::min(256, c - c0), d_L_, fa);
+            FrontArg fj = fa;
+            fj.pp = blk_pp(j);
+            fj.ppa = a_pp(block);
+            launch_gemm_nt(stream, ds_, nullptr, 1, k0, K, c0, c0 + 256, r - c0, std::min(256, c - c0), d_L_, fj);
         }
     } else if (what == 3) {
         if (r > c) launch_syrk_cb_cyclic(stream, ds_, list, r - c, d_L_, d_cb_, g, me, nob);

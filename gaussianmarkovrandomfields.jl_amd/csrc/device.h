@@ -74,7 +74,10 @@ struct SweepTask {
 };
 
 // geometry of one front for the panel kernels: in the kernel arguments (FrontArg) or one record per level-list position
-struct FrontArg { int on, s, c, r, ld, first; long long pp; };
+// ppa (round 6): where the K operand columns of a panel update live when they are NOT in the panel itself -- the received block of a
+// distributed front with block-cyclic storage sits in a window (Device::dist_front_phase); kNoPpa = in the panel, as everywhere else
+constexpr long long kNoPpa = (long long)0x8000000000000000ull;
+struct FrontArg { int on, s, c, r, ld, first; long long pp; long long ppa = kNoPpa; };
 struct FrontView { int s, c, r, ld, first, pad; long long pp; };   // 32 bytes
 
 // Everything a column of the panel assembly (k_assemble_lds) needs to know about its front and the front's first two children,

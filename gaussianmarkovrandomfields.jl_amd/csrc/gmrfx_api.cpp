@@ -338,6 +338,25 @@ extern "C" int32_t gmrfx_shard_dist_fronts(const gmrfx_handle *h, int64_t *count
     return GMRFX_OK;
 }
 // Every contribution-block transfer of the sharded factorisation (symbolic.h: xf_*), ordered by the level of the parent:
+// Where THIS rank keeps panel block `block` (256 columns) of the distributed front `front`, as an offset into gmrfx_device_ptr(h, 1)
+// and a count of doubles (whole columns): the buffer it passes to the broadcast of that block inside the front's group. The owner of
+// the front (and every member of a front that has a contribution block) stores the whole panel: offset = panel + 256 block ld. A
+// member with block-cyclic storage (Symbolic::compact_here) keeps its OWN blocks one behind the other and receives the others into
+// a window of two blocks (block & 1). offset = -1, count = 0 on ranks outside the group.
+extern "C" int32_t gmrfx_dist_front_block(const gmrfx_handle *h, int32_t front, int32_t block, int64_t *offset, int64_t *count) {
+    if (!h || !offset || !count) return GMRFX_ERR_INVALID_ARG;
+    const Symbolic &S = h->S;
+    if (front < 0 || front >= S.nsuper || !S.is_dist(front) || block < 0 || block >= S.panel_blocks(front)) return GMRFX_ERR_INVALID_ARG;
+    const i32 g = S.group_size(front), me = S.group_pos(front, S.shard_rank);
+    *offset = -1; *count = 0;
+    if (me < 0) return GMRFX_OK;
+    const i64 ld = S.ld[front];
+    *count = (i64)std::min<i64>(256, S.ncols(front) - 256 * (i64)block) * ld;
+    if (!S.compact_here(front)) *offset = S.panelptr[front] + 256 * (i64)block * ld;
+    else if (block % g == me) *offset = S.panelptr[front] + (i64)(block / g) * 256 * ld;
+    else *offset = S.panelptr[front] + S.compact_window(front, block & 1);
+    return GMRFX_OK;
+}
 // `count` doubles at `offset` of the arena (gmrfx_device_ptr(h, 0)) -- whole columns of `child`'s block -- go src -> dst before
 // the fronts of `level` are assembled; col0 = the first of these columns. (Edges between fronts of one owner, neither
 // distributed, have no entry.)
@@ -910,9 +929,18 @@ extern "C" int32_t gmrfx_symbolic_get(const gmrfx_handle *h, int64_t *super_firs
         // a sharded handle stores the panels of its own fronts only: the entries of Q that go into another rank's panel
         // have no destination here (-1)
         if (S.shard_plan)
-            for (i32 s = 0; s < ns; s++)
-                if (!S.stored_here(s))      // (every member of its group stores the panel of a distributed front)
+            for (i32 s = 0; s < ns; s++) {
+                if (!S.stored_here(s))      // (every member of its group stores the panel of a distributed front ...)
                     for (i64 k = S.qptr[s]; k < S.qptr[s + 1]; k++) q_dst[k] = -1;
+                else if (S.compact_here(s)) {   // (... or, block-cyclic storage, its own 256-column blocks one behind the other)
+                    const i64 ld = S.ld[s];
+                    const i32 g = S.group_size(s), me = S.group_pos(s, S.shard_rank);
+                    for (i64 k = S.qptr[s]; k < S.qptr[s + 1]; k++) {
+                        const i64 rel = S.qdst[k] - S.panelptr[s], col = rel / ld, row = rel % ld, b = col >> 8;
+                        q_dst[k] = b % g != me ? -1 : S.panelptr[s] + (col - 256 * (b - b / g)) * ld + row;
+                    }
+                }
+            }
     }
     return GMRFX_OK;
 }

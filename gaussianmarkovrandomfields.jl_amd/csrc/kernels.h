@@ -410,7 +410,7 @@ void launch_fwd_own_update(hipStream_t st, const DevSym &S, const int *list, int
                            const double *Y, double *X, int nr, int ldx, int blk, int cap);
 // iperm: position of original row i in the elimination order (nullptr: identity)
 void launch_assemble_cyclic(hipStream_t st, const DevSym &S, const int *list, int ncols, const double *nzval, double *L, double *CB,
-                            int cyc_w, int cyc_r);
+                            int cyc_w, int cyc_r, bool compact = false);     // compact: block-cyclic STORAGE (own blocks one behind the other)
 void launch_syrk_cb_cyclic(hipStream_t st, const DevSym &S, const int *list, int trail, const double *L, double *CB, int cyc_w, int cyc_r, int cyc_b0);
 void launch_level_mark(hipStream_t st, int phase, int level);   // phase 1 = forward sweep, 2 = backward sweep, 3 = factorisation, 4 = selected inversion
 void launch_permute(hipStream_t st, const int *iperm, int n, double *Bc, long long ldb, double *X, int nr, int ldx, int dir);

@@ -64,7 +64,7 @@ __device__ __forceinline__ void wave_lower_bound2(const int *__restrict__ a, con
 template <int WIDE>   // 0: one WAVE per column; 1: one WORKGROUP per column (levels with a few tall fronts)
 __global__ __launch_bounds__(256) void k_assemble(DevSym S, const int *__restrict__ list,
                                                   const double *__restrict__ nzval, double *__restrict__ L,
-                                                  double *__restrict__ CB, int cyc_w, int cyc_r) {
+                                                  double *__restrict__ CB, int cyc_w, int cyc_r, int cyc_compact) {
     // PANEL part of the front only (front-local columns < c). The contribution-block part is
     // assembled inside k_syrk_cb (children gathered into an LDS tile, CB written exactly once).
     // WIDE: a column of a top-of-tree front has thousands of rows and the level only has a handful
@@ -80,7 +80,10 @@ __global__ __launch_bounds__(256) void k_assemble(DevSym S, const int *__restric
     // distributed root (cyc_w > 0): this rank assembles the 256-column blocks it owns, block b on rank b mod cyc_w
     if (cyc_w > 0 && (tc >> 8) % cyc_w != cyc_r) return;
     const int ld = S.ld[s];
-    double *Pc = L + S.panelptr[s] + (long long)tc * ld;
+    // block-cyclic STORAGE (cyc_compact; round 6): this rank keeps only its own 256-column blocks of the front, one behind the
+    // other -- block b at local position b / cyc_w: column tc sits 256 (b - b / cyc_w) columns further down than in the full panel
+    const int tcs = cyc_compact ? tc - 256 * ((tc >> 8) - (tc >> 8) / cyc_w) : tc;
+    double *Pc = L + S.panelptr[s] + (long long)tcs * ld;
     for (int i = 2 * tl; i < ld; i += 2 * NL) *(d2u *)(Pc + i) = (d2u){0.0, 0.0};      // ld is even
     if (WIDE) __syncthreads();
     {   // Q's entries of this column: [qcolptr[k], qcolptr[k + 1]) for column k of L (no search)
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(DevSym S, const FrontView *__re
     const int ld = fv.ld;
     double *P = L + fv.pp;
     const int M = r - c0, N = min(c1, c) - c0, ldc = ld;
-    const double *A = P + c0 + (long long)k0 * ld;
+    const double *A = (fa.on && fa.ppa != kNoPpa ? L + fa.ppa : P) + c0 + (long long)k0 * ld;
     double *C = P + c0 + (long long)c0 * ld;
     const int bi = blockIdx.x, bj = blockIdx.y;
     constexpr int WT = 16 * TW, GT = 2 * WT;
@@ -1767,14 +1770,14 @@ void launch_assemble(hipStream_t st, const DevSym &S, const int *list, const Asm
     }
 hbm:
     if ((long long)cdiv(max_cols, ASM_CW) * nfronts <= 2200)
-        hipLaunchKernelGGL(k_assemble<1>, dim3(odd(max_cols), nfronts), dim3(256), 0, st, S, list, nzval, L, CB, 0, 0);
+        hipLaunchKernelGGL(k_assemble<1>, dim3(odd(max_cols), nfronts), dim3(256), 0, st, S, list, nzval, L, CB, 0, 0, 0);
     else
-        hipLaunchKernelGGL(k_assemble<0>, dim3(odd(cdiv(max_cols, ASM_CW)), nfronts), dim3(256), 0, st, S, list, nzval, L, CB, 0, 0);
+        hipLaunchKernelGGL(k_assemble<0>, dim3(odd(cdiv(max_cols, ASM_CW)), nfronts), dim3(256), 0, st, S, list, nzval, L, CB, 0, 0, 0);
 }
 // the distributed root: one front, only the 256-column blocks b with b mod cyc_w == cyc_r (one workgroup per column)
 void launch_assemble_cyclic(hipStream_t st, const DevSym &S, const int *list, int ncols, const double *nzval, double *L, double *CB,
-                            int cyc_w, int cyc_r) {
-    hipLaunchKernelGGL(k_assemble<1>, dim3(odd(ncols), 1), dim3(256), 0, st, S, list, nzval, L, CB, cyc_w, cyc_r);
+                            int cyc_w, int cyc_r, bool compact) {
+    hipLaunchKernelGGL(k_assemble<1>, dim3(odd(ncols), 1), dim3(256), 0, st, S, list, nzval, L, CB, cyc_w, cyc_r, compact ? 1 : 0);
 }
 void launch_syrk_cb(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_trail, const double *L, double *CB) {
     if (nfronts <= 0 || max_trail <= 0) return;
@@ -1902,7 +1905,8 @@ __global__ __launch_bounds__(512) void k_gemm_nt_big(const FrontView *__restrict
     const int c = fv.c;
     if (c0 >= c) return;
     double *P = L + fv.pp;
-    gemm_nt_big_tile(P + c0 + (long long)k0 * fv.ld, fv.ld, P + c0 + (long long)c0 * fv.ld, fv.ld, fv.r - c0, min(c1, c) - c0, K);
+    const double *PA = fa.on && fa.ppa != kNoPpa ? L + fa.ppa : P;
+    gemm_nt_big_tile(PA + c0 + (long long)k0 * fv.ld, fv.ld, P + c0 + (long long)c0 * fv.ld, fv.ld, fv.r - c0, min(c1, c) - c0, K);
 }
 // The contribution block's product on the same tiles: CB -= L21 L21' behind a gather-only pass of k_syrk_cb_rec (noprod). At
 // cfg 4 the one-pass kernel's 64 x 64 tiles stream K = 8 000-16 000 columns of both operands per tile (8 flop per byte: it ran at

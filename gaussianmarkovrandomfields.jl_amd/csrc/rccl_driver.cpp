@@ -101,7 +101,13 @@ void factor_distributed_front(gmrfx_rccl *d, const double *d_nz, const DistFront
     const int g = (int)f.group.size();
     const int64_t nb = (f.cols + 255) / 256;
     double *panels = buf(d, 1);
-    auto view = [&](int64_t b, double *&p, int64_t &cnt) { p = panels + f.poff + 256 * b * f.ld; cnt = std::min<int64_t>(256, f.cols - 256 * b) * f.ld; };
+    // where THIS rank keeps block b: the whole panel, or its own blocks + a window of two received ones (gmrfx_dist_front_block)
+    auto view = [&](int64_t b, double *&p, int64_t &cnt) {
+        int64_t off = -1;
+        ck(gmrfx_dist_front_block(h, f.s, (int32_t)b, &off, &cnt), h, "gmrfx_dist_front_block");
+        if (off < 0) throw Fail("gmrfx_dist_front_block: not a member of the front's group");
+        p = panels + off;
+    };
     ck(gmrfx_dist_front_phase(h, d_nz, f.s, 0, 0), h, "dist front: assemble");
     ck(gmrfx_dist_front_phase(h, d_nz, f.s, 1, 0), h, "dist front: factor block 0");
     double *p; int64_t cnt;

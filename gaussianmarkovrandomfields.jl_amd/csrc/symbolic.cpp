@@ -573,7 +573,7 @@ void analyze(i64 n, const i64 *colptr, const i64 *rowval, int base, const i64 *u
         i64 off = 0;
         for (i32 s = 0; s < ns; s++) {
             S.panelptr[s] = off;
-            if (S.stored_here(s)) off += panel_span(S.ld[s], S.ncols(s));
+            if (S.stored_here(s)) off += S.compact_here(s) ? S.compact_span(s) : panel_span(S.ld[s], S.ncols(s));
         }
         S.panelptr[ns] = off;
         for (i32 s = 0; s < ns; s++)

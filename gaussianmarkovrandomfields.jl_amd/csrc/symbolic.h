@@ -172,6 +172,15 @@ struct Symbolic {
     // rank holding panel block b / contribution-block column block q of front s
     i32 panel_owner(i32 s, i32 b) const { return is_dist(s) ? group_rank(s, b % group_size(s)) : owner[s]; }
     i32 cb_owner(i32 s, i32 q) const { return is_dist(s) ? group_rank(s, (panel_blocks(s) + q) % group_size(s)) : owner[s]; }
+    // BLOCK-CYCLIC STORAGE (round 6): a distributed front WITHOUT trailing rows (the root: the largest panel of a 3-D problem, 18 GB
+    // at cfg 4) is stored whole only by its owner (which sweeps / inverts it); every other member of its group keeps its OWN
+    // 256-column blocks, one behind the other at full height (block b at local position b / g), and a window of two blocks for
+    // the block columns it receives. (A front WITH a contribution block needs all of L21 on every member for its own column
+    // blocks of that block: it stays replicated.)
+    bool compact_here(i32 s) const { return is_dist(s) && nrows(s) == ncols(s) && owner[s] != shard_rank && group_pos(s, shard_rank) >= 0; }
+    i32 own_blocks(i32 s) const { const i32 g = group_size(s), me = group_pos(s, shard_rank), nb = panel_blocks(s); return me < 0 ? 0 : (nb - me + g - 1) / g; }
+    i64 compact_span(i32 s) const { return ((i64)(own_blocks(s) + 2) * 256 * ld[s] + 16 + 15) & ~i64(15); }
+    i64 compact_window(i32 s, i32 slot) const { return (i64)(own_blocks(s) + slot) * 256 * ld[s]; }      // offset of window `slot` inside the stored span
     bool stored_here(i32 s) const { return !shard_plan || owner[s] == shard_rank || (is_dist(s) && group_pos(s, shard_rank) >= 0); }
     std::vector<i32> shard_sub_root, shard_sub_col0;   // ALL assigned subtrees: root supernode, first column (columns [col0, sfirst[root+1]) are theirs)
     // the caller's pattern (0-based) and which stored triangle defines Q: kept for the quadratic form

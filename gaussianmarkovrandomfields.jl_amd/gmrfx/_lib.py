@@ -66,7 +66,7 @@ EXPORTS = [
     "gmrfx_shard_rows", "gmrfx_set_prior", "gmrfx_refactorize_update", "gmrfx_refactorize_update_dev",
     "gmrfx_quadform", "gmrfx_quadform_dev", "gmrfx_selinv_dot", "gmrfx_selinv_row_diag", "gmrfx_kl_cholesky",
     "gmrfx_selinv_row_diag_plan", "gmrfx_selinv_row_diag_apply", "gmrfx_selinv_row_diag_free",
-    "gmrfx_symbolic_sweep_tasks", "gmrfx_symbolic_sweep_chunks", "gmrfx_selinv_phase", "gmrfx_host_io_plan",
+    "gmrfx_symbolic_sweep_tasks", "gmrfx_symbolic_sweep_chunks", "gmrfx_selinv_phase", "gmrfx_host_io_plan", "gmrfx_dist_front_block",
 ]
 
 
@@ -161,6 +161,7 @@ def lib():
         L.gmrfx_selinv_row_diag_apply.argtypes = [vp, i64, vp, vp]
         L.gmrfx_selinv_row_diag_free.argtypes = [vp, i64]
         L.gmrfx_host_io_plan.argtypes = [i64, i64, i32, vp]
+        L.gmrfx_dist_front_block.argtypes = [vp, i32, i32, C.POINTER(i64), C.POINTER(i64)]
         for nm in EXPORTS[2:]:
             if nm not in ("gmrfx_destroy", "gmrfx_device_ptr"):
                 getattr(L, nm).restype = i32

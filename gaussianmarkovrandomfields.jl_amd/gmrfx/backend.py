@@ -543,6 +543,13 @@ class MI355XBackend:
         check(lib().gmrfx_level_times(self._h, which, ptr(out), out.size, C.byref(cnt)), self._h)
         return out[:cnt.value]
 
+    def dist_front_block(self, front: int, block: int):
+        """(offset, count) in doubles of THIS rank's copy of panel block `block` of the distributed front `front` inside
+        device_ptr(1): the whole panel on the front's owner, own blocks + a two-block window on a member with block-cyclic storage"""
+        off, cnt = C.c_int64(0), C.c_int64(0)
+        check(lib().gmrfx_dist_front_block(self._h, int(front), int(block), C.byref(off), C.byref(cnt)), self._h)
+        return off.value, cnt.value
+
     def device_ptr(self, which: int) -> int:
         return int(lib().gmrfx_device_ptr(self._h, which) or 0)
 

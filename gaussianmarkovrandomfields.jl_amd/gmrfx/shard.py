@@ -188,8 +188,8 @@ class ShardedFactor:
 
     def _factor_distributed_front(self, d_nzval_ptr: int, i: int) -> None:
         """A top front factored by its group: per 256-column panel block its owner factors the block column and broadcasts it
-        inside the group (whole columns, one contiguous piece of the panel every member stores), every member updates its own
-        later blocks; then every member computes its own column blocks of the contribution block. The children's blocks have
+        inside the group (whole columns: one contiguous piece of the panel where a member stores it whole, of its window of two
+        received blocks where it keeps only its own blocks -- gmrfx_dist_front_block), every member updates its own later blocks; then every member computes its own column blocks of the contribution block. The children's blocks have
         arrived as column ranges at the owners of the blocks they fall into (the level's transfers).
         LOOK-AHEAD (round 4): once block b has arrived, the owner of block b + 1 applies b to that block FIRST (phase 4), factors
         it and posts its broadcast asynchronously; everybody applies b to the rest of its blocks (phase 5) while that broadcast is
@@ -200,8 +200,8 @@ class ShardedFactor:
         pg = self._pg[tuple(G)]
         nb = (c + 255) // 256
         views = self._df_views.get(i)
-        if views is None:                                           # built once per front
-            views = [self._view(1, int(df["panel_offset"][i]) + 256 * b * ld, min(256, c - 256 * b) * ld) for b in range(nb)]
+        if views is None:                                           # built once per front: where THIS rank keeps block b (the whole
+            views = [self._view(1, *be.dist_front_block(s, b)) for b in range(nb)]     # panel, or own blocks + a two-block window)
             self._df_views[i] = views
         be.dist_front_phase(d_nzval_ptr, s, 0)                      # assemble my panel blocks
         be.dist_front_phase(d_nzval_ptr, s, 1, 0)                   # its owner factors block 0

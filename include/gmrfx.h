@@ -210,8 +210,9 @@ int32_t gmrfx_set_stream(gmrfx_handle *h, void *hip_stream, int32_t use_external
  * factored by the WHOLE GROUP: the dense top fronts of a 3-D problem hold most of the flops (cfg 4: the root alone has 47 628
  * columns) and the single-address-space call this replaces, `cholesky!(F, S; check = false)` (src/workspace/backend.jl:165-189),
  * has no notion of it. Panel columns and contribution-block columns are cut into 256-column blocks dealt cyclically over the
- * group (panel block b -> group[b mod g], contribution-block block q -> group[(panel blocks + q) mod g]); every member stores
- * the whole panel; sweeps and selected inversion of the front stay on its owner.
+ * group (panel block b -> group[b mod g], contribution-block block q -> group[(panel blocks + q) mod g]); a front WITH a contribution
+ * block is stored whole by every member, one without (the root) only by its owner (gmrfx_dist_front_block below); sweeps and
+ * selected inversion of the front stay on its owner.
  *   gmrfx_shard_dist_fronts: counts[0] fronts, [1] group entries, [2] transfers, [3] world; per front (nullable): supernode,
  *     columns, rows, panel offset in gmrfx_device_ptr(h, 1), panel leading dimension, tree level; gptr / grank: its group.
  *   gmrfx_shard_transfers: every contribution-block transfer of the factorisation, ordered by the parent's level: `count`
@@ -229,6 +230,13 @@ int32_t gmrfx_shard_dist_fronts(const gmrfx_handle *h, int64_t *counts /* 4 */, 
 int32_t gmrfx_shard_transfers(const gmrfx_handle *h, int64_t *child, int64_t *src, int64_t *dst, int64_t *level,
                               int64_t *offset, int64_t *count, int64_t *col0);
 int32_t gmrfx_dist_front_phase(gmrfx_handle *h, const double *d_nzval, int32_t front, int32_t what, int32_t block);
+/* Block-cyclic STORAGE of a distributed front without trailing rows (the root; round 6): only the front's owner -- which sweeps and
+ * inverts it -- stores the whole panel; every other member keeps its own 256-column blocks and a window of two received blocks
+ * (cfg 4 at world 8: 18 GB -> 2.5 GB on seven of eight ranks). gmrfx_dist_front_block tells a rank where IT keeps panel block
+ * `block` -- offset into gmrfx_device_ptr(h, 1) and doubles (whole columns) --: the buffer it hands to the broadcast of that block
+ * (the ends of a broadcast have different offsets). -1 / 0 outside the group. Fronts with a contribution block stay replicated
+ * (every member needs all of L21 for its own column blocks of that block). */
+int32_t gmrfx_dist_front_block(const gmrfx_handle *h, int32_t front, int32_t block, int64_t *offset, int64_t *count);
 /* Profiling aid (handles created under GMRFX_LEVEL_MARK=1): HIP-event time of every tree level of the most recent
  * factorisation (which = 0), forward (1) or backward (2) sweep: ms[0] = the sweep tasks, ms[1 + l] = level l; *count = entries
  * written (0 when the marks are off). gmrfx/shard.py turns them into the TIME bound of a sharding plan (plan_summary). */

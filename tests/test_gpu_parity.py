@@ -603,11 +603,32 @@ def _shard_gpu_worker(rank, world, port, q, case="2d"):
         for i, s_ in enumerate(sf.df["front"]):     # after its last broadcast EVERY member of the group holds a distributed front's panel
             if rank in sf.df["group"][i]:
                 check.add(int(s_))
+        dist_pos = {int(s_): i for i, s_ in enumerate(sf.df["front"])}
+        n_compact = 0
         for s in sorted(check):
             a, ar = int(sy.panel_ptr[s]), int(rsy.panel_ptr[s])
             c, r, ldp = int(sy.super_first[s + 1] - sy.super_first[s]), int(sy.row_ptr[s + 1] - sy.row_ptr[s]), int(sy.panel_ld[s])
-            Pa = vals[a:a + ldp * c].reshape(c, ldp).T[:r]
             Pb = rv[ar:ar + ldp * c].reshape(c, ldp).T[:r]
+            if s in dist_pos and r == c and owner[s] != rank:
+                # block-cyclic STORAGE (round 6): a member that is not the owner of a front without trailing rows keeps its own
+                # 256-column blocks only (gmrfx_dist_front_block says where): those must equal the unsharded factor's columns
+                G_ = sf.df["group"][dist_pos[s]]
+                pos = G_.index(rank)
+                n_compact += 1
+                for b in range((c + 255) // 256):
+                    if b % len(G_) != pos:
+                        continue
+                    off, cnt = sf.be.dist_front_block(s, b)
+                    nc = min(256, c - 256 * b)
+                    assert cnt == nc * ldp and off == a + (b // len(G_)) * 256 * ldp
+                    Pa = vals[off:off + cnt].reshape(nc, ldp).T[:r]
+                    Pbb = Pb[:, 256 * b:256 * b + nc]
+                    msk = np.arange(r)[:, None] >= (256 * b + np.arange(nc))[None, :]
+                    if not np.array_equal(Pa * msk, Pbb * msk):
+                        same = False
+                        why.append(f"own block {b} of the distributed front {s} differs by {np.abs((Pa - Pbb) * msk).max():.3e}")
+                continue
+            Pa = vals[a:a + ldp * c].reshape(c, ldp).T[:r]
             if not np.array_equal(np.tril(Pa), np.tril(Pb)):
                 same = False
                 why.append(f"panel {s} (c={c}, r={r}) differs by {np.abs(np.tril(Pa) - np.tril(Pb)).max():.3e}")
@@ -689,7 +710,7 @@ def _shard_gpu_worker(rank, world, port, q, case="2d"):
         if not (np.array_equal(dsh, dref) if case == "2d" else np.abs(dsh - dref).max() <= 1e-11 * np.abs(dref).max()):
             same = False
             why.append(f"sharded selinv diagonal differs from the unsharded one by {np.abs(dsh - dref).max():.3e} (rel {np.abs(dsh / dref - 1).max():.3e})")
-        info = dict(sf.be.shard_info()); info["why"] = why[:5]; info["n_dist"] = len(sf.df["front"])
+        info = dict(sf.be.shard_info()); info["why"] = why[:5]; info["n_dist"] = len(sf.df["front"]); info["n_compact"] = n_compact
         info["n_dist_cb"] = int(sum(1 for i in range(len(sf.df["front"])) if sf.df["rows"][i] > sf.df["cols"][i] and len(sf.df["group"][i]) > 1))
         st, rst = sf.be.stats(), ref.stats()
         info["mem"] = {k: (float(st[k]), float(rst[k])) for k in ("bytes_factor", "bytes_cb_arena", "bytes_device_total")}
@@ -766,6 +787,8 @@ def test_distributed_top_fronts_rehearsal_on_one_gpu(world):
         if world == 4:
             assert info["n_dist_cb"] >= 1, info        # a distributed front WITH a contribution block was exercised
         assert abs(ld - ld_ref) <= 1e-12 * abs(ld_ref)
+    # the root (no trailing rows) is stored whole by its owner only: every other rank went through the block-cyclic storage path
+    assert sum(1 for *_, info in got if info["n_compact"] >= 1) == world - 1, [info["n_compact"] for *_, info in got]
 
 
 def test_randomised_pattern_sweep():

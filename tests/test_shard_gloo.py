@@ -267,7 +267,12 @@ def _dist_fronts_worker(rank, world, port, q, kind="dense"):
     owner, is_top = be.shard_owner(with_top=True)
     info, df, X = be.shard_info(), be.shard_dist_fronts(), be.shard_transfers()
     L0, K = info["shard_level"], info["n_top_levels"]
-    sim = HostSim(sy, n, np.asarray(Q.data))
+    # the host walk keeps EVERY panel whole in its own numpy storage (round 6: the library stores a distributed front without
+    # trailing rows block-cyclically on the members that do not own it): storage from an unsharded analysis of the same ordering,
+    # plan (owners, levels, groups, transfers) from this rank's sharded one
+    sy_full = gmrfx.MI355XBackend(Q, ordering=be.ordering_permutation(), symbolic_only=True).symbolic()
+    assert np.array_equal(sy_full.super_first, sy.super_first) and np.array_equal(sy_full.row_ptr, sy.row_ptr)
+    sim = HostSim(sy_full, n, np.asarray(Q.data))
     ns = sim.ns
     dfi = {int(s): i for i, s in enumerate(df["front"])}
     R = int(np.flatnonzero(sy.super_parent == -1)[-1])
