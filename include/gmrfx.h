@@ -173,7 +173,10 @@ int32_t gmrfx_refactorize_update_solve_dev(gmrfx_handle *h, const double *d_hval
  *                                       gmrfx_refactorize_phase(h, nzval, 1 + k)   this rank's fronts of top level k
  *   log det Q        all-reduce (sum) of gmrfx_logdet_partial; pivot failures: all-reduce (min) of gmrfx_stats.fail_col
  *   solve (1..64 right-hand sides, device buffers)
- *                    gmrfx_solve_phase(.., 0)                  transpose in + forward sweep over the own subtrees
+ *                    gmrfx_solve_phase(.., 0)                  transpose in + forward sweep over the own subtrees. Of d_B a rank
+ *                                                              READS only the rows of the columns it owns (its subtrees' and its
+ *                                                              own top fronts': gmrfx_shard_rows kinds 3 and 2 with owner = rank,
+ *                                                              through gmrfx_get_perm): B may be row-sharded over the ranks
  *                    for k = 0 .. K-1:  [update vectors W of the level's edges: src -> dst]   gmrfx_solve_phase(.., 100 + k)
  *                    for k = K-1 .. 0:  gmrfx_solve_phase(.., 200 + k)   [x of that level's top fronts: owner -> all,
  *                                       gmrfx_shard_rows(kind 2)]
@@ -196,7 +199,7 @@ int32_t gmrfx_shard_owner(const gmrfx_handle *h, int64_t *owner /* nsuper, >= 0 
 void   *gmrfx_device_ptr(gmrfx_handle *h, int32_t which /* 0: contribution-block arena, 1: factor panels, 2: X, 3: W */);
 int32_t gmrfx_solve_phase(gmrfx_handle *h, const double *d_B, int64_t ldb, int64_t nrhs, double *d_X, int64_t ldx, int32_t phase);
 /* Backward-only sharded solve, X = P' L^-T Z (`F.UP \ z`, src/workspace/backend.jl:281-284), through the same entry point:
- * phase 10 = take Z (full, on every rank) in elimination order; 300 + k = backward over top level k [then broadcast that
+ * phase 10 = take Z in elimination order (a rank reads the rows of its own columns only, as above); 300 + k = backward over top level k [then broadcast that
  * level's x rows, as after 200 + k]; 12 = backward over the own subtrees; [gather on rank 0]; 3 = transpose out.
  *
  * gmrfx_set_stream: the caller's HIP stream becomes the handle's main stream (use_external = 1; 0 restores the handle's
