@@ -37,6 +37,13 @@ def test_single_gpu_line_has_the_contract_fields():
     assert r["launches_per_step"] >= 1 and r["ms_per_step"] > 0.0          # live HIP events around every launch
     assert d["roofline_sweep"]["bound"] == "hbm" and d["roofline_sweep"]["peak"] == 8000.0 and 0.0 < d["roofline_sweep"]["frac"] < 1.0
     assert 0.0 < d["roofline_factor"]["frac"] < 1.0
+    # round 6: the sweep's bytes use the TRUE nnz(L); a ceiling that concedes the multifrontal schedule is printed beside the fraction
+    rs = d["roofline_sweep"]
+    assert rs["frac_on_stored_entries"] >= rs["frac"] and rs["copy_peak_measured"] > 500.0
+    mb = rs["model_bound_ms"]
+    assert 0.0 < mb["fwd"] and 0.0 < mb["bwd"] and abs(mb["mean"] - 0.5 * (mb["fwd"] + mb["bwd"])) < 1e-12
+    assert 0.0 < rs["frac_of_model_bound"] < 1.5 and rs["model_bound"]["fwd_launches"] >= 1 and rs["model_bound"]["handoff_bytes_fwd"] >= 0.0
+    assert rs["model_bound_ms_at_guide_copy_peak"]["copy_peak_gbs"] == 6290.0
     assert d["check"]["rel_residual"] < 1e-10 and d["check"]["fail_col"] == -1
     ph = d["phases_ms"]
     assert ph["factor"] > 0 and ph["solve"] > 0 and abs(ph["solve"] - (ph["solve_fwd"] + ph["solve_bwd"] + ph["solve_perm"])) < 0.3 * ph["solve"]
@@ -56,6 +63,10 @@ def test_two_rank_rehearsal_line_is_sharded_strong_scaling():
     assert "error" not in sh and sh["check"]["info"] == 0 and sh["check"]["rel_residual"] < 1e-10
     assert abs(sh["check"]["logdet"] - d["check"]["logdet"]) < 1e-11 * abs(d["check"]["logdet"])
     assert d["value"] == sh["value"] and d["ms_per_step"] == sh["ms_per_step"]
+    # round 6: the headline gathers X on rank 0 (the N = 1 step's work), the distributed-X step is timed beside it; B is row-sharded;
+    # the line says how many ranks the collective library spans (an all-reduce of ones)
+    assert sh["ms_per_step_x_distributed"] > 0 and sh["value_x_distributed"] > 0 and "gathered" in sh["x"] and "row-sharded" in sh["b"]
+    assert sh["rccl_ranks"] == 2 and sh["world_size"] == 2 and sh["collective_backend"] == "gloo"
     # the plan carries the flop bound AND the time bounds built from one unsharded step's per-level event times
     pl = sh["plan"]
     assert 1.0 <= pl["time_bound_speedup_latency"] <= pl["time_bound_speedup_share"] <= 2.0 + 1e-9 and pl["flop_bound_speedup"] <= 2.0 + 1e-9
