@@ -21,6 +21,24 @@ import os
 import sys
 import time
 
+T_START = time.time()              # N > 1: the line must be out before the launcher's limit (see --deadline)
+
+
+def launch_time():
+    """When the RUN started: the creation time of the launcher (`python -m torch.distributed.run` / torchrun, whose own first
+    `import torch` on a fresh box can take a minute or two before any rank exists) when this process is one of its ranks, else the
+    import time of this module."""
+    try:
+        import psutil
+        p = psutil.Process(os.getppid())
+        cmd = " ".join(p.cmdline())
+        if "torch.distributed.run" in cmd or "torchrun" in cmd or "torch/distributed" in cmd:
+            return min(T_START, p.create_time())
+    except Exception:
+        pass
+    return T_START
+
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "gaussianmarkovrandomfields.jl_amd"))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -364,6 +382,13 @@ def main():
     ap.add_argument("--extras", action="store_true", help="also time predictor variances diag(A Sigma A') and the Newton iterate (f1, f4)")
     ap.add_argument("--shard-timeout", type=float, default=300.0,
                     help="N > 1: seconds the sharded strong-scaling run may take before the replica line is printed without it")
+    ap.add_argument("--deadline", type=float, default=540.0,
+                    help="N > 1: seconds after the start of the run (of the launcher, when there is one) by which rank 0's line must be out "
+                         "(the driver gives a bench run 600 s): the watchdog of the sharded cfg-2 run is cut to fit, and the additional cfg-4 line is only started "
+                         "when --cfg4-budget seconds of it are left")
+    ap.add_argument("--cfg4-budget", type=float, default=300.0,
+                    help="N > 1: what the cfg-4 sharded line needs at most (126^3 mesh + Q on the host 110-130 s per rank, two symbolic "
+                         "analyses 50 s, allocation, 3 steps, the residual check): skipped, and said so, when less of --deadline is left")
     ap.add_argument("--no-shard", action="store_true",
                     help="N > 1: only time the independent replicas (weak scaling); by default the headline of an N > 1 run is "
                          "ONE factorisation sharded over the N GPUs (strong scaling, gmrfx/shard.py) and the replicas are reported beside it")
@@ -849,8 +874,12 @@ def main():
                     printed[0] = True
             if rank != 0:
                 time.sleep(1.0)     # the launcher ends all ranks when the first one fails: rank 0 prints first
-            os._exit(SHARD_TIMEOUT_EXIT)
-        watchdog = threading.Timer(args.shard_timeout, give_up)
+            # (the cfg-4 leg is an extra: the cfg-2 headline of the line is complete and checked, its time-out is recorded in the
+            #  line and does not fail the run)
+            os._exit(SHARD_TIMEOUT_EXIT if stage[0] == "cfg2" else 0)
+        t_launch = launch_time()
+        remaining = lambda: args.deadline - (time.time() - t_launch)
+        watchdog = threading.Timer(min(args.shard_timeout, max(30.0, remaining() - 15.0)), give_up)
         watchdog.daemon = True
         watchdog.start()
         try:
@@ -877,12 +906,20 @@ def main():
     if dist is not None and not args.no_shard and not args.no_cfg4:
         # the configuration that CAN scale (3-D: the flops sit in a few huge fronts), next to the graded cfg-2 line; its
         # failure is recorded in the line but does not change the exit code (the headline is cfg 2)
-        flag = torch.tensor([1 if shard_raised else 0], dtype=torch.int64, device="cpu" if args.rehearse else dev)
+        # every rank takes the same decision: 2 = the sharded cfg-2 run raised somewhere, 1 = some rank has less than --cfg4-budget
+        # seconds of --deadline left (the line is printed AFTER this leg: a leg that outlives the launcher's limit would take the
+        # cfg-2 headline down with it)
+        flag = torch.tensor([2 if shard_raised else 1 if remaining() < args.cfg4_budget else 0], dtype=torch.int64,
+                            device="cpu" if args.rehearse else dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()) == 1 and rank == 0:
+            with out_lock:
+                out["cfg4_sharded"] = {"status": f"skipped: {remaining():.0f} s of --deadline {args.deadline:.0f} s left, the leg is given "
+                                                 f"--cfg4-budget {args.cfg4_budget:.0f} s"}
         if int(flag.item()) == 0:
             stage[0] = "cfg4"
             watchdog.cancel()
-            watchdog = threading.Timer(max(args.shard_timeout, 900.0), give_up)
+            watchdog = threading.Timer(max(30.0, remaining() - 10.0), give_up)
             watchdog.daemon = True
             watchdog.start()
             try:

@@ -86,3 +86,13 @@ def test_sharded_run_that_hangs_exits_non_zero_with_the_replica_line():
               "--shard-timeout", "0.001"], expect_rc=1)      # torch.distributed.run maps any failed rank to exit code 1
     assert d["scaling"] == "weak" and "error" in d["sharded"] and "did not finish" in d["sharded"]["error"]
     assert d["replicas"]["value"] == d["value"]
+
+
+def test_cfg4_line_is_skipped_and_says_so_when_the_deadline_leaves_no_room():
+    """round 6: the line is printed behind the additional cfg-4 leg, so the leg only starts when --cfg4-budget seconds of --deadline are
+    left (the driver ends a bench run after 600 s; 126^3 nodes cost ~170 s of host work per rank before the first kernel): the cfg-2
+    headline stays, the skip is recorded, rc == 0."""
+    d = _run(["--gpus", "2", "--rehearse", "--grid", "200", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-logpdf", "--no-cfg3",
+              "--cfg4-grid", "14", "--cfg4-budget", "100000"])
+    assert d["scaling"] == "strong" and "error" not in d["sharded"]
+    assert d["cfg4_sharded"]["status"].startswith("skipped") and "--deadline" in d["cfg4_sharded"]["status"]
