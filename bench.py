@@ -22,6 +22,9 @@ import sys
 import time
 
 T_START = time.time()              # N > 1: the line must be out before the launcher's limit (see --deadline)
+# the host driver of this pool only supports dmabuf IPC: without it RCCL across processes fails with `hipIpcGetMemHandle: invalid
+# argument` (exported on the boxes already; kept here for any environment that is built from scratch -- before anything loads HIP)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
 def launch_time():
