@@ -529,6 +529,7 @@ void Device::upload(const Symbolic &S) {
     // estimated cost -- one per XCD. One self-contained record per tile (kernels.hip, k_syrk_cb_rec).
     {
         if (const char *e = std::getenv("GMRFX_SYRK_XCD")) syrk_xcd_ = std::atoi(e) != 0;
+        if (const char *e = std::getenv("GMRFX_SYRK_PIPED")) syrk_piped_min_ = std::atoi(e);
         std::vector<SyrkTile> recs;
         std::vector<double> cost;
         constexpr int SQ = 8;
@@ -1010,7 +1011,9 @@ void Device::factor_levels(int lo, int hi) {
             HC(hipEventRecord(ev_syrk_[2 * nsy], stream));
             // levels of HUGE fronts (3-D problems): the children's extend-add alone, then the product on 128 x 128 staged tiles
             const bool huge = syrk_xcd_ && !sharded() && level_max_trail(L) >= 4096 && L.max_cols >= 1024;
-            if (syrk_xcd_) launch_syrk_cb_recs(stream, ds_, d_syrk_recs_ + L.syrk_off, L.syrk_split, L.syrk_per, d_L_, d_cb_, huge ? 1 : 0);
+            // levels of wide fronts (the product dominates the tile): the software-pipelined product loop (kernels.hip, k_syrk_cb_rec<true>;
+            // same sums in the same order: a level's choice does not show in the bits)
+            if (syrk_xcd_) launch_syrk_cb_recs(stream, ds_, d_syrk_recs_ + L.syrk_off, L.syrk_split, L.syrk_per, d_L_, d_cb_, huge ? 1 : 0, L.max_cols >= syrk_piped_min_);
             else launch_syrk_cb(stream, ds_, list, nf, level_max_trail(L), d_L_, d_cb_);
             if (huge) launch_syrk_big(stream, ds_, list, nf, level_max_trail(L), d_L_, d_cb_);
             HC(hipEventRecord(ev_syrk_[2 * nsy + 1], stream));

@@ -8,6 +8,8 @@
 
 #include "symbolic.h"
 
+namespace gmrfx { constexpr int kSyrkPipedMinCols = 128; }     // see DeviceFactor::syrk_piped_min_
+
 namespace gmrfx {
 
 // One record per (child -> parent) edge of the assembly tree, in childptr order: everything a
@@ -275,6 +277,8 @@ private:
     std::vector<EdgeRec> h_edges_;      // host copies of the edge records / tile tables between upload() and init()
     std::vector<int> h_etile_;
     std::vector<long long> h_wptr_;
+    int syrk_piped_min_ = kSyrkPipedMinCols;      // GMRFX_SYRK_PIPED=N: levels whose widest front has >= N columns take the software-pipelined
+                                                  // product loop of k_syrk_cb_rec (0: every level; a huge N: none) -- same bits either way
     bool syrk_xcd_ = true;          // GMRFX_SYRK_XCD=0: k_syrk_cb on a plain 3-D grid (front, tile row, tile column) instead
     FrontView *d_frec_ = nullptr, *d_frec2_ = nullptr, *d_sel_frec_ = nullptr;   // geometry records parallel to the level lists
     int *d_levellist2_ = nullptr;   // per level: the big fronts re-ordered [even positions..., odd positions...] (two-stream panel chains)

@@ -22,7 +22,10 @@ void launch_assemble(hipStream_t st, const DevSym &S, const int *list, const Asm
 void launch_syrk_cb(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_trail, const double *L, double *CB);
 // The same tiles from self-contained records, one contiguous run per XCD (workgroup id mod 8 = XCD): see k_syrk_cb_rec.
 void launch_syrk_cb_recs(hipStream_t st, const DevSym &S, const SyrkTile *recs, const SyrkSplit &split, int per_xcd, const double *L, double *CB,
-                         int noprod = 0);
+                         int noprod = 0, bool piped = false);
+// piped: the product loop in three stages of two k-steps, each requested two stages ahead (levels whose widest front has at least
+// kSyrkPipedMinCols columns, device.h; measured on cfg 2, round 6: k_syrk_cb_rec 3.60-3.69 -> 3.37-3.45 ms per step with 32 / 64 / 128 /
+// 200 / 300 alike, 600: 3.56)
 // CB -= L21 L21' on 128 x 128 LDS-staged tiles (behind a gather-only pass: noprod = 1), for levels of huge fronts
 void launch_syrk_big(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_trail, const double *L, double *CB);
 // blocks at most 32 columns wide, factorisation only (k_trsm<0, 0>'s arithmetic on half the registers)
@@ -117,6 +120,9 @@ __device__ __forceinline__ void wave_gemm_32x32_pm(gmrfx_d4 (&acc)[2][2], int m0
     }
 }
 // qlo, qhi multiples of 4
+// (Round 6, measured and dropped: the three-stage software pipeline of k_syrk_cb_rec<true> for ranges of >= 48 -- k_sel_dense 107 -> 123
+//  VGPRs, still three waves per SIMD, bit-identical; selected inversion of cfg 3 12.59 / 12.65 -> 13.10 / 13.11 ms on the same box: that
+//  kernel runs at the fabric's bandwidth limit already, requests further ahead only deepen the queues.)
 __device__ __forceinline__ void wave_gemm_32x32_rr(gmrfx_d4 (&acc)[2][2], const double *pa2, long long sa, const double *pb2,
                                                    long long sb, int qlo, int qhi, int lk) {
     constexpr int KU = 4;

@@ -404,7 +404,9 @@ __global__ __launch_bounds__(256) void k_gemm_nt(DevSym S, const FrontView *__re
     const int kfull = K / (4 * KU) * (4 * KU);
     // single-buffered batches: latency is hidden by the other resident waves (4-5 per SIMD at
     // this register budget); hipcc turns a register double-buffer into vmcnt(0) at the loop head
-    // anyway, which defeats the overlap.
+    // anyway, which defeats the overlap. (Round 6: the three-stage loop of k_syrk_cb_rec<true> -- unconditional refills, scheduling
+    // barriers -- does overlap; built here for K >= 48, bit-identical, and dropped: factor 8.44 / 8.44 -> 8.34 / 8.46 ms on one box, inside
+    // the noise -- these launches sit on the panel chain and are bounded by their own latency, not by the product loop.)
     for (int k0 = 0; k0 < kfull; k0 += 4 * KU) {
         fetch(k0, ca, cb);
         mma(ca, cb);
@@ -563,6 +565,8 @@ __global__ __launch_bounds__(256) void k_syrk_cb(DevSym S, const int *__restrict
 // tile -> front geometry -> edge records -> tile ranges), the first k-batch of the product and the first child's entries
 // are requested right behind it, and only then does anything wait. Children are still added one after the other, the k
 // order is unchanged: bit-identical to k_syrk_cb.
+struct SyrkOps { d2u a[2], b[2]; };       // the operands of two k-steps (rows in pairs): one stage of the pipelined product loop
+template <bool PIPED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_syrk_cb_rec(DevSym S, const SyrkTile *__restrict__ recs, const SyrkSplit split,
                                                      const double *__restrict__ L, double *__restrict__ CB, int noprod) {
     // noprod: the children's extend-add only -- the product follows as its own launch on 128 x 128 staged tiles (k_syrk_big: the
@@ -599,7 +603,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
             bv[u][0] = xb.x; bv[u][1] = xb.y;
         }
     };
-    if (live && !noprod) request(0);
+    // Tiles of WIDE fronts (c >= pipe_min): the product loop in three stages of two k-steps, each stage requested two stages ahead
+    // (see the loop below)
+    constexpr bool piped = PIPED;
+    SyrkOps oA, oB, oC;
+    // Addresses without vector arithmetic: a SCALAR base per k-step (the record is the same for every lane) + a 32-bit lane offset
+    // (the lane's row pair + its column lk of the k-step). Requests behind the last k-step are clamped to the last four columns of
+    // the PADDED panel (symbolic.cpp, panel_span: zero columns up to a multiple of 4): in vain, or masked in the tail.
+    const unsigned voa = (unsigned)(min(j0 + 2 * lm, mlast) + lk * ld) * 8u, vob = (unsigned)(min(i0 + 2 * lm, mlast) + lk * ld) * 8u;
+    const int cp4 = ((c + 3) & ~3) - 4;
+    auto req2 = [&](SyrkOps &x, int q0) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const char *sb = (const char *)(A + (long long)min(q0 + 4 * u, cp4) * ld);
+            x.a[u] = *(const d2u *)(sb + voa); x.b[u] = *(const d2u *)(sb + vob);
+        }
+    };
+    if (live && !noprod) {
+        if (piped) { req2(oA, 0); req2(oB, 8); req2(oC, 16); }
+        else request(0);
+    }
     // the first two children's entries: (row la, column lb + 4 u) of the child's rows / columns inside this tile.
     // Round trips: record -> [k-batch 0 + child 0] -> child 1 -> k-batch 1 ...
     // Every vector memory instruction costs the CU's address unit ~16 cycles whatever its lanes do, and these levels
@@ -655,18 +678,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
                     acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][a] * mk, bv[u][b], acc[a][b], 0, 0, 0);
         }
     };
-    if (T.nch > 0) fetch(0);
+    if (T.nch > 0 && !piped) fetch(0);        // (piped: behind the product -- its three operand stages take the registers of a child's entries)
     for (int idx = tid; idx < 64 * 65; idx += 256) Tl[idx] = 0.0;
     // The product needs nothing from the children: it runs HERE, between the children's requests and their use, so that its
     // MFMAs cover the children's round trips (the accumulators meet the gathered tile only in the epilogue). Measured by
     // compiling parts out (profiles/r04_syrk_parts.txt): gather, product and store used to follow each other, a third of a
     // mid-level tile's time each.
     // D[m_ = j][n = i] = sum_q L21[j][q] L21[i][q]: rows i on the lanes (contiguous in column-major CB)
-    if (live && !noprod)
-        for (int q0 = 0; q0 < c; q0 += 4 * KU) {
-            if (q0 > 0) request(q0);
-            mfma_batch(q0);
+    auto mma2 = [&](const SyrkOps &x, int q0, bool masked) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const double mk = (!masked || (q0 + 4 * u + lk) < c) ? 1.0 : 0.0;
+            const double a0 = masked ? x.a[u].x * mk : x.a[u].x, a1 = masked ? x.a[u].y * mk : x.a[u].y;
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, x.b[u].x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, x.b[u].y, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, x.b[u].x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, x.b[u].y, acc[1][1], 0, 0, 0);
         }
+    };
+    if (live && !noprod) {
+        if (piped) {
+            // same k-steps in the same order as the plain loop (bit-identical sums); a stage's registers are refilled as soon as
+            // its MFMAs have read them, two stages (16 MFMAs) before they are used again. The refills are UNCONDITIONAL (clamped
+            // rows: the last ones of a tile are requested in vain): a conditional request makes the compiler count zero loads behind
+            // every stage, i.e. wait for everything in flight.
+            int q0 = 0;
+            for (; q0 + 24 <= c; q0 += 24) {
+                // (the scheduler would sink all refills to the end of the iteration: one exposed round trip per iteration again)
+                mma2(oA, q0, false); __builtin_amdgcn_sched_barrier(0); req2(oA, q0 + 24); __builtin_amdgcn_sched_barrier(0);
+                mma2(oB, q0 + 8, false); __builtin_amdgcn_sched_barrier(0); req2(oB, q0 + 32); __builtin_amdgcn_sched_barrier(0);
+                mma2(oC, q0 + 16, false); __builtin_amdgcn_sched_barrier(0); req2(oC, q0 + 40); __builtin_amdgcn_sched_barrier(0);
+            }
+            if (q0 < c) {
+                mma2(oA, q0, true);
+                if (q0 + 8 < c) {
+                    mma2(oB, q0 + 8, true);
+                    if (q0 + 16 < c) mma2(oC, q0 + 16, true);
+                }
+            }
+        } else
+            for (int q0 = 0; q0 < c; q0 += 4 * KU) {
+                if (q0 > 0) request(q0);
+                mfma_batch(q0);
+            }
+    }
+    if (T.nch > 0 && piped) fetch(0);
     if (T.nch > 1) fetch(1);        // (the second child's registers would not fit beside the product's: behind it, before the first is added)
     __syncthreads();
     if (T.nch > 0) {
@@ -1788,9 +1844,10 @@ void launch_syrk_cb_cyclic(hipStream_t st, const DevSym &S, const int *list, int
     hipLaunchKernelGGL(k_syrk_cb, dim3(odd(cdiv(trail, 64)), odd(cdiv(trail, 64)), 1), dim3(256), 0, st, S, list, L, CB, cyc_w, cyc_r, cyc_b0);
 }
 void launch_syrk_cb_recs(hipStream_t st, const DevSym &S, const SyrkTile *recs, const SyrkSplit &split, int per_xcd, const double *L, double *CB,
-                         int noprod) {
+                         int noprod, bool piped) {
     if (per_xcd <= 0) return;
-    hipLaunchKernelGGL(k_syrk_cb_rec, dim3(8 * (unsigned)per_xcd), dim3(256), 0, st, S, recs, split, L, CB, noprod);
+    if (piped) hipLaunchKernelGGL(k_syrk_cb_rec<true>, dim3(8 * (unsigned)per_xcd), dim3(256), 0, st, S, recs, split, L, CB, noprod);
+    else hipLaunchKernelGGL(k_syrk_cb_rec<false>, dim3(8 * (unsigned)per_xcd), dim3(256), 0, st, S, recs, split, L, CB, noprod);
 }
 __global__ void k_syrk_big(DevSym S, const int *__restrict__ list, const double *__restrict__ L, double *__restrict__ CB);   // with k_gemm_nt_big, below
 void launch_syrk_big(hipStream_t st, const DevSym &S, const int *list, int nfronts, int max_trail, const double *L, double *CB) {

@@ -1192,6 +1192,35 @@ def test_tile_records_and_plain_grid_give_the_same_bits_on_a_mesh_with_many_tile
     assert np.array_equal(rec.backend_backward_solve(Z), grid.backend_backward_solve(Z))
 
 
+@pytest.mark.parametrize("name", ["matern64_coords", "cfg1_alpha3_65x65", "matern3d_10", "rand400", "mesh300"])
+def test_pipelined_syrk_product_loop_gives_the_same_bits(name, monkeypatch):
+    """Round 6: k_syrk_cb_rec<true> runs the product of a contribution-block tile as three stages of two k-steps, each requested two
+    stages ahead (levels whose widest front has >= 128 columns by default). GMRFX_SYRK_PIPED=0 sends EVERY level through it (fronts of
+    1 .. 64 columns too: ranges shorter than one round, column counts that are no multiple of 4, the clamped requests behind the last
+    k-step), a huge value none: the same factor bit for bit in all three, and against the oracle."""
+    if name == "mesh300":
+        mesh = spde.grid_mesh_2d(300, 300, jitter=0.25, seed=3)
+        Q, kw = sp.csc_matrix(spde.matern_precision(mesh, 0, 0.2)), {"coords": mesh.points}
+    else:
+        Q, kw = next((sp.csc_matrix(q), k) for n, q, k in CASES if n == name)
+    dflt = gmrfx.MI355XBackend(Q, **kw)
+    perm = dflt.ordering_permutation()
+    monkeypatch.setenv("GMRFX_SYRK_PIPED", "0")
+    every = gmrfx.MI355XBackend(Q, ordering=perm)
+    monkeypatch.setenv("GMRFX_SYRK_PIPED", "1000000000")
+    none = gmrfx.MI355XBackend(Q, ordering=perm)
+    monkeypatch.delenv("GMRFX_SYRK_PIPED")
+    a = dflt.factor_values()
+    assert np.array_equal(a, every.factor_values()) and np.array_equal(a, none.factor_values())
+    assert dflt.compute_logdet() == every.compute_logdet() == none.compute_logdet()
+    if name != "mesh300":
+        F = orc.OracleFactor(Q, perm)
+        Lg, Lo = every.factor_csc(), F.L()
+        assert abs(Lg - Lo).max() <= 1e-10 * abs(Lo).max()
+    for be in (dflt, every, none):
+        be.close()
+
+
 @pytest.mark.parametrize("mode", ["wg", "wave"])
 @pytest.mark.parametrize("nrhs", [1, 17, 33, 64])
 def test_sweep_task_forms_match_the_oracle(mode, nrhs, monkeypatch):
