@@ -1406,6 +1406,12 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_gemm_longk(DevSym S, const int 
     //  * the row indices of those rows the same way;
     //  * x along the right-hand sides: column tile t is right-hand side 32 (t >> 1) + 2 lm + (t & 1).
     // Per batch of 16 rows: 2 NA + 8 + 2 loads instead of 4 NA + 16 + 4.
+    // (Round 6, measured and dropped: this loop as a three-stage software pipeline of half-batches -- operands requested two stages
+    //  ahead, their row indices three, unconditional requests and scheduling barriers as in k_syrk_cb_rec<true>; 126 / 166 VGPRs for
+    //  the <1, 8> / <2, 8> forms, same occupancy, bit-identical. Backward sweep of cfg 2: 1.434-1.441 ms without, 1.434-1.440 with it on
+    //  either or both forms. The top-level launches are not a chain of exposed round trips: a level of 126 workgroups puts 2000 MFMAs
+    //  on each of 126 compute units -- 13.8 us at the pipe's peak -- while the other half of the chip idles; only spreading a front's
+    //  work over more compute units would shorten them.)
     const int jb[2] = {min(2 * lm, nr - 1), min(32 + 2 * lm, nr - 1)};
     constexpr int KU = 4;
     // The row indices of batch k+1 are requested together with the operands of batch k: one round
