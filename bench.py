@@ -737,12 +737,17 @@ def main():
         n_launch = max(int(st["syrk_launches"]), 1)
         syrk_tf = st["syrk_flops"] / (ms_syrk * 1e-3) / 1e12
         per_k = (pmc or {}).get("per_kernel_GB_per_step", {})
-        pk = per_k.get("k_syrk_cb_rec") or per_k.get("k_syrk_cb")
+        # (round 6: two instantiations -- <true>: the software-pipelined product loop of the levels of wide fronts, <false>: the rest;
+        #  one launch per level, either one or the other: their bytes and launches add up to the kernel's)
+        inst = [v for k, v in per_k.items() if k == "k_syrk_cb_rec" or k.startswith("k_syrk_cb_rec<")]
+        pk = ({"fetch_x2": sum(v["fetch_x2"] for v in inst), "write": sum(v["write"] for v in inst)} if inst else per_k.get("k_syrk_cb"))
         roof_kernel = {"bound": "mfma", "achieved": syrk_tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                        "frac": syrk_tf / FP64_MFMA_PEAK_TF,
                        "traffic": (1e9 * (pk["fetch_x2"] + pk["write"]) / n_launch) if pk else None,
                        "peak_measured": FP64_MFMA_MEASURED_TF, "frac_of_measured_peak": syrk_tf / FP64_MFMA_MEASURED_TF,
-                       "kernel": "k_syrk_cb_rec", "launches_per_step": n_launch, "avg_launch_ms": ms_syrk / n_launch,
+                       "kernel": "k_syrk_cb_rec", "instantiations": "k_syrk_cb_rec<true> (levels whose widest front has >= 128 columns: pipelined "
+                                                                     "product loop) + k_syrk_cb_rec<false> (the levels below)",
+                       "launches_per_step": n_launch, "avg_launch_ms": ms_syrk / n_launch,
                        "flops_per_launch": st["syrk_flops"] / n_launch, "ms_per_step": ms_syrk,
                        "note": "achieved = algorithmic flops of the launches of one step / their summed HIP-event time over the "
                                "timed (pipelined) steps -- the forward sweep of the same step runs beside some of them; "
